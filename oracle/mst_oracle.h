@@ -1,0 +1,187 @@
+/*
+ * mst_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A plain-C restatement of the reference's per-frame compositing arithmetic
+ * (wangzjpku/StitchingVideo = vendored OpenCV 2.4.11 `stitching` module + the
+ * OpenCV 2.4.11 core/imgproc primitives it calls).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (libmi355stitch.so) never links or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" -- the reference ships no tests, no golden
+ * vectors and no source for OpenCV 2.4.11 imgproc/core (Windows DLLs only), and
+ * cannot be compiled or run in this image.  Reference-owned
+ * loops (the .cpp files under R64/src) are followed line by line and cited below; the
+ * OpenCV 2.4.11 primitive semantics (remap, pyrDown, pyrUp, resize,
+ * copyMakeBorder, saturating add/subtract, convertTo) are restated from the
+ * published 2.4.11 algorithm, each isolated in one function with a
+ * known-answer test in tests/test_oracle_kat.py.
+ *
+ * Path alias: R64 = /root/reference/stitching/OpenCV2.4.11-Stitching-64bit/
+ *                   OpenCV2.4.11-Stitching
+ */
+#ifndef MST_ORACLE_H
+#define MST_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums (values follow OpenCV 2.4.11 / the reference headers) ---------- */
+enum { MO_WARP_PLANE = 0, MO_WARP_SPHERICAL = 1, MO_WARP_CYLINDRICAL = 2 };
+enum { MO_INTER_NEAREST = 0, MO_INTER_LINEAR = 1 };
+enum { MO_BORDER_CONSTANT = 0, MO_BORDER_REPLICATE = 1, MO_BORDER_REFLECT = 2,
+       MO_BORDER_WRAP = 3, MO_BORDER_REFLECT_101 = 4 };
+/* R64/include/opencv2/stitching/detail/blenders.hpp:58 */
+enum { MO_BLEND_NO = 0, MO_BLEND_FEATHER = 1, MO_BLEND_MULTI_BAND = 2 };
+/* R64/include/opencv2/stitching/detail/exposure_compensate.hpp:56 */
+enum { MO_EXPOS_NO = 0, MO_EXPOS_GAIN = 1, MO_EXPOS_GAIN_BLOCKS = 2 };
+enum { MO_WEIGHT_32F = 0, MO_WEIGHT_16S = 1 };
+
+typedef struct { int x, y, width, height; } mo_rect;
+
+/* ProjectorBase state, R64/include/opencv2/stitching/detail/warpers.hpp:75-86 */
+typedef struct {
+    float scale;
+    float k[9];
+    float rinv[9];
+    float r_kinv[9];
+    float k_rinv[9];
+    float t[3];
+} mo_projector;
+
+/* worker threads for the row-parallel loops (OpenMP); results do not depend on it */
+void mo_set_num_threads(int n);
+int  mo_get_num_threads(void);
+
+/* ---- scalar conversion helpers (x64/SSE2 semantics) ------------------------ */
+int      mo_cv_round(double v);            /* cvRound: RNE, INT_MIN when unrepresentable */
+int      mo_cv_floor(double v);
+int16_t  mo_sat_s16(int v);
+uint8_t  mo_sat_u8(int v);
+int16_t  mo_trunc_s16(float v);            /* static_cast<short>(float) as MSVC x64 emits it */
+int      mo_border_interpolate(int p, int len, int border_type);
+
+/* ---- camera / projector (a1-a5) ------------------------------------------- */
+void mo_camera_K(double focal, double aspect, double ppx, double ppy, float K[9]);
+void mo_invert3x3_32f(const float m[9], float out[9], int *ok);
+void mo_matmul3x3_32f(const float a[9], const float b[9], float out[9]);
+void mo_set_camera_params(mo_projector *p, const float K[9], const float R[9], const float T[3]);
+void mo_map_forward(const mo_projector *p, int kind, float x, float y, float *u, float *v);
+void mo_map_backward(const mo_projector *p, int kind, float u, float v, float *x, float *y);
+/* inclusive tl / br, exactly as RotationWarperBase::detectResultRoi returns them */
+void mo_detect_result_roi(const mo_projector *p, int kind, int src_w, int src_h,
+                          int *tl_x, int *tl_y, int *br_x, int *br_y);
+/* RotationWarper::warpRoi: Rect(tl, br+1) */
+mo_rect mo_warp_roi(int kind, float scale, const float K[9], const float R[9], const float T[3],
+                    int src_w, int src_h);
+/* RotationWarper::buildMaps: xmap/ymap must hold roi.width*roi.height floats of warpRoi() */
+mo_rect mo_build_maps(int kind, float scale, const float K[9], const float R[9], const float T[3],
+                      int src_w, int src_h, float *xmap, float *ymap);
+
+/* ---- cv::remap (a6) --------------------------------------------------------- */
+void mo_remap_8u(const uint8_t *src, int sw, int sh, size_t sstride, int cn,
+                 uint8_t *dst, int dw, int dh, size_t dstride,
+                 const float *xmap, const float *ymap, size_t map_stride_elems,
+                 int interp, int border_type);
+/* RotationWarper::warp = buildMaps + remap; dst is warpRoi() sized, tightly packed */
+mo_rect mo_warp_8u(int kind, float scale, const float K[9], const float R[9], const float T[3],
+                   const uint8_t *src, int sw, int sh, size_t sstride, int cn,
+                   int interp, int border_type, uint8_t *dst);
+const int16_t *mo_bilinear_tab_i(void);   /* [1024][4] fixed-point weights, for KATs */
+
+/* ---- exposure (a7) ---------------------------------------------------------- */
+void mo_resize_linear_32f(const float *src, int sw, int sh, float *dst, int dw, int dh);
+void mo_blocks_gain_apply(uint8_t *img, int w, int h, size_t stride,
+                          const float *gain_map, int gw, int gh);
+void mo_gain_apply(uint8_t *img, int w, int h, size_t stride, int cn, double gain);
+
+/* ---- core/imgproc primitives used by the blenders --------------------------- */
+void mo_convert_8u_16s(const uint8_t *src, size_t sstride, int16_t *dst, size_t dstride_elems,
+                       int w_elems, int h);
+void mo_convert_16s_8u(const int16_t *src, size_t sstride_elems, uint8_t *dst, size_t dstride,
+                       int w_elems, int h);
+void mo_copy_make_border_16s(const int16_t *src, int w, int h, int cn, int16_t *dst,
+                             int top, int bottom, int left, int right, int border_type);
+void mo_copy_make_border_32f(const float *src, int w, int h, float *dst,
+                             int top, int bottom, int left, int right, int border_type);
+void mo_pyr_down_16s(const int16_t *src, int w, int h, int cn, int16_t *dst);   /* dst ((w+1)/2,(h+1)/2) */
+void mo_pyr_down_32f(const float *src, int w, int h, int cn, float *dst);
+void mo_pyr_up_16s(const int16_t *src, int sw, int sh, int cn, int16_t *dst, int dw, int dh);
+void mo_add_16s(const int16_t *a, const int16_t *b, int16_t *dst, size_t n);
+void mo_subtract_16s(const int16_t *a, const int16_t *b, int16_t *dst, size_t n);
+void mo_distance_transform_l1(const uint8_t *mask, int w, int h, float *dist);
+
+/* ---- util (a10) -------------------------------------------------------------- */
+mo_rect mo_result_roi(const int *corners_xy, const int *sizes_wh, int n);
+int mo_overlap_roi(int tl1x, int tl1y, int tl2x, int tl2y, int w1, int h1, int w2, int h2, mo_rect *roi);
+
+/* ---- blenders (a11, a13-a21) -------------------------------------------------- */
+void mo_normalize_using_weight_map_32f(const float *weight, int16_t *src, int w, int h);
+void mo_normalize_using_weight_map_16s(const int16_t *weight, int16_t *src, int w, int h);
+void mo_create_weight_map(const uint8_t *mask, int w, int h, float sharpness, float *weight);
+/* pyr[i] must hold level sizes ((w_i+1)/2 chain) * cn shorts; pyr[0] is overwritten in place */
+void mo_create_laplace_pyr_16s(int16_t **pyr, int w, int h, int cn, int num_levels);
+void mo_restore_image_from_laplace_pyr(int16_t **pyr, int w, int h, int cn, int num_levels);
+
+typedef struct mo_blender mo_blender;
+mo_blender *mo_blender_create(int kind, int num_bands, float sharpness, int weight_type);
+void mo_blender_destroy(mo_blender *b);
+void mo_blender_prepare(mo_blender *b, const int *corners_xy, const int *sizes_wh, int n);
+void mo_blender_prepare_rect(mo_blender *b, mo_rect dst_roi);
+/* img: CV_16SC3 tightly packed w*h*3, mask: CV_8U tightly packed w*h */
+void mo_blender_feed(mo_blender *b, const int16_t *img, const uint8_t *mask, int w, int h,
+                     int tl_x, int tl_y);
+/* returns result size; *dst (16SC3) and *dst_mask (8U) are malloc'd, caller frees with mo_free */
+mo_rect mo_blender_blend(mo_blender *b, int16_t **dst, uint8_t **dst_mask);
+void mo_free(void *p);
+/* introspection for stage-level parity tests (valid between feed and blend) */
+int  mo_blender_num_bands(const mo_blender *b);
+mo_rect mo_blender_dst_roi(const mo_blender *b);
+const int16_t *mo_blender_band(const mo_blender *b, int level, int *w, int *h);
+const float   *mo_blender_band_weight(const mo_blender *b, int level, int *w, int *h);
+/* MultiBandBlender::feed ROI alignment only (a15): out[8] = tl_new.x, tl_new.y, br_new.x,
+ * br_new.y, top, left, bottom, right */
+void mo_multiband_feed_geometry(mo_rect dst_roi, int num_bands, int tl_x, int tl_y, int w, int h,
+                                int out[8]);
+
+/* ---- whole compose loop (stitcher.cpp:264-313 / CLI:705-760) ------------------- */
+typedef struct {
+    int   warp_kind;
+    float scale;                 /* warped_image_scale */
+    int   blend_kind;
+    int   num_bands;             /* MultiBandBlender::setNumBands */
+    float sharpness;             /* FeatherBlender::setSharpness */
+    int   weight_type;
+    int   expos_kind;
+    int   num_threads;           /* OpenMP threads over cameras for warp/gain (DRV:736,748); 1 = serial */
+} mo_compose_config;
+
+typedef struct {
+    float K[9], R[9], T[3];
+    const uint8_t *frame;        /* CV_8UC3 BGR */
+    int src_w, src_h; size_t src_stride;
+    const float *gain_map; int gain_w, gain_h;   /* GAIN_BLOCKS */
+    double gain;                                 /* GAIN */
+    const uint8_t *mask;         /* final mask_warped (stitcher.cpp:294), warpRoi sized, tight */
+} mo_compose_camera;
+
+/* pano (CV_8UC3) and pano_mask (CV_8U) malloc'd; free with mo_free.  Returns canvas rect. */
+mo_rect mo_compose_panorama(const mo_compose_config *cfg, const mo_compose_camera *cams, int n,
+                            uint8_t **pano, uint8_t **pano_mask);
+
+/* the reference driver's own fast path (DRV:94-177): hard-seam LUT composite */
+typedef struct mo_lut mo_lut;
+mo_lut *mo_lut_build(const int *corners_xy, const int *sizes_wh, const uint8_t *const *masks, int n);
+mo_rect mo_lut_canvas(const mo_lut *l);
+/* feedSizeRemap + convertTo(8U); imgs are per-camera CV_16SC3 warped images; crop margins as DRV:47 */
+mo_rect mo_lut_compose(const mo_lut *l, const int16_t *const *imgs, float upblack, float downblack,
+                       float leftblack, float rightblack, uint8_t **pano);
+void mo_lut_destroy(mo_lut *l);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MST_ORACLE_H */
