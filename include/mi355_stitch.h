@@ -1,0 +1,194 @@
+/*
+ * mi355_stitch.h -- C ABI of the MI355X-native per-frame panorama compositing engine
+ * (libmi355stitch.so).  Plain pointers and sizes only: no C++ types, no OpenCV types,
+ * no torch types.  This is what the reference's VC++ host binds instead of its own
+ * per-frame loop; INTEGRATION.md shows the reference-side shim.
+ *
+ * Reference interfaces replaced (R64 = /root/reference/stitching/
+ * OpenCV2.4.11-Stitching-64bit/OpenCV2.4.11-Stitching):
+ *
+ *   mst_create / mst_update   <- Stitcher setters, createDefault R64/src/stitcher.cpp:49-88,
+ *                                 the cached calibration globals + UpdateMat()
+ *                                 R64/stitching_detailed.cpp:29-53, 696-722
+ *   mst_compose               <- StitchingAll() frame loop       R64/stitching_detailed.cpp:724-770
+ *                                 Stitcher::composePanorama      R64/src/stitcher.cpp:264-313
+ *                                 (warp -> exposure apply -> convertTo(16S) -> Blender::feed ...
+ *                                  Blender::blend -> convertTo(8U))
+ *   mst_canvas                <- resultRoi()                     R64/src/util.cpp:127-140
+ *   mst_camera_roi, mst_warp_roi <- RotationWarper::warpRoi      detail/warpers_inl.hpp:129-140
+ *   mst_build_maps            <- RotationWarper::buildMaps       detail/warpers_inl.hpp:62-85
+ *   mst_warp                  <- RotationWarper::warp            detail/warpers_inl.hpp:88-99
+ *   mst_exposure_apply        <- ExposureCompensator::apply      R64/src/exposure_compensate.cpp:150-153,
+ *                                                                 225-246 (== BlockApply, DRV:310-331)
+ *   mst_multiband_geometry    <- MultiBandBlender::prepare/feed ROI maths  R64/src/blenders.cpp:203-269
+ *
+ * Conventions (mirroring cv::Mat): images are 8-bit, BGR interleaved for colour, row-major
+ * with an explicit byte stride (cv::Mat::data / cv::Mat::step); the caller owns every frame
+ * and panorama buffer; the engine owns device memory and the cached calibration.  Every
+ * function returns MST_OK (0) or a negative error code; no exception crosses the ABI.  A bad
+ * type/size is an error (where the reference would CV_Assert).  mst_compose* may be called from
+ * one thread at a time per engine (the reference's frame loop is single-caller); mst_update may
+ * be called concurrently from a calibration thread and takes effect at the next compose.
+ *
+ * There is NO CPU fallback: every entry point that computes pixels runs hand-written HIP
+ * kernels on gfx950 and fails with MST_ERR_NO_DEVICE / MST_ERR_HIP when no GPU is usable.
+ */
+#ifndef MI355_STITCH_H
+#define MI355_STITCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MST_VERSION 100
+
+/* error codes */
+#define MST_OK                 0
+#define MST_ERR_INVALID_ARG   -1   /* CV_Assert-class failure: bad kind, size, null pointer */
+#define MST_ERR_NOT_CALIBRATED -2  /* compose before the first successful mst_update */
+#define MST_ERR_HIP           -3   /* a HIP runtime call or kernel launch failed */
+#define MST_ERR_NO_DEVICE     -4   /* no usable gfx950 device */
+#define MST_ERR_NEED_MORE_IMGS -5  /* Stitcher::ERR_NEED_MORE_IMGS (stitcher.hpp:62) */
+#define MST_ERR_OUT_OF_MEMORY -6
+
+/* --warp (CLI:102); projector kinds of detail/warpers.hpp */
+#define MST_WARP_PLANE        0
+#define MST_WARP_SPHERICAL    1
+#define MST_WARP_CYLINDRICAL  2
+/* --blend (CLI:112); Blender::NO/FEATHER/MULTI_BAND, detail/blenders.hpp:58 */
+#define MST_BLEND_NO          0
+#define MST_BLEND_FEATHER     1
+#define MST_BLEND_MULTI_BAND  2
+/* --expos_comp (CLI:110); ExposureCompensator::NO/GAIN/GAIN_BLOCKS */
+#define MST_EXPOS_NO          0
+#define MST_EXPOS_GAIN        1
+#define MST_EXPOS_GAIN_BLOCKS 2
+/* cv:: interpolation / border codes used by RotationWarper::warp */
+#define MST_INTER_NEAREST     0
+#define MST_INTER_LINEAR      1
+#define MST_BORDER_CONSTANT   0
+#define MST_BORDER_REFLECT    2
+
+/* mst_config.flags */
+#define MST_FLAG_DRIVER_LUT   1u   /* the driver's hard-seam LUT composite with crop margins
+                                      (feedSizeRemap, DRV:150-177); requires MST_BLEND_NO */
+
+#define MST_MAX_CAMERAS 16
+#define MST_MAX_BANDS   10
+
+typedef struct mst_engine mst_engine;
+
+typedef struct mst_config {
+    int32_t  struct_size;        /* sizeof(mst_config) */
+    int32_t  num_cameras;        /* 1..MST_MAX_CAMERAS (DRV:29 num_images) */
+    int32_t  warp_kind;          /* MST_WARP_* */
+    int32_t  blend_kind;         /* MST_BLEND_* */
+    int32_t  num_bands;          /* MultiBandBlender::setNumBands; <= 0 -> 5 (blenders.hpp:101) */
+    float    feather_sharpness;  /* FeatherBlender::setSharpness; <= 0 -> 0.02f (blenders.hpp:75) */
+    int32_t  expos_kind;         /* MST_EXPOS_* */
+    int32_t  device;             /* HIP device ordinal */
+    uint32_t flags;              /* MST_FLAG_* */
+    float    upblack, downblack, leftblack, rightblack;   /* DRV:47 crop margins (LUT path) */
+} mst_config;
+
+typedef struct mst_camera {
+    int32_t  src_width, src_height;       /* frame size (cv::Mat cols, rows) */
+    float    K[9];                        /* CameraParams::K() as CV_32F, row-major (stitcher.cpp:271-272) */
+    float    R[9];                        /* CameraParams::R as CV_32F, row-major */
+    float    T[3];                        /* PlaneWarper translation; zeros otherwise */
+    const float *gain_map;                /* GAIN_BLOCKS: gain_maps_[i], gain_h x gain_w floats, tight */
+    int32_t  gain_w, gain_h;
+    float    gain;                        /* GAIN: gains_(i) */
+    const uint8_t *mask;                  /* final mask_warped (stitcher.cpp:294): CV_8U, must be
+                                             exactly the warpRoi() size of this camera */
+    int32_t  mask_width, mask_height;
+    size_t   mask_stride;                 /* bytes */
+} mst_camera;
+
+typedef struct mst_calibration {
+    int32_t  struct_size;                 /* sizeof(mst_calibration) */
+    int32_t  num_cameras;                 /* must equal the engine's */
+    float    warped_image_scale;          /* warper scale (stitcher.cpp:239-240) */
+    const mst_camera *cameras;
+} mst_calibration;
+
+typedef struct mst_rect { int32_t x, y, width, height; } mst_rect;
+
+/* ---- engine lifetime ------------------------------------------------------------------- */
+int  mst_create(const mst_config *cfg, mst_engine **out);
+void mst_destroy(mst_engine *e);
+/* message of the last failure on this engine (or of the last failed call without an engine
+ * when e == NULL); valid until the next call on the same thread */
+const char *mst_last_error(const mst_engine *e);
+
+/* Publish a calibration: builds every frame-invariant product on the device (ROI geometry,
+ * backward-map tables, gain tables, weight pyramids, weight sums, canvas mask) into a fresh
+ * state and swaps it in atomically; the next mst_compose uses it (UpdateMat, DRV:696-722). */
+int  mst_update(mst_engine *e, const mst_calibration *calib);
+
+/* resultRoi of the current calibration; with MST_FLAG_DRIVER_LUT the cropped output rect */
+int  mst_canvas(const mst_engine *e, mst_rect *canvas);
+/* corners[i] / sizes[i] */
+int  mst_camera_roi(const mst_engine *e, int camera, mst_rect *roi);
+/* number of bands actually used (MultiBandBlender::prepare crop, blenders.cpp:207-209) */
+int  mst_num_bands(const mst_engine *e, int *num_bands);
+
+/* ---- the per-frame hot path ------------------------------------------------------------ */
+/* Host buffers (cv::Mat data/step): H2D copy of the N frames, compose, D2H of the panorama.
+ * pano is canvas.width x canvas.height BGR; pano_mask (nullable) is the blender's dst_mask. */
+int  mst_compose(mst_engine *e, const uint8_t *const *frames, const size_t *frame_strides,
+                 uint8_t *pano, size_t pano_stride, uint8_t *pano_mask, size_t pano_mask_stride);
+/* Device buffers already resident in HBM; enqueued on `stream` (a hipStream_t, NULL = the
+ * engine's own stream) and asynchronous: call mst_synchronize or sync the stream yourself. */
+int  mst_compose_device(mst_engine *e, const void *const *d_frames, const size_t *frame_strides,
+                        void *d_pano, size_t pano_stride, void *d_pano_mask, size_t pano_mask_stride,
+                        void *stream);
+int  mst_synchronize(mst_engine *e);
+
+/* ---- stage-level entry points (the reference's plugin interfaces) ------------------------ */
+/* RotationWarper::warpRoi -- host only, no device needed */
+int  mst_warp_roi(int warp_kind, float scale, const float K[9], const float R[9], const float T[3],
+                  int src_width, int src_height, mst_rect *roi);
+/* RotationWarper::buildMaps: xmap/ymap are roi.height x roi.width floats (host, tight).
+ * Runs the same in-register backward map the warp kernel uses and materialises it. */
+int  mst_build_maps(int device, int warp_kind, float scale, const float K[9], const float R[9],
+                    const float T[3], int src_width, int src_height, float *xmap, float *ymap);
+/* Host-only variant of the above (same tables, same float operation order, no device): used to
+ * derive calibration inputs such as all-255 warped masks where no GPU is present. */
+int  mst_build_maps_host(int warp_kind, float scale, const float K[9], const float R[9],
+                         const float T[3], int src_width, int src_height, float *xmap, float *ymap);
+/* RotationWarper::warp for CV_8UC1 / CV_8UC3 host images; dst is the warpRoi() size.
+ * interp/border: (LINEAR, REFLECT) for images, (NEAREST, CONSTANT) for masks. */
+int  mst_warp(int device, int warp_kind, float scale, const float K[9], const float R[9],
+              const float T[3], const uint8_t *src, int src_width, int src_height, size_t src_stride,
+              int channels, int interp, int border, uint8_t *dst, size_t dst_stride);
+/* ExposureCompensator::apply on a CV_8UC3 host image, in place.
+ * GAIN_BLOCKS: gain_map gain_h x gain_w; GAIN: scalar `gain`. */
+int  mst_exposure_apply(int device, int expos_kind, uint8_t *image, int width, int height,
+                        size_t stride, const float *gain_map, int gain_w, int gain_h, float gain);
+/* MultiBandBlender::prepare + feed integer geometry -- host only.
+ * out[0..3] = tl_new.x, tl_new.y, br_new.x, br_new.y; out[4..7] = top, left, bottom, right */
+int  mst_multiband_geometry(mst_rect canvas, int num_bands, mst_rect image, mst_rect *padded_canvas,
+                            int *used_bands, int out[8]);
+
+/* ---- introspection for parity tests ------------------------------------------------------ */
+#define MST_DBG_CAM_WARPED_S16   1   /* bordered level-0 image of camera c, planar 3 x h x w int16 */
+#define MST_DBG_CAM_GAUSS_S16    2   /* Gaussian level `level` of camera c, planar int16 */
+#define MST_DBG_CAM_WEIGHT_F32   3   /* weight pyramid level of camera c, h x w float */
+#define MST_DBG_BAND_WEIGHT_F32  4   /* dst_band_weights_[level], h x w float */
+#define MST_DBG_CANVAS_S16       5   /* collapsed canvas level, planar 3 x h x w int16 */
+/* Query (buf == NULL) or copy out the buffer of the last compose / current calibration. */
+int  mst_debug_read(mst_engine *e, int what, int camera, int level, void *buf, size_t buf_bytes,
+                    int *width, int *height);
+
+/* ---- synthetic inputs (SURVEY.md section 8d / BASELINE.md section 3) ---------------------- */
+/* Frame `frame_index` of camera `camera`: smooth texture + PCG32 noise, BGR u8.  Host only. */
+int  mst_synth_frame(int camera, int frame_index, int width, int height, uint8_t *dst, size_t stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_STITCH_H */

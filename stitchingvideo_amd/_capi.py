@@ -1,0 +1,126 @@
+"""ctypes binding of libmi355stitch.so -- the C ABI declared in include/mi355_stitch.h.
+
+The library is the product: hand-written HIP kernels for gfx950 behind plain-C entry points.
+There is no Python or CPU fallback; if the shared object is missing the import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355stitch.so")
+
+MST_OK = 0
+ERR_INVALID_ARG, ERR_NOT_CALIBRATED, ERR_HIP, ERR_NO_DEVICE, ERR_NEED_MORE_IMGS, ERR_OUT_OF_MEMORY = \
+    -1, -2, -3, -4, -5, -6
+WARP_PLANE, WARP_SPHERICAL, WARP_CYLINDRICAL = 0, 1, 2
+BLEND_NO, BLEND_FEATHER, BLEND_MULTI_BAND = 0, 1, 2
+EXPOS_NO, EXPOS_GAIN, EXPOS_GAIN_BLOCKS = 0, 1, 2
+INTER_NEAREST, INTER_LINEAR = 0, 1
+BORDER_CONSTANT, BORDER_REFLECT = 0, 2
+FLAG_DRIVER_LUT = 1
+MAX_CAMERAS, MAX_BANDS = 16, 10
+DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, DBG_CANVAS_S16 = 1, 2, 3, 4, 5
+
+EXPORTS = [
+    "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_canvas", "mst_camera_roi",
+    "mst_num_bands", "mst_compose", "mst_compose_device", "mst_synchronize", "mst_warp_roi",
+    "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
+    "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("num_cameras", C.c_int32), ("warp_kind", C.c_int32),
+                ("blend_kind", C.c_int32), ("num_bands", C.c_int32), ("feather_sharpness", C.c_float),
+                ("expos_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("upblack", C.c_float), ("downblack", C.c_float), ("leftblack", C.c_float),
+                ("rightblack", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("src_width", C.c_int32), ("src_height", C.c_int32), ("K", C.c_float * 9),
+                ("R", C.c_float * 9), ("T", C.c_float * 3), ("gain_map", C.c_void_p),
+                ("gain_w", C.c_int32), ("gain_h", C.c_int32), ("gain", C.c_float),
+                ("mask", C.c_void_p), ("mask_width", C.c_int32), ("mask_height", C.c_int32),
+                ("mask_stride", C.c_size_t)]
+
+
+class Calibration(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("num_cameras", C.c_int32),
+                ("warped_image_scale", C.c_float), ("cameras", C.POINTER(Camera))]
+
+
+class Rect(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("width", C.c_int32), ("height", C.c_int32)]
+
+    def tuple(self):
+        return (self.x, self.y, self.width, self.height)
+
+
+class StitchError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mi355stitch error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen the product library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C stitchingvideo_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    fp, vp, ip = C.POINTER(C.c_float), C.c_void_p, C.POINTER(C.c_int)
+    L.mst_create.restype = C.c_int
+    L.mst_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.mst_destroy.restype = None
+    L.mst_destroy.argtypes = [vp]
+    L.mst_last_error.restype = C.c_char_p
+    L.mst_last_error.argtypes = [vp]
+    L.mst_update.restype = C.c_int
+    L.mst_update.argtypes = [vp, C.POINTER(Calibration)]
+    L.mst_canvas.restype = C.c_int
+    L.mst_canvas.argtypes = [vp, C.POINTER(Rect)]
+    L.mst_camera_roi.restype = C.c_int
+    L.mst_camera_roi.argtypes = [vp, C.c_int, C.POINTER(Rect)]
+    L.mst_num_bands.restype = C.c_int
+    L.mst_num_bands.argtypes = [vp, ip]
+    L.mst_compose.restype = C.c_int
+    L.mst_compose.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), vp, C.c_size_t, vp, C.c_size_t]
+    L.mst_compose_device.restype = C.c_int
+    L.mst_compose_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), vp, C.c_size_t, vp,
+                                     C.c_size_t, vp]
+    L.mst_synchronize.restype = C.c_int
+    L.mst_synchronize.argtypes = [vp]
+    L.mst_warp_roi.restype = C.c_int
+    L.mst_warp_roi.argtypes = [C.c_int, C.c_float, fp, fp, fp, C.c_int, C.c_int, C.POINTER(Rect)]
+    L.mst_build_maps.restype = C.c_int
+    L.mst_build_maps.argtypes = [C.c_int, C.c_int, C.c_float, fp, fp, fp, C.c_int, C.c_int, vp, vp]
+    L.mst_build_maps_host.restype = C.c_int
+    L.mst_build_maps_host.argtypes = [C.c_int, C.c_float, fp, fp, fp, C.c_int, C.c_int, vp, vp]
+    L.mst_warp.restype = C.c_int
+    L.mst_warp.argtypes = [C.c_int, C.c_int, C.c_float, fp, fp, fp, vp, C.c_int, C.c_int, C.c_size_t,
+                           C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
+    L.mst_exposure_apply.restype = C.c_int
+    L.mst_exposure_apply.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_int,
+                                     C.c_int, C.c_float]
+    L.mst_multiband_geometry.restype = C.c_int
+    L.mst_multiband_geometry.argtypes = [Rect, C.c_int, Rect, C.POINTER(Rect), ip, ip]
+    L.mst_debug_read.restype = C.c_int
+    L.mst_debug_read.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, ip, ip]
+    L.mst_synth_frame.restype = C.c_int
+    L.mst_synth_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
+    _lib = L
+    return L
+
+
+def check(rc, handle=None):
+    if rc != MST_OK:
+        msg = load().mst_last_error(handle)
+        raise StitchError(rc, msg.decode("utf-8", "replace") if msg else "")

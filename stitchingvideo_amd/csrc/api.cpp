@@ -1,0 +1,348 @@
+// api.cpp -- the C ABI declared in include/mi355_stitch.h.  No exception crosses it.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "engine.hpp"
+#include "kernels.hpp"
+
+struct mst_engine {
+    mst::Engine impl;
+    explicit mst_engine(const mst_config& c) : impl(c) {}
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(mst_engine* e, const mst::Error& err)
+{
+    g_last_error = err.msg;
+    if (e) e->impl.last_error = err.msg;
+    return err.code;
+}
+
+template <typename F> int guarded(mst_engine* e, F&& f)
+{
+    try {
+        f();
+        return MST_OK;
+    } catch (const mst::Error& err) {
+        return fail(e, err);
+    } catch (const std::bad_alloc&) {
+        return fail(e, mst::Error{MST_ERR_OUT_OF_MEMORY, "host allocation failed"});
+    } catch (const std::exception& ex) {
+        return fail(e, mst::Error{MST_ERR_INVALID_ARG, ex.what()});
+    }
+}
+
+void require(bool cond, const char* msg)
+{
+    if (!cond) throw mst::Error{MST_ERR_INVALID_ARG, msg};
+}
+
+bool valid_warp(int k) { return k == MST_WARP_PLANE || k == MST_WARP_SPHERICAL || k == MST_WARP_CYLINDRICAL; }
+
+mst::Projector make_projector(int kind, float scale, const float K[9], const float R[9], const float T[3])
+{
+    require(valid_warp(kind), "unknown warp kind");
+    require(K && R, "K and R must not be null");
+    require(scale > 0.f, "scale must be > 0");
+    mst::Projector p;
+    p.kind = kind;
+    p.scale = scale;
+    p.set(K, R, T);
+    return p;
+}
+
+// one-camera device context for the stage-level calls
+struct StageCtx {
+    mst::DevicePool pool;
+    hipStream_t s = nullptr;
+    mst::CamDesc desc{};
+    mst::CamDesc* d_desc = nullptr;
+    ~StageCtx() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } }
+};
+
+}  // namespace
+
+extern "C" {
+
+int mst_create(const mst_config* cfg, mst_engine** out)
+{
+    if (out) *out = nullptr;
+    mst_engine* created = nullptr;
+    int rc = guarded(nullptr, [&] {
+        require(cfg && out, "null config or output pointer");
+        require(cfg->struct_size == static_cast<int32_t>(sizeof(mst_config)), "mst_config.struct_size mismatch");
+        require(cfg->num_cameras >= 1 && cfg->num_cameras <= MST_MAX_CAMERAS, "num_cameras out of range");
+        require(valid_warp(cfg->warp_kind), "unknown warp kind");
+        require(cfg->blend_kind >= MST_BLEND_NO && cfg->blend_kind <= MST_BLEND_MULTI_BAND, "unsupported blending method");
+        require(cfg->expos_kind >= MST_EXPOS_NO && cfg->expos_kind <= MST_EXPOS_GAIN_BLOCKS,
+                "unsupported exposure compensation method");
+        require(cfg->num_bands <= MST_MAX_BANDS, "too many bands");
+        require(!(cfg->flags & MST_FLAG_DRIVER_LUT) || cfg->blend_kind == MST_BLEND_NO,
+                "MST_FLAG_DRIVER_LUT requires MST_BLEND_NO");
+        created = new mst_engine(*cfg);
+        created->impl.init();
+    });
+    if (rc != MST_OK) {
+        delete created;
+        return rc;
+    }
+    *out = created;
+    return MST_OK;
+}
+
+void mst_destroy(mst_engine* e)
+{
+    delete e;
+}
+
+const char* mst_last_error(const mst_engine* e)
+{
+    if (e) return e->impl.last_error.c_str();
+    return g_last_error.c_str();
+}
+
+int mst_update(mst_engine* e, const mst_calibration* calib)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] {
+        require(calib != nullptr, "null calibration");
+        require(calib->struct_size == static_cast<int32_t>(sizeof(mst_calibration)), "mst_calibration.struct_size mismatch");
+        e->impl.update(*calib);
+    });
+}
+
+int mst_canvas(const mst_engine* e, mst_rect* canvas)
+{
+    if (!e || !canvas) return MST_ERR_INVALID_ARG;
+    auto st = e->impl.state();
+    if (!st) return MST_ERR_NOT_CALIBRATED;
+    canvas->x = st->canvas.x + st->crop_x;
+    canvas->y = st->canvas.y + st->crop_y;
+    canvas->width = st->out_w;
+    canvas->height = st->out_h;
+    return MST_OK;
+}
+
+int mst_camera_roi(const mst_engine* e, int camera, mst_rect* roi)
+{
+    if (!e || !roi) return MST_ERR_INVALID_ARG;
+    auto st = e->impl.state();
+    if (!st) return MST_ERR_NOT_CALIBRATED;
+    if (camera < 0 || camera >= st->n) return MST_ERR_INVALID_ARG;
+    const mst::Rect& r = st->cams[camera].roi;
+    roi->x = r.x; roi->y = r.y; roi->width = r.width; roi->height = r.height;
+    return MST_OK;
+}
+
+int mst_num_bands(const mst_engine* e, int* num_bands)
+{
+    if (!e || !num_bands) return MST_ERR_INVALID_ARG;
+    auto st = e->impl.state();
+    if (!st) return MST_ERR_NOT_CALIBRATED;
+    *num_bands = st->num_bands;
+    return MST_OK;
+}
+
+int mst_compose(mst_engine* e, const uint8_t* const* frames, const size_t* frame_strides, uint8_t* pano,
+                size_t pano_stride, uint8_t* pano_mask, size_t pano_mask_stride)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.compose_host(frames, frame_strides, pano, pano_stride, pano_mask, pano_mask_stride); });
+}
+
+int mst_compose_device(mst_engine* e, const void* const* d_frames, const size_t* frame_strides, void* d_pano,
+                       size_t pano_stride, void* d_pano_mask, size_t pano_mask_stride, void* stream)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] {
+        e->impl.compose_device(d_frames, frame_strides, d_pano, pano_stride, d_pano_mask, pano_mask_stride,
+                               static_cast<hipStream_t>(stream));
+    });
+}
+
+int mst_synchronize(mst_engine* e)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.synchronize(); });
+}
+
+int mst_debug_read(mst_engine* e, int what, int camera, int level, void* buf, size_t buf_bytes, int* width, int* height)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.debug_read(what, camera, level, buf, buf_bytes, width, height); });
+}
+
+// ---- stage-level ---------------------------------------------------------------------------------
+
+int mst_warp_roi(int warp_kind, float scale, const float K[9], const float R[9], const float T[3], int src_width,
+                 int src_height, mst_rect* roi)
+{
+    return guarded(nullptr, [&] {
+        require(roi != nullptr, "null roi");
+        require(src_width > 0 && src_height > 0, "bad source size");
+        mst::Projector p = make_projector(warp_kind, scale, K, R, T);
+        mst::Rect r = mst::warp_roi(p, src_width, src_height);
+        roi->x = r.x; roi->y = r.y; roi->width = r.width; roi->height = r.height;
+    });
+}
+
+int mst_build_maps_host(int warp_kind, float scale, const float K[9], const float R[9], const float T[3],
+                        int src_width, int src_height, float* xmap, float* ymap)
+{
+    return guarded(nullptr, [&] {
+        require(xmap && ymap, "null map pointer");
+        require(src_width > 0 && src_height > 0, "bad source size");
+        mst::Projector p = make_projector(warp_kind, scale, K, R, T);
+        mst::Rect r = mst::warp_roi(p, src_width, src_height);
+        mst::MapTables t = mst::build_map_tables(p, r);
+        mst::backward_map_host(p, r, t, xmap, ymap);
+    });
+}
+
+int mst_build_maps(int device, int warp_kind, float scale, const float K[9], const float R[9], const float T[3],
+                   int src_width, int src_height, float* xmap, float* ymap)
+{
+    return guarded(nullptr, [&] {
+        require(xmap && ymap, "null map pointer");
+        require(src_width > 0 && src_height > 0, "bad source size");
+        mst::Projector p = make_projector(warp_kind, scale, K, R, T);
+        mst::Rect r = mst::warp_roi(p, src_width, src_height);
+        mst::select_device(device);
+        StageCtx ctx;
+        mst::check_hip(hipStreamCreate(&ctx.s), "hipStreamCreate");
+        mst::fill_camera_desc(ctx.pool, ctx.s, p, r, src_width, src_height, MST_EXPOS_NO, nullptr, 0, 0, 1.f, ctx.desc);
+        ctx.d_desc = ctx.pool.upload(&ctx.desc, 1, ctx.s);
+        const size_t n = static_cast<size_t>(r.width) * r.height;
+        float* dx = ctx.pool.alloc<float>(n);
+        float* dy = ctx.pool.alloc<float>(n);
+        mst::launch_build_maps(ctx.d_desc, dx, dy, r.width, r.height, ctx.s);
+        mst::check_hip(hipGetLastError(), "k_build_maps");
+        mst::check_hip(hipMemcpyAsync(xmap, dx, n * sizeof(float), hipMemcpyDeviceToHost, ctx.s), "hipMemcpyAsync");
+        mst::check_hip(hipMemcpyAsync(ymap, dy, n * sizeof(float), hipMemcpyDeviceToHost, ctx.s), "hipMemcpyAsync");
+        mst::check_hip(hipStreamSynchronize(ctx.s), "hipStreamSynchronize");
+    });
+}
+
+int mst_warp(int device, int warp_kind, float scale, const float K[9], const float R[9], const float T[3],
+             const uint8_t* src, int src_width, int src_height, size_t src_stride, int channels, int interp,
+             int border, uint8_t* dst, size_t dst_stride)
+{
+    return guarded(nullptr, [&] {
+        require(src && dst, "null image pointer");
+        require(src_width > 0 && src_height > 0, "bad source size");
+        require(channels == 1 || channels == 3, "only CV_8UC1 / CV_8UC3");
+        require(interp == MST_INTER_NEAREST || interp == MST_INTER_LINEAR, "unsupported interpolation");
+        require(border == MST_BORDER_CONSTANT || border == MST_BORDER_REFLECT, "unsupported border mode");
+        require(src_stride >= static_cast<size_t>(src_width) * channels, "source stride too small");
+        mst::Projector p = make_projector(warp_kind, scale, K, R, T);
+        mst::Rect r = mst::warp_roi(p, src_width, src_height);
+        require(dst_stride >= static_cast<size_t>(r.width) * channels, "destination stride too small");
+        mst::select_device(device);
+        StageCtx ctx;
+        mst::check_hip(hipStreamCreate(&ctx.s), "hipStreamCreate");
+        mst::fill_camera_desc(ctx.pool, ctx.s, p, r, src_width, src_height, MST_EXPOS_NO, nullptr, 0, 0, 1.f, ctx.desc);
+        ctx.d_desc = ctx.pool.upload(&ctx.desc, 1, ctx.s);
+        const size_t srow = static_cast<size_t>(src_width) * channels, drow = static_cast<size_t>(r.width) * channels;
+        uint8_t* d_src = ctx.pool.alloc<uint8_t>(srow * src_height);
+        uint8_t* d_dst = ctx.pool.alloc<uint8_t>(drow * r.height);
+        mst::check_hip(hipMemcpy2DAsync(d_src, srow, src, src_stride, srow, src_height, hipMemcpyHostToDevice, ctx.s),
+                       "hipMemcpy2DAsync");
+        mst::launch_warp_u8(ctx.d_desc, d_src, srow, channels, interp, border, d_dst, drow, r.width, r.height, ctx.s);
+        mst::check_hip(hipGetLastError(), "k_warp_u8");
+        mst::check_hip(hipMemcpy2DAsync(dst, dst_stride, d_dst, drow, drow, r.height, hipMemcpyDeviceToHost, ctx.s),
+                       "hipMemcpy2DAsync");
+        mst::check_hip(hipStreamSynchronize(ctx.s), "hipStreamSynchronize");
+    });
+}
+
+int mst_exposure_apply(int device, int expos_kind, uint8_t* image, int width, int height, size_t stride,
+                       const float* gain_map, int gain_w, int gain_h, float gain)
+{
+    return guarded(nullptr, [&] {
+        require(image != nullptr, "null image");
+        require(width > 0 && height > 0 && stride >= static_cast<size_t>(width) * 3, "bad CV_8UC3 image");
+        require(expos_kind >= MST_EXPOS_NO && expos_kind <= MST_EXPOS_GAIN_BLOCKS, "unsupported exposure compensation method");
+        if (expos_kind == MST_EXPOS_NO) return;      // NoExposureCompensator::apply
+        mst::select_device(device);
+        StageCtx ctx;
+        mst::check_hip(hipStreamCreate(&ctx.s), "hipStreamCreate");
+        // identity projector: only the gain fields of the descriptor are used by the kernel
+        const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        mst::Projector p;
+        p.kind = MST_WARP_PLANE; p.scale = 1.f;
+        p.set(I, I, nullptr);
+        mst::Rect r; r.x = 0; r.y = 0; r.width = width; r.height = height;
+        mst::fill_camera_desc(ctx.pool, ctx.s, p, r, width, height, expos_kind, gain_map, gain_w, gain_h, gain, ctx.desc);
+        ctx.d_desc = ctx.pool.upload(&ctx.desc, 1, ctx.s);
+        const size_t row = static_cast<size_t>(width) * 3;
+        uint8_t* d_img = ctx.pool.alloc<uint8_t>(row * height);
+        mst::check_hip(hipMemcpy2DAsync(d_img, row, image, stride, row, height, hipMemcpyHostToDevice, ctx.s), "hipMemcpy2DAsync");
+        mst::launch_exposure_apply(ctx.d_desc, d_img, row, width, height, ctx.s);
+        mst::check_hip(hipGetLastError(), "k_exposure_apply");
+        mst::check_hip(hipMemcpy2DAsync(image, stride, d_img, row, row, height, hipMemcpyDeviceToHost, ctx.s), "hipMemcpy2DAsync");
+        mst::check_hip(hipStreamSynchronize(ctx.s), "hipStreamSynchronize");
+    });
+}
+
+int mst_multiband_geometry(mst_rect canvas, int num_bands, mst_rect image, mst_rect* padded_canvas, int* used_bands,
+                           int out[8])
+{
+    return guarded(nullptr, [&] {
+        require(canvas.width > 0 && canvas.height > 0 && image.width > 0 && image.height > 0, "empty rectangle");
+        require(num_bands >= 0 && num_bands <= MST_MAX_BANDS, "bad band count");
+        mst::Rect c; c.x = canvas.x; c.y = canvas.y; c.width = canvas.width; c.height = canvas.height;
+        mst::Rect im; im.x = image.x; im.y = image.y; im.width = image.width; im.height = image.height;
+        const int nb = mst::multiband_num_bands(num_bands, c);
+        mst::Rect pad = mst::multiband_padded_roi(c, nb);
+        if (padded_canvas) { padded_canvas->x = pad.x; padded_canvas->y = pad.y; padded_canvas->width = pad.width; padded_canvas->height = pad.height; }
+        if (used_bands) *used_bands = nb;
+        if (out) {
+            mst::BandGeometry g = mst::multiband_feed_geometry(pad, nb, im);
+            out[0] = g.tl_br.x; out[1] = g.tl_br.y; out[2] = g.tl_br.x + g.tl_br.width; out[3] = g.tl_br.y + g.tl_br.height;
+            out[4] = g.top; out[5] = g.left; out[6] = g.bottom; out[7] = g.right;
+        }
+    });
+}
+
+// ---- synthetic frames ------------------------------------------------------------------------------
+
+int mst_synth_frame(int camera, int frame_index, int width, int height, uint8_t* dst, size_t stride)
+{
+    return guarded(nullptr, [&] {
+        require(dst && width > 0 && height > 0 && stride >= static_cast<size_t>(width) * 3, "bad frame buffer");
+        // PCG32 (O'Neill, pcg32_srandom_r / pcg32_random_r): state seeded per camera, stream per frame
+        uint64_t state = 0u, inc = (static_cast<uint64_t>(static_cast<uint32_t>(frame_index)) << 1u) | 1u;
+        auto next = [&]() -> uint32_t {
+            uint64_t old = state;
+            state = old * 6364136223846793005ULL + inc;
+            uint32_t xorshifted = static_cast<uint32_t>(((old >> 18u) ^ old) >> 27u);
+            uint32_t rot = static_cast<uint32_t>(old >> 59u);
+            return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+        };
+        next();
+        state += 0x5717C4ULL + static_cast<uint64_t>(camera);
+        next();
+        const double two_pi = 6.283185307179586476925286766559;
+        std::vector<double> sx(width), cy(height);
+        for (int x = 0; x < width; ++x) sx[x] = std::sin(two_pi * (x / 97.0 + camera / 7.0));
+        for (int y = 0; y < height; ++y) cy[y] = std::cos(two_pi * y / 61.0);
+        for (int y = 0; y < height; ++y) {
+            uint8_t* row = dst + static_cast<size_t>(y) * stride;
+            for (int x = 0; x < width; ++x) {
+                const double base = 128.0 + 80.0 * sx[x] * cy[y];
+                for (int c = 0; c < 3; ++c) {
+                    const int noise = static_cast<int>((static_cast<uint64_t>(next()) * 33u) >> 32) - 16;
+                    double v = base + 20.0 * c + noise;
+                    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+                    row[3 * x + c] = static_cast<uint8_t>(std::lrint(v));
+                }
+            }
+        }
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,436 @@
+// engine.cpp -- see engine.hpp.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+
+#include "kernels.hpp"
+
+namespace mst {
+
+void check_hip(hipError_t e, const char* what)
+{
+    if (e != hipSuccess)
+        throw Error{e == hipErrorOutOfMemory ? MST_ERR_OUT_OF_MEMORY : MST_ERR_HIP,
+                    std::string(what) + ": " + hipGetErrorString(e)};
+}
+
+void select_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        throw Error{MST_ERR_NO_DEVICE, "no HIP device is visible (this engine has no CPU fallback)"};
+    if (device < 0 || device >= count)
+        throw Error{MST_ERR_NO_DEVICE, "device ordinal out of range"};
+    check_hip(hipSetDevice(device), "hipSetDevice");
+}
+
+// ---- DevicePool ------------------------------------------------------------------------------
+
+DevicePool::~DevicePool()
+{
+    for (void* p : ptrs_) (void)hipFree(p);
+}
+
+void* DevicePool::alloc_bytes(size_t bytes)
+{
+    void* p = nullptr;
+    check_hip(hipMalloc(&p, std::max<size_t>(bytes, 16)), "hipMalloc");
+    ptrs_.push_back(p);
+    total_ += bytes;
+    return p;
+}
+
+template <typename T> T* DevicePool::upload(const T* host, size_t n, hipStream_t s)
+{
+    T* d = alloc<T>(n);
+    if (n) check_hip(hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, s), "hipMemcpyAsync(H2D)");
+    return d;
+}
+template float* DevicePool::upload<float>(const float*, size_t, hipStream_t);
+template int32_t* DevicePool::upload<int32_t>(const int32_t*, size_t, hipStream_t);
+template uint8_t* DevicePool::upload<uint8_t>(const uint8_t*, size_t, hipStream_t);
+template CamDesc* DevicePool::upload<CamDesc>(const CamDesc*, size_t, hipStream_t);
+
+CalibState::~CalibState()
+{
+    // kernels of an earlier compose may still read this state
+    (void)hipDeviceSynchronize();
+}
+
+// ---- camera descriptor -------------------------------------------------------------------------
+
+void fill_camera_desc(DevicePool& pool, hipStream_t s, const Projector& proj, const Rect& roi, int src_w, int src_h,
+                      int expos_kind, const float* gain_map, int gw, int gh, float gain, CamDesc& d)
+{
+    d.kind = proj.kind;
+    d.roi_w = roi.width; d.roi_h = roi.height;
+    d.src_w = src_w; d.src_h = src_h;
+    std::memcpy(d.kr, proj.k_rinv, sizeof(d.kr));
+    d.one_minus_t2 = 1 - proj.t[2];
+    // host tables are pageable and freed on return: the async copies must have consumed them
+    MapTables t = build_map_tables(proj, roi);
+    d.col_a = pool.upload(t.col_a, s); d.col_b = pool.upload(t.col_b, s);
+    d.row_a = pool.upload(t.row_a, s); d.row_b = pool.upload(t.row_b, s);
+    d.expos = expos_kind;
+    d.gain = gain;
+    d.gain_map = nullptr; d.gw = d.gh = 0;
+    if (expos_kind == MST_EXPOS_GAIN_BLOCKS) {
+        if (!gain_map || gw <= 0 || gh <= 0) throw Error{MST_ERR_INVALID_ARG, "GAIN_BLOCKS needs a gain map"};
+        d.gain_map = pool.upload(gain_map, static_cast<size_t>(gw) * gh, s);
+        d.gw = gw; d.gh = gh;
+        ResizeAxis ax = build_gain_axis_x(gw, roi.width), ay = build_gain_axis_y(gh, roi.height);
+        d.gx0 = pool.upload(ax.ofs0, s); d.gx1 = pool.upload(ax.ofs1, s);
+        d.gxw0 = pool.upload(ax.w0, s);  d.gxw1 = pool.upload(ax.w1, s);
+        d.gy0 = pool.upload(ay.ofs0, s); d.gy1 = pool.upload(ay.ofs1, s);
+        d.gyw0 = pool.upload(ay.w0, s);  d.gyw1 = pool.upload(ay.w1, s);
+        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+    } else {
+        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+    }
+}
+
+namespace {
+
+// cv::distanceTransform(CV_DIST_L1, 3) + threshold(TRUNC): createWeightMap, blenders.cpp:427-432.
+// Frame-invariant, so evaluated once per calibration on the host (sequential two-pass chamfer).
+std::vector<float> feather_weight_map(const uint8_t* mask, size_t stride, int w, int h, float sharpness)
+{
+    const unsigned kInit = static_cast<unsigned>(INT_MAX >> 2), kA = 1u << 16, kB = 2u << 16;
+    const int step = w + 2;
+    std::vector<unsigned> tmp(static_cast<size_t>(step) * (h + 2), kInit);
+    for (int y = 0; y < h; ++y) {
+        unsigned* t = tmp.data() + static_cast<size_t>(y + 1) * step + 1;
+        const uint8_t* s = mask + static_cast<size_t>(y) * stride;
+        for (int x = 0; x < w; ++x) {
+            if (!s[x]) { t[x] = 0; continue; }
+            unsigned v = std::min(std::min(t[x - step - 1] + kB, t[x - step] + kA),
+                                  std::min(t[x - step + 1] + kB, t[x - 1] + kA));
+            t[x] = v;
+        }
+    }
+    std::vector<float> out(static_cast<size_t>(w) * h);
+    const float scale = 1.f / 65536.f;
+    for (int y = h - 1; y >= 0; --y) {
+        unsigned* t = tmp.data() + static_cast<size_t>(y + 1) * step + 1;
+        for (int x = w - 1; x >= 0; --x) {
+            unsigned v = t[x];
+            if (v > kA) {
+                v = std::min(v, std::min(std::min(t[x + step + 1] + kB, t[x + step] + kA),
+                                         std::min(t[x + step - 1] + kB, t[x + 1] + kA)));
+                t[x] = v;
+            }
+            float d = static_cast<float>(v) * scale;
+            d = d * sharpness + 0.f;
+            out[static_cast<size_t>(y) * w + x] = d > 1.f ? 1.f : d;
+        }
+    }
+    return out;
+}
+
+SegTable make_seg_table(const std::vector<CamDesc>& desc, int level)
+{
+    SegTable seg{};
+    int acc = 0;
+    for (size_t i = 0; i < desc.size(); ++i) {
+        const int tx = (desc[i].lw[level] + 63) / 64, ty = (desc[i].lh[level] + 3) / 4;
+        seg.start[i] = acc;
+        seg.tiles_x[i] = tx;
+        acc += tx * ty;
+    }
+    for (size_t i = desc.size(); i <= static_cast<size_t>(kMaxCams); ++i) seg.start[i] = acc;
+    return seg;
+}
+
+}  // namespace
+
+// ---- Engine ------------------------------------------------------------------------------------
+
+Engine::Engine(const mst_config& cfg) : cfg_(cfg)
+{
+    if (cfg_.num_bands <= 0) cfg_.num_bands = 5;
+    if (cfg_.feather_sharpness <= 0.f) cfg_.feather_sharpness = 0.02f;
+}
+
+void Engine::init()
+{
+    select_device(cfg_.device);
+    check_hip(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    check_hip(hipStreamCreateWithFlags(&calib_stream_, hipStreamNonBlocking), "hipStreamCreate");
+}
+
+Engine::~Engine()
+{
+    (void)hipSetDevice(cfg_.device);
+    (void)hipDeviceSynchronize();
+    current_.reset();
+    in_flight_.reset();
+    for (uint8_t* p : d_frames_) (void)hipFree(p);
+    if (d_pano_) (void)hipFree(d_pano_);
+    if (d_mask_) (void)hipFree(d_mask_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+    if (calib_stream_) (void)hipStreamDestroy(calib_stream_);
+}
+
+std::shared_ptr<CalibState> Engine::state() const
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    return current_;
+}
+
+void Engine::synchronize()
+{
+    select_device(cfg_.device);
+    check_hip(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
+void Engine::update(const mst_calibration& calib)
+{
+    select_device(cfg_.device);
+    if (calib.num_cameras != cfg_.num_cameras || !calib.cameras)
+        throw Error{MST_ERR_INVALID_ARG, "calibration camera count does not match the engine"};
+    if (!(calib.warped_image_scale > 0.f)) throw Error{MST_ERR_INVALID_ARG, "warped_image_scale must be > 0"};
+    hipStream_t s = calib_stream_;
+    auto st = std::make_shared<CalibState>();
+    const int n = cfg_.num_cameras;
+    st->n = n;
+    st->blend_kind = cfg_.blend_kind;
+    st->cams.resize(n);
+    st->desc.assign(n, CamDesc{});
+    std::vector<Rect> rois(n);
+
+    for (int i = 0; i < n; ++i) {
+        const mst_camera& c = calib.cameras[i];
+        if (c.src_width <= 0 || c.src_height <= 0) throw Error{MST_ERR_INVALID_ARG, "bad source size"};
+        CameraSetup& cs = st->cams[i];
+        cs.proj.kind = cfg_.warp_kind;
+        cs.proj.scale = calib.warped_image_scale;
+        cs.proj.set(c.K, c.R, c.T);
+        cs.src_w = c.src_width; cs.src_h = c.src_height;
+        cs.roi = warp_roi(cs.proj, c.src_width, c.src_height);
+        if (cs.roi.width <= 0 || cs.roi.height <= 0 || cs.roi.width > 65536 || cs.roi.height > 65536)
+            throw Error{MST_ERR_INVALID_ARG, "degenerate warp ROI (DRV:661-665)"};
+        rois[i] = cs.roi;
+        if (!c.mask || c.mask_width != cs.roi.width || c.mask_height != cs.roi.height ||
+            c.mask_stride < static_cast<size_t>(c.mask_width))
+            throw Error{MST_ERR_INVALID_ARG, "mask must be CV_8U of exactly the camera's warpRoi size"};
+        CamDesc& d = st->desc[i];
+        fill_camera_desc(st->pool, s, cs.proj, cs.roi, c.src_width, c.src_height, cfg_.expos_kind, c.gain_map,
+                         c.gain_w, c.gain_h, c.gain, d);
+        // tight copy of the mask
+        std::vector<uint8_t> tight(static_cast<size_t>(cs.roi.width) * cs.roi.height);
+        for (int y = 0; y < cs.roi.height; ++y)
+            std::memcpy(&tight[static_cast<size_t>(y) * cs.roi.width], c.mask + static_cast<size_t>(y) * c.mask_stride,
+                        cs.roi.width);
+        d.mask = st->pool.upload(tight, s);
+        if (cfg_.blend_kind == MST_BLEND_FEATHER) {
+            std::vector<float> fw = feather_weight_map(tight.data(), cs.roi.width, cs.roi.width, cs.roi.height,
+                                                       cfg_.feather_sharpness);
+            d.feather_w = st->pool.upload(fw, s);
+            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
+        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+    }
+
+    st->canvas = result_roi(rois);
+    for (int i = 0; i < n; ++i) {
+        st->desc[i].corner_x = rois[i].x - st->canvas.x;
+        st->desc[i].corner_y = rois[i].y - st->canvas.y;
+    }
+    st->crop_x = st->crop_y = 0;
+    st->out_w = st->canvas.width; st->out_h = st->canvas.height;
+
+    if (cfg_.blend_kind == MST_BLEND_MULTI_BAND) {
+        const int nb = multiband_num_bands(cfg_.num_bands, st->canvas);
+        if (nb + 1 > kMaxLevels) throw Error{MST_ERR_INVALID_ARG, "too many bands"};
+        st->num_bands = nb;
+        st->padded = multiband_padded_roi(st->canvas, nb);
+        CanvasDesc& cv = st->cv;
+        cv.n_cams = n; cv.nlev = nb + 1;
+        cv.final_w = st->canvas.width; cv.final_h = st->canvas.height;
+        cv.cw[0] = st->padded.width; cv.ch[0] = st->padded.height;
+        for (int l = 1; l <= nb; ++l) { cv.cw[l] = (cv.cw[l - 1] + 1) / 2; cv.ch[l] = (cv.ch[l - 1] + 1) / 2; }
+        std::vector<float*> ws(nb + 1);
+        for (int l = 0; l <= nb; ++l) {
+            const size_t px = static_cast<size_t>(cv.cw[l]) * cv.ch[l];
+            cv.C[l] = st->pool.alloc<int16_t>(px * 3);
+            ws[l] = st->pool.alloc<float>(px);
+            cv.WS[l] = ws[l];
+        }
+        std::vector<std::vector<float*>> wpyr(n, std::vector<float*>(nb + 1));
+        for (int i = 0; i < n; ++i) {
+            CamDesc& d = st->desc[i];
+            BandGeometry g = multiband_feed_geometry(st->padded, nb, rois[i]);
+            d.top = g.top; d.left = g.left; d.nlev = nb + 1;
+            d.lw[0] = g.tl_br.width; d.lh[0] = g.tl_br.height;
+            d.ox[0] = g.tl_br.x - st->padded.x; d.oy[0] = g.tl_br.y - st->padded.y;
+            for (int l = 1; l <= nb; ++l) {
+                d.lw[l] = (d.lw[l - 1] + 1) / 2; d.lh[l] = (d.lh[l - 1] + 1) / 2;
+                d.ox[l] = d.ox[l - 1] / 2; d.oy[l] = d.oy[l - 1] / 2;     // blenders.cpp:327-328
+            }
+            for (int l = 0; l <= nb; ++l) {
+                const size_t px = static_cast<size_t>(d.lw[l]) * d.lh[l];
+                d.G[l] = st->pool.alloc<int16_t>(px * 3);
+                wpyr[i][l] = st->pool.alloc<float>(px);
+                d.W[l] = wpyr[i][l];
+            }
+        }
+        for (int l = 0; l <= nb; ++l) st->seg_level[l] = make_seg_table(st->desc, l);
+        st->d_desc = st->pool.upload(st->desc, s);
+        for (int i = 0; i < n; ++i) {
+            const CamDesc& d = st->desc[i];
+            launch_weight_level0(st->d_desc, i, wpyr[i][0], d.lw[0], d.lh[0], s);
+            for (int l = 0; l < nb; ++l) launch_pyrdown_f32(wpyr[i][l], d.lw[l], d.lh[l], wpyr[i][l + 1], s);
+        }
+        for (int l = 0; l <= nb; ++l) launch_band_weight_sum(st->d_desc, n, l, ws[l], cv.cw[l], cv.ch[l], s);
+    } else {
+        st->d_desc = st->pool.upload(st->desc, s);
+        if (cfg_.blend_kind == MST_BLEND_FEATHER) {
+            st->d_feather_ws = st->pool.alloc<float>(static_cast<size_t>(st->canvas.width) * st->canvas.height);
+            launch_feather_weight_sum(st->d_desc, n, st->d_feather_ws, st->canvas.width, st->canvas.height, s);
+        } else if (cfg_.flags & MST_FLAG_DRIVER_LUT) {
+            // UpdateMat / feedSizeRemap crop arithmetic (DRV:153, 702): int op float -> float -> int
+            const float up = cfg_.upblack, down = cfg_.downblack, left = cfg_.leftblack, right = cfg_.rightblack;
+            st->out_w = static_cast<int>(static_cast<float>(st->canvas.width) - left - right);
+            st->out_h = static_cast<int>(static_cast<float>(st->canvas.height) * (1 - up - down));
+            st->crop_y = static_cast<int>(static_cast<float>(st->out_h) / (1 - up - down) * up);
+            st->crop_x = static_cast<int>(left);
+            if (st->out_w <= 0 || st->out_h <= 0 || st->crop_x < 0 || st->crop_y < 0 ||
+                st->crop_x + st->out_w > st->canvas.width || st->crop_y + st->out_h > st->canvas.height)
+                throw Error{MST_ERR_INVALID_ARG, "crop margins leave no output"};
+        }
+    }
+    check_hip(hipGetLastError(), "calibration kernels");
+    check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(calibration)");
+
+    std::lock_guard<std::mutex> lk(mu_);
+    current_ = std::move(st);     // takes effect at the next compose (Upflag / UpdateMat)
+}
+
+void Engine::compose_device(const void* const* d_frames, const size_t* strides, void* d_pano, size_t pano_stride,
+                            void* d_mask, size_t mask_stride, hipStream_t stream)
+{
+    select_device(cfg_.device);
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
+    if (!d_frames || !strides || !d_pano) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama pointer"};
+    hipStream_t s = stream ? stream : stream_;
+    FrameArgs fa{};
+    for (int i = 0; i < st->n; ++i) {
+        if (!d_frames[i]) throw Error{MST_ERR_INVALID_ARG, "null frame pointer"};
+        if (strides[i] < static_cast<size_t>(st->cams[i].src_w) * 3) throw Error{MST_ERR_INVALID_ARG, "frame stride too small"};
+        fa.ptr[i] = static_cast<const uint8_t*>(d_frames[i]);
+        fa.stride[i] = strides[i];
+    }
+    if (pano_stride < static_cast<size_t>(st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
+    if (d_mask && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
+    uint8_t* pano = static_cast<uint8_t*>(d_pano);
+    uint8_t* pmask = static_cast<uint8_t*>(d_mask);
+
+    if (st->blend_kind == MST_BLEND_MULTI_BAND) {
+        const int nb = st->num_bands;
+        launch_warp_border_s16(st->d_desc, st->seg_level[0], fa, s);
+        for (int l = 0; l < nb; ++l) launch_pyrdown_s16(st->d_desc, st->seg_level[l + 1], l, s);
+        for (int l = nb; l >= 1; --l) launch_band_blend(st->d_desc, st->cv, l, s);
+        launch_band_final(st->d_desc, st->cv, pano, pano_stride, pmask, mask_stride, s);
+    } else if (st->blend_kind == MST_BLEND_FEATHER) {
+        launch_feather_compose(st->d_desc, st->n, fa, st->d_feather_ws, st->canvas.width, st->canvas.height, pano,
+                               pano_stride, pmask, mask_stride, s);
+    } else {
+        launch_paste_compose(st->d_desc, st->n, fa, st->canvas.width, st->canvas.height, st->crop_x, st->crop_y,
+                             st->out_w, st->out_h, (cfg_.flags & MST_FLAG_DRIVER_LUT) ? 1 : 0, pano, pano_stride,
+                             pmask, mask_stride, s);
+    }
+    check_hip(hipGetLastError(), "compose kernels");
+    std::lock_guard<std::mutex> lk(mu_);
+    in_flight_ = std::move(st);
+}
+
+void Engine::compose_host(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride,
+                          uint8_t* pano_mask, size_t mask_stride)
+{
+    select_device(cfg_.device);
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
+    if (!frames || !strides || !pano) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama pointer"};
+    const int n = st->n;
+    if (d_frames_.size() != static_cast<size_t>(n)) { d_frames_.assign(n, nullptr); d_frame_bytes_.assign(n, 0); }
+    std::vector<const void*> dptr(n);
+    std::vector<size_t> dstride(n);
+    for (int i = 0; i < n; ++i) {
+        const int w = st->cams[i].src_w, h = st->cams[i].src_h;
+        if (!frames[i] || strides[i] < static_cast<size_t>(w) * 3) throw Error{MST_ERR_INVALID_ARG, "bad frame"};
+        const size_t row = static_cast<size_t>(w) * 3, bytes = row * h;
+        if (d_frame_bytes_[i] < bytes) {
+            if (d_frames_[i]) (void)hipFree(d_frames_[i]);
+            d_frames_[i] = nullptr;
+            check_hip(hipMalloc(reinterpret_cast<void**>(&d_frames_[i]), bytes), "hipMalloc(frame)");
+            d_frame_bytes_[i] = bytes;
+        }
+        check_hip(hipMemcpy2DAsync(d_frames_[i], row, frames[i], strides[i], row, h, hipMemcpyHostToDevice, stream_),
+                  "hipMemcpy2DAsync(frame)");
+        dptr[i] = d_frames_[i];
+        dstride[i] = row;
+    }
+    const size_t prow = static_cast<size_t>(st->out_w) * 3, pbytes = prow * st->out_h;
+    const size_t mrow = st->out_w, mbytes = mrow * st->out_h;
+    if (d_pano_bytes_ < pbytes) {
+        if (d_pano_) (void)hipFree(d_pano_);
+        d_pano_ = nullptr;
+        check_hip(hipMalloc(reinterpret_cast<void**>(&d_pano_), pbytes), "hipMalloc(pano)");
+        d_pano_bytes_ = pbytes;
+    }
+    if (pano_mask && d_mask_bytes_ < mbytes) {
+        if (d_mask_) (void)hipFree(d_mask_);
+        d_mask_ = nullptr;
+        check_hip(hipMalloc(reinterpret_cast<void**>(&d_mask_), mbytes), "hipMalloc(mask)");
+        d_mask_bytes_ = mbytes;
+    }
+    compose_device(dptr.data(), dstride.data(), d_pano_, prow, pano_mask ? d_mask_ : nullptr, mrow, stream_);
+    check_hip(hipMemcpy2DAsync(pano, pano_stride, d_pano_, prow, prow, st->out_h, hipMemcpyDeviceToHost, stream_),
+              "hipMemcpy2DAsync(pano)");
+    if (pano_mask)
+        check_hip(hipMemcpy2DAsync(pano_mask, mask_stride, d_mask_, mrow, mrow, st->out_h, hipMemcpyDeviceToHost,
+                                   stream_), "hipMemcpy2DAsync(mask)");
+    check_hip(hipStreamSynchronize(stream_), "hipStreamSynchronize(compose)");
+}
+
+void Engine::debug_read(int what, int camera, int level, void* buf, size_t buf_bytes, int* w, int* h)
+{
+    select_device(cfg_.device);
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "no calibration"};
+    if (st->blend_kind != MST_BLEND_MULTI_BAND) throw Error{MST_ERR_INVALID_ARG, "debug buffers exist for multi-band only"};
+    if (level < 0 || level > st->num_bands) throw Error{MST_ERR_INVALID_ARG, "bad level"};
+    const void* src = nullptr;
+    size_t bytes = 0;
+    int ww = 0, hh = 0;
+    const bool per_cam = what == MST_DBG_CAM_WARPED_S16 || what == MST_DBG_CAM_GAUSS_S16 || what == MST_DBG_CAM_WEIGHT_F32;
+    if (per_cam) {
+        if (camera < 0 || camera >= st->n) throw Error{MST_ERR_INVALID_ARG, "bad camera"};
+        const CamDesc& d = st->desc[camera];
+        if (what == MST_DBG_CAM_WARPED_S16) level = 0;
+        ww = d.lw[level]; hh = d.lh[level];
+        if (what == MST_DBG_CAM_WEIGHT_F32) { src = d.W[level]; bytes = sizeof(float) * ww * hh; }
+        else { src = d.G[level]; bytes = sizeof(int16_t) * 3 * static_cast<size_t>(ww) * hh; }
+    } else if (what == MST_DBG_BAND_WEIGHT_F32) {
+        ww = st->cv.cw[level]; hh = st->cv.ch[level];
+        src = st->cv.WS[level]; bytes = sizeof(float) * static_cast<size_t>(ww) * hh;
+    } else if (what == MST_DBG_CANVAS_S16) {
+        if (level == 0) throw Error{MST_ERR_INVALID_ARG, "canvas level 0 is written straight to the panorama"};
+        ww = st->cv.cw[level]; hh = st->cv.ch[level];
+        src = st->cv.C[level]; bytes = sizeof(int16_t) * 3 * static_cast<size_t>(ww) * hh;
+    } else {
+        throw Error{MST_ERR_INVALID_ARG, "unknown debug buffer"};
+    }
+    if (w) *w = ww;
+    if (h) *h = hh;
+    if (!buf) return;
+    if (buf_bytes < bytes) throw Error{MST_ERR_INVALID_ARG, "debug buffer too small"};
+    check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    check_hip(hipMemcpy(buf, src, bytes, hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+}
+
+}  // namespace mst

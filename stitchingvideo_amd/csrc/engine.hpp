@@ -1,0 +1,109 @@
+// engine.hpp -- host side of the compositing engine: calibration state (double-buffered),
+// device memory ownership, and the per-frame launch sequence.
+//
+// Mirrors the reference's cached-calibration design: GetPreStruct() produces a state,
+// UpdateMat() swaps it in between frames (R64/stitching_detailed.cpp:696-722, 835-836), and
+// StitchingAll() only runs per-frame work against it (R64/stitching_detailed.cpp:724-770).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355_stitch.h"
+#include "device_types.hpp"
+#include "geometry.hpp"
+
+namespace mst {
+
+struct Error {
+    int code;
+    std::string msg;
+};
+
+// Owns every device allocation of one calibration state (or one stage-level call).
+class DevicePool {
+public:
+    DevicePool() = default;
+    DevicePool(const DevicePool&) = delete;
+    DevicePool& operator=(const DevicePool&) = delete;
+    ~DevicePool();
+    void* alloc_bytes(size_t bytes);
+    template <typename T> T* alloc(size_t n) { return static_cast<T*>(alloc_bytes(n * sizeof(T))); }
+    template <typename T> T* upload(const T* host, size_t n, hipStream_t s);
+    template <typename T> T* upload(const std::vector<T>& v, hipStream_t s) { return upload(v.data(), v.size(), s); }
+    size_t bytes() const { return total_; }
+private:
+    std::vector<void*> ptrs_;
+    size_t total_ = 0;
+};
+
+// Host-side description of one camera, enough to fill a CamDesc.
+struct CameraSetup {
+    Projector proj;
+    Rect roi;
+    int src_w = 0, src_h = 0;
+};
+
+struct CalibState {
+    DevicePool pool;
+    int n = 0;
+    int blend_kind = 0;
+    std::vector<CameraSetup> cams;
+    std::vector<CamDesc> desc;      // host copy of the device array
+    CamDesc* d_desc = nullptr;
+    Rect canvas;                    // resultRoi(corners, sizes)
+    // multi-band
+    int num_bands = 0;
+    Rect padded;
+    CanvasDesc cv{};
+    SegTable seg_level[kMaxLevels]{};   // seg_level[l]: tiles over level-l images of all cameras
+    // feather
+    float* d_feather_ws = nullptr;
+    // output rectangle (== canvas unless the driver LUT crop is active)
+    int crop_x = 0, crop_y = 0, out_w = 0, out_h = 0;
+    ~CalibState();
+};
+
+class Engine {
+public:
+    explicit Engine(const mst_config& cfg);
+    ~Engine();
+    void init();                                       // throws Error
+    void update(const mst_calibration& calib);         // throws Error
+    void compose_device(const void* const* d_frames, const size_t* strides, void* d_pano, size_t pano_stride,
+                        void* d_mask, size_t mask_stride, hipStream_t stream);
+    void compose_host(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride,
+                      uint8_t* pano_mask, size_t mask_stride);
+    void synchronize();
+    std::shared_ptr<CalibState> state() const;
+    void debug_read(int what, int camera, int level, void* buf, size_t buf_bytes, int* w, int* h);
+
+    const mst_config& config() const { return cfg_; }
+    std::string last_error;
+
+private:
+    mst_config cfg_;
+    hipStream_t stream_ = nullptr;        // compose stream
+    hipStream_t calib_stream_ = nullptr;  // mst_update builds the next state here
+    mutable std::mutex mu_;
+    std::shared_ptr<CalibState> current_;
+    std::shared_ptr<CalibState> in_flight_;   // state used by the most recent compose
+    // staging for compose_host
+    std::vector<uint8_t*> d_frames_;
+    std::vector<size_t> d_frame_bytes_;
+    uint8_t* d_pano_ = nullptr; size_t d_pano_bytes_ = 0;
+    uint8_t* d_mask_ = nullptr; size_t d_mask_bytes_ = 0;
+};
+
+// Fill the warp + exposure part of a CamDesc (tables uploaded through `pool`).
+void fill_camera_desc(DevicePool& pool, hipStream_t s, const Projector& proj, const Rect& roi, int src_w, int src_h,
+                      int expos_kind, const float* gain_map, int gw, int gh, float gain, CamDesc& d);
+
+void check_hip(hipError_t e, const char* what);
+void select_device(int device);
+
+}  // namespace mst

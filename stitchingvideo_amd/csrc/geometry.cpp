@@ -1,0 +1,332 @@
+// geometry.cpp -- see geometry.hpp for the reference lines each function follows.
+#include "geometry.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+namespace mst {
+
+namespace {
+
+constexpr double kPi = 3.1415926535897932384626433832795;   // CV_PI
+
+// cv::Mat::inv() for a 3x3 CV_32F matrix (closed form of cv::invert): determinant evaluated in
+// float, adjugate terms in double, each scaled by 1/det and rounded to float.
+void invert3x3(const float m[9], float out[9])
+{
+    auto S = [&](int r, int c) { return m[r * 3 + c]; };
+    double det = S(0, 0) * (S(1, 1) * S(2, 2) - S(1, 2) * S(2, 1)) -
+                 S(0, 1) * (S(1, 0) * S(2, 2) - S(1, 2) * S(2, 0)) +
+                 S(0, 2) * (S(1, 0) * S(2, 1) - S(1, 1) * S(2, 0));
+    if (det == 0.) {
+        std::memset(out, 0, 9 * sizeof(float));
+        return;
+    }
+    const double d = 1. / det;
+    auto D = [&](int r, int c) { return static_cast<double>(m[r * 3 + c]); };
+    float t[9];
+    t[0] = static_cast<float>((D(1, 1) * S(2, 2) - D(1, 2) * S(2, 1)) * d);
+    t[1] = static_cast<float>((D(0, 2) * S(2, 1) - D(0, 1) * S(2, 2)) * d);
+    t[2] = static_cast<float>((D(0, 1) * S(1, 2) - D(0, 2) * S(1, 1)) * d);
+    t[3] = static_cast<float>((D(1, 2) * S(2, 0) - D(1, 0) * S(2, 2)) * d);
+    t[4] = static_cast<float>((D(0, 0) * S(2, 2) - D(0, 2) * S(2, 0)) * d);
+    t[5] = static_cast<float>((D(0, 2) * S(1, 0) - D(0, 0) * S(1, 2)) * d);
+    t[6] = static_cast<float>((D(1, 0) * S(2, 1) - D(1, 1) * S(2, 0)) * d);
+    t[7] = static_cast<float>((D(0, 1) * S(2, 0) - D(0, 0) * S(2, 1)) * d);
+    t[8] = static_cast<float>((D(0, 0) * S(1, 1) - D(0, 1) * S(1, 0)) * d);
+    std::memcpy(out, t, sizeof(t));
+}
+
+// cv::Mat operator* on 3x3 CV_32F (gemm small-matrix path): float products, summed in order.
+void mul3x3(const float a[9], const float b[9], float out[9])
+{
+    float t[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            t[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
+    std::memcpy(out, t, sizeof(t));
+}
+
+struct Bounds {
+    float tl_u = FLT_MAX, tl_v = FLT_MAX, br_u = -FLT_MAX, br_v = -FLT_MAX;
+    void add(float u, float v)
+    {
+        tl_u = std::min(tl_u, u); tl_v = std::min(tl_v, v);
+        br_u = std::max(br_u, u); br_v = std::max(br_v, v);
+    }
+};
+
+Bounds border_walk(const Projector& p, int w, int h)
+{
+    Bounds b;
+    float u, v;
+    for (float x = 0; x < w; ++x) {
+        p.forward(x, 0, u, v);                          b.add(u, v);
+        p.forward(x, static_cast<float>(h - 1), u, v);  b.add(u, v);
+    }
+    for (int y = 0; y < h; ++y) {
+        p.forward(0, static_cast<float>(y), u, v);                         b.add(u, v);
+        p.forward(static_cast<float>(w - 1), static_cast<float>(y), u, v); b.add(u, v);
+    }
+    return b;
+}
+
+int floor_to_int(double v)
+{
+    double r = std::floor(v);
+    if (!(r >= -2147483648.0 && r <= 2147483647.0)) return INT_MIN;
+    return static_cast<int>(r);
+}
+
+}  // namespace
+
+void Projector::set(const float K[9], const float R[9], const float T[3])
+{
+    std::memcpy(k, K, sizeof(k));
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            rinv[r * 3 + c] = R[c * 3 + r];
+    float kinv[9];
+    invert3x3(K, kinv);
+    mul3x3(R, kinv, r_kinv);
+    mul3x3(K, rinv, k_rinv);
+    for (int i = 0; i < 3; ++i) t[i] = T ? T[i] : 0.f;
+}
+
+void Projector::forward(float x, float y, float& u, float& v) const
+{
+    float x_ = r_kinv[0] * x + r_kinv[1] * y + r_kinv[2];
+    float y_ = r_kinv[3] * x + r_kinv[4] * y + r_kinv[5];
+    float z_ = r_kinv[6] * x + r_kinv[7] * y + r_kinv[8];
+    switch (kind) {
+    case kPlane:
+        x_ = t[0] + x_ / z_ * (1 - t[2]);
+        y_ = t[1] + y_ / z_ * (1 - t[2]);
+        u = scale * x_;
+        v = scale * y_;
+        break;
+    case kSpherical: {
+        u = scale * atan2f(x_, z_);
+        float w = y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_);
+        v = scale * (static_cast<float>(kPi) - acosf(w == w ? w : 0));
+        break;
+    }
+    default:
+        u = scale * atan2f(x_, z_);
+        v = scale * y_ / sqrtf(x_ * x_ + z_ * z_);
+        break;
+    }
+}
+
+void detect_result_roi(const Projector& p, int src_w, int src_h, int& tl_x, int& tl_y, int& br_x, int& br_y)
+{
+    Bounds b;
+    if (p.kind == kPlane) {
+        float u, v;
+        p.forward(0, 0, u, v);                                                        b.add(u, v);
+        p.forward(0, static_cast<float>(src_h - 1), u, v);                            b.add(u, v);
+        p.forward(static_cast<float>(src_w - 1), 0, u, v);                            b.add(u, v);
+        p.forward(static_cast<float>(src_w - 1), static_cast<float>(src_h - 1), u, v); b.add(u, v);
+    } else {
+        b = border_walk(p, src_w, src_h);
+        if (p.kind == kSpherical) {
+            // the integer bounds go back to float before the pole tests (warpers.cpp:175-178)
+            float tl_uf = static_cast<float>(static_cast<int>(b.tl_u));
+            float tl_vf = static_cast<float>(static_cast<int>(b.tl_v));
+            float br_uf = static_cast<float>(static_cast<int>(b.br_u));
+            float br_vf = static_cast<float>(static_cast<int>(b.br_v));
+            for (int pole = 0; pole < 2; ++pole) {
+                float x = p.rinv[1];
+                float y = pole == 0 ? p.rinv[4] : -p.rinv[4];
+                float z = p.rinv[7];
+                if (y > 0.f) {
+                    float x_ = (p.k[0] * x + p.k[1] * y) / z + p.k[2];
+                    float y_ = p.k[4] * y / z + p.k[5];
+                    if (x_ > 0.f && x_ < src_w && y_ > 0.f && y_ < src_h) {
+                        float pv = pole == 0 ? static_cast<float>(kPi * p.scale) : 0.f;
+                        tl_uf = std::min(tl_uf, 0.f); tl_vf = std::min(tl_vf, pv);
+                        br_uf = std::max(br_uf, 0.f); br_vf = std::max(br_vf, pv);
+                    }
+                }
+            }
+            b.tl_u = tl_uf; b.tl_v = tl_vf; b.br_u = br_uf; b.br_v = br_vf;
+        }
+    }
+    tl_x = static_cast<int>(b.tl_u); tl_y = static_cast<int>(b.tl_v);
+    br_x = static_cast<int>(b.br_u); br_y = static_cast<int>(b.br_v);
+}
+
+Rect warp_roi(const Projector& p, int src_w, int src_h)
+{
+    int tlx, tly, brx, bry;
+    detect_result_roi(p, src_w, src_h, tlx, tly, brx, bry);
+    Rect r;
+    r.x = tlx; r.y = tly; r.width = brx + 1 - tlx; r.height = bry + 1 - tly;
+    return r;
+}
+
+Rect result_roi(const std::vector<Rect>& rois)
+{
+    int tlx = INT_MAX, tly = INT_MAX, brx = INT_MIN, bry = INT_MIN;
+    for (const Rect& r : rois) {
+        tlx = std::min(tlx, r.x); tly = std::min(tly, r.y);
+        brx = std::max(brx, r.br_x()); bry = std::max(bry, r.br_y());
+    }
+    Rect out;
+    out.x = tlx; out.y = tly; out.width = brx - tlx; out.height = bry - tly;
+    return out;
+}
+
+MapTables build_map_tables(const Projector& p, const Rect& roi)
+{
+    MapTables t;
+    t.col_a.resize(roi.width); t.col_b.resize(roi.width);
+    t.row_a.resize(roi.height); t.row_b.resize(roi.height);
+    for (int i = 0; i < roi.width; ++i) {
+        float u = static_cast<float>(roi.x + i);
+        if (p.kind == kPlane) {
+            t.col_a[i] = u / p.scale - p.t[0];
+            t.col_b[i] = 0.f;
+        } else {
+            u /= p.scale;
+            t.col_a[i] = sinf(u);
+            t.col_b[i] = cosf(u);
+        }
+    }
+    for (int j = 0; j < roi.height; ++j) {
+        float v = static_cast<float>(roi.y + j);
+        if (p.kind == kPlane) {
+            t.row_a[j] = v / p.scale - p.t[1];
+            t.row_b[j] = 0.f;
+        } else if (p.kind == kSpherical) {
+            v /= p.scale;
+            t.row_a[j] = sinf(static_cast<float>(kPi) - v);
+            t.row_b[j] = cosf(static_cast<float>(kPi) - v);
+        } else {
+            t.row_a[j] = v / p.scale;
+            t.row_b[j] = 0.f;
+        }
+    }
+    return t;
+}
+
+void backward_map_host(const Projector& p, const Rect& roi, const MapTables& t, float* xmap, float* ymap)
+{
+    const float* kr = p.k_rinv;
+    for (int j = 0; j < roi.height; ++j)
+        for (int i = 0; i < roi.width; ++i) {
+            float x, y, z;
+            if (p.kind == kPlane) {
+                float u = t.col_a[i], v = t.row_a[j];
+                x = kr[0] * u + kr[1] * v + kr[2] * (1 - p.t[2]);
+                y = kr[3] * u + kr[4] * v + kr[5] * (1 - p.t[2]);
+                z = kr[6] * u + kr[7] * v + kr[8] * (1 - p.t[2]);
+                x /= z;
+                y /= z;
+            } else {
+                float x_, y_, z_;
+                if (p.kind == kSpherical) {
+                    x_ = t.row_a[j] * t.col_a[i];
+                    y_ = t.row_b[j];
+                    z_ = t.row_a[j] * t.col_b[i];
+                } else {
+                    x_ = t.col_a[i];
+                    y_ = t.row_a[j];
+                    z_ = t.col_b[i];
+                }
+                x = kr[0] * x_ + kr[1] * y_ + kr[2] * z_;
+                y = kr[3] * x_ + kr[4] * y_ + kr[5] * z_;
+                z = kr[6] * x_ + kr[7] * y_ + kr[8] * z_;
+                if (z > 0) { x /= z; y /= z; }
+                else x = y = -1;
+            }
+            xmap[static_cast<size_t>(j) * roi.width + i] = x;
+            ymap[static_cast<size_t>(j) * roi.width + i] = y;
+        }
+}
+
+ResizeAxis build_gain_axis_x(int src_len, int dst_len)
+{
+    ResizeAxis a;
+    a.ofs0.resize(dst_len); a.ofs1.resize(dst_len); a.w0.resize(dst_len); a.w1.resize(dst_len);
+    const double inv_scale = static_cast<double>(dst_len) / src_len;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dst_len; ++d) {
+        float f = static_cast<float>((d + 0.5) * scale - 0.5);
+        int s = floor_to_int(f);
+        f -= s;
+        if (s < 0) { f = 0; s = 0; }
+        if (s >= src_len - 1) { f = 0; s = src_len - 1; }
+        a.ofs0[d] = s;
+        a.ofs1[d] = std::min(s + 1, src_len - 1);
+        a.w0[d] = 1.f - f;
+        a.w1[d] = f;
+    }
+    return a;
+}
+
+ResizeAxis build_gain_axis_y(int src_len, int dst_len)
+{
+    ResizeAxis a;
+    a.ofs0.resize(dst_len); a.ofs1.resize(dst_len); a.w0.resize(dst_len); a.w1.resize(dst_len);
+    const double inv_scale = static_cast<double>(dst_len) / src_len;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dst_len; ++d) {
+        float f = static_cast<float>((d + 0.5) * scale - 0.5);
+        int s = floor_to_int(f);
+        f -= s;
+        // rows are clipped into the image, the weights are kept
+        a.ofs0[d] = std::clamp(s, 0, src_len - 1);
+        a.ofs1[d] = std::clamp(s + 1, 0, src_len - 1);
+        a.w0[d] = 1.f - f;
+        a.w1[d] = f;
+    }
+    return a;
+}
+
+int multiband_num_bands(int actual_num_bands, const Rect& dst_roi)
+{
+    double max_len = static_cast<double>(std::max(dst_roi.width, dst_roi.height));
+    return std::min(actual_num_bands, static_cast<int>(std::ceil(std::log(max_len) / std::log(2.0))));
+}
+
+Rect multiband_padded_roi(const Rect& dst_roi, int num_bands)
+{
+    Rect r = dst_roi;
+    const int m = 1 << num_bands;
+    r.width += (m - r.width % m) % m;
+    r.height += (m - r.height % m) % m;
+    return r;
+}
+
+BandGeometry multiband_feed_geometry(const Rect& roi, int num_bands, const Rect& img)
+{
+    const int gap = 3 * (1 << num_bands);
+    const int m = 1 << num_bands;
+    int tlx = std::max(roi.x, img.x - gap), tly = std::max(roi.y, img.y - gap);
+    int brx = std::min(roi.br_x(), img.x + img.width + gap);
+    int bry = std::min(roi.br_y(), img.y + img.height + gap);
+    tlx = roi.x + (((tlx - roi.x) >> num_bands) << num_bands);
+    tly = roi.y + (((tly - roi.y) >> num_bands) << num_bands);
+    int width = brx - tlx, height = bry - tly;
+    width += (m - width % m) % m;
+    height += (m - height % m) % m;
+    brx = tlx + width;
+    bry = tly + height;
+    const int dy = std::max(bry - roi.br_y(), 0);
+    const int dx = std::max(brx - roi.br_x(), 0);
+    tlx -= dx; brx -= dx;
+    tly -= dy; bry -= dy;
+    BandGeometry g;
+    g.tl_br.x = tlx; g.tl_br.y = tly; g.tl_br.width = brx - tlx; g.tl_br.height = bry - tly;
+    g.top = img.y - tly;
+    g.left = img.x - tlx;
+    g.bottom = bry - img.y - img.height;
+    g.right = brx - img.x - img.width;
+    return g;
+}
+
+}  // namespace mst

@@ -1,0 +1,82 @@
+// geometry.hpp -- host-side, per-calibration geometry of the compositing engine.
+//
+// Everything here runs once per mst_update on the host CPU (the north star keeps
+// registration-time work on the host); nothing here touches pixels.  It produces the small
+// tables the HIP kernels consume so that the backward map and the gain field are evaluated
+// in registers, bit-exactly, with no per-pixel map traffic.
+//
+// Reference behaviour followed (R64 = /root/reference/stitching/OpenCV2.4.11-Stitching-64bit/
+// OpenCV2.4.11-Stitching):
+//   Projector::set             ProjectorBase::setCameraParams      R64/src/warpers.cpp:50-78
+//   Projector::forward         {Plane,Spherical,Cylindrical}Projector::mapForward
+//                                                                  detail/warpers_inl.hpp:206-300
+//   detect_result_roi          detectResultRoi / ...ByBorder       detail/warpers_inl.hpp:143-203,
+//                              PlaneWarper / SphericalWarper        R64/src/warpers.cpp:139-212
+//   result_roi                 resultRoi                            R64/src/util.cpp:127-140
+//   multiband_prepare/feed     MultiBandBlender::prepare / feed     R64/src/blenders.cpp:203-269
+//   build_gain_axis            cv::resize(INTER_LINEAR) index/weight tables as used by
+//                              BlocksGainCompensator::apply         R64/src/exposure_compensate.cpp:233
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+namespace mst {
+
+struct Rect {
+    int x = 0, y = 0, width = 0, height = 0;
+    int br_x() const { return x + width; }
+    int br_y() const { return y + height; }
+};
+
+enum WarpKind { kPlane = 0, kSpherical = 1, kCylindrical = 2 };
+
+struct Projector {
+    int kind = kSpherical;
+    float scale = 1.f;
+    float k[9], rinv[9], r_kinv[9], k_rinv[9], t[3];
+
+    void set(const float K[9], const float R[9], const float T[3]);
+    void forward(float x, float y, float& u, float& v) const;
+};
+
+// inclusive top-left / bottom-right, as the reference's detectResultRoi returns them
+void detect_result_roi(const Projector& p, int src_w, int src_h, int& tl_x, int& tl_y, int& br_x, int& br_y);
+Rect warp_roi(const Projector& p, int src_w, int src_h);   // Rect(tl, br + 1)
+Rect result_roi(const std::vector<Rect>& rois);
+
+// Per-axis tables of the backward map.  For destination column u (= roi.x + i) and row v
+// (= roi.y + j) the kernels form the unit ray / plane point from
+//   plane:        col_a[i] = u/scale - t0                      row_a[j] = v/scale - t1
+//   spherical:    col_a[i] = sinf(u/scale), col_b[i] = cosf(u/scale)
+//                 row_a[j] = sinf(pi - v/scale), row_b[j] = cosf(pi - v/scale)
+//   cylindrical:  col_a[i] = sinf(u/scale), col_b[i] = cosf(u/scale)   row_a[j] = v/scale
+// and finish with k_rinv multiply-adds and the perspective divide in IEEE float, in the
+// operation order of mapBackward (detail/warpers_inl.hpp:221-300).
+struct MapTables {
+    std::vector<float> col_a, col_b, row_a, row_b;
+};
+MapTables build_map_tables(const Projector& p, const Rect& roi);
+
+// Host evaluation of the same table-based backward map (mst_build_maps_host).
+void backward_map_host(const Projector& p, const Rect& roi, const MapTables& t, float* xmap, float* ymap);
+
+// cv::resize(..., INTER_LINEAR) tables for one axis, float source (resizeGeneric_ set-up code).
+// ofs0/ofs1 are the two source indices (already clamped), w0/w1 their weights.
+struct ResizeAxis {
+    std::vector<int32_t> ofs0, ofs1;
+    std::vector<float> w0, w1;
+};
+ResizeAxis build_gain_axis_x(int src_len, int dst_len);
+ResizeAxis build_gain_axis_y(int src_len, int dst_len);
+
+// MultiBandBlender integer geometry.
+struct BandGeometry {
+    Rect tl_br;                 // x,y = tl_new ; width,height = br_new - tl_new (bordered size)
+    int top = 0, left = 0, bottom = 0, right = 0;
+};
+int  multiband_num_bands(int actual_num_bands, const Rect& dst_roi);     // blenders.cpp:207-209
+Rect multiband_padded_roi(const Rect& dst_roi, int num_bands);           // blenders.cpp:211-213
+BandGeometry multiband_feed_geometry(const Rect& padded_roi, int num_bands, const Rect& image);
+
+}  // namespace mst

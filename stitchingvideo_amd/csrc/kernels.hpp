@@ -1,0 +1,39 @@
+// kernels.hpp -- launchers of the hand-written HIP kernels (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device_types.hpp"
+
+namespace mst {
+
+// ---- stage-level (RotationWarper / ExposureCompensator mirrors) ----
+void launch_build_maps(const CamDesc* d_cam, float* d_xmap, float* d_ymap, int w, int h, hipStream_t s);
+void launch_warp_u8(const CamDesc* d_cam, const uint8_t* d_src, size_t src_stride, int channels,
+                    int interp, int border, uint8_t* d_dst, size_t dst_stride, int w, int h, hipStream_t s);
+void launch_exposure_apply(const CamDesc* d_cam, uint8_t* d_img, size_t stride, int w, int h, hipStream_t s);
+
+// ---- calibration-time static products ----
+void launch_weight_level0(const CamDesc* d_cams, int cam, float* d_w0, int bw, int bh, hipStream_t s);
+void launch_pyrdown_f32(const float* d_src, int w, int h, float* d_dst, hipStream_t s);
+void launch_band_weight_sum(const CamDesc* d_cams, int n_cams, int level, float* d_ws, int cw, int ch,
+                            hipStream_t s);
+void launch_feather_weight_sum(const CamDesc* d_cams, int n_cams, float* d_ws, int cw, int ch, hipStream_t s);
+
+// ---- per-frame hot path: multi-band ----
+void launch_warp_border_s16(const CamDesc* d_cams, const SegTable& seg, const FrameArgs& frames, hipStream_t s);
+void launch_pyrdown_s16(const CamDesc* d_cams, const SegTable& seg, int level, hipStream_t s);
+void launch_band_blend(const CamDesc* d_cams, const CanvasDesc& cv, int level, hipStream_t s);
+void launch_band_final(const CamDesc* d_cams, const CanvasDesc& cv, uint8_t* d_pano, size_t pano_stride,
+                       uint8_t* d_pano_mask, size_t mask_stride, hipStream_t s);
+
+// ---- per-frame hot path: feather / paste (fully fused: warp + gain + blend in one kernel) ----
+void launch_feather_compose(const CamDesc* d_cams, int n_cams, const FrameArgs& frames, const float* d_ws,
+                            int cw, int ch, uint8_t* d_pano, size_t pano_stride, uint8_t* d_pano_mask,
+                            size_t mask_stride, hipStream_t s);
+// driver_lut: 0 = Blender::NO semantics; 1 = feedSizeRemap semantics (crop, no mask test)
+void launch_paste_compose(const CamDesc* d_cams, int n_cams, const FrameArgs& frames, int cw, int ch,
+                          int crop_x, int crop_y, int out_w, int out_h, int driver_lut, uint8_t* d_pano,
+                          size_t pano_stride, uint8_t* d_pano_mask, size_t mask_stride, hipStream_t s);
+
+}  // namespace mst

@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's per-frame interfaces, bound to the C ABI.
+
+Names, argument meaning and error behaviour follow the reference (R64 =
+/root/reference/stitching/OpenCV2.4.11-Stitching-64bit/OpenCV2.4.11-Stitching):
+
+  RotationWarper.warpRoi / buildMaps / warp     detail/warpers.hpp:53-72, warpers_inl.hpp:62-140
+  ExposureCompensator.apply                     detail/exposure_compensate.hpp:51-64
+  PanoramaEngine.update / compose               UpdateMat + StitchingAll, R64/stitching_detailed.cpp:696-770;
+                                                Stitcher::composePanorama, R64/src/stitcher.cpp:264-313
+
+Every pixel is computed by the HIP kernels in libmi355stitch.so; numpy is only the container
+for host images (a cv::Mat stand-in: data + step).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def _f9(a):
+    return (C.c_float * 9)(*np.asarray(a, np.float32).reshape(-1))
+
+
+def _f3(a):
+    if a is None:
+        a = (0.0, 0.0, 0.0)
+    return (C.c_float * 3)(*np.asarray(a, np.float32).reshape(-1))
+
+
+class RotationWarper:
+    """cv::detail::RotationWarper for the three projections on the hot path."""
+
+    kind = None
+
+    def __init__(self, scale, device=0):
+        self.scale = float(scale)
+        self.device = device
+
+    def warpRoi(self, src_size, K, R, T=None):
+        """src_size = (width, height) -> (x, y, width, height).  Host only."""
+        r = capi.Rect()
+        capi.check(capi.load().mst_warp_roi(self.kind, self.scale, _f9(K), _f9(R), _f3(T),
+                                            int(src_size[0]), int(src_size[1]), C.byref(r)))
+        return r.tuple()
+
+    def buildMaps(self, src_size, K, R, T=None, host=False):
+        """-> (roi, xmap, ymap); xmap/ymap are CV_32F of the roi size."""
+        roi = self.warpRoi(src_size, K, R, T)
+        xmap = np.empty((roi[3], roi[2]), np.float32)
+        ymap = np.empty((roi[3], roi[2]), np.float32)
+        L = capi.load()
+        if host:
+            rc = L.mst_build_maps_host(self.kind, self.scale, _f9(K), _f9(R), _f3(T), int(src_size[0]),
+                                       int(src_size[1]), xmap.ctypes.data, ymap.ctypes.data)
+        else:
+            rc = L.mst_build_maps(self.device, self.kind, self.scale, _f9(K), _f9(R), _f3(T),
+                                  int(src_size[0]), int(src_size[1]), xmap.ctypes.data, ymap.ctypes.data)
+        capi.check(rc)
+        return roi, xmap, ymap
+
+    def warp(self, src, K, R, interp_mode=capi.INTER_LINEAR, border_mode=capi.BORDER_REFLECT, T=None):
+        """-> (corner (x, y), dst).  src is CV_8UC1 (H, W) or CV_8UC3 (H, W, 3)."""
+        src = np.asarray(src)
+        if src.dtype != np.uint8 or src.ndim not in (2, 3) or (src.ndim == 3 and src.shape[2] != 3):
+            raise capi.StitchError(capi.ERR_INVALID_ARG, "warp expects CV_8UC1 or CV_8UC3")
+        if src.strides[-1] != 1 or (src.ndim == 3 and src.strides[1] != 3):
+            src = np.ascontiguousarray(src)
+        h, w = src.shape[:2]
+        cn = 1 if src.ndim == 2 else 3
+        roi = self.warpRoi((w, h), K, R, T)
+        dst = np.empty((roi[3], roi[2]) + (() if cn == 1 else (3,)), np.uint8)
+        capi.check(capi.load().mst_warp(self.device, self.kind, self.scale, _f9(K), _f9(R), _f3(T),
+                                        src.ctypes.data, w, h, src.strides[0], cn, interp_mode, border_mode,
+                                        dst.ctypes.data, dst.strides[0]))
+        return (roi[0], roi[1]), dst
+
+
+class PlaneWarper(RotationWarper):
+    kind = capi.WARP_PLANE
+
+
+class SphericalWarper(RotationWarper):
+    kind = capi.WARP_SPHERICAL
+
+
+class CylindricalWarper(RotationWarper):
+    kind = capi.WARP_CYLINDRICAL
+
+
+WARPERS = {"plane": PlaneWarper, "spherical": SphericalWarper, "cylindrical": CylindricalWarper}
+WARP_KINDS = {"plane": capi.WARP_PLANE, "spherical": capi.WARP_SPHERICAL, "cylindrical": capi.WARP_CYLINDRICAL}
+BLEND_KINDS = {"no": capi.BLEND_NO, "feather": capi.BLEND_FEATHER, "multiband": capi.BLEND_MULTI_BAND}
+EXPOS_KINDS = {"no": capi.EXPOS_NO, "gain": capi.EXPOS_GAIN, "gain_blocks": capi.EXPOS_GAIN_BLOCKS}
+
+
+class GainCompensator:
+    """apply(): image *= gain (exposure_compensate.cpp:150-153)."""
+
+    def __init__(self, gains, device=0):
+        self.gains = list(gains)
+        self.device = device
+
+    def apply(self, index, corner, image, mask=None):
+        _exposure_apply(self.device, capi.EXPOS_GAIN, image, None, float(self.gains[index]))
+
+
+class BlocksGainCompensator:
+    """apply(): bilinearly up-sized block gain map (exposure_compensate.cpp:225-246)."""
+
+    def __init__(self, gain_maps, device=0):
+        self.gain_maps = [np.ascontiguousarray(g, np.float32) for g in gain_maps]
+        self.device = device
+
+    def apply(self, index, corner, image, mask=None):
+        _exposure_apply(self.device, capi.EXPOS_GAIN_BLOCKS, image, self.gain_maps[index], 1.0)
+
+
+def _exposure_apply(device, kind, image, gain_map, gain):
+    if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3 or image.strides[2] != 1 \
+            or image.strides[1] != 3:
+        raise capi.StitchError(capi.ERR_INVALID_ARG, "apply expects a CV_8UC3 image")   # CV_Assert :227
+    gp, gw, gh = None, 0, 0
+    if gain_map is not None:
+        gp, gw, gh = gain_map.ctypes.data, gain_map.shape[1], gain_map.shape[0]
+    capi.check(capi.load().mst_exposure_apply(device, kind, image.ctypes.data, image.shape[1], image.shape[0],
+                                              image.strides[0], gp, gw, gh, gain))
+
+
+def multiband_geometry(canvas, num_bands, image):
+    """MultiBandBlender::prepare/feed integer geometry.  -> (padded_canvas, used_bands, out[8])"""
+    pad, nb, out = capi.Rect(), C.c_int(), (C.c_int * 8)()
+    capi.check(capi.load().mst_multiband_geometry(capi.Rect(*canvas), num_bands, capi.Rect(*image),
+                                                  C.byref(pad), C.byref(nb), out))
+    return pad.tuple(), nb.value, list(out)
+
+
+def synth_frame(camera, frame_index, width, height):
+    """Synthetic BGR frame of SURVEY.md section 8d (texture + PCG32 noise)."""
+    out = np.empty((height, width, 3), np.uint8)
+    capi.check(capi.load().mst_synth_frame(camera, frame_index, width, height, out.ctypes.data, out.strides[0]))
+    return out
+
+
+class PanoramaEngine:
+    """N frames in, one panorama out, every frame (the reference's StitchingAll loop).
+
+    cameras passed to update(): list of dicts with
+      K (3x3), R (3x3), optional T (3), size (width, height), mask (roi-sized uint8),
+      optional gain_map (2-D float32) / gain (float).
+    """
+
+    def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
+                 feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0)):
+        self._L = capi.load()
+        self._h = C.c_void_p()
+        cfg = capi.Config()
+        cfg.struct_size = C.sizeof(capi.Config)
+        cfg.num_cameras = num_cameras
+        cfg.warp_kind = WARP_KINDS[warp] if isinstance(warp, str) else warp
+        cfg.blend_kind = BLEND_KINDS[blend] if isinstance(blend, str) else blend
+        cfg.expos_kind = EXPOS_KINDS[expos] if isinstance(expos, str) else expos
+        cfg.num_bands = num_bands
+        cfg.feather_sharpness = feather_sharpness
+        cfg.device = device
+        cfg.flags = capi.FLAG_DRIVER_LUT if driver_lut else 0
+        cfg.upblack, cfg.downblack, cfg.leftblack, cfg.rightblack = crop
+        self.num_cameras = num_cameras
+        self.device = device
+        capi.check(self._L.mst_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.mst_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        capi.check(rc, self._h)
+
+    def update(self, scale, cameras):
+        n = len(cameras)
+        arr = (capi.Camera * n)()
+        keep = []
+        for i, c in enumerate(cameras):
+            arr[i].src_width, arr[i].src_height = int(c["size"][0]), int(c["size"][1])
+            arr[i].K = _f9(c["K"])
+            arr[i].R = _f9(c["R"])
+            arr[i].T = _f3(c.get("T"))
+            g = c.get("gain_map")
+            if g is not None:
+                g = np.ascontiguousarray(g, np.float32)
+                keep.append(g)
+                arr[i].gain_map, arr[i].gain_w, arr[i].gain_h = g.ctypes.data, g.shape[1], g.shape[0]
+            arr[i].gain = float(c.get("gain", 1.0))
+            m = np.ascontiguousarray(c["mask"], np.uint8)
+            keep.append(m)
+            arr[i].mask, arr[i].mask_width, arr[i].mask_height = m.ctypes.data, m.shape[1], m.shape[0]
+            arr[i].mask_stride = m.strides[0]
+        cal = capi.Calibration(C.sizeof(capi.Calibration), n, float(scale), arr)
+        self._check(self._L.mst_update(self._h, C.byref(cal)))
+
+    def canvas(self):
+        r = capi.Rect()
+        self._check(self._L.mst_canvas(self._h, C.byref(r)))
+        return r.tuple()
+
+    def camera_roi(self, i):
+        r = capi.Rect()
+        self._check(self._L.mst_camera_roi(self._h, i, C.byref(r)))
+        return r.tuple()
+
+    def num_bands(self):
+        v = C.c_int()
+        self._check(self._L.mst_num_bands(self._h, C.byref(v)))
+        return v.value
+
+    def compose(self, frames, want_mask=True):
+        """frames: list of (H, W, 3) uint8 host arrays -> (pano uint8 (H, W, 3), mask uint8 or None)."""
+        n = len(frames)
+        fr = [f if (f.dtype == np.uint8 and f.strides[2] == 1 and f.strides[1] == 3) else np.ascontiguousarray(f, np.uint8)
+              for f in frames]
+        ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in fr])
+        strides = (C.c_size_t * n)(*[f.strides[0] for f in fr])
+        _, _, w, h = self.canvas()
+        pano = np.empty((h, w, 3), np.uint8)
+        mask = np.empty((h, w), np.uint8) if want_mask else None
+        self._check(self._L.mst_compose(self._h, ptrs, strides, pano.ctypes.data, pano.strides[0],
+                                        mask.ctypes.data if want_mask else None, w))
+        return pano, mask
+
+    def compose_device(self, frame_ptrs, frame_strides, pano_ptr, pano_stride, mask_ptr=None, mask_stride=0,
+                       stream=None):
+        """Device pointers (ints) already resident in HBM; asynchronous on `stream`."""
+        n = len(frame_ptrs)
+        ptrs = (C.c_void_p * n)(*frame_ptrs)
+        strides = (C.c_size_t * n)(*frame_strides)
+        self._check(self._L.mst_compose_device(self._h, ptrs, strides, pano_ptr, pano_stride, mask_ptr,
+                                               mask_stride, stream))
+
+    def make_device_call(self, frame_ptrs, frame_strides, pano_ptr, pano_stride, mask_ptr=None, mask_stride=0,
+                         stream=None):
+        """Pre-marshal a compose_device call; returns a zero-argument callable (for tight frame loops)."""
+        n = len(frame_ptrs)
+        ptrs = (C.c_void_p * n)(*frame_ptrs)
+        strides = (C.c_size_t * n)(*frame_strides)
+        f, h = self._L.mst_compose_device, self._h
+        pano_ptr, mask_ptr, stream = C.c_void_p(pano_ptr), C.c_void_p(mask_ptr), C.c_void_p(stream)
+
+        def call():
+            rc = f(h, ptrs, strides, pano_ptr, pano_stride, mask_ptr, mask_stride, stream)
+            if rc:
+                self._check(rc)
+        return call
+
+    def synchronize(self):
+        self._check(self._L.mst_synchronize(self._h))
+
+    def debug_read(self, what, camera=0, level=0):
+        w, h = C.c_int(), C.c_int()
+        self._check(self._L.mst_debug_read(self._h, what, camera, level, None, 0, C.byref(w), C.byref(h)))
+        if what in (capi.DBG_CAM_WEIGHT_F32, capi.DBG_BAND_WEIGHT_F32):
+            buf = np.empty((h.value, w.value), np.float32)
+        else:
+            buf = np.empty((3, h.value, w.value), np.int16)
+        self._check(self._L.mst_debug_read(self._h, what, camera, level, buf.ctypes.data, buf.nbytes,
+                                           C.byref(w), C.byref(h)))
+        return buf

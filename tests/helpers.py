@@ -1,0 +1,34 @@
+"""Shared helpers for the parity tests: run the same inputs through the oracle and the engine."""
+import numpy as np
+
+import oracle_lib as O
+import stitchingvideo_amd as S
+from stitchingvideo_amd import rig as rigmod
+
+WARP_O = {"plane": O.WARP_PLANE, "spherical": O.WARP_SPHERICAL, "cylindrical": O.WARP_CYLINDRICAL}
+BLEND_O = {"no": O.BLEND_NO, "feather": O.BLEND_FEATHER, "multiband": O.BLEND_MULTI_BAND}
+EXPOS_O = {"no": O.EXPOS_NO, "gain": O.EXPOS_GAIN, "gain_blocks": O.EXPOS_GAIN_BLOCKS}
+
+
+def oracle_compose(rig, frames, blend=None, num_bands=5, sharpness=0.02, threads=1):
+    cams = []
+    for c, f in zip(rig["cameras"], frames):
+        cams.append(dict(K=c["K"], R=c["R"], frame=f, mask=c["mask"], gain_map=c.get("gain_map"),
+                         gain=c.get("gain", 1.0)))
+    return O.compose_panorama(WARP_O[rig["warp"]], rig["scale"], BLEND_O[blend or rig["blend"]],
+                              EXPOS_O[rig["expos"]], cams, num_bands=num_bands, sharpness=sharpness,
+                              num_threads=threads)
+
+
+def make_engine(rig, blend=None, num_bands=5, sharpness=0.02, **kw):
+    eng = S.PanoramaEngine(len(rig["cameras"]), warp=rig["warp"], blend=blend or rig["blend"],
+                           expos=rig["expos"], num_bands=num_bands, feather_sharpness=sharpness, **kw)
+    eng.update(rig["scale"], rig["cameras"])
+    return eng
+
+
+def diff_report(a, b):
+    a = np.asarray(a).astype(np.int64)
+    b = np.asarray(b).astype(np.int64)
+    d = np.abs(a - b)
+    return "max|d|=%d, mismatches=%d of %d" % (d.max() if d.size else 0, int((d != 0).sum()), d.size)
