@@ -147,6 +147,13 @@ int  mst_compose_device(mst_engine *e, const void *const *d_frames, const size_t
                         void *d_pano, size_t pano_stride, void *d_pano_mask, size_t pano_mask_stride,
                         void *stream);
 int  mst_synchronize(mst_engine *e);
+/* One frame of mst_compose_device with a HIP event recorded on `stream` between consecutive
+ * kernel launches: the counterpart of the reference's getTickCount() brackets
+ * ("Stitching, time: ..." DRV:760).  names[i] / stage_ms[i] receive the kernel name and its
+ * duration in milliseconds for up to max_stages launches; *num_stages = launches in the frame. */
+int  mst_compose_profile(mst_engine *e, const void *const *d_frames, const size_t *frame_strides,
+                         void *d_pano, size_t pano_stride, void *stream, int max_stages,
+                         char (*names)[32], float *stage_ms, int *num_stages);
 
 /* ---- stage-level entry points (the reference's plugin interfaces) ------------------------ */
 /* RotationWarper::warpRoi -- host only, no device needed */

@@ -23,7 +23,7 @@ DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, 
 
 EXPORTS = [
     "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_canvas", "mst_camera_roi",
-    "mst_num_bands", "mst_compose", "mst_compose_device", "mst_synchronize", "mst_warp_roi",
+    "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_profile", "mst_synchronize", "mst_warp_roi",
     "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
     "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame",
 ]
@@ -98,6 +98,9 @@ def load():
                                      C.c_size_t, vp]
     L.mst_synchronize.restype = C.c_int
     L.mst_synchronize.argtypes = [vp]
+    L.mst_compose_profile.restype = C.c_int
+    L.mst_compose_profile.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), vp, C.c_size_t, vp, C.c_int,
+                                      vp, fp, ip]
     L.mst_warp_roi.restype = C.c_int
     L.mst_warp_roi.argtypes = [C.c_int, C.c_float, fp, fp, fp, C.c_int, C.c_int, C.POINTER(Rect)]
     L.mst_build_maps.restype = C.c_int

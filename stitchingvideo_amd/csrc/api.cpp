@@ -164,6 +164,29 @@ int mst_compose_device(mst_engine* e, const void* const* d_frames, const size_t*
     });
 }
 
+int mst_compose_profile(mst_engine* e, const void* const* d_frames, const size_t* frame_strides, void* d_pano,
+                        size_t pano_stride, void* stream, int max_stages, char (*names)[32], float* stage_ms,
+                        int* num_stages)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] {
+        require(max_stages >= 0 && num_stages != nullptr, "bad stage buffer");
+        mst::StageTimer timer;
+        e->impl.compose_device(d_frames, frame_strides, d_pano, pano_stride, nullptr, 0,
+                               static_cast<hipStream_t>(stream), &timer);
+        std::vector<std::pair<std::string, float>> stages;
+        timer.collect(stages);
+        *num_stages = static_cast<int>(stages.size());
+        for (int i = 0; i < *num_stages && i < max_stages; ++i) {
+            if (names) {
+                std::strncpy(names[i], stages[i].first.c_str(), 31);
+                names[i][31] = 0;
+            }
+            if (stage_ms) stage_ms[i] = stages[i].second;
+        }
+    });
+}
+
 int mst_synchronize(mst_engine* e)
 {
     if (!e) return MST_ERR_INVALID_ARG;

@@ -146,6 +146,43 @@ SegTable make_seg_table(const std::vector<CamDesc>& desc, int level)
 
 }  // namespace
 
+// ---- StageTimer --------------------------------------------------------------------------------
+
+StageTimer::~StageTimer()
+{
+    for (hipEvent_t e : events_) (void)hipEventDestroy(e);
+}
+
+void StageTimer::begin(hipStream_t s)
+{
+    names_.clear();
+    used_ = 0;
+    mark(nullptr, s);
+}
+
+void StageTimer::mark(const char* name, hipStream_t s)
+{
+    if (used_ == events_.size()) {
+        hipEvent_t e;
+        check_hip(hipEventCreate(&e), "hipEventCreate");
+        events_.push_back(e);
+    }
+    check_hip(hipEventRecord(events_[used_++], s), "hipEventRecord");
+    if (name) names_.push_back(name);
+}
+
+void StageTimer::collect(std::vector<std::pair<std::string, float>>& out)
+{
+    out.clear();
+    if (used_ < 2) return;
+    check_hip(hipEventSynchronize(events_[used_ - 1]), "hipEventSynchronize");
+    for (size_t i = 0; i + 1 < used_; ++i) {
+        float ms = 0.f;
+        check_hip(hipEventElapsedTime(&ms, events_[i], events_[i + 1]), "hipEventElapsedTime");
+        out.emplace_back(names_[i], ms);
+    }
+}
+
 // ---- Engine ------------------------------------------------------------------------------------
 
 Engine::Engine(const mst_config& cfg) : cfg_(cfg)
@@ -310,7 +347,7 @@ void Engine::update(const mst_calibration& calib)
 }
 
 void Engine::compose_device(const void* const* d_frames, const size_t* strides, void* d_pano, size_t pano_stride,
-                            void* d_mask, size_t mask_stride, hipStream_t stream)
+                            void* d_mask, size_t mask_stride, hipStream_t stream, StageTimer* timer)
 {
     select_device(cfg_.device);
     std::shared_ptr<CalibState> st = state();
@@ -329,19 +366,31 @@ void Engine::compose_device(const void* const* d_frames, const size_t* strides, 
     uint8_t* pano = static_cast<uint8_t*>(d_pano);
     uint8_t* pmask = static_cast<uint8_t*>(d_mask);
 
+    auto mark = [&](const char* name) { if (timer) timer->mark(name, s); };
+    if (timer) timer->begin(s);
     if (st->blend_kind == MST_BLEND_MULTI_BAND) {
         const int nb = st->num_bands;
         launch_warp_border_s16(st->d_desc, st->seg_level[0], fa, s);
-        for (int l = 0; l < nb; ++l) launch_pyrdown_s16(st->d_desc, st->seg_level[l + 1], l, s);
-        for (int l = nb; l >= 1; --l) launch_band_blend(st->d_desc, st->cv, l, s);
+        mark("k_warp_border_s16");
+        for (int l = 0; l < nb; ++l) {
+            launch_pyrdown_s16(st->d_desc, st->seg_level[l + 1], l, s);
+            mark(l == 0 ? "k_pyrdown_s16[L0]" : "k_pyrdown_s16[L1+]");
+        }
+        for (int l = nb; l >= 1; --l) {
+            launch_band_blend(st->d_desc, st->cv, l, s);
+            mark(l == 1 ? "k_band_blend[L1]" : "k_band_blend[L2+]");
+        }
         launch_band_final(st->d_desc, st->cv, pano, pano_stride, pmask, mask_stride, s);
+        mark("k_band_final");
     } else if (st->blend_kind == MST_BLEND_FEATHER) {
         launch_feather_compose(st->d_desc, st->n, fa, st->d_feather_ws, st->canvas.width, st->canvas.height, pano,
                                pano_stride, pmask, mask_stride, s);
+        mark("k_feather_compose");
     } else {
         launch_paste_compose(st->d_desc, st->n, fa, st->canvas.width, st->canvas.height, st->crop_x, st->crop_y,
                              st->out_w, st->out_h, (cfg_.flags & MST_FLAG_DRIVER_LUT) ? 1 : 0, pano, pano_stride,
                              pmask, mask_stride, s);
+        mark("k_paste_compose");
     }
     check_hip(hipGetLastError(), "compose kernels");
     std::lock_guard<std::mutex> lk(mu_);

@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mi355_stitch.h"
@@ -68,6 +69,19 @@ struct CalibState {
     ~CalibState();
 };
 
+// Records a HIP event on the compose stream between consecutive kernel launches of one frame.
+class StageTimer {
+public:
+    ~StageTimer();
+    void begin(hipStream_t s);
+    void mark(const char* name, hipStream_t s);
+    void collect(std::vector<std::pair<std::string, float>>& out);   // waits for the last event
+private:
+    std::vector<hipEvent_t> events_;
+    std::vector<const char*> names_;
+    size_t used_ = 0;
+};
+
 class Engine {
 public:
     explicit Engine(const mst_config& cfg);
@@ -75,7 +89,7 @@ public:
     void init();                                       // throws Error
     void update(const mst_calibration& calib);         // throws Error
     void compose_device(const void* const* d_frames, const size_t* strides, void* d_pano, size_t pano_stride,
-                        void* d_mask, size_t mask_stride, hipStream_t stream);
+                        void* d_mask, size_t mask_stride, hipStream_t stream, StageTimer* timer = nullptr);
     void compose_host(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride,
                       uint8_t* pano_mask, size_t mask_stride);
     void synchronize();

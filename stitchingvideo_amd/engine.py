@@ -260,6 +260,19 @@ class PanoramaEngine:
                 self._check(rc)
         return call
 
+    def profile_stages(self, frame_ptrs, frame_strides, pano_ptr, pano_stride, stream=None, max_stages=64):
+        """One frame with a HIP event between consecutive launches -> [(kernel name, ms), ...]."""
+        n = len(frame_ptrs)
+        ptrs = (C.c_void_p * n)(*frame_ptrs)
+        strides = (C.c_size_t * n)(*frame_strides)
+        names = ((C.c_char * 32) * max_stages)()
+        ms = (C.c_float * max_stages)()
+        count = C.c_int()
+        self._check(self._L.mst_compose_profile(self._h, ptrs, strides, pano_ptr, pano_stride, stream, max_stages,
+                                                C.cast(names, C.c_void_p), ms, C.byref(count)))
+        k = min(count.value, max_stages)
+        return [(names[i].value.decode(), float(ms[i])) for i in range(k)]
+
     def synchronize(self):
         self._check(self._L.mst_synchronize(self._h))
 
