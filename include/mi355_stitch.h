@@ -76,6 +76,8 @@ extern "C" {
 #define MST_FLAG_DRIVER_LUT   1u   /* the driver's hard-seam LUT composite with crop margins
                                       (feedSizeRemap, DRV:150-177); requires MST_BLEND_NO */
 
+#define MST_FLAG_DEBUG        2u   /* keep a copy of the collapsed canvas levels for mst_debug_read */
+
 #define MST_MAX_CAMERAS 16
 #define MST_MAX_BANDS   10
 
@@ -186,7 +188,10 @@ int  mst_multiband_geometry(mst_rect canvas, int num_bands, mst_rect image, mst_
 #define MST_DBG_CAM_GAUSS_S16    2   /* Gaussian level `level` of camera c, planar int16 */
 #define MST_DBG_CAM_WEIGHT_F32   3   /* weight pyramid level of camera c, h x w float */
 #define MST_DBG_BAND_WEIGHT_F32  4   /* dst_band_weights_[level], h x w float */
-#define MST_DBG_CANVAS_S16       5   /* collapsed canvas level, planar 3 x h x w int16 */
+#define MST_DBG_CANVAS_S16       5   /* collapsed canvas level (>= 1), planar 3 x h x w int16; needs MST_FLAG_DEBUG */
+#define MST_DBG_CAM_NEED_U8      6   /* h x w bytes: 1 where the Gaussian pixel of camera c / level can reach
+                                        the panorama (the engine skips tiles without any such pixel; skipped
+                                        pixels of the two buffers above read as 0) */
 /* Query (buf == NULL) or copy out the buffer of the last compose / current calibration. */
 int  mst_debug_read(mst_engine *e, int what, int camera, int level, void *buf, size_t buf_bytes,
                     int *width, int *height);

@@ -18,8 +18,10 @@ EXPOS_NO, EXPOS_GAIN, EXPOS_GAIN_BLOCKS = 0, 1, 2
 INTER_NEAREST, INTER_LINEAR = 0, 1
 BORDER_CONSTANT, BORDER_REFLECT = 0, 2
 FLAG_DRIVER_LUT = 1
+FLAG_DEBUG = 2
 MAX_CAMERAS, MAX_BANDS = 16, 10
-DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, DBG_CANVAS_S16 = 1, 2, 3, 4, 5
+DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, DBG_CANVAS_S16, DBG_CAM_NEED_U8 = \
+    1, 2, 3, 4, 5, 6
 
 EXPORTS = [
     "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_canvas", "mst_camera_roi",

@@ -9,6 +9,28 @@ namespace mst {
 constexpr int kMaxCams = 16;
 constexpr int kMaxLevels = 11;   // MST_MAX_BANDS + 1
 
+// Per roi column / row constants of the backward map and of the gain field, laid out so that a
+// thread fetches everything it needs for one axis with 16-byte loads.
+//
+// mapBackward forms  X_i = k_rinv[3i]*x_ + k_rinv[3i+1]*y_ + k_rinv[3i+2]*z_  evaluated left to right,
+// i.e. (A_i + B_i) + C_i.  B_i depends only on the row for all three projections; A_i and C_i depend
+// only on the column for the plane and cylindrical projections (for the spherical one x_ = ra*ca and
+// z_ = ra*cb need one multiply per pixel first).  The products are the same IEEE float products the
+// reference forms, just hoisted.
+struct ColEntry {          // one per roi column (48 bytes)
+    float ca, cb;          // backward-map column terms (geometry.hpp MapTables)
+    float a[3];            // k_rinv[0,3,6] * x_      (plane / cylindrical)
+    float c[3];            // k_rinv[2,5,8] * z_      (plane: * (1 - t2); cylindrical: * cb)
+    int32_t gx0, gx1;      // gain map columns (cv::resize xofs)
+    float gxw0, gxw1;      // their weights
+};
+struct RowEntry {          // one per roi row (32 bytes)
+    float ra;              // spherical: sinf(pi - v/scale)
+    float b[3];            // k_rinv[1,4,7] * y_
+    int32_t gy0, gy1;      // gain map row offsets (row * gw)
+    float gyw0, gyw1;      // their weights
+};
+
 // One camera of one calibration state.  Lives in device memory as an array; kernels index it
 // with a block-uniform camera id so every field is fetched with scalar loads.
 struct CamDesc {
@@ -20,6 +42,8 @@ struct CamDesc {
     float   one_minus_t2;          // (1 - t[2]) of the plane projector
     const float* col_a; const float* col_b;
     const float* row_a; const float* row_b;
+    const ColEntry* cols;          // same data, packed per column (fused kernels)
+    const RowEntry* rows;
     // ---- exposure (a7)
     int32_t expos;                 // MST_EXPOS_*
     float   gain;                  // GAIN
@@ -36,27 +60,44 @@ struct CamDesc {
     int32_t nlev;                  // num_bands + 1
     int32_t lw[kMaxLevels], lh[kMaxLevels];   // bordered pyramid level sizes
     int32_t ox[kMaxLevels], oy[kMaxLevels];   // window origin inside the canvas level
-    int16_t* G[kMaxLevels];        // Gaussian pyramid, planar 3 x lh x lw
-    const float* W[kMaxLevels];    // weight pyramid, lh x lw
+    // Gaussian pyramid.  Every level of a CV_8U-sourced pyramid stays in [0,255] ((sum+128)>>8 of
+    // bytes), so a pixel is stored as one dword B | G<<8 | R<<16 instead of three shorts.
+    uint32_t* G[kMaxLevels];       // lh x lw dwords; G[0] = warped + gained + bordered level 0
+    const float* W[kMaxLevels];    // weight pyramid, lh x lw floats (W[0] = mask/255 with border)
 };
 
 struct FrameArgs {                 // per-frame source pointers, passed by value
     const uint8_t* ptr[kMaxCams];
-    size_t stride[kMaxCams];
+    uint32_t stride[kMaxCams];
 };
 
 struct CanvasDesc {
     int32_t n_cams;
     int32_t nlev;
     int32_t cw[kMaxLevels], ch[kMaxLevels];   // padded canvas pyramid level sizes
-    int16_t* C[kMaxLevels];        // collapsed canvas level, planar 3 x ch x cw
-    const float* WS[kMaxLevels];   // dst_band_weights_
+    int16_t* C[kMaxLevels];        // debug copy of the collapsed canvas levels, planar 3 x ch x cw (optional)
+    const float* WS[kMaxLevels];   // dst_band_weights_ (kept for introspection; kernels re-sum the weights)
     int32_t final_w, final_h;      // dst_roi_final_ (un-padded)
 };
 
-struct SegTable {                  // block index -> (camera, local block) for batched launches
-    int32_t start[kMaxCams + 1];
-    int32_t tiles_x[kMaxCams];
+// Arguments of the fused canvas kernel (k_blend), passed by value.
+struct BlendArgs {
+    int32_t nlev, n_cams;
+    int32_t cw[kMaxLevels], ch[kMaxLevels];   // padded canvas pyramid level sizes
+    int32_t final_w, final_h;                 // dst_roi_final_
+    uint8_t* pano; uint32_t pano_stride;
+    uint8_t* pano_mask; uint32_t mask_stride;
+    const uint32_t* block_cams;               // per block: bit i set = camera i has non-zero weight under the tile
+    int32_t tiles_x;
+    int32_t lds_off[kMaxLevels];              // LDS offset (in pixels) of each level's region buffer
+    int16_t* dbg_C[kMaxLevels];               // optional dump of the collapsed levels (MST_FLAG_DEBUG)
+    float alpha;                              // (float)(1./255.)
+};
+
+// Work lists (static per calibration): only tiles whose output can reach the panorama are launched.
+struct TileList {
+    const uint32_t* tiles;         // cam << 24 | ty << 12 | tx
+    int32_t count;
 };
 
 }  // namespace mst

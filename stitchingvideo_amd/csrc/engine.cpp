@@ -53,6 +53,9 @@ template float* DevicePool::upload<float>(const float*, size_t, hipStream_t);
 template int32_t* DevicePool::upload<int32_t>(const int32_t*, size_t, hipStream_t);
 template uint8_t* DevicePool::upload<uint8_t>(const uint8_t*, size_t, hipStream_t);
 template CamDesc* DevicePool::upload<CamDesc>(const CamDesc*, size_t, hipStream_t);
+template ColEntry* DevicePool::upload<ColEntry>(const ColEntry*, size_t, hipStream_t);
+template RowEntry* DevicePool::upload<RowEntry>(const RowEntry*, size_t, hipStream_t);
+template uint32_t* DevicePool::upload<uint32_t>(const uint32_t*, size_t, hipStream_t);
 
 CalibState::~CalibState()
 {
@@ -77,19 +80,47 @@ void fill_camera_desc(DevicePool& pool, hipStream_t s, const Projector& proj, co
     d.expos = expos_kind;
     d.gain = gain;
     d.gain_map = nullptr; d.gw = d.gh = 0;
+    ResizeAxis ax, ay;
     if (expos_kind == MST_EXPOS_GAIN_BLOCKS) {
         if (!gain_map || gw <= 0 || gh <= 0) throw Error{MST_ERR_INVALID_ARG, "GAIN_BLOCKS needs a gain map"};
         d.gain_map = pool.upload(gain_map, static_cast<size_t>(gw) * gh, s);
         d.gw = gw; d.gh = gh;
-        ResizeAxis ax = build_gain_axis_x(gw, roi.width), ay = build_gain_axis_y(gh, roi.height);
+        ax = build_gain_axis_x(gw, roi.width);
+        ay = build_gain_axis_y(gh, roi.height);
         d.gx0 = pool.upload(ax.ofs0, s); d.gx1 = pool.upload(ax.ofs1, s);
         d.gxw0 = pool.upload(ax.w0, s);  d.gxw1 = pool.upload(ax.w1, s);
         d.gy0 = pool.upload(ay.ofs0, s); d.gy1 = pool.upload(ay.ofs1, s);
         d.gyw0 = pool.upload(ay.w0, s);  d.gyw1 = pool.upload(ay.w1, s);
-        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
-    } else {
-        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
     }
+    // the same constants packed per column / per row for the fused kernels (device_types.hpp)
+    const float* kr = proj.k_rinv;
+    std::vector<ColEntry> cols(roi.width);
+    for (int i = 0; i < roi.width; ++i) {
+        ColEntry& e = cols[i];
+        e = ColEntry{};
+        e.ca = t.col_a[i]; e.cb = t.col_b[i];
+        for (int r = 0; r < 3; ++r) {
+            e.a[r] = kr[3 * r] * e.ca;
+            e.c[r] = proj.kind == kPlane ? kr[3 * r + 2] * d.one_minus_t2 : kr[3 * r + 2] * e.cb;
+        }
+        if (expos_kind == MST_EXPOS_GAIN_BLOCKS) {
+            e.gx0 = ax.ofs0[i]; e.gx1 = ax.ofs1[i]; e.gxw0 = ax.w0[i]; e.gxw1 = ax.w1[i];
+        }
+    }
+    std::vector<RowEntry> rows(roi.height);
+    for (int j = 0; j < roi.height; ++j) {
+        RowEntry& e = rows[j];
+        e = RowEntry{};
+        e.ra = t.row_a[j];
+        const float y_ = proj.kind == kSpherical ? t.row_b[j] : t.row_a[j];
+        for (int r = 0; r < 3; ++r) e.b[r] = kr[3 * r + 1] * y_;
+        if (expos_kind == MST_EXPOS_GAIN_BLOCKS) {
+            e.gy0 = ay.ofs0[j] * gw; e.gy1 = ay.ofs1[j] * gw; e.gyw0 = ay.w0[j]; e.gyw1 = ay.w1[j];
+        }
+    }
+    d.cols = pool.upload(cols, s);
+    d.rows = pool.upload(rows, s);
+    check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
 }
 
 namespace {
@@ -128,20 +159,6 @@ std::vector<float> feather_weight_map(const uint8_t* mask, size_t stride, int w,
         }
     }
     return out;
-}
-
-SegTable make_seg_table(const std::vector<CamDesc>& desc, int level)
-{
-    SegTable seg{};
-    int acc = 0;
-    for (size_t i = 0; i < desc.size(); ++i) {
-        const int tx = (desc[i].lw[level] + 63) / 64, ty = (desc[i].lh[level] + 3) / 4;
-        seg.start[i] = acc;
-        seg.tiles_x[i] = tx;
-        acc += tx * ty;
-    }
-    for (size_t i = desc.size(); i <= static_cast<size_t>(kMaxCams); ++i) seg.start[i] = acc;
-    return seg;
 }
 
 }  // namespace
@@ -289,10 +306,15 @@ void Engine::update(const mst_calibration& calib)
         cv.final_w = st->canvas.width; cv.final_h = st->canvas.height;
         cv.cw[0] = st->padded.width; cv.ch[0] = st->padded.height;
         for (int l = 1; l <= nb; ++l) { cv.cw[l] = (cv.cw[l - 1] + 1) / 2; cv.ch[l] = (cv.ch[l - 1] + 1) / 2; }
+        const bool debug = (cfg_.flags & MST_FLAG_DEBUG) != 0;
         std::vector<float*> ws(nb + 1);
         for (int l = 0; l <= nb; ++l) {
             const size_t px = static_cast<size_t>(cv.cw[l]) * cv.ch[l];
-            cv.C[l] = st->pool.alloc<int16_t>(px * 3);
+            cv.C[l] = nullptr;
+            if (debug && l >= 1) {
+                cv.C[l] = st->pool.alloc<int16_t>(px * 3);
+                check_hip(hipMemsetAsync(cv.C[l], 0, px * 3 * sizeof(int16_t), s), "hipMemsetAsync");
+            }
             ws[l] = st->pool.alloc<float>(px);
             cv.WS[l] = ws[l];
         }
@@ -309,12 +331,13 @@ void Engine::update(const mst_calibration& calib)
             }
             for (int l = 0; l <= nb; ++l) {
                 const size_t px = static_cast<size_t>(d.lw[l]) * d.lh[l];
-                d.G[l] = st->pool.alloc<int16_t>(px * 3);
+                d.G[l] = st->pool.alloc<uint32_t>(px);
+                // tiles the work lists skip are never written: keep them deterministic
+                check_hip(hipMemsetAsync(d.G[l], 0, px * sizeof(uint32_t), s), "hipMemsetAsync");
                 wpyr[i][l] = st->pool.alloc<float>(px);
                 d.W[l] = wpyr[i][l];
             }
         }
-        for (int l = 0; l <= nb; ++l) st->seg_level[l] = make_seg_table(st->desc, l);
         st->d_desc = st->pool.upload(st->desc, s);
         for (int i = 0; i < n; ++i) {
             const CamDesc& d = st->desc[i];
@@ -322,6 +345,39 @@ void Engine::update(const mst_calibration& calib)
             for (int l = 0; l < nb; ++l) launch_pyrdown_f32(wpyr[i][l], d.lw[l], d.lh[l], wpyr[i][l + 1], s);
         }
         for (int l = 0; l <= nb; ++l) launch_band_weight_sum(st->d_desc, n, l, ws[l], cv.cw[l], cv.ch[l], s);
+        check_hip(hipGetLastError(), "weight pyramid kernels");
+
+        // work lists of the fused kernels: read the weight pyramids back once and walk the dependencies
+        std::vector<std::vector<std::vector<float>>> wh(n, std::vector<std::vector<float>>(nb + 1));
+        for (int i = 0; i < n; ++i)
+            for (int l = 0; l <= nb; ++l) {
+                const size_t px = static_cast<size_t>(st->desc[i].lw[l]) * st->desc[i].lh[l];
+                wh[i][l].resize(px);
+                check_hip(hipMemcpyAsync(wh[i][l].data(), wpyr[i][l], px * sizeof(float), hipMemcpyDeviceToHost, s),
+                          "hipMemcpyAsync(D2H weights)");
+            }
+        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(weights)");
+        BlendArgs& ba = st->blend;
+        ba = BlendArgs{};
+        ba.nlev = nb + 1; ba.n_cams = n;
+        for (int l = 0; l <= nb; ++l) { ba.cw[l] = cv.cw[l]; ba.ch[l] = cv.ch[l]; ba.dbg_C[l] = cv.C[l]; }
+        ba.final_w = cv.final_w; ba.final_h = cv.final_h;
+        ba.alpha = static_cast<float>(1. / 255.);
+        build_mb_plan(st->desc, wh, ba, st->plan);
+        const MbPlanHost& plan = st->plan;
+        ba.tiles_x = plan.blend_tiles_x;
+        for (int l = 0; l <= nb; ++l) ba.lds_off[l] = plan.lds_off[l];
+        if (plan.lds_bytes > 64 * 1024) throw Error{MST_ERR_INVALID_ARG, "canvas kernel LDS budget exceeded"};
+        ba.block_cams = st->pool.upload(plan.block_cams, s);
+        st->warp_list.tiles = st->pool.upload(plan.warp_tiles, s);
+        st->warp_list.count = static_cast<int32_t>(plan.warp_tiles.size());
+        st->chain_lists.clear();
+        for (const MbPlanHost::ChainStep& step : plan.chain) {
+            TileList tl;
+            tl.tiles = st->pool.upload(step.tiles, s);
+            tl.count = static_cast<int32_t>(step.tiles.size());
+            st->chain_lists.push_back(tl);
+        }
     } else {
         st->d_desc = st->pool.upload(st->desc, s);
         if (cfg_.blend_kind == MST_BLEND_FEATHER) {
@@ -369,19 +425,17 @@ void Engine::compose_device(const void* const* d_frames, const size_t* strides, 
     auto mark = [&](const char* name) { if (timer) timer->mark(name, s); };
     if (timer) timer->begin(s);
     if (st->blend_kind == MST_BLEND_MULTI_BAND) {
-        const int nb = st->num_bands;
-        launch_warp_border_s16(st->d_desc, st->seg_level[0], fa, s);
-        mark("k_warp_border_s16");
-        for (int l = 0; l < nb; ++l) {
-            launch_pyrdown_s16(st->d_desc, st->seg_level[l + 1], l, s);
-            mark(l == 0 ? "k_pyrdown_s16[L0]" : "k_pyrdown_s16[L1+]");
+        launch_warp_pyr(st->d_desc, cfg_.warp_kind, st->warp_list, fa, s);
+        mark("k_warp_pyr");
+        for (size_t i = 0; i < st->chain_lists.size(); ++i) {
+            launch_pyr_chain(st->d_desc, st->chain_lists[i], st->plan.chain[i].base, st->plan.chain[i].k, s);
+            mark("k_pyr_chain");
         }
-        for (int l = nb; l >= 1; --l) {
-            launch_band_blend(st->d_desc, st->cv, l, s);
-            mark(l == 1 ? "k_band_blend[L1]" : "k_band_blend[L2+]");
-        }
-        launch_band_final(st->d_desc, st->cv, pano, pano_stride, pmask, mask_stride, s);
-        mark("k_band_final");
+        BlendArgs ba = st->blend;
+        ba.pano = pano; ba.pano_stride = static_cast<uint32_t>(pano_stride);
+        ba.pano_mask = pmask; ba.mask_stride = static_cast<uint32_t>(mask_stride);
+        launch_blend(st->d_desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, st->plan.lds_bytes, s);
+        mark("k_blend");
     } else if (st->blend_kind == MST_BLEND_FEATHER) {
         launch_feather_compose(st->d_desc, st->n, fa, st->d_feather_ws, st->canvas.width, st->canvas.height, pano,
                                pano_stride, pmask, mask_stride, s);
@@ -456,19 +510,47 @@ void Engine::debug_read(int what, int camera, int level, void* buf, size_t buf_b
     const void* src = nullptr;
     size_t bytes = 0;
     int ww = 0, hh = 0;
-    const bool per_cam = what == MST_DBG_CAM_WARPED_S16 || what == MST_DBG_CAM_GAUSS_S16 || what == MST_DBG_CAM_WEIGHT_F32;
+    const bool per_cam = what == MST_DBG_CAM_WARPED_S16 || what == MST_DBG_CAM_GAUSS_S16 ||
+                         what == MST_DBG_CAM_WEIGHT_F32 || what == MST_DBG_CAM_NEED_U8;
     if (per_cam) {
         if (camera < 0 || camera >= st->n) throw Error{MST_ERR_INVALID_ARG, "bad camera"};
         const CamDesc& d = st->desc[camera];
         if (what == MST_DBG_CAM_WARPED_S16) level = 0;
         ww = d.lw[level]; hh = d.lh[level];
-        if (what == MST_DBG_CAM_WEIGHT_F32) { src = d.W[level]; bytes = sizeof(float) * ww * hh; }
-        else { src = d.G[level]; bytes = sizeof(int16_t) * 3 * static_cast<size_t>(ww) * hh; }
+        const size_t px = static_cast<size_t>(ww) * hh;
+        if (what == MST_DBG_CAM_NEED_U8) {
+            // host-side work-list mask: which Gaussian pixels of this level can reach the panorama
+            if (w) *w = ww;
+            if (h) *h = hh;
+            if (!buf) return;
+            if (buf_bytes < px) throw Error{MST_ERR_INVALID_ARG, "debug buffer too small"};
+            std::memcpy(buf, st->plan.cams[camera].need[level].data(), px);
+            return;
+        }
+        if (what == MST_DBG_CAM_WEIGHT_F32) { src = d.W[level]; bytes = sizeof(float) * px; }
+        else {
+            // packed B | G<<8 | R<<16 dwords on the device -> planar CV_16S for the caller
+            if (w) *w = ww;
+            if (h) *h = hh;
+            if (!buf) return;
+            if (buf_bytes < sizeof(int16_t) * 3 * px) throw Error{MST_ERR_INVALID_ARG, "debug buffer too small"};
+            std::vector<uint32_t> packed(px);
+            check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+            check_hip(hipMemcpy(packed.data(), d.G[level], px * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+            int16_t* out = static_cast<int16_t*>(buf);
+            for (size_t i = 0; i < px; ++i) {
+                out[i] = static_cast<int16_t>(packed[i] & 0xFF);
+                out[px + i] = static_cast<int16_t>((packed[i] >> 8) & 0xFF);
+                out[2 * px + i] = static_cast<int16_t>((packed[i] >> 16) & 0xFF);
+            }
+            return;
+        }
     } else if (what == MST_DBG_BAND_WEIGHT_F32) {
         ww = st->cv.cw[level]; hh = st->cv.ch[level];
         src = st->cv.WS[level]; bytes = sizeof(float) * static_cast<size_t>(ww) * hh;
     } else if (what == MST_DBG_CANVAS_S16) {
         if (level == 0) throw Error{MST_ERR_INVALID_ARG, "canvas level 0 is written straight to the panorama"};
+        if (!st->cv.C[level]) throw Error{MST_ERR_INVALID_ARG, "create the engine with MST_FLAG_DEBUG to dump canvas levels"};
         ww = st->cv.cw[level]; hh = st->cv.ch[level];
         src = st->cv.C[level]; bytes = sizeof(int16_t) * 3 * static_cast<size_t>(ww) * hh;
     } else {

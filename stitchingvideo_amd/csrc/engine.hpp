@@ -17,6 +17,7 @@
 #include "../../include/mi355_stitch.h"
 #include "device_types.hpp"
 #include "geometry.hpp"
+#include "mb_plan.hpp"
 
 namespace mst {
 
@@ -61,7 +62,10 @@ struct CalibState {
     int num_bands = 0;
     Rect padded;
     CanvasDesc cv{};
-    SegTable seg_level[kMaxLevels]{};   // seg_level[l]: tiles over level-l images of all cameras
+    MbPlanHost plan;                    // work lists of the fused kernels (host copy, for introspection)
+    TileList warp_list{};               // kernel A
+    std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step
+    BlendArgs blend{};                  // kernel C (pano pointers filled per frame)
     // feather
     float* d_feather_ws = nullptr;
     // output rectangle (== canvas unless the driver LUT crop is active)

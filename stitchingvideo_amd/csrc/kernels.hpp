@@ -20,12 +20,12 @@ void launch_band_weight_sum(const CamDesc* d_cams, int n_cams, int level, float*
                             hipStream_t s);
 void launch_feather_weight_sum(const CamDesc* d_cams, int n_cams, float* d_ws, int cw, int ch, hipStream_t s);
 
-// ---- per-frame hot path: multi-band ----
-void launch_warp_border_s16(const CamDesc* d_cams, const SegTable& seg, const FrameArgs& frames, hipStream_t s);
-void launch_pyrdown_s16(const CamDesc* d_cams, const SegTable& seg, int level, hipStream_t s);
-void launch_band_blend(const CamDesc* d_cams, const CanvasDesc& cv, int level, hipStream_t s);
-void launch_band_final(const CamDesc* d_cams, const CanvasDesc& cv, uint8_t* d_pano, size_t pano_stride,
-                       uint8_t* d_pano_mask, size_t mask_stride, hipStream_t s);
+// ---- per-frame hot path: multi-band (kernels_mb.hip) ----
+void mb_tile_dims(int* a_tw0, int* a_th0, int* b_t, int* c_tw, int* c_th);
+void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4]);   // x0, y0, x1, y1
+void launch_warp_pyr(const CamDesc* d_cams, int kind, const TileList& list, const FrameArgs& frames, hipStream_t s);
+void launch_pyr_chain(const CamDesc* d_cams, const TileList& list, int base, int k, hipStream_t s);
+void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, size_t lds_bytes, hipStream_t s);
 
 // ---- per-frame hot path: feather / paste (fully fused: warp + gain + blend in one kernel) ----
 void launch_feather_compose(const CamDesc* d_cams, int n_cams, const FrameArgs& frames, const float* d_ws,

@@ -1,0 +1,175 @@
+// kernels_common.hpp -- device helpers shared by kernels.hip and kernels_mb.hip.
+//
+// Scalar semantics follow the reference's x64/SSE2 build bit for bit (see kernels.hip header
+// for the reference lines).  Everything is compiled with -ffp-contract=off and IEEE-correct
+// f32 division.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "device_types.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mst {
+namespace dev {
+
+constexpr float kWeightEps = 1e-5f;   // WEIGHT_EPS, blenders.cpp:50
+
+// cvRound on x64 (cvtsd2si / cvtps2dq): round-half-even, 0x80000000 when unrepresentable
+__device__ __forceinline__ int cv_round(float v)
+{
+    float r = rintf(v);
+    return (r >= -2147483648.f && r < 2147483648.f) ? static_cast<int>(r) : INT_MIN;
+}
+
+__device__ __forceinline__ int sat_s16(int v) { return min(max(v, -32768), 32767); }
+__device__ __forceinline__ int sat_u8(int v) { return min(max(v, 0), 255); }
+
+// static_cast<short>(float) as the x64 build performs it: cvttss2si, keep the low 16 bits
+__device__ __forceinline__ int trunc_s16(float v)
+{
+    int t = (v > -2147483904.f && v < 2147483648.f) ? static_cast<int>(v) : INT_MIN;
+    return static_cast<int>(static_cast<short>(t));
+}
+
+__device__ __forceinline__ int wrap_s16(int v) { return static_cast<int>(static_cast<short>(v)); }
+
+template <int DELTA>   // DELTA 0 = BORDER_REFLECT, 1 = BORDER_REFLECT_101 (cv::borderInterpolate)
+__device__ __forceinline__ int reflect(int p, int len)
+{
+    if (static_cast<unsigned>(p) < static_cast<unsigned>(len)) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p - 1 + DELTA;
+        else p = len - 1 - (p - len) - DELTA;
+    } while (static_cast<unsigned>(p) >= static_cast<unsigned>(len));
+    return p;
+}
+
+// ---- backward map (generic form, table per axis) -------------------------------------------------
+__device__ __forceinline__ void backward_map(const CamDesc& c, int x, int y, float& mx, float& my)
+{
+    const float ca = c.col_a[x];
+    const float ra = c.row_a[y];
+    float X, Y, Z;
+    if (c.kind == 0) {
+        const float omt = c.one_minus_t2;
+        X = c.kr[0] * ca + c.kr[1] * ra + c.kr[2] * omt;
+        Y = c.kr[3] * ca + c.kr[4] * ra + c.kr[5] * omt;
+        Z = c.kr[6] * ca + c.kr[7] * ra + c.kr[8] * omt;
+        mx = X / Z;
+        my = Y / Z;
+        return;
+    }
+    float x_, y_, z_;
+    const float cb = c.col_b[x];
+    if (c.kind == 1) {
+        x_ = ra * ca;
+        y_ = c.row_b[y];
+        z_ = ra * cb;
+    } else {
+        x_ = ca;
+        y_ = ra;
+        z_ = cb;
+    }
+    X = c.kr[0] * x_ + c.kr[1] * y_ + c.kr[2] * z_;
+    Y = c.kr[3] * x_ + c.kr[4] * y_ + c.kr[5] * z_;
+    Z = c.kr[6] * x_ + c.kr[7] * y_ + c.kr[8] * z_;
+    if (Z > 0) { mx = X / Z; my = Y / Z; }
+    else { mx = -1.f; my = -1.f; }
+}
+
+struct Taps {
+    int x0, x1, y0, y1;     // tap coordinates (already border-resolved, or -1 for constant border)
+    int w00, w01, w10, w11; // 15-bit weights, sum 32768
+};
+
+// fixed-point coordinates of cv::remap: cvRound(map*32), integer part saturated to short
+template <bool REFLECT_BORDER>
+__device__ __forceinline__ Taps linear_taps(float mx, float my, int sw, int sh)
+{
+    const int fsx = cv_round(mx * 32.f), fsy = cv_round(my * 32.f);
+    const int fx = fsx & 31, fy = fsy & 31;
+    const int sx = sat_s16(fsx >> 5), sy = sat_s16(fsy >> 5);
+    Taps t;
+    // BilinearTab_i: (1-fy)(1-fx), (1-fy)fx, fy(1-fx), fy*fx scaled by 2^15.  The table's entry
+    // for fx=fy=0 is {32767,0,0,1} after OpenCV's sum fix-up; on 8-bit data that entry and the
+    // exact {32768,0,0,0} produce the same byte for every input (tests/test_oracle_kat.py), so the
+    // closed form is used.
+    t.w00 = (32 - fx) * (32 - fy) * 32;
+    t.w01 = fx * (32 - fy) * 32;
+    t.w10 = (32 - fx) * fy * 32;
+    t.w11 = fx * fy * 32;
+    if (REFLECT_BORDER) {
+        t.x0 = reflect<0>(sx, sw);     t.x1 = reflect<0>(sx + 1, sw);
+        t.y0 = reflect<0>(sy, sh);     t.y1 = reflect<0>(sy + 1, sh);
+    } else {
+        t.x0 = static_cast<unsigned>(sx) < static_cast<unsigned>(sw) ? sx : -1;
+        t.x1 = static_cast<unsigned>(sx + 1) < static_cast<unsigned>(sw) ? sx + 1 : -1;
+        t.y0 = static_cast<unsigned>(sy) < static_cast<unsigned>(sh) ? sy : -1;
+        t.y1 = static_cast<unsigned>(sy + 1) < static_cast<unsigned>(sh) ? sy + 1 : -1;
+    }
+    return t;
+}
+
+__device__ __forceinline__ int tap_u8(const uint8_t* __restrict__ src, size_t stride, int cn, int x, int y, int k)
+{
+    return (x < 0 || y < 0) ? 0 : static_cast<int>(src[static_cast<size_t>(y) * stride + x * cn + k]);
+}
+
+__device__ __forceinline__ int blend_taps(const Taps& t, int v00, int v01, int v10, int v11)
+{
+    return sat_u8((v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11 + (1 << 14)) >> 15);
+}
+
+// INTER_LINEAR + BORDER_REFLECT on CV_8UC3: the image path of RotationWarper::warp
+__device__ __forceinline__ void sample_linear_reflect_c3(const uint8_t* __restrict__ src, size_t stride,
+                                                         int sw, int sh, float mx, float my, int out[3])
+{
+    const Taps t = linear_taps<true>(mx, my, sw, sh);
+    const uint8_t* r0 = src + static_cast<size_t>(t.y0) * stride;
+    const uint8_t* r1 = src + static_cast<size_t>(t.y1) * stride;
+    const uint8_t* p00 = r0 + t.x0 * 3; const uint8_t* p01 = r0 + t.x1 * 3;
+    const uint8_t* p10 = r1 + t.x0 * 3; const uint8_t* p11 = r1 + t.x1 * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        out[k] = blend_taps(t, p00[k], p01[k], p10[k], p11[k]);
+}
+
+__device__ __forceinline__ float gain_at(const CamDesc& c, int x, int y)
+{
+    if (c.expos == 2) {
+        const int x0 = c.gx0[x], x1 = c.gx1[x];
+        const float a0 = c.gxw0[x], a1 = c.gxw1[x];
+        const float* g0 = c.gain_map + c.gy0[y] * c.gw;
+        const float* g1 = c.gain_map + c.gy1[y] * c.gw;
+        const float b0 = c.gyw0[y], b1 = c.gyw1[y];
+        const float r0 = g0[x0] * a0 + g0[x1] * a1;    // HResizeLinear
+        const float r1 = g1[x0] * a0 + g1[x1] * a1;
+        return r0 * b0 + r1 * b1;                      // VResizeLinear
+    }
+    return c.gain;
+}
+
+// saturate_cast<uchar>(uchar * float)
+__device__ __forceinline__ int apply_gain(int v, float g) { return sat_u8(cv_round(static_cast<float>(v) * g)); }
+
+// warped + exposure-compensated pixel of camera c at roi position (x, y), as CV_16S values
+__device__ __forceinline__ void warped_pixel(const CamDesc& c, const uint8_t* __restrict__ src, size_t stride,
+                                             int x, int y, int out[3])
+{
+    float mx, my;
+    backward_map(c, x, y, mx, my);
+    sample_linear_reflect_c3(src, stride, c.src_w, c.src_h, mx, my, out);
+    if (c.expos != 0) {
+        const float g = gain_at(c, x, y);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] = apply_gain(out[k], g);
+    }
+}
+
+}  // namespace dev
+}  // namespace mst

@@ -1,0 +1,186 @@
+// mb_plan.cpp -- see mb_plan.hpp.
+#include "mb_plan.hpp"
+
+#include <algorithm>
+
+#include "kernels.hpp"
+
+namespace mst {
+
+namespace {
+
+int reflect101(int p, int len)
+{
+    if (static_cast<unsigned>(p) < static_cast<unsigned>(len)) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    } while (static_cast<unsigned>(p) >= static_cast<unsigned>(len));
+    return p;
+}
+
+// source indices cv::pyrUp reads around coarse index j (same clamping as the kernels' up_idx)
+void up_idx(int j, int n, int& jm, int& jp)
+{
+    jm = j == 0 ? std::min(1, n - 1) : j - 1;
+    jp = std::min(j + 1, n - 1);
+}
+
+// mark, at the coarser level, the 3x3 pyrUp sources of every set pixel of the finer level
+void mark_parents(const std::vector<uint8_t>& fine, int fw, int fh, std::vector<uint8_t>& coarse, int cw, int ch)
+{
+    for (int y = 0; y < fh; ++y) {
+        const uint8_t* row = fine.data() + static_cast<size_t>(y) * fw;
+        int im, ip;
+        const int i = y >> 1;
+        up_idx(i, ch, im, ip);
+        const int ys[3] = {im, i, ip};
+        for (int x = 0; x < fw; ++x) {
+            if (!row[x]) continue;
+            int jm, jp;
+            const int j = x >> 1;
+            up_idx(j, cw, jm, jp);
+            for (int yy : ys) {
+                uint8_t* d = coarse.data() + static_cast<size_t>(yy) * cw;
+                d[jm] = 1; d[j] = 1; d[jp] = 1;
+            }
+        }
+    }
+}
+
+// mark, at the finer level, the 5x5 pyrDown footprint (REFLECT_101) of every set pixel of the coarser level
+void mark_footprint(const std::vector<uint8_t>& coarse, int cw, int ch, std::vector<uint8_t>& fine, int fw, int fh)
+{
+    for (int y = 0; y < ch; ++y) {
+        const uint8_t* row = coarse.data() + static_cast<size_t>(y) * cw;
+        int ys[5];
+        for (int t = 0; t < 5; ++t) ys[t] = reflect101(2 * y + t - 2, fh);
+        for (int x = 0; x < cw; ++x) {
+            if (!row[x]) continue;
+            int xs[5];
+            for (int t = 0; t < 5; ++t) xs[t] = reflect101(2 * x + t - 2, fw);
+            for (int yy : ys) {
+                uint8_t* d = fine.data() + static_cast<size_t>(yy) * fw;
+                for (int xx : xs) d[xx] = 1;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<float>>>& weights,
+                   const BlendArgs& blend, MbPlanHost& plan)
+{
+    const int n = static_cast<int>(desc.size());
+    const int nlev = blend.nlev, nb = nlev - 1;
+    int a_tw0, a_th0, b_t, c_tw, c_th;
+    mb_tile_dims(&a_tw0, &a_th0, &b_t, &c_tw, &c_th);
+
+    plan = MbPlanHost{};
+    plan.cams.resize(n);
+    for (int c = 0; c < n; ++c) {
+        const CamDesc& d = desc[c];
+        MbCameraNeed& cn = plan.cams[c];
+        cn.nz.resize(nlev);
+        cn.need.resize(nlev);
+        for (int l = 0; l < nlev; ++l) {
+            const size_t px = static_cast<size_t>(d.lw[l]) * d.lh[l];
+            cn.nz[l].resize(px);
+            const float* w = weights[c][l].data();
+            for (size_t i = 0; i < px; ++i) cn.nz[l][i] = w[i] != 0.f;
+        }
+        for (int l = nb; l >= 0; --l) {
+            cn.need[l] = cn.nz[l];
+            if (l >= 1) mark_parents(cn.nz[l - 1], d.lw[l - 1], d.lh[l - 1], cn.need[l], d.lw[l], d.lh[l]);
+            if (l < nb) mark_footprint(cn.need[l + 1], d.lw[l + 1], d.lh[l + 1], cn.need[l], d.lw[l], d.lh[l]);
+        }
+    }
+
+    // ---- kernel A: level-0 tiles of a_tw0 x a_th0 pixels
+    for (int c = 0; c < n; ++c) {
+        const CamDesc& d = desc[c];
+        const int tiles_x = (d.lw[0] + a_tw0 - 1) / a_tw0, tiles_y = (d.lh[0] + a_th0 - 1) / a_th0;
+        std::vector<uint8_t> used(static_cast<size_t>(tiles_x) * tiles_y, 0);
+        const std::vector<uint8_t>& need0 = plan.cams[c].need[0];
+        for (int y = 0; y < d.lh[0]; ++y) {
+            const uint8_t* row = need0.data() + static_cast<size_t>(y) * d.lw[0];
+            uint8_t* urow = used.data() + static_cast<size_t>(y / a_th0) * tiles_x;
+            for (int x = 0; x < d.lw[0]; ++x)
+                if (row[x]) urow[x / a_tw0] = 1;
+        }
+        for (int ty = 0; ty < tiles_y; ++ty)
+            for (int tx = 0; tx < tiles_x; ++tx)
+                if (used[static_cast<size_t>(ty) * tiles_x + tx])
+                    plan.warp_tiles.push_back(static_cast<uint32_t>(c) << 24 | static_cast<uint32_t>(ty) << 12 | tx);
+    }
+
+    // ---- kernel B: chains of up to four pyrDown levels, tiles of b_t x b_t pixels at the base level
+    for (int base = 1; base < nb;) {
+        const int k = std::min(4, nb - base);
+        MbPlanHost::ChainStep step;
+        step.base = base;
+        step.k = k;
+        for (int c = 0; c < n; ++c) {
+            const CamDesc& d = desc[c];
+            const int tiles_x = (d.lw[base] + b_t - 1) / b_t, tiles_y = (d.lh[base] + b_t - 1) / b_t;
+            std::vector<uint8_t> used(static_cast<size_t>(tiles_x) * tiles_y, 0);
+            for (int j = 1; j <= k; ++j) {
+                const int l = base + j, shift = 6 - j;      // b_t == 64
+                const std::vector<uint8_t>& need = plan.cams[c].need[l];
+                for (int y = 0; y < d.lh[l]; ++y) {
+                    const uint8_t* row = need.data() + static_cast<size_t>(y) * d.lw[l];
+                    uint8_t* urow = used.data() + static_cast<size_t>(y >> shift) * tiles_x;
+                    for (int x = 0; x < d.lw[l]; ++x)
+                        if (row[x]) urow[x >> shift] = 1;
+                }
+            }
+            for (int ty = 0; ty < tiles_y; ++ty)
+                for (int tx = 0; tx < tiles_x; ++tx)
+                    if (used[static_cast<size_t>(ty) * tiles_x + tx])
+                        step.tiles.push_back(static_cast<uint32_t>(c) << 24 | static_cast<uint32_t>(ty) << 12 | tx);
+        }
+        plan.chain.push_back(std::move(step));
+        base += k;
+    }
+
+    // ---- kernel C: canvas tiles, camera bit masks, LDS layout
+    plan.blend_tiles_x = (blend.cw[0] + c_tw - 1) / c_tw;
+    plan.blend_tiles_y = (blend.ch[0] + c_th - 1) / c_th;
+    plan.block_cams.assign(static_cast<size_t>(plan.blend_tiles_x) * plan.blend_tiles_y, 0u);
+    std::vector<int> max_area(nlev, 0);
+    for (int ty = 0; ty < plan.blend_tiles_y; ++ty)
+        for (int tx = 0; tx < plan.blend_tiles_x; ++tx) {
+            uint32_t bits = 0;
+            for (int l = 0; l < nlev; ++l) {
+                int r[4];
+                mb_blend_region(blend, tx, ty, l, r);
+                max_area[l] = std::max(max_area[l], (r[2] - r[0]) * (r[3] - r[1]));
+                for (int c = 0; c < n; ++c) {
+                    if (bits >> c & 1u) continue;
+                    const CamDesc& d = desc[c];
+                    const int x0 = std::max(r[0] - d.ox[l], 0), y0 = std::max(r[1] - d.oy[l], 0);
+                    const int x1 = std::min(r[2] - d.ox[l], d.lw[l]), y1 = std::min(r[3] - d.oy[l], d.lh[l]);
+                    if (x0 >= x1 || y0 >= y1) continue;
+                    const std::vector<uint8_t>& nz = plan.cams[c].nz[l];
+                    bool any = false;
+                    for (int y = y0; y < y1 && !any; ++y) {
+                        const uint8_t* row = nz.data() + static_cast<size_t>(y) * d.lw[l];
+                        for (int x = x0; x < x1; ++x)
+                            if (row[x]) { any = true; break; }
+                    }
+                    if (any) bits |= 1u << c;
+                }
+            }
+            plan.block_cams[static_cast<size_t>(ty) * plan.blend_tiles_x + tx] = bits;
+        }
+    int off = 0;
+    for (int l = 1; l < nlev; ++l) {
+        plan.lds_off[l] = off;
+        off += (max_area[l] + 1) & ~1;
+    }
+    plan.lds_bytes = static_cast<size_t>(off) * 8;
+}
+
+}  // namespace mst

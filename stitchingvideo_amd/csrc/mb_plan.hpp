@@ -1,0 +1,45 @@
+// mb_plan.hpp -- per-calibration work lists of the fused multi-band kernels (host side).
+//
+// The blend weight of a camera is non-zero only near its seam mask (the mask dilated by the
+// [1 4 6 4 1] support of each pyramid level).  Everything outside cannot reach the panorama:
+// short(laplacian * 0.f) == 0 (R64/src/blenders.cpp:321-323).  The plan walks that dependency
+// backwards once per calibration and keeps only the tiles that matter:
+//
+//   nz[l]    where W_c[l] != 0                                (read back from the device)
+//   need[l]  Gaussian pixels of level l that some kept output reads:
+//            need[L] = nz[L] | pyrUp-parents(nz[L-1])
+//            need[l] = nz[l] | pyrUp-parents(nz[l-1]) | pyrDown-footprint(need[l+1])
+//
+// A camera that straddles the +-pi seam of a 360-degree canvas has a roi as wide as the canvas
+// (detectResultRoiByBorder, detail/warpers_inl.hpp:169-203); with these lists it costs no more
+// than any other camera.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "device_types.hpp"
+
+namespace mst {
+
+struct MbCameraNeed {
+    // [level] -> lh*lw bytes
+    std::vector<std::vector<uint8_t>> nz, need;
+};
+
+struct MbPlanHost {
+    std::vector<uint32_t> warp_tiles;                         // kernel A
+    struct ChainStep { int base, k; std::vector<uint32_t> tiles; };
+    std::vector<ChainStep> chain;                             // kernel B launches
+    std::vector<uint32_t> block_cams;                         // kernel C, one entry per canvas tile
+    int blend_tiles_x = 0, blend_tiles_y = 0;
+    int lds_off[kMaxLevels] = {};
+    size_t lds_bytes = 0;
+    std::vector<MbCameraNeed> cams;
+};
+
+// weights[c][l]: host copies of the weight pyramids.  `blend` must have nlev/cw/ch filled in.
+void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<float>>>& weights,
+                   const BlendArgs& blend, MbPlanHost& plan);
+
+}  // namespace mst

@@ -151,7 +151,7 @@ class PanoramaEngine:
     """
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
-                 feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0)):
+                 feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -163,7 +163,7 @@ class PanoramaEngine:
         cfg.num_bands = num_bands
         cfg.feather_sharpness = feather_sharpness
         cfg.device = device
-        cfg.flags = capi.FLAG_DRIVER_LUT if driver_lut else 0
+        cfg.flags = (capi.FLAG_DRIVER_LUT if driver_lut else 0) | (capi.FLAG_DEBUG if debug else 0)
         cfg.upblack, cfg.downblack, cfg.leftblack, cfg.rightblack = crop
         self.num_cameras = num_cameras
         self.device = device
@@ -281,6 +281,8 @@ class PanoramaEngine:
         self._check(self._L.mst_debug_read(self._h, what, camera, level, None, 0, C.byref(w), C.byref(h)))
         if what in (capi.DBG_CAM_WEIGHT_F32, capi.DBG_BAND_WEIGHT_F32):
             buf = np.empty((h.value, w.value), np.float32)
+        elif what == capi.DBG_CAM_NEED_U8:
+            buf = np.empty((h.value, w.value), np.uint8)
         else:
             buf = np.empty((3, h.value, w.value), np.int16)
         self._check(self._L.mst_debug_read(self._h, what, camera, level, buf.ctypes.data, buf.nbytes,
