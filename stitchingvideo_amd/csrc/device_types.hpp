@@ -27,7 +27,7 @@ struct ColEntry {          // one per roi column (48 bytes)
 struct RowEntry {          // one per roi row (32 bytes)
     float ra;              // spherical: sinf(pi - v/scale)
     float b[3];            // k_rinv[1,4,7] * y_
-    int32_t gy0, gy1;      // gain map row offsets (row * gw)
+    int32_t gy0, gy1;      // gain map rows (cv::resize yofs, clipped into the map)
     float gyw0, gyw1;      // their weights
 };
 
@@ -53,6 +53,8 @@ struct CamDesc {
     const int32_t* gy0; const int32_t* gy1; const float* gyw0; const float* gyw1;   // per roi row
     // ---- static per-calibration rasters
     const uint8_t* mask;           // final mask_warped, roi_h x roi_w, tight
+    const uint8_t* mask_b;         // the same mask inside the bordered level-0 window (lh[0] x lw[0], zeros around
+                                   // the roi = copyMakeBorder(BORDER_CONSTANT)); multi-band only
     const float*   feather_w;      // createWeightMap(mask), roi_h x roi_w (feather only)
     int32_t corner_x, corner_y;    // corners[i] - canvas.tl  (feather / paste)
     // ---- multi-band (a15-a18): bordered image geometry and pyramids

@@ -115,7 +115,7 @@ void fill_camera_desc(DevicePool& pool, hipStream_t s, const Projector& proj, co
         const float y_ = proj.kind == kSpherical ? t.row_b[j] : t.row_a[j];
         for (int r = 0; r < 3; ++r) e.b[r] = kr[3 * r + 1] * y_;
         if (expos_kind == MST_EXPOS_GAIN_BLOCKS) {
-            e.gy0 = ay.ofs0[j] * gw; e.gy1 = ay.ofs1[j] * gw; e.gyw0 = ay.w0[j]; e.gyw1 = ay.w1[j];
+            e.gy0 = ay.ofs0[j]; e.gy1 = ay.ofs1[j]; e.gyw0 = ay.w0[j]; e.gyw1 = ay.w1[j];
         }
     }
     d.cols = pool.upload(cols, s);
@@ -319,6 +319,7 @@ void Engine::update(const mst_calibration& calib)
             cv.WS[l] = ws[l];
         }
         std::vector<std::vector<float*>> wpyr(n, std::vector<float*>(nb + 1));
+        std::vector<uint8_t*> mask_b(n, nullptr);
         for (int i = 0; i < n; ++i) {
             CamDesc& d = st->desc[i];
             BandGeometry g = multiband_feed_geometry(st->padded, nb, rois[i]);
@@ -337,10 +338,13 @@ void Engine::update(const mst_calibration& calib)
                 wpyr[i][l] = st->pool.alloc<float>(px);
                 d.W[l] = wpyr[i][l];
             }
+            mask_b[i] = st->pool.alloc<uint8_t>(static_cast<size_t>(d.lw[0]) * d.lh[0] + 16);
+            d.mask_b = mask_b[i];
         }
         st->d_desc = st->pool.upload(st->desc, s);
         for (int i = 0; i < n; ++i) {
             const CamDesc& d = st->desc[i];
+            launch_border_mask(st->d_desc, i, mask_b[i], d.lw[0], d.lh[0], s);
             launch_weight_level0(st->d_desc, i, wpyr[i][0], d.lw[0], d.lh[0], s);
             for (int l = 0; l < nb; ++l) launch_pyrdown_f32(wpyr[i][l], d.lw[l], d.lh[l], wpyr[i][l + 1], s);
         }

@@ -106,6 +106,21 @@ __global__ __launch_bounds__(256) void k_weight_level0(const CamDesc* __restrict
     w0[static_cast<size_t>(y) * bw + x] = w;
 }
 
+// the final mask inside the bordered level-0 window: copyMakeBorder(mask, BORDER_CONSTANT 0)   blenders.cpp:295
+__global__ __launch_bounds__(256) void k_border_mask(const CamDesc* __restrict__ cams, int cam,
+                                                     uint8_t* __restrict__ out, int bw, int bh)
+{
+    const int x = blockIdx.x * kTileW + threadIdx.x, y = blockIdx.y * kTileH + threadIdx.y;
+    if (x >= bw || y >= bh) return;
+    const CamDesc& c = cams[cam];
+    const int rx = x - c.left, ry = y - c.top;
+    uint8_t m = 0;
+    if (static_cast<unsigned>(rx) < static_cast<unsigned>(c.roi_w) &&
+        static_cast<unsigned>(ry) < static_cast<unsigned>(c.roi_h))
+        m = c.mask[static_cast<size_t>(ry) * c.roi_w + rx];
+    out[static_cast<size_t>(y) * bw + x] = m;
+}
+
 // cv::pyrDown CV_32FC1: scalar horizontal pass, then the vertical pass in the order of the x64
 // build: PyrDownVec_32f (SSE) for x < width - width%8, scalar tail after it.
 __global__ __launch_bounds__(256) void k_pyrdown_f32(const float* __restrict__ src, int w, int h,
@@ -276,6 +291,11 @@ void launch_weight_level0(const CamDesc* d_cams, int cam, float* d_w0, int bw, i
 {
     const float alpha = static_cast<float>(1. / 255.);
     hipLaunchKernelGGL(k_weight_level0, grid2d(bw, bh), block2d(), 0, s, d_cams, cam, d_w0, bw, bh, alpha);
+}
+
+void launch_border_mask(const CamDesc* d_cams, int cam, uint8_t* d_out, int bw, int bh, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_border_mask, grid2d(bw, bh), block2d(), 0, s, d_cams, cam, d_out, bw, bh);
 }
 
 void launch_pyrdown_f32(const float* d_src, int w, int h, float* d_dst, hipStream_t s)

@@ -15,6 +15,7 @@ void launch_exposure_apply(const CamDesc* d_cam, uint8_t* d_img, size_t stride, 
 
 // ---- calibration-time static products ----
 void launch_weight_level0(const CamDesc* d_cams, int cam, float* d_w0, int bw, int bh, hipStream_t s);
+void launch_border_mask(const CamDesc* d_cams, int cam, uint8_t* d_out, int bw, int bh, hipStream_t s);
 void launch_pyrdown_f32(const float* d_src, int w, int h, float* d_dst, hipStream_t s);
 void launch_band_weight_sum(const CamDesc* d_cams, int n_cams, int level, float* d_ws, int cw, int ch,
                             hipStream_t s);
@@ -22,6 +23,7 @@ void launch_feather_weight_sum(const CamDesc* d_cams, int n_cams, float* d_ws, i
 
 // ---- per-frame hot path: multi-band (kernels_mb.hip) ----
 void mb_tile_dims(int* a_tw0, int* a_th0, int* b_t, int* c_tw, int* c_th);
+int  mb_chain_depth();                                                           // levels per k_pyr_chain launch
 void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4]);   // x0, y0, x1, y1
 void launch_warp_pyr(const CamDesc* d_cams, int kind, const TileList& list, const FrameArgs& frames, hipStream_t s);
 void launch_pyr_chain(const CamDesc* d_cams, const TileList& list, int base, int k, hipStream_t s);

@@ -1,15 +1,15 @@
-// kernels_mb.hip -- the multi-band frame path as three fused HIP kernels for gfx950.
+// kernels_mb.hip -- the multi-band frame path as fused HIP kernels for gfx950.
 //
 //   A  k_warp_pyr    per camera tile: backward map + fixed-point bilinear sample + exposure gain
 //                    -> level 0 of the BORDER_REFLECT-padded image (kept in LDS, also stored packed)
 //                    -> cv::pyrDown to level 1, straight from LDS.
 //                    (RotationWarper::warp, ExposureCompensator::apply, convertTo(16S),
 //                     copyMakeBorder, first pyrDown: stitcher.cpp:275-285, blenders.cpp:272-274,481)
-//   B  k_pyr_chain   per camera tile: up to four further pyrDown levels inside LDS (blenders.cpp:481)
-//   C  k_blend       per canvas tile, all bands coarse-to-fine in one block: Laplacian = G_l - pyrUp(G_l+1)
+//   B  k_pyr_chain   per camera tile: two further pyrDown levels inside LDS per launch (blenders.cpp:481)
+//   C  k_blend       per canvas tile, all bands in one block: Laplacian = G_l - pyrUp(G_l+1)
 //                    (blenders.cpp:482-487), short(lap * w) accumulate over cameras (:306-330),
-//                    normalise by the re-summed weights (:383-405), add pyrUp of the coarser collapsed
-//                    level held in LDS (:520-530), crop + mask + convertTo(8U) (:369-376, stitcher.cpp:313).
+//                    normalise by the re-summed weights (:383-405), collapse inside LDS (:520-530),
+//                    crop + mask + convertTo(8U) (:369-376, stitcher.cpp:313).
 //
 // Data layout: every Gaussian level of a CV_8U-sourced pyramid stays within [0,255], so a pixel is
 // one dword B | G<<8 | R<<16.  The [1 4 6 4 1] sums are evaluated two channels at a time in the 16-bit
@@ -17,7 +17,12 @@
 // integer arithmetic, identical to the reference's int accumulators.
 //
 // Work lists: only tiles whose output can reach the panorama (non-zero blend weight somewhere down
-// the chain) are launched; the lists are built once per calibration on the host.
+// the chain) are launched; the lists are built once per calibration on the host (mb_plan.cpp).
+//
+// Tuning notes (MI355X, rocprofv3, profiles/): these kernels are bound by dependent-load latency, not
+// by HBM bytes or VALU issue, so they are shaped for occupancy (<= 20 KB LDS and <= 64 VGPRs per
+// block: 8 waves per SIMD) and for memory-level parallelism (the next pixel's gather is issued before
+// the current one is blended; all loads of a quad are issued before the first use).
 #include "kernels.hpp"
 #include "kernels_common.hpp"
 
@@ -33,6 +38,19 @@ namespace {
 __device__ __forceinline__ uint32_t lanes_br(uint32_t p) { return p & 0x00FF00FFu; }
 __device__ __forceinline__ uint32_t lane_g(uint32_t p) { return (p >> 8) & 0xFFu; }
 
+// vertical/horizontal [1 4 6 4 1] on five packed pixels: (B,R lanes) and G
+__device__ __forceinline__ void tap5(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, uint32_t& hbr,
+                                     uint32_t& hg)
+{
+    hbr = lanes_br(p0) + lanes_br(p4) + 4u * (lanes_br(p1) + lanes_br(p3)) + 6u * lanes_br(p2);
+    hg = lane_g(p0) + lane_g(p4) + 4u * (lane_g(p1) + lane_g(p3)) + 6u * lane_g(p2);
+}
+
+__device__ __forceinline__ uint32_t pyrdown_finish(uint32_t vbr, uint32_t vg)
+{
+    return (((vbr + 0x00800080u) >> 8) & 0x00FF00FFu) | (((vg + 128u) >> 8) << 8);
+}
+
 // ======================================================================================================
 // A: warp + gain -> level 0 (LDS + global) -> pyrDown -> level 1
 // ======================================================================================================
@@ -40,18 +58,44 @@ constexpr int A_TW0 = 124, A_TH0 = 32;         // level-0 interior of a tile
 constexpr int A_LW = A_TW0 + 4, A_LH = A_TH0 + 4;   // with the 2-pixel pyrDown halo: 128 x 36
 constexpr int A_TW1 = A_TW0 / 2, A_TH1 = A_TH0 / 2; // level-1 outputs: 62 x 16
 constexpr int A_ROWS_PER_THREAD = A_LH / 2;    // 256 threads = 128 columns x 2 row halves
+constexpr int A_GAIN_ROWS = 4;                 // gain-map rows a tile may span and still stay in registers
 
-// one warped, gain-compensated pixel, packed B | G<<8 | R<<16
+// saturate_cast<uchar>(uchar * float): cvRound + clamp.  For gain < 8e6 the product is far inside
+// int range and clamping in float first is the same function (NaN -> 0 both ways).
+__device__ __forceinline__ int apply_gain_bounded(int v, float g)
+{
+    const float f = rintf(static_cast<float>(v) * g);
+    return static_cast<int>(fminf(fmaxf(f, 0.f), 255.f));
+}
+
+struct PixelFetch {           // one pixel between "addresses issued" and "blended"
+    uint32_t a0, a1, a2, c0, c1, c2;   // raw dwords covering the two 6-byte pixel pairs (fast path)
+    uint32_t sh0, sh1;                 // byte offsets of the pairs inside those dwords
+    int w00, w01, w10, w11;            // 15-bit bilinear weights
+    int sx, sy;                        // integer source coordinate (slow path)
+    float gain;
+    bool fast;
+};
+
+struct WarpConsts {           // per-camera scalars, copied out of the descriptor once
+    float kr[9];
+    int src_w, src_h, expos, gw, gh;
+    float gain;
+    const float* gain_map;
+    const uint8_t* src;
+    uint32_t stride;
+};
+
 template <int KIND>
-__device__ __forceinline__ uint32_t warp_gain_packed(const CamDesc& c, const ColEntry& ce, const RowEntry& re,
-                                                     const uint8_t* __restrict__ src, uint32_t stride)
+__device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const ColEntry& ce, const RowEntry& re, const float H[A_GAIN_ROWS],
+                                            int gmin, bool gain_in_regs, PixelFetch& f)
 {
     float X, Y, Z, mx, my;
     if (KIND == 1) {
         const float x_ = re.ra * ce.ca, z_ = re.ra * ce.cb;
-        X = (c.kr[0] * x_ + re.b[0]) + c.kr[2] * z_;
-        Y = (c.kr[3] * x_ + re.b[1]) + c.kr[5] * z_;
-        Z = (c.kr[6] * x_ + re.b[2]) + c.kr[8] * z_;
+        X = (k.kr[0] * x_ + re.b[0]) + k.kr[2] * z_;
+        Y = (k.kr[3] * x_ + re.b[1]) + k.kr[5] * z_;
+        Z = (k.kr[6] * x_ + re.b[2]) + k.kr[8] * z_;
     } else {
         X = (ce.a[0] + re.b[0]) + ce.c[0];
         Y = (ce.a[1] + re.b[1]) + ce.c[1];
@@ -62,51 +106,69 @@ __device__ __forceinline__ uint32_t warp_gain_packed(const CamDesc& c, const Col
 
     const int fsx = cv_round(mx * 32.f), fsy = cv_round(my * 32.f);
     const int fx = fsx & 31, fy = fsy & 31;
-    const int sx = sat_s16(fsx >> 5), sy = sat_s16(fsy >> 5);
-    const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32;
-    const int w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
-    int b, g, r;
-    if (static_cast<unsigned>(sx) < static_cast<unsigned>(c.src_w - 3) &&
-        static_cast<unsigned>(sy) < static_cast<unsigned>(c.src_h - 1)) {
+    f.sx = sat_s16(fsx >> 5);
+    f.sy = sat_s16(fsy >> 5);
+    f.w00 = (32 - fx) * (32 - fy) * 32; f.w01 = fx * (32 - fy) * 32;
+    f.w10 = (32 - fx) * fy * 32;        f.w11 = fx * fy * 32;
+    f.fast = static_cast<unsigned>(f.sx) < static_cast<unsigned>(k.src_w - 3) &&
+             static_cast<unsigned>(f.sy) < static_cast<unsigned>(k.src_h - 1);
+    if (f.fast) {
         // all four taps inside and 12 readable bytes from the aligned address below: fetch the two
-        // 6-byte pixel pairs with aligned dwordx3 loads and a byte funnel shift
-        const uint8_t* p0 = src + static_cast<uint32_t>(sy) * stride + static_cast<uint32_t>(sx) * 3u;
-        const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p0)) & 3u;
-        const uint32_t* q0 = reinterpret_cast<const uint32_t*>(p0 - sh);
-        const uint8_t* p1 = p0 + stride;
-        const uint32_t sh1 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p1)) & 3u;
-        const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p1 - sh1);
-        const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
-        const uint32_t c0 = q1[0], c1 = q1[1], c2 = q1[2];
-        const uint32_t lo0 = __builtin_amdgcn_alignbyte(a1, a0, sh), hi0 = __builtin_amdgcn_alignbyte(a2, a1, sh);
-        const uint32_t lo1 = __builtin_amdgcn_alignbyte(c1, c0, sh1), hi1 = __builtin_amdgcn_alignbyte(c2, c1, sh1);
-        b = ((lo0 & 0xFF) * w00 + (lo0 >> 24) * w01 + (lo1 & 0xFF) * w10 + (lo1 >> 24) * w11 + (1 << 14)) >> 15;
-        g = (((lo0 >> 8) & 0xFF) * w00 + (hi0 & 0xFF) * w01 + ((lo1 >> 8) & 0xFF) * w10 + (hi1 & 0xFF) * w11 + (1 << 14)) >> 15;
-        r = (((lo0 >> 16) & 0xFF) * w00 + ((hi0 >> 8) & 0xFF) * w01 + ((lo1 >> 16) & 0xFF) * w10 +
-             ((hi1 >> 8) & 0xFF) * w11 + (1 << 14)) >> 15;
+        // 6-byte pixel pairs with aligned dword loads; the byte funnel shift happens at blend time
+        const uint8_t* p0 = k.src + static_cast<uint32_t>(f.sy) * k.stride + static_cast<uint32_t>(f.sx) * 3u;
+        f.sh0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p0)) & 3u;
+        const uint32_t* q0 = reinterpret_cast<const uint32_t*>(p0 - f.sh0);
+        const uint8_t* p1 = p0 + k.stride;
+        f.sh1 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p1)) & 3u;
+        const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p1 - f.sh1);
+        f.a0 = q0[0]; f.a1 = q0[1]; f.a2 = q0[2];
+        f.c0 = q1[0]; f.c1 = q1[1]; f.c2 = q1[2];
+    }
+    f.gain = k.gain;
+    if (k.expos == 2) {
+        float r0, r1;
+        if (gain_in_regs) {
+            const int k0 = re.gy0 - gmin, k1 = re.gy1 - gmin;
+            r0 = k0 == 0 ? H[0] : (k0 == 1 ? H[1] : (k0 == 2 ? H[2] : H[3]));
+            r1 = k1 == 0 ? H[0] : (k1 == 1 ? H[1] : (k1 == 2 ? H[2] : H[3]));
+        } else {
+            const float* g0 = k.gain_map + re.gy0 * k.gw;
+            const float* g1 = k.gain_map + re.gy1 * k.gw;
+            r0 = g0[ce.gx0] * ce.gxw0 + g0[ce.gx1] * ce.gxw1;       // HResizeLinear
+            r1 = g1[ce.gx0] * ce.gxw0 + g1[ce.gx1] * ce.gxw1;
+        }
+        f.gain = r0 * re.gyw0 + r1 * re.gyw1;                        // VResizeLinear
+    }
+}
+
+__device__ __forceinline__ uint32_t blend_pixel(const WarpConsts& k, const PixelFetch& f)
+{
+    int b, g, r;
+    if (f.fast) {
+        const uint32_t lo0 = __builtin_amdgcn_alignbyte(f.a1, f.a0, f.sh0), hi0 = __builtin_amdgcn_alignbyte(f.a2, f.a1, f.sh0);
+        const uint32_t lo1 = __builtin_amdgcn_alignbyte(f.c1, f.c0, f.sh1), hi1 = __builtin_amdgcn_alignbyte(f.c2, f.c1, f.sh1);
+        b = ((lo0 & 0xFF) * f.w00 + (lo0 >> 24) * f.w01 + (lo1 & 0xFF) * f.w10 + (lo1 >> 24) * f.w11 + (1 << 14)) >> 15;
+        g = (((lo0 >> 8) & 0xFF) * f.w00 + (hi0 & 0xFF) * f.w01 + ((lo1 >> 8) & 0xFF) * f.w10 + (hi1 & 0xFF) * f.w11 +
+             (1 << 14)) >> 15;
+        r = (((lo0 >> 16) & 0xFF) * f.w00 + ((hi0 >> 8) & 0xFF) * f.w01 + ((lo1 >> 16) & 0xFF) * f.w10 +
+             ((hi1 >> 8) & 0xFF) * f.w11 + (1 << 14)) >> 15;
     } else {
-        const int x0 = reflect<0>(sx, c.src_w), x1 = reflect<0>(sx + 1, c.src_w);
-        const int y0 = reflect<0>(sy, c.src_h), y1 = reflect<0>(sy + 1, c.src_h);
-        const uint8_t* r0 = src + static_cast<uint32_t>(y0) * stride;
-        const uint8_t* r1 = src + static_cast<uint32_t>(y1) * stride;
+        const int x0 = reflect<0>(f.sx, k.src_w), x1 = reflect<0>(f.sx + 1, k.src_w);
+        const int y0 = reflect<0>(f.sy, k.src_h), y1 = reflect<0>(f.sy + 1, k.src_h);
+        const uint8_t* r0 = k.src + static_cast<uint32_t>(y0) * k.stride;
+        const uint8_t* r1 = k.src + static_cast<uint32_t>(y1) * k.stride;
         const uint8_t* p00 = r0 + x0 * 3; const uint8_t* p01 = r0 + x1 * 3;
         const uint8_t* p10 = r1 + x0 * 3; const uint8_t* p11 = r1 + x1 * 3;
-        b = (p00[0] * w00 + p01[0] * w01 + p10[0] * w10 + p11[0] * w11 + (1 << 14)) >> 15;
-        g = (p00[1] * w00 + p01[1] * w01 + p10[1] * w10 + p11[1] * w11 + (1 << 14)) >> 15;
-        r = (p00[2] * w00 + p01[2] * w01 + p10[2] * w10 + p11[2] * w11 + (1 << 14)) >> 15;
+        b = (p00[0] * f.w00 + p01[0] * f.w01 + p10[0] * f.w10 + p11[0] * f.w11 + (1 << 14)) >> 15;
+        g = (p00[1] * f.w00 + p01[1] * f.w01 + p10[1] * f.w10 + p11[1] * f.w11 + (1 << 14)) >> 15;
+        r = (p00[2] * f.w00 + p01[2] * f.w01 + p10[2] * f.w10 + p11[2] * f.w11 + (1 << 14)) >> 15;
     }
-    if (c.expos != 0) {
-        float gain = c.gain;
-        if (c.expos == 2) {
-            const float* g0 = c.gain_map + re.gy0;
-            const float* g1 = c.gain_map + re.gy1;
-            const float r0 = g0[ce.gx0] * ce.gxw0 + g0[ce.gx1] * ce.gxw1;
-            const float r1 = g1[ce.gx0] * ce.gxw0 + g1[ce.gx1] * ce.gxw1;
-            gain = r0 * re.gyw0 + r1 * re.gyw1;
+    if (k.expos != 0) {
+        if (f.gain >= 8.0e6f) {
+            b = apply_gain(b, f.gain); g = apply_gain(g, f.gain); r = apply_gain(r, f.gain);
+        } else {
+            b = apply_gain_bounded(b, f.gain); g = apply_gain_bounded(g, f.gain); r = apply_gain_bounded(r, f.gain);
         }
-        b = apply_gain(b, gain);
-        g = apply_gain(g, gain);
-        r = apply_gain(r, gain);
     }
     return static_cast<uint32_t>(b) | (static_cast<uint32_t>(g) << 8) | (static_cast<uint32_t>(r) << 16);
 }
@@ -114,100 +176,124 @@ __device__ __forceinline__ uint32_t warp_gain_packed(const CamDesc& c, const Col
 template <int KIND>
 __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ cams, TileList list, FrameArgs frames)
 {
-    __shared__ uint32_t s_l0[A_LH][A_LW];       // level-0 tile with halo, packed pixels (18 KB)
-    __shared__ uint2 s_h[A_LH][A_TW1];          // horizontal [1 4 6 4 1] sums: (B,R lanes | G)  (17.4 KB)
+    __shared__ __attribute__((aligned(16))) uint32_t s_l0[A_LH][A_LW];   // level-0 tile with halo, packed (18 KB)
     __shared__ RowEntry s_rows[A_LH];
+    __shared__ int s_gain_span[2];
 
     const uint32_t t = list.tiles[blockIdx.x];
     const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
-    const int bw = c.lw[0], bh = c.lh[0];
+    const int bw = c.lw[0], bh = c.lh[0], nlev = c.nlev;
     const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;    // level-0 origin of the halo'd tile
     const int tid = threadIdx.x;
+    uint32_t* __restrict__ g0out = c.G[0];
+    uint32_t* __restrict__ g1out = c.G[1];
+    const int lw1 = c.lw[1], lh1 = c.lh[1];
+
+    WarpConsts k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k.kr[i] = c.kr[i];
+    k.src_w = c.src_w; k.src_h = c.src_h; k.expos = c.expos; k.gw = c.gw; k.gh = c.gh;
+    k.gain = c.gain; k.gain_map = c.gain_map;
+    k.src = frames.ptr[cam]; k.stride = frames.stride[cam];
 
     // per tile row: pyrDown's REFLECT_101 into the bordered image, then copyMakeBorder's REFLECT into the roi
-    if (tid < A_LH) {
-        const int by = reflect<1>(ly0 + tid, bh);
-        const int ry = reflect<0>(by - c.top, c.roi_h);
-        s_rows[tid] = c.rows[ry];
+    if (tid < 64) {
+        int gy_lo = INT_MAX, gy_hi = INT_MIN;
+        if (tid < A_LH) {
+            const int by = reflect<1>(ly0 + tid, bh);
+            const int ry = reflect<0>(by - c.top, c.roi_h);
+            const RowEntry re = c.rows[ry];
+            s_rows[tid] = re;
+            gy_lo = re.gy0; gy_hi = re.gy1;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            gy_lo = min(gy_lo, __shfl_xor(gy_lo, o));
+            gy_hi = max(gy_hi, __shfl_xor(gy_hi, o));
+        }
+        if (tid == 0) { s_gain_span[0] = gy_lo; s_gain_span[1] = gy_hi; }
     }
     const int col = tid & (A_LW - 1);
     const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int bx = reflect<1>(lx0 + col, bw);
     const int rx = reflect<0>(bx - c.left, c.roi_w);
     const ColEntry ce = c.cols[rx];
-    const uint8_t* __restrict__ src = frames.ptr[cam];
-    const uint32_t stride = frames.stride[cam];
     __syncthreads();
+
+    // BlocksGainCompensator's resize(gain_map): this column's horizontal interpolation of the few gain-map
+    // rows the tile touches, kept in registers (same float products and sums as the per-pixel form)
+    const int gmin = s_gain_span[0];
+    const bool gain_in_regs = k.expos == 2 && (s_gain_span[1] - gmin) < A_GAIN_ROWS;
+    float H[A_GAIN_ROWS] = {0.f, 0.f, 0.f, 0.f};
+    if (gain_in_regs) {
+#pragma unroll
+        for (int i = 0; i < A_GAIN_ROWS; ++i) {
+            const float* g = k.gain_map + min(gmin + i, k.gh - 1) * k.gw;
+            H[i] = g[ce.gx0] * ce.gxw0 + g[ce.gx1] * ce.gxw1;
+        }
+    }
 
     const int gx = lx0 + col;
     const bool col_interior = col >= 2 && col < A_LW - 2 && gx < bw;
+    const int row0 = half * A_ROWS_PER_THREAD;
+    // software pipeline: the gather of pixel it+1 is in flight while pixel it is blended
+    PixelFetch cur, nxt;
+    fetch_pixel<KIND>(k, ce, s_rows[row0], H, gmin, gain_in_regs, cur);
+#pragma unroll 2
     for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
-        const int row = half * A_ROWS_PER_THREAD + it;
-        const RowEntry re = s_rows[row];
-        const uint32_t px = warp_gain_packed<KIND>(c, ce, re, src, stride);
+        const int row = row0 + it;
+        if (it + 1 < A_ROWS_PER_THREAD) fetch_pixel<KIND>(k, ce, s_rows[row + 1], H, gmin, gain_in_regs, nxt);
+        const uint32_t px = blend_pixel(k, cur);
         s_l0[row][col] = px;
         const int gy = ly0 + row;
         if (col_interior && row >= 2 && row < A_LH - 2 && gy < bh)
-            c.G[0][static_cast<uint32_t>(gy) * bw + gx] = px;
+            g0out[static_cast<uint32_t>(gy) * bw + gx] = px;
+        cur = nxt;
     }
-    if (c.nlev < 2) return;
+    if (nlev < 2) return;
     __syncthreads();
 
-    // horizontal pass
-    for (int idx = tid; idx < A_LH * A_TW1; idx += 256) {
-        const int row = idx / A_TW1, j = idx - row * A_TW1;
-        const uint32_t* p = &s_l0[row][2 * j];
-        const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
-        const uint32_t hbr = lanes_br(p0) + lanes_br(p4) + 4u * (lanes_br(p1) + lanes_br(p3)) + 6u * lanes_br(p2);
-        const uint32_t hg = lane_g(p0) + lane_g(p4) + 4u * (lane_g(p1) + lane_g(p3)) + 6u * lane_g(p2);
-        s_h[row][j] = make_uint2(hbr, hg);
-    }
-    __syncthreads();
-    // vertical pass + (v + 128) >> 8
-    const int lw1 = c.lw[1], lh1 = c.lh[1];
+    // pyrDown straight from the LDS tile: output (j, i) reads rows 2i..2i+4, columns 2j..2j+4
     const int x1 = tx * A_TW1, y1 = ty * A_TH1;
     for (int idx = tid; idx < A_TH1 * A_TW1; idx += 256) {
         const int i = idx / A_TW1, j = idx - i * A_TW1;
         if (x1 + j >= lw1 || y1 + i >= lh1) continue;
-        const uint2 h0 = s_h[2 * i][j], h1 = s_h[2 * i + 1][j], h2 = s_h[2 * i + 2][j], h3 = s_h[2 * i + 3][j],
-                    h4 = s_h[2 * i + 4][j];
-        const uint32_t vbr = h0.x + h4.x + 4u * (h1.x + h3.x) + 6u * h2.x;
-        const uint32_t vg = h0.y + h4.y + 4u * (h1.y + h3.y) + 6u * h2.y;
-        const uint32_t obr = ((vbr + 0x00800080u) >> 8) & 0x00FF00FFu;
-        const uint32_t og = (vg + 128u) >> 8;
-        c.G[1][static_cast<uint32_t>(y1 + i) * lw1 + x1 + j] = obr | (og << 8);
-    }
-}
-
-// ======================================================================================================
-// B: pyrDown chain level b -> b+1 .. b+k (k <= 4) inside LDS
-// ======================================================================================================
-constexpr int B_T = 64;                         // base-level interior of a tile
-constexpr int B_E0 = 109, B_E1 = 53, B_E2 = 25, B_E3 = 11;   // extents for a full k = 4 chain (e4 = 4)
-
-__device__ __forceinline__ uint32_t pyrdown_tap25(const uint32_t* __restrict__ s, int pitch, const int xi[5],
-                                                  const int yi[5])
-{
-    uint32_t vbr = 0, vg = 0;
+        uint32_t vbr = 0, vg = 0;
 #pragma unroll
-    for (int ky = 0; ky < 5; ++ky) {
-        const uint32_t* r = s + yi[ky] * pitch;
-        const uint32_t p0 = r[xi[0]], p1 = r[xi[1]], p2 = r[xi[2]], p3 = r[xi[3]], p4 = r[xi[4]];
-        const uint32_t hbr = lanes_br(p0) + lanes_br(p4) + 4u * (lanes_br(p1) + lanes_br(p3)) + 6u * lanes_br(p2);
-        const uint32_t hg = lane_g(p0) + lane_g(p4) + 4u * (lane_g(p1) + lane_g(p3)) + 6u * lane_g(p2);
-        const uint32_t wy = (ky == 2) ? 6u : ((ky == 1 || ky == 3) ? 4u : 1u);
-        vbr += wy * hbr;
-        vg += wy * hg;
+        for (int ky = 0; ky < 5; ++ky) {
+            const uint32_t* r = &s_l0[2 * i + ky][2 * j];
+            const uint2 p01 = *reinterpret_cast<const uint2*>(r);          // 8-byte aligned: 2j is even
+            const uint2 p23 = *reinterpret_cast<const uint2*>(r + 2);
+            const uint32_t p4 = r[4];
+            uint32_t hbr, hg;
+            tap5(p01.x, p01.y, p23.x, p23.y, p4, hbr, hg);
+            const uint32_t wy = (ky == 2) ? 6u : ((ky == 1 || ky == 3) ? 4u : 1u);
+            vbr += wy * hbr;
+            vg += wy * hg;
+        }
+        g1out[static_cast<uint32_t>(y1 + i) * lw1 + x1 + j] = pyrdown_finish(vbr, vg);
     }
-    return (((vbr + 0x00800080u) >> 8) & 0x00FF00FFu) | (((vg + 128u) >> 8) << 8);
 }
 
-__global__ __launch_bounds__(256) void k_pyr_chain(const CamDesc* __restrict__ cams, TileList list, int base, int k)
+// ======================================================================================================
+// B: pyrDown chain level b -> b+1 .. b+k (k <= B_KMAX) inside LDS
+// ======================================================================================================
+// Measured on MI355X (C3): a 4-deep chain per block needs 62 KB of LDS and serialises four
+// barrier-separated phases in too few resident blocks (36-67 us); 2-deep launches with many threads per
+// tile keep the per-thread instruction stream short, which is what bounds these small kernels.
+constexpr int B_T = 64;                         // base-level interior of a tile
+constexpr int B_THREADS = 1024;
+constexpr int B_KMAX = 2;
+constexpr int B_E0 = 73, B_E1 = 35;             // region extents for a full k = 2 chain (e2 = 16)
+
+template <int K>
+__global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restrict__ cams, TileList list, int base)
 {
-    // regions of levels base .. base+3, back to back (47.5 + 11.2 + 2.5 + 0.5 KB)
-    constexpr int kOff1 = B_E0 * B_E0, kOff2 = kOff1 + B_E1 * B_E1, kOff3 = kOff2 + B_E2 * B_E2;
-    __shared__ uint32_t s_all[kOff3 + B_E3 * B_E3];
+    constexpr int k = K;
+    // regions of levels base and base+1, back to back (21.3 + 4.9 KB)
+    constexpr int kOff1 = B_E0 * B_E0;
+    __shared__ uint32_t s_all[kOff1 + B_E1 * B_E1];
     uint32_t* const s_e0 = s_all;
 
     const uint32_t t = list.tiles[blockIdx.x];
@@ -215,55 +301,91 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const CamDesc* __restrict__ c
     const CamDesc& c = cams[cam];
     const int tid = threadIdx.x;
 
-    // extents e[j] and origins lo[j] (in level base+j coordinates) of the regions each level must cover
-    int e[5], lox[5], loy[5];
-    e[k] = B_T >> k;
+    // extents e[j] (compile-time) and origins lo[j] (in level base+j coordinates) of the regions each level covers
+    constexpr int e[B_KMAX + 1] = {K == 2 ? 73 : 67, K == 2 ? 35 : 32, 16};
+    int lox[B_KMAX + 1], loy[B_KMAX + 1];
     lox[k] = (tx * B_T) >> k;
     loy[k] = (ty * B_T) >> k;
+#pragma unroll
     for (int j = k - 1; j >= 0; --j) {
-        e[j] = 2 * e[j + 1] + 3;
         lox[j] = 2 * lox[j + 1] - 2;
         loy[j] = 2 * loy[j + 1] - 2;
     }
-    const int offs[4] = {0, kOff1, kOff2, kOff3};
+    constexpr int offs[B_KMAX] = {0, kOff1};
 
     // load the base region (coordinates outside the image are never referenced: taps are reflected first)
     {
         const int w = c.lw[base], h = c.lh[base];
         const uint32_t* __restrict__ g = c.G[base];
-        for (int idx = tid; idx < e[0] * e[0]; idx += 256) {
+        constexpr int n0 = e[0] * e[0];
+        constexpr int kBatch = (n0 + B_THREADS - 1) / B_THREADS;       // 6 independent loads per thread
+        uint32_t v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int idx = tid + u * B_THREADS;
             const int yy = idx / e[0], xx = idx - yy * e[0];
             const int gx = lox[0] + xx, gy = loy[0] + yy;
-            uint32_t v = 0;
-            if (static_cast<unsigned>(gx) < static_cast<unsigned>(w) && static_cast<unsigned>(gy) < static_cast<unsigned>(h))
-                v = g[static_cast<uint32_t>(gy) * w + gx];
-            s_e0[idx] = v;
+            v[u] = 0;
+            if (idx < n0 && static_cast<unsigned>(gx) < static_cast<unsigned>(w) &&
+                static_cast<unsigned>(gy) < static_cast<unsigned>(h))
+                v[u] = g[static_cast<uint32_t>(gy) * w + gx];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int idx = tid + u * B_THREADS;
+            if (idx < n0) s_e0[idx] = v[u];
         }
     }
     __syncthreads();
 
+#pragma unroll
     for (int j = 0; j < k; ++j) {
         const int sw = c.lw[base + j], sh = c.lh[base + j];          // source level size
         const int dw = c.lw[base + j + 1], dh = c.lh[base + j + 1];  // destination level size
         const uint32_t* __restrict__ s = s_all + offs[j];
-        uint32_t* __restrict__ d = (j + 1 < 4) ? s_all + offs[j + 1] : nullptr;
+        uint32_t* __restrict__ d = (j + 1 < B_KMAX) ? s_all + offs[j + 1] : nullptr;
         uint32_t* __restrict__ gout = c.G[base + j + 1];
+        constexpr int dummy = 0; (void)dummy;
         const int en = e[j + 1], es = e[j];
         // interior of this tile at the destination level
         const int ix0 = (tx * B_T) >> (j + 1), iy0 = (ty * B_T) >> (j + 1), isz = B_T >> (j + 1);
-        for (int idx = tid; idx < en * en; idx += 256) {
+        for (int idx = tid; idx < en * en; idx += B_THREADS) {
             const int yy = idx / en, xx = idx - yy * en;
             const int ox = lox[j + 1] + xx, oy = loy[j + 1] + yy;    // destination coordinates
             if (static_cast<unsigned>(ox) >= static_cast<unsigned>(dw) ||
                 static_cast<unsigned>(oy) >= static_cast<unsigned>(dh))
                 continue;
-            int xi[5], yi[5];
+            uint32_t vbr = 0, vg = 0;
+            // lox[j] == 2*lox[j+1] - 2, so away from the image border tap q of output xx is column 2*xx + q
+            const bool interior = 2 * ox - 2 >= 0 && 2 * ox + 2 < sw && 2 * oy - 2 >= 0 && 2 * oy + 2 < sh;
+            if (interior) {
+                const uint32_t* r = s + (2 * yy) * es + 2 * xx;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                xi[q] = reflect<1>(2 * ox + q - 2, sw) - lox[j];
-                yi[q] = reflect<1>(2 * oy + q - 2, sh) - loy[j];
+                for (int ky = 0; ky < 5; ++ky, r += es) {
+                    uint32_t hbr, hg;
+                    tap5(r[0], r[1], r[2], r[3], r[4], hbr, hg);
+                    const uint32_t wy = (ky == 2) ? 6u : ((ky == 1 || ky == 3) ? 4u : 1u);
+                    vbr += wy * hbr;
+                    vg += wy * hg;
+                }
+            } else {
+                int xi[5], yi[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    xi[q] = reflect<1>(2 * ox + q - 2, sw) - lox[j];
+                    yi[q] = reflect<1>(2 * oy + q - 2, sh) - loy[j];
+                }
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    const uint32_t* r = s + yi[ky] * es;
+                    uint32_t hbr, hg;
+                    tap5(r[xi[0]], r[xi[1]], r[xi[2]], r[xi[3]], r[xi[4]], hbr, hg);
+                    const uint32_t wy = (ky == 2) ? 6u : ((ky == 1 || ky == 3) ? 4u : 1u);
+                    vbr += wy * hbr;
+                    vg += wy * hg;
+                }
             }
-            const uint32_t v = pyrdown_tap25(s, es, xi, yi);
+            const uint32_t v = pyrdown_finish(vbr, vg);
             if (d && j + 1 < k) d[idx] = v;
             if (ox >= ix0 && ox < ix0 + isz && oy >= iy0 && oy < iy0 + isz)
                 gout[static_cast<uint32_t>(oy) * dw + ox] = v;
@@ -273,9 +395,10 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const CamDesc* __restrict__ c
 }
 
 // ======================================================================================================
-// C: all bands of one canvas tile, coarse to fine, one block
+// C: all bands of one canvas tile in one block
 // ======================================================================================================
-constexpr int C_TW = 128, C_TH = 64;
+constexpr int C_TW = 128, C_TH = 32;
+constexpr int C_THREADS = 256;
 
 struct Region { int x0, y0, x1, y1; };
 
@@ -302,30 +425,29 @@ __device__ __forceinline__ void up_idx(int j, int n, int& jm, int& jp)
     jp = min(j + 1, n - 1);
 }
 
-// pyrUp of the packed (unsigned) Gaussian level around coarse pixel (j, i): four fine outputs as
-// (B,R lanes) and G words, before the (v + 32) >> 6 rounding
-__device__ __forceinline__ void pyrup_quad_packed(const uint32_t* __restrict__ g, int sw, int sh, int j, int i,
-                                                  uint32_t obr[4], uint32_t og[4])
+// pyrUp of a packed (unsigned) Gaussian level from its 3x3 source neighbourhood nb[row][col]: four fine
+// outputs per channel pair, already (v + 32) >> 6.  Quad order: (x even,y even), (x odd,y even),
+// (x even,y odd), (x odd,y odd).
+__device__ __forceinline__ void pyrup_quad_packed(const uint32_t nb[3][3], uint32_t obr[4], uint32_t og[4])
 {
-    int jm, jp, im, ip;
-    up_idx(j, sw, jm, jp);
-    up_idx(i, sh, im, ip);
     uint32_t hebr[3], hobr[3], heg[3], hog[3];
-    const int rows[3] = {im, i, ip};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        const uint32_t* p = g + static_cast<uint32_t>(rows[r]) * sw;
-        const uint32_t a = p[jm], b = p[j], c = p[jp];
+        const uint32_t a = nb[r][0], b = nb[r][1], c = nb[r][2];
         hebr[r] = lanes_br(a) + 6u * lanes_br(b) + lanes_br(c);
         hobr[r] = 4u * (lanes_br(b) + lanes_br(c));
         heg[r] = lane_g(a) + 6u * lane_g(b) + lane_g(c);
         hog[r] = 4u * (lane_g(b) + lane_g(c));
     }
-    // quad order: (x even,y even), (x odd,y even), (x even,y odd), (x odd,y odd)
     obr[0] = hebr[0] + 6u * hebr[1] + hebr[2];  og[0] = heg[0] + 6u * heg[1] + heg[2];
     obr[1] = hobr[0] + 6u * hobr[1] + hobr[2];  og[1] = hog[0] + 6u * hog[1] + hog[2];
     obr[2] = 4u * (hebr[1] + hebr[2]);          og[2] = 4u * (heg[1] + heg[2]);
     obr[3] = 4u * (hobr[1] + hobr[2]);          og[3] = 4u * (hog[1] + hog[2]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        obr[q] = ((obr[q] + 0x00200020u) >> 6) & 0x03FF03FFu;
+        og[q] = (og[q] + 32u) >> 6;
+    }
 }
 
 __device__ __forceinline__ int s16_lo(uint32_t v) { return static_cast<int>(static_cast<short>(v & 0xFFFFu)); }
@@ -369,12 +491,14 @@ __device__ __forceinline__ void pyrup_quad_lds(const uint2* __restrict__ s, int 
     }
 }
 
-// One 2x2 quad of canvas level `l` at even coordinates (x, y).  TOP: coarsest level (no pyrUp anywhere);
-// FINAL: level 0 (weights come from the masks, result goes to the panorama).
+// The normalised band of one 2x2 quad of canvas level `l` at even coordinates (x, y): the weighted sum over
+// cameras of their Laplacians divided by the re-summed weights.  It does not depend on any other canvas
+// level, so all levels of a tile are computed without a barrier in between; only the cheap pyrUp + add
+// collapse that follows is sequential.  TOP: coarsest level (the Laplacian is the Gaussian itself and
+// camera windows may start on odd coordinates); FINAL: level 0 (weights come from the masks).
 template <bool TOP, bool FINAL>
-__device__ __forceinline__ void blend_quad(const CamDesc* __restrict__ cams, const BlendArgs& a, int l, int x, int y,
-                                           const bool valid[4], uint32_t cam_bits, const uint2* __restrict__ s_up,
-                                           const Region& up_r, int out[4][3], float ws[4])
+__device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, const BlendArgs& a, int l, int x, int y,
+                                          const bool valid[4], uint32_t cam_bits, int out[4][3], float ws[4])
 {
     int acc[4][3];
 #pragma unroll
@@ -387,62 +511,76 @@ __device__ __forceinline__ void blend_quad(const CamDesc* __restrict__ cams, con
         const int lw = c.lw[l], lh = c.lh[l];
         const int lx = x - c.ox[l], ly = y - c.oy[l];
         float w[4];
-        bool in[4];
+        uint32_t g[4];
+        uint32_t nb[3][3];
         if (TOP) {
             // windows may start on odd coordinates at the coarsest level: test pixel by pixel
+            bool any = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int px = lx + (q & 1), py = ly + (q >> 1);
-                in[q] = valid[q] && static_cast<unsigned>(px) < static_cast<unsigned>(lw) &&
-                        static_cast<unsigned>(py) < static_cast<unsigned>(lh);
-                w[q] = in[q] ? (FINAL ? 0.f : c.W[l][static_cast<uint32_t>(py) * lw + px]) : 0.f;
+                const bool in = valid[q] && static_cast<unsigned>(px) < static_cast<unsigned>(lw) &&
+                                static_cast<unsigned>(py) < static_cast<unsigned>(lh);
+                const uint32_t off = static_cast<uint32_t>(py) * lw + px;
+                w[q] = 0.f;
+                g[q] = 0u;
+                if (in) {
+                    w[q] = FINAL ? static_cast<float>(c.mask_b[off]) * a.alpha + 0.f : c.W[l][off];
+                    g[q] = c.G[l][off];
+                    any = true;
+                }
             }
+            if (!any) continue;
         } else {
             // below the top level every window origin and size is even: the quad is inside or outside as a whole
             const bool inside = static_cast<unsigned>(lx) < static_cast<unsigned>(lw) &&
                                 static_cast<unsigned>(ly) < static_cast<unsigned>(lh);
             if (!inside) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) in[q] = valid[q];
-            if (!FINAL) {
-                const float2 w0 = *reinterpret_cast<const float2*>(c.W[l] + static_cast<uint32_t>(ly) * lw + lx);
-                const float2 w1 = *reinterpret_cast<const float2*>(c.W[l] + static_cast<uint32_t>(ly + 1) * lw + lx);
+            const uint32_t off = static_cast<uint32_t>(ly) * lw + lx;
+            // issue every load of this camera before the first use: weights, Gaussian quad, pyrUp sources
+            uint32_t m01 = 0;
+            float2 w0 = make_float2(0.f, 0.f), w1 = w0;
+            if (FINAL) {
+                // level-0 weight = mask.convertTo(32F, 1/255) with BORDER_CONSTANT 0 around the roi (mask_b)
+                m01 = static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(c.mask_b + off)) |
+                      static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(c.mask_b + off + lw)) << 16;
+            } else {
+                w0 = *reinterpret_cast<const float2*>(c.W[l] + off);
+                w1 = *reinterpret_cast<const float2*>(c.W[l] + off + lw);
+            }
+            const uint2 g0 = *reinterpret_cast<const uint2*>(c.G[l] + off);
+            const uint2 g1 = *reinterpret_cast<const uint2*>(c.G[l] + off + lw);
+            {
+                const int sw = c.lw[l + 1], sh = c.lh[l + 1];
+                int jm, jp, im, ip;
+                const int j = lx >> 1, i = ly >> 1;
+                up_idx(j, sw, jm, jp);
+                up_idx(i, sh, im, ip);
+                const uint32_t* __restrict__ gu = c.G[l + 1];
+                const uint32_t r0 = static_cast<uint32_t>(im) * sw, r1 = static_cast<uint32_t>(i) * sw,
+                               r2 = static_cast<uint32_t>(ip) * sw;
+                nb[0][0] = gu[r0 + jm]; nb[0][1] = gu[r0 + j]; nb[0][2] = gu[r0 + jp];
+                nb[1][0] = gu[r1 + jm]; nb[1][1] = gu[r1 + j]; nb[1][2] = gu[r1 + jp];
+                nb[2][0] = gu[r2 + jm]; nb[2][1] = gu[r2 + j]; nb[2][2] = gu[r2 + jp];
+            }
+            if (FINAL) {
+                w[0] = static_cast<float>(m01 & 0xFF) * a.alpha + 0.f;
+                w[1] = static_cast<float>((m01 >> 8) & 0xFF) * a.alpha + 0.f;
+                w[2] = static_cast<float>((m01 >> 16) & 0xFF) * a.alpha + 0.f;
+                w[3] = static_cast<float>(m01 >> 24) * a.alpha + 0.f;
+            } else {
                 w[0] = w0.x; w[1] = w0.y; w[2] = w1.x; w[3] = w1.y;
             }
-        }
-        if (FINAL) {
-            // level-0 weight: mask.convertTo(32F, 1/255) inside the roi, BORDER_CONSTANT 0 around it
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rx = lx + (q & 1) - c.left, ry = ly + (q >> 1) - c.top;
-                const bool inr = in[q] && static_cast<unsigned>(rx) < static_cast<unsigned>(c.roi_w) &&
-                                 static_cast<unsigned>(ry) < static_cast<unsigned>(c.roi_h);
-                w[q] = inr ? static_cast<float>(c.mask[static_cast<uint32_t>(ry) * c.roi_w + rx]) * a.alpha + 0.f : 0.f;
-            }
+            for (int q = 0; q < 4; ++q) if (!valid[q]) w[q] = 0.f;
+            g[0] = g0.x; g[1] = g0.y; g[2] = g1.x; g[3] = g1.y;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) ws[q] += w[q];              // dst_weight_row[x] += weight_row[x_]
         if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;   // short(v * 0.f) == 0
 
-        uint32_t g[4];
-        if (TOP) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                g[q] = in[q] ? c.G[l][static_cast<uint32_t>(ly + (q >> 1)) * lw + lx + (q & 1)] : 0u;
-        } else {
-            const uint2 g0 = *reinterpret_cast<const uint2*>(c.G[l] + static_cast<uint32_t>(ly) * lw + lx);
-            const uint2 g1 = *reinterpret_cast<const uint2*>(c.G[l] + static_cast<uint32_t>(ly + 1) * lw + lx);
-            g[0] = g0.x; g[1] = g0.y; g[2] = g1.x; g[3] = g1.y;
-        }
         uint32_t ubr[4] = {0, 0, 0, 0}, ug[4] = {0, 0, 0, 0};
-        if (!TOP) {
-            pyrup_quad_packed(c.G[l + 1], c.lw[l + 1], c.lh[l + 1], lx >> 1, ly >> 1, ubr, ug);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ubr[q] = ((ubr[q] + 0x00200020u) >> 6) & 0x03FF03FFu;
-                ug[q] = (ug[q] + 32u) >> 6;
-            }
-        }
+        if (!TOP) pyrup_quad_packed(nb, ubr, ug);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             // laplacian = cv::subtract(G_l, pyrUp(G_l+1)) (|.| <= 255, the saturation cannot trigger);
@@ -456,72 +594,155 @@ __device__ __forceinline__ void blend_quad(const CamDesc* __restrict__ cams, con
         }
     }
 
-    int up[4][3];
-    if (!TOP) pyrup_quad_lds(s_up, up_r.x0, up_r.y0, up_r.x1 - up_r.x0, a.cw[l + 1], a.ch[l + 1], x >> 1, y >> 1, up);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float d = ws[q] + kWeightEps;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
+        for (int ch = 0; ch < 3; ++ch)
             // normalizeUsingWeightMap: static_cast<short>(v / (w + eps)); |v / d| < 2^31 always (d >= 1e-5)
-            int v = wrap_s16(static_cast<int>(static_cast<float>(acc[q][ch]) / d));
-            if (!TOP) v = sat_s16(up[q][ch] + v);                   // restoreImageFromLaplacePyr: cv::add saturates
-            out[q][ch] = v;
-        }
+            out[q][ch] = wrap_s16(static_cast<int>(static_cast<float>(acc[q][ch]) / d));
     }
 }
 
-template <bool TOP, bool FINAL>
-__device__ __forceinline__ void blend_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int l, int tx, int ty,
-                                            uint32_t cam_bits, uint2* __restrict__ lds)
-{
-    const Region r = blend_region(a, tx, ty, l);
-    Region ur = r;
-    const uint2* s_up = nullptr;
-    if (!TOP) {
-        ur = blend_region(a, tx, ty, l + 1);
-        s_up = lds + a.lds_off[l + 1];
+struct QuadIter {
+    Region r;
+    int rw, qw, nq;
+    __device__ __forceinline__ QuadIter(const Region& reg) : r(reg)
+    {
+        rw = r.x1 - r.x0;
+        qw = (rw + 1) >> 1;
+        nq = qw * ((r.y1 - r.y0 + 1) >> 1);
     }
-    uint2* s_out = FINAL ? nullptr : lds + a.lds_off[l];
-    const int rw = r.x1 - r.x0, rh = r.y1 - r.y0;
-    const int qw = (rw + 1) >> 1, qh = (rh + 1) >> 1;
-    const int cw = a.cw[l], ch = a.ch[l];
-    for (int q = threadIdx.x; q < qw * qh; q += 256) {
+    __device__ __forceinline__ void at(int q, int& x, int& y, bool valid[4]) const
+    {
         const int qy = q / qw, qx = q - qy * qw;
-        const int x = r.x0 + 2 * qx, y = r.y0 + 2 * qy;
-        bool valid[4];
+        x = r.x0 + 2 * qx;
+        y = r.y0 + 2 * qy;
 #pragma unroll
         for (int k = 0; k < 4; ++k) valid[k] = (x + (k & 1)) < r.x1 && (y + (k >> 1)) < r.y1;
-        int out[4][3];
+    }
+};
+
+// phase 1: normalised band of one coarse level into its LDS region
+template <bool TOP>
+__device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int l, int tx, int ty,
+                                           uint32_t cam_bits, uint2* __restrict__ lds)
+{
+    const QuadIter it(blend_region(a, tx, ty, l));
+    uint2* s_out = lds + a.lds_off[l];
+    for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
+        int x, y;
+        bool valid[4];
+        it.at(q, x, y, valid);
+        int n[4][3];
         float ws[4];
-        blend_quad<TOP, FINAL>(cams, a, l, x, y, valid, cam_bits, s_up, ur, out, ws);
+        band_quad<TOP, false>(cams, a, l, x, y, valid, cam_bits, n, ws);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (valid[k])
+                s_out[(y + (k >> 1) - it.r.y0) * it.rw + (x + (k & 1) - it.r.x0)] = pack3(n[k][0], n[k][1], n[k][2]);
+    }
+}
+
+__device__ __forceinline__ void dump_level(const BlendArgs& a, int l, int px, int py, const int v[3])
+{
+    const uint32_t plane = static_cast<uint32_t>(a.cw[l]) * a.ch[l];
+    int16_t* dd = a.dbg_C[l] + static_cast<uint32_t>(py) * a.cw[l] + px;
+    dd[0] = static_cast<int16_t>(v[0]);
+    dd[plane] = static_cast<int16_t>(v[1]);
+    dd[2 * plane] = static_cast<int16_t>(v[2]);
+}
+
+// phase 2: restoreImageFromLaplacePyr inside LDS: level l <- saturate(pyrUp(level l+1) + level l)
+__device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx, int ty, uint2* __restrict__ lds)
+{
+    const QuadIter it(blend_region(a, tx, ty, l));
+    const Region ur = blend_region(a, tx, ty, l + 1);
+    const uint2* s_up = lds + a.lds_off[l + 1];
+    uint2* s_io = lds + a.lds_off[l];
+    for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
+        int x, y;
+        bool valid[4];
+        it.at(q, x, y, valid);
+        int up[4][3];
+        pyrup_quad_lds(s_up, ur.x0, ur.y0, ur.x1 - ur.x0, a.cw[l + 1], a.ch[l + 1], x >> 1, y >> 1, up);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!valid[k]) continue;
             const int px = x + (k & 1), py = y + (k >> 1);
-            if (FINAL) {
-                if (px >= a.final_w || py >= a.final_h) continue;       // crop to dst_roi_final_
-                const bool m = ws[k] > kWeightEps;                      // dst_mask_ = dst_band_weights_[0] > eps
-                uint8_t* o = a.pano + static_cast<uint32_t>(py) * a.pano_stride + px * 3;
-                o[0] = m ? static_cast<uint8_t>(sat_u8(out[k][0])) : 0;
-                o[1] = m ? static_cast<uint8_t>(sat_u8(out[k][1])) : 0;
-                o[2] = m ? static_cast<uint8_t>(sat_u8(out[k][2])) : 0;
-                if (a.pano_mask) a.pano_mask[static_cast<uint32_t>(py) * a.mask_stride + px] = m ? 255 : 0;
-            } else {
-                s_out[(py - r.y0) * rw + (px - r.x0)] = pack3(out[k][0], out[k][1], out[k][2]);
-                if (a.dbg_C[l]) {
-                    const uint32_t plane = static_cast<uint32_t>(cw) * ch;
-                    int16_t* dd = a.dbg_C[l] + static_cast<uint32_t>(py) * cw + px;
-                    dd[0] = static_cast<int16_t>(out[k][0]);
-                    dd[plane] = static_cast<int16_t>(out[k][1]);
-                    dd[2 * plane] = static_cast<int16_t>(out[k][2]);
+            uint2* p = s_io + (py - it.r.y0) * it.rw + (px - it.r.x0);
+            const uint2 n = *p;
+            const int v[3] = {sat_s16(up[k][0] + s16_lo(n.x)), sat_s16(up[k][1] + s16_hi(n.x)),
+                              sat_s16(up[k][2] + s16_lo(n.y))};           // cv::add saturates
+            *p = pack3(v[0], v[1], v[2]);
+            if (a.dbg_C[l]) dump_level(a, l, px, py, v);
+        }
+    }
+}
+
+// phase 3: level 0 band + pyrUp of collapsed level 1 -> crop, mask, convertTo(8U), panorama
+template <bool TOP>
+__device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int tx, int ty,
+                                            uint32_t cam_bits, const uint2* __restrict__ lds)
+{
+    const QuadIter it(blend_region(a, tx, ty, 0));
+    Region ur = it.r;
+    const uint2* s_up = nullptr;
+    if (!TOP) {
+        ur = blend_region(a, tx, ty, 1);
+        s_up = lds + a.lds_off[1];
+    }
+    // two bytes per store when the panorama rows allow it (even base and stride)
+    const bool pair_stores = ((reinterpret_cast<uintptr_t>(a.pano) | a.pano_stride) & 1u) == 0;
+    for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
+        int x, y;
+        bool valid[4];
+        it.at(q, x, y, valid);
+        int n[4][3];
+        float ws[4];
+        band_quad<TOP, true>(cams, a, 0, x, y, valid, cam_bits, n, ws);
+        int up[4][3];
+        if (!TOP) pyrup_quad_lds(s_up, ur.x0, ur.y0, ur.x1 - ur.x0, a.cw[1], a.ch[1], x >> 1, y >> 1, up);
+        uint32_t o8[4][3];
+        bool m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = ws[k] > kWeightEps;                                           // dst_mask_ = weights > eps
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const int v = TOP ? n[k][ch] : sat_s16(up[k][ch] + n[k][ch]);
+                o8[k][ch] = m[k] ? static_cast<uint32_t>(sat_u8(v)) : 0u;
+            }
+        }
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry) {
+            const int py = y + ry;
+            if (py >= a.final_h || !valid[2 * ry]) continue;                     // crop to dst_roi_final_
+            uint8_t* o = a.pano + static_cast<uint32_t>(py) * a.pano_stride + x * 3;
+            const uint32_t* p0 = o8[2 * ry];
+            const uint32_t* p1 = o8[2 * ry + 1];
+            const bool both = valid[2 * ry + 1] && x + 1 < a.final_w;
+            if (x < a.final_w) {
+                if (both && pair_stores) {
+                    uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
+                    o16[0] = static_cast<uint16_t>(p0[0] | p0[1] << 8);
+                    o16[1] = static_cast<uint16_t>(p0[2] | p1[0] << 8);
+                    o16[2] = static_cast<uint16_t>(p1[1] | p1[2] << 8);
+                } else {
+                    o[0] = static_cast<uint8_t>(p0[0]); o[1] = static_cast<uint8_t>(p0[1]); o[2] = static_cast<uint8_t>(p0[2]);
+                    if (both) { o[3] = static_cast<uint8_t>(p1[0]); o[4] = static_cast<uint8_t>(p1[1]); o[5] = static_cast<uint8_t>(p1[2]); }
+                }
+                if (a.pano_mask) {
+                    uint8_t* om = a.pano_mask + static_cast<uint32_t>(py) * a.mask_stride + x;
+                    om[0] = m[2 * ry] ? 255 : 0;
+                    if (both) om[1] = m[2 * ry + 1] ? 255 : 0;
                 }
             }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_blend(const CamDesc* __restrict__ cams, BlendArgs a)
+__global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__ cams, BlendArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* lds = reinterpret_cast<uint2*>(smem);
@@ -529,16 +750,30 @@ __global__ __launch_bounds__(256) void k_blend(const CamDesc* __restrict__ cams,
     const uint32_t cam_bits = a.block_cams[blockIdx.x];
     const int top = a.nlev - 1;
     if (top == 0) {
-        blend_level<true, true>(cams, a, 0, tx, ty, cam_bits, lds);
+        final_level<true>(cams, a, tx, ty, cam_bits, lds);
         return;
     }
-    blend_level<true, false>(cams, a, top, tx, ty, cam_bits, lds);
+    // phase 1: every coarse band, independent of each other -> no barrier until all are in LDS
+    band_level<true>(cams, a, top, tx, ty, cam_bits, lds);
+    for (int l = top - 1; l >= 1; --l) band_level<false>(cams, a, l, tx, ty, cam_bits, lds);
     __syncthreads();
+    // phase 2: collapse coarse to fine (LDS only)
+    if (a.dbg_C[top]) {
+        const QuadIter it(blend_region(a, tx, ty, top));
+        const uint2* s = lds + a.lds_off[top];
+        for (int i = threadIdx.x; i < it.rw * (it.r.y1 - it.r.y0); i += C_THREADS) {
+            const int py = it.r.y0 + i / it.rw, px = it.r.x0 + i % it.rw;
+            const uint2 n = s[i];
+            const int v[3] = {s16_lo(n.x), s16_hi(n.x), s16_lo(n.y)};
+            dump_level(a, top, px, py, v);
+        }
+    }
     for (int l = top - 1; l >= 1; --l) {
-        blend_level<false, false>(cams, a, l, tx, ty, cam_bits, lds);
+        collapse_level(a, l, tx, ty, lds);
         __syncthreads();
     }
-    blend_level<false, true>(cams, a, 0, tx, ty, cam_bits, lds);
+    // phase 3
+    final_level<false>(cams, a, tx, ty, cam_bits, lds);
 }
 
 }  // namespace
@@ -551,6 +786,8 @@ void mb_tile_dims(int* a_tw0, int* a_th0, int* b_t, int* c_tw, int* c_th)
 {
     *a_tw0 = A_TW0; *a_th0 = A_TH0; *b_t = B_T; *c_tw = C_TW; *c_th = C_TH;
 }
+
+int mb_chain_depth() { return B_KMAX; }
 
 void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4])
 {
@@ -569,12 +806,13 @@ void launch_warp_pyr(const CamDesc* d_cams, int kind, const TileList& list, cons
 void launch_pyr_chain(const CamDesc* d_cams, const TileList& list, int base, int k, hipStream_t s)
 {
     if (list.count <= 0 || k <= 0) return;
-    hipLaunchKernelGGL(k_pyr_chain, dim3(list.count), dim3(256), 0, s, d_cams, list, base, k);
+    if (k == 1) hipLaunchKernelGGL(k_pyr_chain<1>, dim3(list.count), dim3(B_THREADS), 0, s, d_cams, list, base);
+    else hipLaunchKernelGGL(k_pyr_chain<2>, dim3(list.count), dim3(B_THREADS), 0, s, d_cams, list, base);
 }
 
 void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, size_t lds_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_blend, dim3(num_blocks), dim3(256), lds_bytes, s, d_cams, a);
+    hipLaunchKernelGGL(k_blend, dim3(num_blocks), dim3(C_THREADS), lds_bytes, s, d_cams, a);
 }
 
 }  // namespace mst

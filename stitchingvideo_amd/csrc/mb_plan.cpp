@@ -118,7 +118,7 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
 
     // ---- kernel B: chains of up to four pyrDown levels, tiles of b_t x b_t pixels at the base level
     for (int base = 1; base < nb;) {
-        const int k = std::min(4, nb - base);
+        const int k = std::min(mb_chain_depth(), nb - base);
         MbPlanHost::ChainStep step;
         step.base = base;
         step.k = k;

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (kernel stats + PMC passes) into a small text table.
+Usage: tools/summarize_prof.py gpurun_out/prof_<tag> [> profiles/<name>.txt]"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def short(name):
+    import re
+    m = re.search(r"(k_[a-z0-9_]+)(<[^>]*>)?", name)
+    if m:
+        return m.group(1) + (m.group(2) or "")
+    return name[:40]
+
+
+print("# rocprofv3 summary of: python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline")
+for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    print("\n## kernel stats (%s)" % os.path.relpath(f, root))
+    rows = list(csv.DictReader(open(f)))
+    print("%-28s %8s %12s %12s %12s %8s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
+    for r in rows:
+        if "k_" not in r["Name"]:
+            continue
+        print("%-28s %8s %12.2f %12.2f %12.2f %8s" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                      float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+counters = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        counters[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if counters:
+    print("\n## PMC counters, mean per launch")
+    names = sorted({c for k in counters.values() for c in k})
+    for k, d in sorted(counters.items()):
+        if not k.startswith("k_"):
+            continue
+        print("\n%s" % k)
+        for c in names:
+            if c in d:
+                v = sum(d[c]) / len(d[c])
+                extra = ""
+                if c == "FETCH_SIZE":
+                    extra = "  KB -> x2 (gfx950 wide-read correction) = %.1f MB" % (v * 2 / 1024)
+                if c == "WRITE_SIZE":
+                    extra = "  KB = %.1f MB" % (v / 1024)
+                print("  %-26s %16.1f%s" % (c, v, extra))
