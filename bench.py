@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--frame-sets", type=int, default=3, help="distinct synthetic frame sets cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="do not overlap consecutive frames (latency mode)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = sized to ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = min(host cores, 32))")
     return ap.parse_args()
@@ -84,7 +85,10 @@ def main():
     rig = rigmod.build_rig(cfg)
     blend = cfg["blend"]
     n_cam = len(rig["cameras"])
-    eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank)
+    # throughput mode: frame t+1's per-camera kernels overlap frame t's canvas kernel (frames are resident in
+    # HBM before each call, as MST_FLAG_OVERLAP_FRAMES requires); --no-overlap keeps one stream
+    eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
+                           overlap_frames=not args.no_overlap and blend == "multiband")
     eng.update(rig["scale"], rig["cameras"])
     cx, cy, cw, ch = eng.canvas()
 

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355stitch.so")
+LIB_PATH = os.environ.get("MST_LIB") or os.path.join(_HERE, "libmi355stitch.so")   # MST_LIB: tuning variants
 
 MST_OK = 0
 ERR_INVALID_ARG, ERR_NOT_CALIBRATED, ERR_HIP, ERR_NO_DEVICE, ERR_NEED_MORE_IMGS, ERR_OUT_OF_MEMORY = \
@@ -19,6 +19,7 @@ INTER_NEAREST, INTER_LINEAR = 0, 1
 BORDER_CONSTANT, BORDER_REFLECT = 0, 2
 FLAG_DRIVER_LUT = 1
 FLAG_DEBUG = 2
+FLAG_OVERLAP_FRAMES = 4
 MAX_CAMERAS, MAX_BANDS = 16, 10
 DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, DBG_CANVAS_S16, DBG_CAM_NEED_U8 = \
     1, 2, 3, 4, 5, 6

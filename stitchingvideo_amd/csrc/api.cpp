@@ -83,6 +83,8 @@ int mst_create(const mst_config* cfg, mst_engine** out)
         require(cfg->num_bands <= MST_MAX_BANDS, "too many bands");
         require(!(cfg->flags & MST_FLAG_DRIVER_LUT) || cfg->blend_kind == MST_BLEND_NO,
                 "MST_FLAG_DRIVER_LUT requires MST_BLEND_NO");
+        require(!(cfg->flags & MST_FLAG_OVERLAP_FRAMES) || !(cfg->flags & MST_FLAG_DEBUG),
+                "MST_FLAG_OVERLAP_FRAMES cannot be combined with MST_FLAG_DEBUG");
         created = new mst_engine(*cfg);
         created->impl.init();
     });

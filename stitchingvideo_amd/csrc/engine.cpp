@@ -213,6 +213,11 @@ void Engine::init()
     select_device(cfg_.device);
     check_hip(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     check_hip(hipStreamCreateWithFlags(&calib_stream_, hipStreamNonBlocking), "hipStreamCreate");
+    check_hip(hipStreamCreateWithFlags(&front_stream_, hipStreamNonBlocking), "hipStreamCreate");
+    for (int i = 0; i < 2; ++i) {
+        check_hip(hipEventCreateWithFlags(&ev_front_done_[i], hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&ev_canvas_done_[i], hipEventDisableTiming), "hipEventCreate");
+    }
 }
 
 Engine::~Engine()
@@ -226,6 +231,11 @@ Engine::~Engine()
     if (d_mask_) (void)hipFree(d_mask_);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (calib_stream_) (void)hipStreamDestroy(calib_stream_);
+    if (front_stream_) (void)hipStreamDestroy(front_stream_);
+    for (int i = 0; i < 2; ++i) {
+        if (ev_front_done_[i]) (void)hipEventDestroy(ev_front_done_[i]);
+        if (ev_canvas_done_[i]) (void)hipEventDestroy(ev_canvas_done_[i]);
+    }
 }
 
 std::shared_ptr<CalibState> Engine::state() const
@@ -342,6 +352,19 @@ void Engine::update(const mst_calibration& calib)
             d.mask_b = mask_b[i];
         }
         st->d_desc = st->pool.upload(st->desc, s);
+        if (cfg_.flags & MST_FLAG_OVERLAP_FRAMES) {
+            // second set of Gaussian pyramids: frame t+1's per-camera kernels write it while frame t's
+            // canvas kernel still reads the first
+            std::vector<CamDesc> alt = st->desc;
+            for (int i = 0; i < n; ++i)
+                for (int l = 0; l <= nb; ++l) {
+                    const size_t px = static_cast<size_t>(alt[i].lw[l]) * alt[i].lh[l];
+                    alt[i].G[l] = st->pool.alloc<uint32_t>(px);
+                    check_hip(hipMemsetAsync(alt[i].G[l], 0, px * sizeof(uint32_t), s), "hipMemsetAsync");
+                }
+            st->d_desc_alt = st->pool.upload(alt, s);
+            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
         for (int i = 0; i < n; ++i) {
             const CamDesc& d = st->desc[i];
             launch_border_mask(st->d_desc, i, mask_b[i], d.lw[0], d.lh[0], s);
@@ -429,17 +452,34 @@ void Engine::compose_device(const void* const* d_frames, const size_t* strides, 
     auto mark = [&](const char* name) { if (timer) timer->mark(name, s); };
     if (timer) timer->begin(s);
     if (st->blend_kind == MST_BLEND_MULTI_BAND) {
-        launch_warp_pyr(st->d_desc, cfg_.warp_kind, st->warp_list, fa, s);
+        // Frame pipelining: the per-camera kernels (A, B) of this frame go to front_stream_ and only wait for the
+        // canvas kernel that last read this pyramid set (two frames ago); the canvas kernel (C) stays on the
+        // caller's stream behind them.  Frame t+1's A/B therefore overlap frame t's C.
+        const bool overlap = st->d_desc_alt != nullptr && timer == nullptr && !in_host_compose_;
+        const int slot = overlap ? static_cast<int>(frame_counter_++ & 1u) : 0;
+        const CamDesc* desc = slot ? st->d_desc_alt : st->d_desc;
+        hipStream_t sf = overlap ? front_stream_ : s;
+        if (overlap && canvas_pending_[slot])
+            check_hip(hipStreamWaitEvent(sf, ev_canvas_done_[slot], 0), "hipStreamWaitEvent");
+        launch_warp_pyr(desc, cfg_.warp_kind, st->warp_list, fa, sf);
         mark("k_warp_pyr");
         for (size_t i = 0; i < st->chain_lists.size(); ++i) {
-            launch_pyr_chain(st->d_desc, st->chain_lists[i], st->plan.chain[i].base, st->plan.chain[i].k, s);
+            launch_pyr_chain(desc, st->chain_lists[i], st->plan.chain[i].base, st->plan.chain[i].k, sf);
             mark("k_pyr_chain");
+        }
+        if (overlap) {
+            check_hip(hipEventRecord(ev_front_done_[slot], sf), "hipEventRecord");
+            check_hip(hipStreamWaitEvent(s, ev_front_done_[slot], 0), "hipStreamWaitEvent");
         }
         BlendArgs ba = st->blend;
         ba.pano = pano; ba.pano_stride = static_cast<uint32_t>(pano_stride);
         ba.pano_mask = pmask; ba.mask_stride = static_cast<uint32_t>(mask_stride);
-        launch_blend(st->d_desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, st->plan.lds_bytes, s);
+        launch_blend(desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, st->plan.lds_bytes, s);
         mark("k_blend");
+        if (overlap) {
+            check_hip(hipEventRecord(ev_canvas_done_[slot], s), "hipEventRecord");
+            canvas_pending_[slot] = true;
+        }
     } else if (st->blend_kind == MST_BLEND_FEATHER) {
         launch_feather_compose(st->d_desc, st->n, fa, st->d_feather_ws, st->canvas.width, st->canvas.height, pano,
                                pano_stride, pmask, mask_stride, s);
@@ -495,7 +535,14 @@ void Engine::compose_host(const uint8_t* const* frames, const size_t* strides, u
         check_hip(hipMalloc(reinterpret_cast<void**>(&d_mask_), mbytes), "hipMalloc(mask)");
         d_mask_bytes_ = mbytes;
     }
-    compose_device(dptr.data(), dstride.data(), d_pano_, prow, pano_mask ? d_mask_ : nullptr, mrow, stream_);
+    in_host_compose_ = true;     // the H2D copies above are queued on stream_: keep everything in stream order
+    try {
+        compose_device(dptr.data(), dstride.data(), d_pano_, prow, pano_mask ? d_mask_ : nullptr, mrow, stream_);
+    } catch (...) {
+        in_host_compose_ = false;
+        throw;
+    }
+    in_host_compose_ = false;
     check_hip(hipMemcpy2DAsync(pano, pano_stride, d_pano_, prow, prow, st->out_h, hipMemcpyDeviceToHost, stream_),
               "hipMemcpy2DAsync(pano)");
     if (pano_mask)

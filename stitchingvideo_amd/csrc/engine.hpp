@@ -57,6 +57,7 @@ struct CalibState {
     std::vector<CameraSetup> cams;
     std::vector<CamDesc> desc;      // host copy of the device array
     CamDesc* d_desc = nullptr;
+    CamDesc* d_desc_alt = nullptr;  // same cameras, second set of Gaussian pyramids (frame pipelining)
     Rect canvas;                    // resultRoi(corners, sizes)
     // multi-band
     int num_bands = 0;
@@ -107,6 +108,14 @@ private:
     mst_config cfg_;
     hipStream_t stream_ = nullptr;        // compose stream
     hipStream_t calib_stream_ = nullptr;  // mst_update builds the next state here
+    // Frame pipelining (MST_FLAG_OVERLAP_FRAMES): the per-camera kernels of frame t+1 run on front_stream_
+    // while the canvas kernel of frame t runs on the caller's stream; two pyramid sets alternate.
+    hipStream_t front_stream_ = nullptr;
+    hipEvent_t ev_front_done_[2] = {nullptr, nullptr};   // per-camera work of the slot finished
+    hipEvent_t ev_canvas_done_[2] = {nullptr, nullptr};  // canvas kernel that read the slot finished
+    bool canvas_pending_[2] = {false, false};
+    bool in_host_compose_ = false;
+    uint64_t frame_counter_ = 0;
     mutable std::mutex mu_;
     std::shared_ptr<CalibState> current_;
     std::shared_ptr<CalibState> in_flight_;   // state used by the most recent compose

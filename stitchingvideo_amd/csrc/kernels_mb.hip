@@ -54,7 +54,13 @@ __device__ __forceinline__ uint32_t pyrdown_finish(uint32_t vbr, uint32_t vg)
 // ======================================================================================================
 // A: warp + gain -> level 0 (LDS + global) -> pyrDown -> level 1
 // ======================================================================================================
-constexpr int A_TW0 = 124, A_TH0 = 32;         // level-0 interior of a tile
+#ifndef MST_A_TH0
+#define MST_A_TH0 32
+#endif
+#ifndef MST_A_PATCH
+#define MST_A_PATCH 0      // 1: border pixels in a separate patch pass; 0: inline (measured faster on MI355X)
+#endif
+constexpr int A_TW0 = 124, A_TH0 = MST_A_TH0;  // level-0 interior of a tile
 constexpr int A_LW = A_TW0 + 4, A_LH = A_TH0 + 4;   // with the 2-pixel pyrDown halo: 128 x 36
 constexpr int A_TW1 = A_TW0 / 2, A_TH1 = A_TH0 / 2; // level-1 outputs: 62 x 16
 constexpr int A_ROWS_PER_THREAD = A_LH / 2;    // 256 threads = 128 columns x 2 row halves
@@ -86,7 +92,8 @@ struct WarpConsts {           // per-camera scalars, copied out of the descripto
     uint32_t stride;
 };
 
-template <int KIND>
+// UNIFORM_ROW: every lane of the wave is on the same tile row (true in the main loop, not in the patch pass)
+template <int KIND, bool UNIFORM_ROW = true>
 __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const ColEntry& ce, const RowEntry& re, const float H[A_GAIN_ROWS],
                                             int gmin, bool gain_in_regs, PixelFetch& f)
 {
@@ -112,10 +119,13 @@ __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const ColEntry&
     f.w10 = (32 - fx) * fy * 32;        f.w11 = fx * fy * 32;
     f.fast = static_cast<unsigned>(f.sx) < static_cast<unsigned>(k.src_w - 3) &&
              static_cast<unsigned>(f.sy) < static_cast<unsigned>(k.src_h - 1);
-    if (f.fast) {
-        // all four taps inside and 12 readable bytes from the aligned address below: fetch the two
-        // 6-byte pixel pairs with aligned dword loads; the byte funnel shift happens at blend time
-        const uint8_t* p0 = k.src + static_cast<uint32_t>(f.sy) * k.stride + static_cast<uint32_t>(f.sx) * 3u;
+    if (MST_A_PATCH || f.fast) {
+        // Fast path = all four taps inside and 12 readable bytes from the aligned address below: the two
+        // 6-byte pixel pairs come from aligned dword loads; the byte funnel shift happens at blend time.
+        // The loads are issued unconditionally from a clamped (always valid) address so that no branch sits
+        // between them and their use one iteration later; pixels off the fast path ignore them.
+        const int cx = min(max(f.sx, 0), k.src_w - 4), cy = min(max(f.sy, 0), k.src_h - 2);
+        const uint8_t* p0 = k.src + static_cast<uint32_t>(cy) * k.stride + static_cast<uint32_t>(cx) * 3u;
         f.sh0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p0)) & 3u;
         const uint32_t* q0 = reinterpret_cast<const uint32_t*>(p0 - f.sh0);
         const uint8_t* p1 = p0 + k.stride;
@@ -128,7 +138,9 @@ __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const ColEntry&
     if (k.expos == 2) {
         float r0, r1;
         if (gain_in_regs) {
-            const int k0 = re.gy0 - gmin, k1 = re.gy1 - gmin;
+            // the row is the same for every lane of the wave: scalar selects
+            int k0 = re.gy0 - gmin, k1 = re.gy1 - gmin;
+            if (UNIFORM_ROW) { k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1); }
             r0 = k0 == 0 ? H[0] : (k0 == 1 ? H[1] : (k0 == 2 ? H[2] : H[3]));
             r1 = k1 == 0 ? H[0] : (k1 == 1 ? H[1] : (k1 == 2 ? H[2] : H[3]));
         } else {
@@ -141,10 +153,13 @@ __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const ColEntry&
     }
 }
 
+// SLOW = the border path (per-tap BORDER_REFLECT, byte loads); the main loop only runs the fast form
+// and patches the few border pixels afterwards, so that no divergent load sits inside the pipeline.
+template <bool SLOW>
 __device__ __forceinline__ uint32_t blend_pixel(const WarpConsts& k, const PixelFetch& f)
 {
     int b, g, r;
-    if (f.fast) {
+    if (!SLOW) {
         const uint32_t lo0 = __builtin_amdgcn_alignbyte(f.a1, f.a0, f.sh0), hi0 = __builtin_amdgcn_alignbyte(f.a2, f.a1, f.sh0);
         const uint32_t lo1 = __builtin_amdgcn_alignbyte(f.c1, f.c0, f.sh1), hi1 = __builtin_amdgcn_alignbyte(f.c2, f.c1, f.sh1);
         b = ((lo0 & 0xFF) * f.w00 + (lo0 >> 24) * f.w01 + (lo1 & 0xFF) * f.w10 + (lo1 >> 24) * f.w11 + (1 << 14)) >> 15;
@@ -178,7 +193,6 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_l0[A_LH][A_LW];   // level-0 tile with halo, packed (18 KB)
     __shared__ RowEntry s_rows[A_LH];
-    __shared__ int s_gain_span[2];
 
     const uint32_t t = list.tiles[blockIdx.x];
     const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
@@ -198,21 +212,10 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     k.src = frames.ptr[cam]; k.stride = frames.stride[cam];
 
     // per tile row: pyrDown's REFLECT_101 into the bordered image, then copyMakeBorder's REFLECT into the roi
-    if (tid < 64) {
-        int gy_lo = INT_MAX, gy_hi = INT_MIN;
-        if (tid < A_LH) {
-            const int by = reflect<1>(ly0 + tid, bh);
-            const int ry = reflect<0>(by - c.top, c.roi_h);
-            const RowEntry re = c.rows[ry];
-            s_rows[tid] = re;
-            gy_lo = re.gy0; gy_hi = re.gy1;
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            gy_lo = min(gy_lo, __shfl_xor(gy_lo, o));
-            gy_hi = max(gy_hi, __shfl_xor(gy_hi, o));
-        }
-        if (tid == 0) { s_gain_span[0] = gy_lo; s_gain_span[1] = gy_hi; }
+    if (tid < A_LH) {
+        const int by = reflect<1>(ly0 + tid, bh);
+        const int ry = reflect<0>(by - c.top, c.roi_h);
+        s_rows[tid] = c.rows[ry];
     }
     const int col = tid & (A_LW - 1);
     const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
@@ -223,8 +226,23 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
 
     // BlocksGainCompensator's resize(gain_map): this column's horizontal interpolation of the few gain-map
     // rows the tile touches, kept in registers (same float products and sums as the per-pixel form)
-    const int gmin = s_gain_span[0];
-    const bool gain_in_regs = k.expos == 2 && (s_gain_span[1] - gmin) < A_GAIN_ROWS;
+    int gmin = INT_MAX, gmax = INT_MIN;
+    {
+        const int lane = tid & 63;
+#pragma unroll
+        for (int r = lane; r < A_LH; r += 64) {
+            gmin = min(gmin, s_rows[r].gy0);
+            gmax = max(gmax, s_rows[r].gy1);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            gmin = min(gmin, __shfl_xor(gmin, o));
+            gmax = max(gmax, __shfl_xor(gmax, o));
+        }
+    }
+    gmin = __builtin_amdgcn_readfirstlane(gmin);
+    gmax = __builtin_amdgcn_readfirstlane(gmax);
+    const bool gain_in_regs = k.expos == 2 && (gmax - gmin) < A_GAIN_ROWS;
     float H[A_GAIN_ROWS] = {0.f, 0.f, 0.f, 0.f};
     if (gain_in_regs) {
 #pragma unroll
@@ -237,19 +255,39 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     const int gx = lx0 + col;
     const bool col_interior = col >= 2 && col < A_LW - 2 && gx < bw;
     const int row0 = half * A_ROWS_PER_THREAD;
-    // software pipeline: the gather of pixel it+1 is in flight while pixel it is blended
-    PixelFetch cur, nxt;
-    fetch_pixel<KIND>(k, ce, s_rows[row0], H, gmin, gain_in_regs, cur);
-#pragma unroll 2
-    for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
-        const int row = row0 + it;
-        if (it + 1 < A_ROWS_PER_THREAD) fetch_pixel<KIND>(k, ce, s_rows[row + 1], H, gmin, gain_in_regs, nxt);
-        const uint32_t px = blend_pixel(k, cur);
+    // software pipeline over two explicit register sets: the gather of the next pixel is in flight while
+    // the current one is blended (A_ROWS_PER_THREAD is even; the last prefetch re-reads the last row)
+    static_assert(A_ROWS_PER_THREAD % 2 == 0, "two-stage pipeline needs an even row count");
+    auto emit = [&](int row, uint32_t px) {
         s_l0[row][col] = px;
         const int gy = ly0 + row;
         if (col_interior && row >= 2 && row < A_LH - 2 && gy < bh)
             g0out[static_cast<uint32_t>(gy) * bw + gx] = px;
-        cur = nxt;
+    };
+    const int row_last = row0 + A_ROWS_PER_THREAD - 1;
+    uint64_t slow_rows = 0;           // rows of this column that need the border path
+    PixelFetch fa, fb;
+    fetch_pixel<KIND>(k, ce, s_rows[row0], H, gmin, gain_in_regs, fa);
+    for (int it = 0; it < A_ROWS_PER_THREAD; it += 2) {
+        const int row = row0 + it;
+        fetch_pixel<KIND>(k, ce, s_rows[row + 1], H, gmin, gain_in_regs, fb);
+#if MST_A_PATCH
+        slow_rows |= static_cast<uint64_t>(!fa.fast) << it;
+        emit(row, blend_pixel<false>(k, fa));
+        fetch_pixel<KIND>(k, ce, s_rows[min(row + 2, row_last)], H, gmin, gain_in_regs, fa);
+        slow_rows |= static_cast<uint64_t>(!fb.fast) << (it + 1);
+        emit(row + 1, blend_pixel<false>(k, fb));
+#else
+        emit(row, fa.fast ? blend_pixel<false>(k, fa) : blend_pixel<true>(k, fa));
+        fetch_pixel<KIND>(k, ce, s_rows[min(row + 2, row_last)], H, gmin, gain_in_regs, fa);
+        emit(row + 1, fb.fast ? blend_pixel<false>(k, fb) : blend_pixel<true>(k, fb));
+#endif
+    }
+    while (slow_rows) {               // rare: source taps that touch the frame border
+        const int it = __builtin_ctzll(slow_rows);
+        slow_rows &= slow_rows - 1;
+        fetch_pixel<KIND, false>(k, ce, s_rows[row0 + it], H, gmin, gain_in_regs, fa);
+        emit(row0 + it, blend_pixel<true>(k, fa));
     }
     if (nlev < 2) return;
     __syncthreads();
@@ -397,7 +435,10 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
 // ======================================================================================================
 // C: all bands of one canvas tile in one block
 // ======================================================================================================
-constexpr int C_TW = 128, C_TH = 32;
+#ifndef MST_C_TH
+#define MST_C_TH 64        // 128x64 canvas tiles: 84.5 us vs 87.8 us for 128x32 (C3, MI355X)
+#endif
+constexpr int C_TW = 128, C_TH = MST_C_TH;
 constexpr int C_THREADS = 256;
 
 struct Region { int x0, y0, x1, y1; };

@@ -151,7 +151,8 @@ class PanoramaEngine:
     """
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
-                 feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False):
+                 feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False,
+                 overlap_frames=False):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -163,7 +164,8 @@ class PanoramaEngine:
         cfg.num_bands = num_bands
         cfg.feather_sharpness = feather_sharpness
         cfg.device = device
-        cfg.flags = (capi.FLAG_DRIVER_LUT if driver_lut else 0) | (capi.FLAG_DEBUG if debug else 0)
+        cfg.flags = (capi.FLAG_DRIVER_LUT if driver_lut else 0) | (capi.FLAG_DEBUG if debug else 0) | \
+            (capi.FLAG_OVERLAP_FRAMES if overlap_frames else 0)
         cfg.upblack, cfg.downblack, cfg.leftblack, cfg.rightblack = crop
         self.num_cameras = num_cameras
         self.device = device
