@@ -154,6 +154,11 @@ def main():
         ms_per_step = wall * 1000.0 / args.steps
         dev_ms_per_step = dev_ms / args.steps
         alg_bytes = rigmod.algorithmic_bytes(rig, (cw, ch))
+        traffic = None      # HBM bytes per frame from the committed rocprofv3 PMC passes of this same workload
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.config]["bytes_per_frame"]
+        except (OSError, KeyError, ValueError):
+            pass
         achieved = alg_bytes / (dev_ms_per_step * 1e-3) / 1e9
         out = {
             "metric": "stitched panorama frames/sec, 6x1080p->360deg canvas",
@@ -172,7 +177,7 @@ def main():
                                    % (args.config, n_cam, rig["size"][0], rig["size"][1], rig["warp"], blend, cw, ch),
                        "frames_resident_in_hbm": True, "parallelism": "frames sharded over %d rank(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_frame": alg_bytes,
                          "device_ms_per_frame": round(dev_ms_per_step, 5),
                          "scope": "whole frame (%d launches)" % sum(k["launches_per_frame"] for k in kernels),

@@ -2,11 +2,11 @@
 # Runs on the GPU box (via gpurun): kernel-trace stats + PMC passes of the default bench command.
 # Usage: tools/profile_gpu.sh <tag>      -> gpurun_out/prof_<tag>/...
 set -u
-TAG=${1:-run}
+TAG=${1:-run}; shift; EXTRA="$@"
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 50 --warmup 10 --no-cpu-baseline"
+BENCH="python3 $PWD/bench.py --steps 50 --warmup 10 --no-cpu-baseline $EXTRA"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
 pass() {   # name, counters...
