@@ -164,6 +164,19 @@ int  mst_compose_profile(mst_engine *e, const void *const *d_frames, const size_
                          void *d_pano, size_t pano_stride, void *stream, int max_stages,
                          char (*names)[32], float *stage_ms, int *num_stages);
 
+/* ---- camera streams sharded over GPUs (multi-band only) ---------------------------------------
+ * The reference runs its per-camera work under `#pragma omp parallel for` over cameras (DRV:736,748) and
+ * composites on one thread (DRV:759).  Across GPUs the same split is: every rank holds the full
+ * calibration; rank r runs mst_stage_cameras for the cameras it owns, the per-camera Gaussian pyramid
+ * blocks (mst_pyramid_buffer, one contiguous device buffer per camera, identical size on every rank)
+ * are gathered once per frame into the blending rank's buffers (RCCL send/recv over xGMI), and that rank
+ * runs mst_stage_canvas.  mst_compose_device == stage_cameras(all) + stage_canvas on one GPU. */
+int  mst_stage_cameras(mst_engine *e, uint32_t camera_mask, const void *const *d_frames,
+                       const size_t *frame_strides, void *stream);   /* entries outside the mask are ignored */
+int  mst_stage_canvas(mst_engine *e, void *d_pano, size_t pano_stride, void *d_pano_mask,
+                      size_t pano_mask_stride, void *stream);
+int  mst_pyramid_buffer(mst_engine *e, int camera, void **d_ptr, size_t *bytes);
+
 /* ---- stage-level entry points (the reference's plugin interfaces) ------------------------ */
 /* RotationWarper::warpRoi -- host only, no device needed */
 int  mst_warp_roi(int warp_kind, float scale, const float K[9], const float R[9], const float T[3],

@@ -27,6 +27,7 @@ DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, 
 EXPORTS = [
     "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_canvas", "mst_camera_roi",
     "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_profile", "mst_synchronize", "mst_warp_roi",
+    "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
     "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
     "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame",
 ]
@@ -101,6 +102,12 @@ def load():
                                      C.c_size_t, vp]
     L.mst_synchronize.restype = C.c_int
     L.mst_synchronize.argtypes = [vp]
+    L.mst_stage_cameras.restype = C.c_int
+    L.mst_stage_cameras.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), vp]
+    L.mst_stage_canvas.restype = C.c_int
+    L.mst_stage_canvas.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
+    L.mst_pyramid_buffer.restype = C.c_int
+    L.mst_pyramid_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.mst_compose_profile.restype = C.c_int
     L.mst_compose_profile.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), vp, C.c_size_t, vp, C.c_int,
                                       vp, fp, ip]

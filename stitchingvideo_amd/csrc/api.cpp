@@ -189,6 +189,28 @@ int mst_compose_profile(mst_engine* e, const void* const* d_frames, const size_t
     });
 }
 
+int mst_stage_cameras(mst_engine* e, uint32_t camera_mask, const void* const* d_frames, const size_t* frame_strides,
+                      void* stream)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.stage_cameras(camera_mask, d_frames, frame_strides, static_cast<hipStream_t>(stream)); });
+}
+
+int mst_stage_canvas(mst_engine* e, void* d_pano, size_t pano_stride, void* d_pano_mask, size_t pano_mask_stride,
+                     void* stream)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] {
+        e->impl.stage_canvas(d_pano, pano_stride, d_pano_mask, pano_mask_stride, static_cast<hipStream_t>(stream));
+    });
+}
+
+int mst_pyramid_buffer(mst_engine* e, int camera, void** d_ptr, size_t* bytes)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.pyramid_buffer(camera, d_ptr, bytes); });
+}
+
 int mst_synchronize(mst_engine* e)
 {
     if (!e) return MST_ERR_INVALID_ARG;

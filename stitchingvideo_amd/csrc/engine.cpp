@@ -340,11 +340,19 @@ void Engine::update(const mst_calibration& calib)
                 d.lw[l] = (d.lw[l - 1] + 1) / 2; d.lh[l] = (d.lh[l - 1] + 1) / 2;
                 d.ox[l] = d.ox[l - 1] / 2; d.oy[l] = d.oy[l - 1] / 2;     // blenders.cpp:327-328
             }
+            // one contiguous block per camera for the whole Gaussian pyramid (levels back to back): it is the
+            // unit that travels in the camera-sharded multi-GPU mode (mst_pyramid_buffer)
+            size_t total_px = 0;
+            for (int l = 0; l <= nb; ++l) total_px += static_cast<size_t>(d.lw[l]) * d.lh[l];
+            uint32_t* base = st->pool.alloc<uint32_t>(total_px);
+            // tiles the work lists skip are never written: keep them deterministic
+            check_hip(hipMemsetAsync(base, 0, total_px * sizeof(uint32_t), s), "hipMemsetAsync");
+            st->pyr_base.push_back(base);
+            st->pyr_bytes.push_back(total_px * sizeof(uint32_t));
             for (int l = 0; l <= nb; ++l) {
                 const size_t px = static_cast<size_t>(d.lw[l]) * d.lh[l];
-                d.G[l] = st->pool.alloc<uint32_t>(px);
-                // tiles the work lists skip are never written: keep them deterministic
-                check_hip(hipMemsetAsync(d.G[l], 0, px * sizeof(uint32_t), s), "hipMemsetAsync");
+                d.G[l] = base;
+                base += px;
                 wpyr[i][l] = st->pool.alloc<float>(px);
                 d.W[l] = wpyr[i][l];
             }
@@ -493,6 +501,73 @@ void Engine::compose_device(const void* const* d_frames, const size_t* strides, 
     check_hip(hipGetLastError(), "compose kernels");
     std::lock_guard<std::mutex> lk(mu_);
     in_flight_ = std::move(st);
+}
+
+// ---- camera-sharded multi-GPU mode: per-camera stage and canvas stage as separate calls ----
+
+void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, const size_t* strides, hipStream_t stream)
+{
+    select_device(cfg_.device);
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_stage_cameras before a successful mst_update"};
+    if (st->blend_kind != MST_BLEND_MULTI_BAND) throw Error{MST_ERR_INVALID_ARG, "stage calls exist for multi-band only"};
+    if (!d_frames || !strides) throw Error{MST_ERR_INVALID_ARG, "null frame table"};
+    hipStream_t s = stream ? stream : stream_;
+    FrameArgs fa{};
+    for (int i = 0; i < st->n; ++i) {
+        if (!(camera_mask >> i & 1u)) continue;
+        if (!d_frames[i] || strides[i] < static_cast<size_t>(st->cams[i].src_w) * 3)
+            throw Error{MST_ERR_INVALID_ARG, "bad frame for a camera in the mask"};
+        fa.ptr[i] = static_cast<const uint8_t*>(d_frames[i]);
+        fa.stride[i] = static_cast<uint32_t>(strides[i]);
+    }
+    const MbPlanHost& plan = st->plan;
+    for (int i = 0; i < st->n; ++i) {
+        if (!(camera_mask >> i & 1u)) continue;
+        TileList tl;
+        tl.tiles = st->warp_list.tiles + plan.warp_cam_start[i];
+        tl.count = plan.warp_cam_start[i + 1] - plan.warp_cam_start[i];
+        launch_warp_pyr(st->d_desc, cfg_.warp_kind, tl, fa, s);
+    }
+    for (size_t k = 0; k < st->chain_lists.size(); ++k)
+        for (int i = 0; i < st->n; ++i) {
+            if (!(camera_mask >> i & 1u)) continue;
+            TileList tl;
+            tl.tiles = st->chain_lists[k].tiles + plan.chain[k].cam_start[i];
+            tl.count = plan.chain[k].cam_start[i + 1] - plan.chain[k].cam_start[i];
+            launch_pyr_chain(st->d_desc, tl, plan.chain[k].base, plan.chain[k].k, s);
+        }
+    check_hip(hipGetLastError(), "camera stage kernels");
+    std::lock_guard<std::mutex> lk(mu_);
+    in_flight_ = std::move(st);
+}
+
+void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t mask_stride, hipStream_t stream)
+{
+    select_device(cfg_.device);
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_stage_canvas before a successful mst_update"};
+    if (st->blend_kind != MST_BLEND_MULTI_BAND) throw Error{MST_ERR_INVALID_ARG, "stage calls exist for multi-band only"};
+    if (!d_pano || pano_stride < static_cast<size_t>(st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "bad panorama buffer"};
+    if (d_mask && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
+    hipStream_t s = stream ? stream : stream_;
+    BlendArgs ba = st->blend;
+    ba.pano = static_cast<uint8_t*>(d_pano); ba.pano_stride = static_cast<uint32_t>(pano_stride);
+    ba.pano_mask = static_cast<uint8_t*>(d_mask); ba.mask_stride = static_cast<uint32_t>(mask_stride);
+    launch_blend(st->d_desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, st->plan.lds_bytes, s);
+    check_hip(hipGetLastError(), "canvas stage kernel");
+    std::lock_guard<std::mutex> lk(mu_);
+    in_flight_ = std::move(st);
+}
+
+void Engine::pyramid_buffer(int camera, void** d_ptr, size_t* bytes)
+{
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "no calibration"};
+    if (st->blend_kind != MST_BLEND_MULTI_BAND || camera < 0 || camera >= st->n)
+        throw Error{MST_ERR_INVALID_ARG, "no pyramid for that camera"};
+    if (d_ptr) *d_ptr = st->pyr_base[camera];
+    if (bytes) *bytes = st->pyr_bytes[camera];
 }
 
 void Engine::compose_host(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride,

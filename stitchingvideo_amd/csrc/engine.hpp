@@ -58,6 +58,8 @@ struct CalibState {
     std::vector<CamDesc> desc;      // host copy of the device array
     CamDesc* d_desc = nullptr;
     CamDesc* d_desc_alt = nullptr;  // same cameras, second set of Gaussian pyramids (frame pipelining)
+    std::vector<uint32_t*> pyr_base;   // per camera: the contiguous Gaussian pyramid block (first set)
+    std::vector<size_t> pyr_bytes;
     Rect canvas;                    // resultRoi(corners, sizes)
     // multi-band
     int num_bands = 0;
@@ -97,6 +99,9 @@ public:
                         void* d_mask, size_t mask_stride, hipStream_t stream, StageTimer* timer = nullptr);
     void compose_host(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride,
                       uint8_t* pano_mask, size_t mask_stride);
+    void stage_cameras(uint32_t camera_mask, const void* const* d_frames, const size_t* strides, hipStream_t stream);
+    void stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t mask_stride, hipStream_t stream);
+    void pyramid_buffer(int camera, void** d_ptr, size_t* bytes);
     void synchronize();
     std::shared_ptr<CalibState> state() const;
     void debug_read(int what, int camera, int level, void* buf, size_t buf_bytes, int* w, int* h);

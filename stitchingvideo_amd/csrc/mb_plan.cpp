@@ -100,6 +100,7 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
 
     // ---- kernel A: level-0 tiles of a_tw0 x a_th0 pixels
     for (int c = 0; c < n; ++c) {
+        plan.warp_cam_start.push_back(static_cast<int>(plan.warp_tiles.size()));
         const CamDesc& d = desc[c];
         const int tiles_x = (d.lw[0] + a_tw0 - 1) / a_tw0, tiles_y = (d.lh[0] + a_th0 - 1) / a_th0;
         std::vector<uint8_t> used(static_cast<size_t>(tiles_x) * tiles_y, 0);
@@ -116,13 +117,16 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                     plan.warp_tiles.push_back(static_cast<uint32_t>(c) << 24 | static_cast<uint32_t>(ty) << 12 | tx);
     }
 
-    // ---- kernel B: chains of up to four pyrDown levels, tiles of b_t x b_t pixels at the base level
+    plan.warp_cam_start.push_back(static_cast<int>(plan.warp_tiles.size()));
+
+    // ---- kernel B: chains of pyrDown levels, tiles of b_t x b_t pixels at the base level
     for (int base = 1; base < nb;) {
         const int k = std::min(mb_chain_depth(), nb - base);
         MbPlanHost::ChainStep step;
         step.base = base;
         step.k = k;
         for (int c = 0; c < n; ++c) {
+            step.cam_start.push_back(static_cast<int>(step.tiles.size()));
             const CamDesc& d = desc[c];
             const int tiles_x = (d.lw[base] + b_t - 1) / b_t, tiles_y = (d.lh[base] + b_t - 1) / b_t;
             std::vector<uint8_t> used(static_cast<size_t>(tiles_x) * tiles_y, 0);
@@ -141,6 +145,7 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                     if (used[static_cast<size_t>(ty) * tiles_x + tx])
                         step.tiles.push_back(static_cast<uint32_t>(c) << 24 | static_cast<uint32_t>(ty) << 12 | tx);
         }
+        step.cam_start.push_back(static_cast<int>(step.tiles.size()));
         plan.chain.push_back(std::move(step));
         base += k;
     }

@@ -28,8 +28,9 @@ struct MbCameraNeed {
 };
 
 struct MbPlanHost {
-    std::vector<uint32_t> warp_tiles;                         // kernel A
-    struct ChainStep { int base, k; std::vector<uint32_t> tiles; };
+    std::vector<uint32_t> warp_tiles;                         // kernel A, grouped by camera
+    std::vector<int> warp_cam_start;                          // n+1 offsets into warp_tiles
+    struct ChainStep { int base, k; std::vector<uint32_t> tiles; std::vector<int> cam_start; };
     std::vector<ChainStep> chain;                             // kernel B launches
     std::vector<uint32_t> block_cams;                         // kernel C, one entry per canvas tile
     int blend_tiles_x = 0, blend_tiles_y = 0;

@@ -262,6 +262,27 @@ class PanoramaEngine:
                 self._check(rc)
         return call
 
+    # ---- camera streams sharded over GPUs: per-camera stage, pyramid hand-off, canvas stage ----
+    def stage_cameras(self, cameras, frame_ptrs, frame_strides, stream=None):
+        """Run the per-camera kernels for `cameras` (iterable of indices); frame tables are indexed by camera."""
+        n = self.num_cameras
+        mask = 0
+        for c in cameras:
+            mask |= 1 << c
+        ptrs = (C.c_void_p * n)(*[frame_ptrs.get(i) if isinstance(frame_ptrs, dict) else frame_ptrs[i] for i in range(n)])
+        strides = (C.c_size_t * n)(*[(frame_strides.get(i, 0) if isinstance(frame_strides, dict) else frame_strides[i])
+                                     for i in range(n)])
+        self._check(self._L.mst_stage_cameras(self._h, mask, ptrs, strides, stream))
+
+    def stage_canvas(self, pano_ptr, pano_stride, mask_ptr=None, mask_stride=0, stream=None):
+        self._check(self._L.mst_stage_canvas(self._h, pano_ptr, pano_stride, mask_ptr, mask_stride, stream))
+
+    def pyramid_buffer(self, camera):
+        """-> (device pointer, bytes) of the camera's contiguous Gaussian pyramid block."""
+        p, b = C.c_void_p(), C.c_size_t()
+        self._check(self._L.mst_pyramid_buffer(self._h, camera, C.byref(p), C.byref(b)))
+        return p.value, b.value
+
     def profile_stages(self, frame_ptrs, frame_strides, pano_ptr, pano_stride, stream=None, max_stages=64):
         """One frame with a HIP event between consecutive launches -> [(kernel name, ms), ...]."""
         n = len(frame_ptrs)

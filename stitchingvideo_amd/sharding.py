@@ -82,3 +82,52 @@ gather_stream_tiles.shapes = {}
 def register_tile_shapes(shapes):
     """shapes: {camera: (shape tuple, torch dtype)} -- static per calibration, identical on all ranks."""
     gather_stream_tiles.shapes = dict(shapes)
+
+
+class _DevicePtr:
+    """Zero-copy view of engine-owned device memory as a torch uint8 tensor (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def pyramid_tensor(engine, camera, device):
+    ptr, nbytes = engine.pyramid_buffer(camera)
+    return torch.as_tensor(_DevicePtr(ptr, nbytes), device=device)
+
+
+class ShardedStitcher:
+    """Camera streams sharded one-per-rank, one gather per frame, final blend on `root`.
+
+    Every rank creates the same PanoramaEngine and publishes the same calibration.  Per frame:
+      1. each rank runs the per-camera kernels for the cameras it owns (mst_stage_cameras);
+      2. the owners send those cameras' Gaussian pyramid blocks straight into the root engine's buffers
+         (grouped point-to-point over RCCL: every peer has its own xGMI link to the root; no all-reduce --
+         the payload is ragged and must arrive bit-exact);
+      3. the root runs the canvas kernel (mst_stage_canvas).
+    """
+
+    def __init__(self, engine, rank, world, root=0, device=None):
+        self.engine, self.rank, self.world, self.root = engine, rank, world, root
+        self.device = device
+        n = engine.num_cameras
+        self.owners = [owner_of_stream(c, world) for c in range(n)]
+        self.mine = streams_of_rank(rank, world, n)
+        self.views = {c: pyramid_tensor(engine, c, device) for c in range(n)}
+
+    def compose(self, frame_ptrs, frame_strides, pano_ptr=None, pano_stride=0, stream=None):
+        """frame_ptrs / frame_strides: {camera: value} for the cameras this rank owns."""
+        self.engine.stage_cameras(self.mine, frame_ptrs, frame_strides, stream=stream)
+        if self.world > 1:
+            reqs = []
+            if self.rank == self.root:
+                for c, owner in enumerate(self.owners):
+                    if owner != self.root:
+                        reqs.append(dist.irecv(self.views[c], src=owner, tag=c))
+            else:
+                for c in self.mine:
+                    reqs.append(dist.isend(self.views[c], dst=self.root, tag=c))
+            for r in reqs:
+                r.wait()
+        if self.rank == self.root:
+            self.engine.stage_canvas(pano_ptr, pano_stride, stream=stream)

@@ -56,3 +56,44 @@ def test_overlap_mode_same_output_buffer_keeps_frame_order():
     _, opano, _ = H.oracle_compose(rig, host[4])
     assert np.array_equal(pano.cpu().numpy(), opano)
     eng.close()
+
+
+def test_camera_sharded_stages_match_oracle():
+    """Two engines stand in for two ranks on one GPU: each runs the per-camera stage for its cameras, the
+    odd cameras' pyramid blocks are copied into the 'root' engine (what the RCCL gather does), and the root's
+    canvas stage must reproduce the oracle bit for bit."""
+    import torch
+    from stitchingvideo_amd import sharding as sh
+    rig = rigmod.build_rig(rigmod.scaled_config("C4", 8))
+    frames = rigmod.frames_for(rig, 2)
+    dev = torch.device("cuda", 0)
+    e0, e1 = H.make_engine(rig), H.make_engine(rig)
+    n = len(frames)
+    dfr = [torch.from_numpy(f).to(dev) for f in frames]
+    ptrs = {i: dfr[i].data_ptr() for i in range(n)}
+    strides = {i: dfr[i].stride(0) for i in range(n)}
+    world = 2
+    mine0, mine1 = sh.streams_of_rank(0, world, n), sh.streams_of_rank(1, world, n)
+    assert sorted(mine0 + mine1) == list(range(n))
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        e0.stage_cameras(mine0, {i: ptrs[i] for i in mine0}, {i: strides[i] for i in mine0}, stream=stream.cuda_stream)
+        e1.stage_cameras(mine1, {i: ptrs[i] for i in mine1}, {i: strides[i] for i in mine1}, stream=stream.cuda_stream)
+        for c in mine1:                                      # the gather
+            src, dst = sh.pyramid_tensor(e1, c, dev), sh.pyramid_tensor(e0, c, dev)
+            assert src.numel() == dst.numel() and src.numel() > 0
+            dst.copy_(src)
+        _, _, cw, ch = e0.canvas()
+        pano = torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev)
+        e0.stage_canvas(pano.data_ptr(), pano.stride(0), stream=stream.cuda_stream)
+    stream.synchronize()
+    _, opano, _ = H.oracle_compose(rig, frames)
+    assert np.array_equal(pano.cpu().numpy(), opano), H.diff_report(pano.cpu().numpy(), opano)
+    # world size 1 through the same class
+    st = sh.ShardedStitcher(e1, 0, 1, device=dev)
+    pano2 = torch.empty_like(pano)
+    st.compose(ptrs, strides, pano2.data_ptr(), pano2.stride(0))
+    e1.synchronize()
+    torch.cuda.synchronize()
+    assert np.array_equal(pano2.cpu().numpy(), opano)
+    e0.close(); e1.close()
