@@ -1,0 +1,228 @@
+// stitching_detailed_mi355 -- the reference's command-line / frame-loop surface on top of the C ABI.
+//
+// Mirrors the compositing half of the OpenCV `stitching_detailed` sample the reference ships
+// (/root/reference/stitching/OpenCV2.4.11-Stitching/stitching_detailed.cpp: flags :64-119, defaults :122-143,
+// blender set-up rule :729-749, compositing loop :656-756) and the driver's frame loop
+// (R64/stitching_detailed.cpp:724-770: per frame N Mats in, one Mat out, "Stitching, time: ... sec").
+// Registration (features / matching / bundle adjustment / seams) is out of scope: cameras come from
+// --yaw / --focal (a ring rig, R = R_y(yaw)), seams are `--seam no` (all-255 warped masks).
+//
+//   stitching_detailed_mi355 --synthetic 6 1920x1080 --focal 1250 --warp spherical --blend multiband
+//                            --expos_comp gain_blocks --frames 100 --output result.ppm
+//   stitching_detailed_mi355 img0.ppm img1.ppm --yaw -15,15 --focal 1250 --warp plane --blend feather
+//
+// Build: make -C stitchingvideo_amd/csrc cli     (g++; links libmi355stitch.so only)
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/mi355_stitch.h"
+
+namespace {
+
+struct Image { int w = 0, h = 0; std::vector<uint8_t> bgr; };
+
+bool read_ppm(const std::string& path, Image& im)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0};
+    int maxv = 0;
+    if (std::fscanf(f, "%2s %d %d %d", magic, &im.w, &im.h, &maxv) != 4 || std::strcmp(magic, "P6") || maxv != 255) {
+        std::fclose(f);
+        return false;
+    }
+    std::fgetc(f);
+    std::vector<uint8_t> rgb(static_cast<size_t>(im.w) * im.h * 3);
+    const bool ok = std::fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
+    std::fclose(f);
+    im.bgr.resize(rgb.size());
+    for (size_t i = 0; i + 2 < rgb.size(); i += 3) { im.bgr[i] = rgb[i + 2]; im.bgr[i + 1] = rgb[i + 1]; im.bgr[i + 2] = rgb[i]; }
+    return ok;
+}
+
+bool write_ppm(const std::string& path, const uint8_t* bgr, int w, int h)
+{
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fprintf(f, "P6\n%d %d\n255\n", w, h);
+    std::vector<uint8_t> row(static_cast<size_t>(w) * 3);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* s = bgr + static_cast<size_t>(y) * w * 3;
+        for (int x = 0; x < w; ++x) { row[3 * x] = s[3 * x + 2]; row[3 * x + 1] = s[3 * x + 1]; row[3 * x + 2] = s[3 * x]; }
+        std::fwrite(row.data(), 1, row.size(), f);
+    }
+    std::fclose(f);
+    return true;
+}
+
+void usage()
+{
+    std::printf(
+        "Rotation model images stitcher (compositing on MI355X).\n\n"
+        "stitching_detailed_mi355 img1.ppm img2.ppm [...imgN.ppm] [flags]\n"
+        "stitching_detailed_mi355 --synthetic <N> <WxH> [flags]\n\n"
+        "Flags:\n"
+        "  --yaw a0,a1,...          camera yaw angles in degrees (default: evenly spaced ring)\n"
+        "  --focal <float>          focal length in pixels = warp scale (default 1250)\n"
+        "  --warp (plane|cylindrical|spherical)              default spherical\n"
+        "  --expos_comp (no|gain_blocks)                     default gain_blocks (synthetic block gains)\n"
+        "  --blend (no|feather|multiband)                    default multiband\n"
+        "  --blend_strength <float>   [0,100], default 5 (same rule as the sample: width = sqrt(area)*s/100)\n"
+        "  --lut                      the driver's hard-seam LUT composite with its crop margins\n"
+        "  --frames <K>               frame-loop iterations (default 1)\n"
+        "  --output <result.ppm>      default result.ppm\n");
+}
+
+void rot_y(double deg, float R[9])
+{
+    const double a = deg * 3.14159265358979323846 / 180.0, c = std::cos(a), s = std::sin(a);
+    const double m[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
+    for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(m[i]);
+}
+
+#define CHECK(call)                                                                                  \
+    do {                                                                                             \
+        int rc_ = (call);                                                                            \
+        if (rc_ != MST_OK) { std::fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, mst_last_error(engine)); return -1; } \
+    } while (0)
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    std::vector<std::string> img_names;
+    std::vector<double> yaws;
+    int synthetic_n = 0, W = 0, H = 0, frames = 1;
+    double focal = 1250.0, blend_strength = 5.0;
+    std::string warp_type = "spherical", expos = "gain_blocks", blend = "multiband", result_name = "result.ppm";
+    bool lut = false;
+    mst_engine* engine = nullptr;
+
+    if (argc == 1) { usage(); return -1; }
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); std::exit(-1); } return argv[++i]; };
+        if (a == "--help" || a == "/?") { usage(); return -1; }
+        else if (a == "--synthetic") { synthetic_n = std::atoi(next()); if (std::sscanf(next(), "%dx%d", &W, &H) != 2) { usage(); return -1; } }
+        else if (a == "--yaw") { const char* p = next(); while (*p) { yaws.push_back(std::strtod(p, const_cast<char**>(&p))); if (*p == ',') ++p; } }
+        else if (a == "--focal") focal = std::atof(next());
+        else if (a == "--warp") warp_type = next();
+        else if (a == "--expos_comp") expos = next();
+        else if (a == "--blend") blend = next();
+        else if (a == "--blend_strength") blend_strength = std::atof(next());
+        else if (a == "--frames") frames = std::atoi(next());
+        else if (a == "--output" || a == "--result") result_name = next();
+        else if (a == "--lut") lut = true;
+        else if (a.rfind("--", 0) == 0) { std::printf("Bad flag: %s\n", a.c_str()); return -1; }
+        else img_names.push_back(a);
+    }
+
+    std::vector<Image> stills;
+    int num_images = synthetic_n;
+    if (!synthetic_n) {
+        num_images = static_cast<int>(img_names.size());
+        stills.resize(num_images);
+        for (int i = 0; i < num_images; ++i)
+            if (!read_ppm(img_names[i], stills[i])) { std::printf("Can't open image %s\n", img_names[i].c_str()); return -1; }
+        if (num_images) { W = stills[0].w; H = stills[0].h; }
+    }
+    if (num_images < 2) { std::printf("Need more images\n"); return -1; }           // CLI:343-347
+    if (yaws.empty()) for (int i = 0; i < num_images; ++i) yaws.push_back(360.0 * i / num_images);
+    if (static_cast<int>(yaws.size()) != num_images) { std::printf("--yaw needs one angle per image\n"); return -1; }
+
+    const int warp_kind = warp_type == "plane" ? MST_WARP_PLANE : warp_type == "cylindrical" ? MST_WARP_CYLINDRICAL : MST_WARP_SPHERICAL;
+    int blend_kind = blend == "no" ? MST_BLEND_NO : blend == "feather" ? MST_BLEND_FEATHER : MST_BLEND_MULTI_BAND;
+    const int expos_kind = expos == "no" ? MST_EXPOS_NO : MST_EXPOS_GAIN_BLOCKS;
+    const float scale = static_cast<float>(focal);
+
+    // cameras: K from focal / principal point (CameraParams::K), R = R_y(yaw); corners and sizes from warpRoi
+    std::vector<mst_camera> cams(num_images);
+    std::vector<std::vector<float>> gain_maps(num_images);
+    std::vector<std::vector<uint8_t>> masks(num_images);
+    int tlx = 1 << 30, tly = 1 << 30, brx = -(1 << 30), bry = -(1 << 30);
+    for (int i = 0; i < num_images; ++i) {
+        mst_camera& c = cams[i];
+        std::memset(&c, 0, sizeof(c));
+        c.src_width = W; c.src_height = H;
+        const float K[9] = {static_cast<float>(focal), 0, static_cast<float>(W / 2.0), 0, static_cast<float>(focal),
+                            static_cast<float>(H / 2.0), 0, 0, 1};
+        std::memcpy(c.K, K, sizeof(K));
+        rot_y(yaws[i], c.R);
+        mst_rect roi;
+        CHECK(mst_warp_roi(warp_kind, scale, c.K, c.R, c.T, W, H, &roi));
+        // mask = warp(all-255, INTER_NEAREST, BORDER_CONSTANT)  (CLI:714-717), no seam finder
+        std::vector<uint8_t> ones(static_cast<size_t>(W) * H, 255);
+        masks[i].resize(static_cast<size_t>(roi.width) * roi.height);
+        CHECK(mst_warp(0, warp_kind, scale, c.K, c.R, c.T, ones.data(), W, H, W, 1, MST_INTER_NEAREST, MST_BORDER_CONSTANT,
+                       masks[i].data(), roi.width));
+        c.mask = masks[i].data(); c.mask_width = roi.width; c.mask_height = roi.height; c.mask_stride = roi.width;
+        if (expos_kind == MST_EXPOS_GAIN_BLOCKS) {
+            const int gw = (roi.width + 31) / 32, gh = (roi.height + 31) / 32;        // bl_width_ = bl_height_ = 32
+            gain_maps[i].resize(static_cast<size_t>(gw) * gh);
+            for (int by = 0; by < gh; ++by)
+                for (int bx = 0; bx < gw; ++bx)
+                    gain_maps[i][static_cast<size_t>(by) * gw + bx] =
+                        static_cast<float>(1.0 + 0.1 * std::sin(i + bx / 5.0) * std::cos(by / 3.0));
+            c.gain_map = gain_maps[i].data(); c.gain_w = gw; c.gain_h = gh;
+        }
+        c.gain = 1.f;
+        tlx = std::min(tlx, roi.x); tly = std::min(tly, roi.y);
+        brx = std::max(brx, roi.x + roi.width); bry = std::max(bry, roi.y + roi.height);
+    }
+
+    // blender set-up rule of the sample (CLI:729-749)
+    mst_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = sizeof(cfg);
+    cfg.num_cameras = num_images;
+    cfg.warp_kind = warp_kind;
+    cfg.expos_kind = expos_kind;
+    const float blend_width = std::sqrt(static_cast<float>((brx - tlx)) * static_cast<float>(bry - tly)) *
+                              static_cast<float>(blend_strength) / 100.f;
+    if (blend_width < 1.f) blend_kind = MST_BLEND_NO;
+    else if (blend_kind == MST_BLEND_MULTI_BAND) {
+        cfg.num_bands = static_cast<int>(std::ceil(std::log(blend_width) / std::log(2.)) - 1.);
+        std::printf("Multi-band blender, number of bands: %d\n", cfg.num_bands);
+    } else if (blend_kind == MST_BLEND_FEATHER) {
+        cfg.feather_sharpness = 1.f / blend_width;
+        std::printf("Feather blender, sharpness: %g\n", cfg.feather_sharpness);
+    }
+    cfg.blend_kind = blend_kind;
+    if (lut) {
+        cfg.blend_kind = MST_BLEND_NO; cfg.flags |= MST_FLAG_DRIVER_LUT;
+        cfg.upblack = cfg.downblack = 0.1f; cfg.leftblack = cfg.rightblack = 10.f;   // DRV:47
+    }
+    CHECK(mst_create(&cfg, &engine));
+    mst_calibration cal = {static_cast<int32_t>(sizeof(mst_calibration)), num_images, scale, cams.data()};
+    CHECK(mst_update(engine, &cal));
+    mst_rect canvas;
+    CHECK(mst_canvas(engine, &canvas));
+    std::printf("Warped image scale: %g, canvas [%d x %d] at (%d, %d)\n", scale, canvas.width, canvas.height, canvas.x, canvas.y);
+
+    // the frame loop (StitchingAll): N frames in, one panorama out
+    std::vector<std::vector<uint8_t>> frame(num_images, std::vector<uint8_t>(static_cast<size_t>(W) * H * 3));
+    std::vector<const uint8_t*> ptrs(num_images);
+    std::vector<size_t> strides(num_images, static_cast<size_t>(W) * 3);
+    std::vector<uint8_t> pano(static_cast<size_t>(canvas.width) * canvas.height * 3);
+    double total = 0.0;
+    for (int k = 0; k < frames; ++k) {
+        for (int i = 0; i < num_images; ++i) {
+            if (synthetic_n) CHECK(mst_synth_frame(i, k, W, H, frame[i].data(), strides[i]));
+            ptrs[i] = synthetic_n ? frame[i].data() : stills[i].bgr.data();
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        CHECK(mst_compose(engine, ptrs.data(), strides.data(), pano.data(), static_cast<size_t>(canvas.width) * 3, nullptr, 0));
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        total += dt;
+        std::printf("Stitching, time: %g sec\n", dt);                                  // DRV:760
+    }
+    std::printf("Finished, %d frame(s), mean %g sec (host buffers in, panorama out)\n", frames, total / frames);
+    if (!write_ppm(result_name, pano.data(), canvas.width, canvas.height)) { std::printf("Can't write %s\n", result_name.c_str()); return -1; }
+    mst_destroy(engine);
+    return 0;
+}
