@@ -100,6 +100,7 @@ struct BlendArgs {
 struct TileList {
     const uint32_t* tiles;         // cam << 24 | ty << 12 | tx
     int32_t count;
+    int32_t first;                 // index of tiles[0] in the calibration's full list (per-tile tables)
 };
 
 }  // namespace mst

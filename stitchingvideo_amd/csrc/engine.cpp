@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.hpp"
@@ -406,11 +407,19 @@ void Engine::update(const mst_calibration& calib)
         ba.block_cams = st->pool.upload(plan.block_cams, s);
         st->warp_list.tiles = st->pool.upload(plan.warp_tiles, s);
         st->warp_list.count = static_cast<int32_t>(plan.warp_tiles.size());
+        st->warp_list.first = 0;
+        // frame-invariant backward map of every launched tile, in the order kernel A consumes it
+        if (std::getenv("MST_WARP_TABLE")) {     // tuning switch, see k_warp_pyr
+            st->warp_table = st->pool.alloc<uint2>(mb_warp_table_entries(st->warp_list.count));
+            launch_warp_table(st->d_desc, cfg_.warp_kind, st->warp_list, st->warp_table, s);
+            check_hip(hipGetLastError(), "k_warp_table");
+        }
         st->chain_lists.clear();
         for (const MbPlanHost::ChainStep& step : plan.chain) {
             TileList tl;
             tl.tiles = st->pool.upload(step.tiles, s);
             tl.count = static_cast<int32_t>(step.tiles.size());
+            tl.first = 0;
             st->chain_lists.push_back(tl);
         }
     } else {
@@ -469,7 +478,7 @@ void Engine::compose_device(const void* const* d_frames, const size_t* strides, 
         hipStream_t sf = overlap ? front_stream_ : s;
         if (overlap && canvas_pending_[slot])
             check_hip(hipStreamWaitEvent(sf, ev_canvas_done_[slot], 0), "hipStreamWaitEvent");
-        launch_warp_pyr(desc, cfg_.warp_kind, st->warp_list, fa, sf);
+        launch_warp_pyr(desc, cfg_.warp_kind, st->warp_list, fa, st->warp_table, sf);
         mark("k_warp_pyr");
         for (size_t i = 0; i < st->chain_lists.size(); ++i) {
             launch_pyr_chain(desc, st->chain_lists[i], st->plan.chain[i].base, st->plan.chain[i].k, sf);
@@ -540,7 +549,8 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
         TileList tl;
         tl.tiles = st->warp_list.tiles + plan.warp_cam_start[i];
         tl.count = plan.warp_cam_start[i + 1] - plan.warp_cam_start[i];
-        launch_warp_pyr(st->d_desc, cfg_.warp_kind, tl, fa, s);
+        tl.first = plan.warp_cam_start[i];
+        launch_warp_pyr(st->d_desc, cfg_.warp_kind, tl, fa, st->warp_table, s);
     }
     for (size_t k = 0; k < st->chain_lists.size(); ++k)
         for (int i = 0; i < st->n; ++i) {
@@ -548,6 +558,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
             TileList tl;
             tl.tiles = st->chain_lists[k].tiles + plan.chain[k].cam_start[i];
             tl.count = plan.chain[k].cam_start[i + 1] - plan.chain[k].cam_start[i];
+            tl.first = plan.chain[k].cam_start[i];
             launch_pyr_chain(st->d_desc, tl, plan.chain[k].base, plan.chain[k].k, s);
         }
     check_hip(hipGetLastError(), "camera stage kernels");

@@ -67,6 +67,7 @@ struct CalibState {
     CanvasDesc cv{};
     MbPlanHost plan;                    // work lists of the fused kernels (host copy, for introspection)
     TileList warp_list{};               // kernel A
+    uint2* warp_table = nullptr;        // per-tile backward-map table (frame-invariant), see kernels_mb.hip
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step
     BlendArgs blend{};                  // kernel C (pano pointers filled per frame)
     // feather

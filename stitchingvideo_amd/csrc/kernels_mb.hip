@@ -84,7 +84,6 @@ struct PixelFetch {           // one pixel between "addresses issued" and "blend
 };
 
 struct WarpConsts {           // per-camera scalars, copied out of the descriptor once
-    float kr[9];
     int src_w, src_h, expos, gw, gh;
     float gain;
     const float* gain_map;
@@ -92,17 +91,20 @@ struct WarpConsts {           // per-camera scalars, copied out of the descripto
     uint32_t stride;
 };
 
-// UNIFORM_ROW: every lane of the wave is on the same tile row (true in the main loop, not in the patch pass)
-template <int KIND, bool UNIFORM_ROW = true>
-__device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const ColEntry& ce, const RowEntry& re, const float H[A_GAIN_ROWS],
-                                            int gmin, bool gain_in_regs, PixelFetch& f)
+// The backward map of one destination pixel in the fixed-point form cv::remap uses, packed for the
+// per-calibration table:  x = sx (s16) | sy (s16) << 16,  y = fx | fy << 5 | fast << 10.
+// The map is frame-invariant (the reference's driver caches xmap/ymap the same way, DRV:658-660,712-713), and
+// these kernels are bound by instruction issue, not by bytes: the table trades two IEEE divides, the trig
+// products and the cvRound logic per pixel per frame (~55 VALU instructions) for one coalesced 8-byte load.
+template <int KIND>
+__device__ __forceinline__ uint2 map_entry(const float kr[9], int src_w, int src_h, const ColEntry& ce, const RowEntry& re)
 {
     float X, Y, Z, mx, my;
     if (KIND == 1) {
         const float x_ = re.ra * ce.ca, z_ = re.ra * ce.cb;
-        X = (k.kr[0] * x_ + re.b[0]) + k.kr[2] * z_;
-        Y = (k.kr[3] * x_ + re.b[1]) + k.kr[5] * z_;
-        Z = (k.kr[6] * x_ + re.b[2]) + k.kr[8] * z_;
+        X = (kr[0] * x_ + re.b[0]) + kr[2] * z_;
+        Y = (kr[3] * x_ + re.b[1]) + kr[5] * z_;
+        Z = (kr[6] * x_ + re.b[2]) + kr[8] * z_;
     } else {
         X = (ce.a[0] + re.b[0]) + ce.c[0];
         Y = (ce.a[1] + re.b[1]) + ce.c[1];
@@ -110,15 +112,25 @@ __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const ColEntry&
     }
     if (KIND == 0 || Z > 0) { mx = X / Z; my = Y / Z; }
     else { mx = -1.f; my = -1.f; }
-
     const int fsx = cv_round(mx * 32.f), fsy = cv_round(my * 32.f);
-    const int fx = fsx & 31, fy = fsy & 31;
-    f.sx = sat_s16(fsx >> 5);
-    f.sy = sat_s16(fsy >> 5);
+    const int sx = sat_s16(fsx >> 5), sy = sat_s16(fsy >> 5);
+    const uint32_t fast = static_cast<unsigned>(sx) < static_cast<unsigned>(src_w - 3) &&
+                          static_cast<unsigned>(sy) < static_cast<unsigned>(src_h - 1);
+    return make_uint2((static_cast<uint32_t>(sx) & 0xFFFFu) | (static_cast<uint32_t>(sy) << 16),
+                      static_cast<uint32_t>(fsx & 31) | static_cast<uint32_t>(fsy & 31) << 5 | fast << 10);
+}
+
+// UNIFORM_ROW: every lane of the wave is on the same tile row (true in the main loop, not in the patch pass)
+template <bool UNIFORM_ROW = true>
+__device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const uint2 e, const ColEntry& ce, const RowEntry& re,
+                                            const float H[A_GAIN_ROWS], int gmin, bool gain_in_regs, PixelFetch& f)
+{
+    const int fx = e.y & 31, fy = (e.y >> 5) & 31;
+    f.sx = static_cast<int>(static_cast<short>(e.x & 0xFFFFu));
+    f.sy = static_cast<int>(e.x) >> 16;
     f.w00 = (32 - fx) * (32 - fy) * 32; f.w01 = fx * (32 - fy) * 32;
     f.w10 = (32 - fx) * fy * 32;        f.w11 = fx * fy * 32;
-    f.fast = static_cast<unsigned>(f.sx) < static_cast<unsigned>(k.src_w - 3) &&
-             static_cast<unsigned>(f.sy) < static_cast<unsigned>(k.src_h - 1);
+    f.fast = (e.y >> 10) & 1u;
     if (MST_A_PATCH || f.fast) {
         // Fast path = all four taps inside and 12 readable bytes from the aligned address below: the two
         // 6-byte pixel pairs come from aligned dword loads; the byte funnel shift happens at blend time.
@@ -188,8 +200,45 @@ __device__ __forceinline__ uint32_t blend_pixel(const WarpConsts& k, const Pixel
     return static_cast<uint32_t>(b) | (static_cast<uint32_t>(g) << 8) | (static_cast<uint32_t>(r) << 16);
 }
 
+// Per-calibration: the backward map of every pixel of every launched tile, in the tile/row/column order in
+// which k_warp_pyr's threads consume it.
 template <int KIND>
-__global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ cams, TileList list, FrameArgs frames)
+__global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ cams, TileList list, uint2* __restrict__ table)
+{
+    __shared__ RowEntry s_rows[A_LH];
+    const uint32_t t = list.tiles[blockIdx.x];
+    const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
+    const CamDesc& c = cams[cam];
+    const int bw = c.lw[0], bh = c.lh[0];
+    const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;
+    const int tid = threadIdx.x;
+    float kr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) kr[i] = c.kr[i];
+    if (tid < A_LH) {
+        const int by = reflect<1>(ly0 + tid, bh);
+        const int ry = reflect<0>(by - c.top, c.roi_h);
+        s_rows[tid] = c.rows[ry];
+    }
+    const int col = tid & (A_LW - 1);
+    const int half = tid >> 7;
+    const int bx = reflect<1>(lx0 + col, bw);
+    const int rx = reflect<0>(bx - c.left, c.roi_w);
+    const ColEntry ce = c.cols[rx];
+    __syncthreads();
+    uint2* __restrict__ out = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW) + col;
+    for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
+        const int row = half * A_ROWS_PER_THREAD + it;
+        out[row * A_LW] = map_entry<KIND>(kr, c.src_w, c.src_h, ce, s_rows[row]);
+    }
+}
+
+// USE_TABLE: read the backward map from the per-calibration table instead of evaluating it (fewer VALU
+// instructions, one more dependent load per pixel).  Measured on MI355X (C3): 81.5 us with the table vs
+// 76 us without while the gather comes from global memory, so the default evaluates the map in place.
+template <int KIND, bool USE_TABLE>
+__global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ cams, TileList list, FrameArgs frames,
+                                                  const uint2* __restrict__ table)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_l0[A_LH][A_LW];   // level-0 tile with halo, packed (18 KB)
     __shared__ RowEntry s_rows[A_LH];
@@ -205,11 +254,11 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     const int lw1 = c.lw[1], lh1 = c.lh[1];
 
     WarpConsts k;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) k.kr[i] = c.kr[i];
     k.src_w = c.src_w; k.src_h = c.src_h; k.expos = c.expos; k.gw = c.gw; k.gh = c.gh;
     k.gain = c.gain; k.gain_map = c.gain_map;
     k.src = frames.ptr[cam]; k.stride = frames.stride[cam];
+    // this tile's slice of the per-calibration map table: [row][col], one coalesced 8-byte load per pixel
+    const uint2* __restrict__ tab = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW);
 
     // per tile row: pyrDown's REFLECT_101 into the bordered image, then copyMakeBorder's REFLECT into the roi
     if (tid < A_LH) {
@@ -267,26 +316,37 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     const int row_last = row0 + A_ROWS_PER_THREAD - 1;
     uint64_t slow_rows = 0;           // rows of this column that need the border path
     PixelFetch fa, fb;
-    fetch_pixel<KIND>(k, ce, s_rows[row0], H, gmin, gain_in_regs, fa);
+    const uint2* __restrict__ tcol = tab + col;
+    float kr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) kr[i] = USE_TABLE ? 0.f : c.kr[i];
+    auto entry = [&](int row) -> uint2 {
+        return USE_TABLE ? tcol[row * A_LW] : map_entry<KIND>(kr, k.src_w, k.src_h, ce, s_rows[row]);
+    };
+    // table entries run two rows ahead of the gather, the gather one row ahead of the blend
+    uint2 e0 = entry(row0), e1 = entry(row0 + 1);
+    fetch_pixel(k, e0, ce, s_rows[row0], H, gmin, gain_in_regs, fa);
     for (int it = 0; it < A_ROWS_PER_THREAD; it += 2) {
         const int row = row0 + it;
-        fetch_pixel<KIND>(k, ce, s_rows[row + 1], H, gmin, gain_in_regs, fb);
+        e0 = entry(min(row + 2, row_last));
+        fetch_pixel(k, e1, ce, s_rows[row + 1], H, gmin, gain_in_regs, fb);
+        e1 = entry(min(row + 3, row_last));
 #if MST_A_PATCH
         slow_rows |= static_cast<uint64_t>(!fa.fast) << it;
         emit(row, blend_pixel<false>(k, fa));
-        fetch_pixel<KIND>(k, ce, s_rows[min(row + 2, row_last)], H, gmin, gain_in_regs, fa);
+        fetch_pixel(k, e0, ce, s_rows[min(row + 2, row_last)], H, gmin, gain_in_regs, fa);
         slow_rows |= static_cast<uint64_t>(!fb.fast) << (it + 1);
         emit(row + 1, blend_pixel<false>(k, fb));
 #else
         emit(row, fa.fast ? blend_pixel<false>(k, fa) : blend_pixel<true>(k, fa));
-        fetch_pixel<KIND>(k, ce, s_rows[min(row + 2, row_last)], H, gmin, gain_in_regs, fa);
+        fetch_pixel(k, e0, ce, s_rows[min(row + 2, row_last)], H, gmin, gain_in_regs, fa);
         emit(row + 1, fb.fast ? blend_pixel<false>(k, fb) : blend_pixel<true>(k, fb));
 #endif
     }
     while (slow_rows) {               // rare: source taps that touch the frame border
         const int it = __builtin_ctzll(slow_rows);
         slow_rows &= slow_rows - 1;
-        fetch_pixel<KIND, false>(k, ce, s_rows[row0 + it], H, gmin, gain_in_regs, fa);
+        fetch_pixel<false>(k, entry(row0 + it), ce, s_rows[row0 + it], H, gmin, gain_in_regs, fa);
         emit(row0 + it, blend_pixel<true>(k, fa));
     }
     if (nlev < 2) return;
@@ -537,10 +597,57 @@ __device__ __forceinline__ void pyrup_quad_lds(const uint2* __restrict__ s, int 
 // level, so all levels of a tile are computed without a barrier in between; only the cheap pyrUp + add
 // collapse that follows is sequential.  TOP: coarsest level (the Laplacian is the Gaussian itself and
 // camera windows may start on odd coordinates); FINAL: level 0 (weights come from the masks).
-template <bool TOP, bool FINAL>
+//
+// PURE: the tile lies strictly inside one camera's seam mask, far enough from every seam that this camera's
+// weight is exactly 1.0f over the tile's region at every level and no other camera has a non-zero weight
+// there (checked once per calibration, mb_plan.cpp).  Then  short(lap * 1.0f) == lap,  the weight sum is
+// 1.0f, and  short(lap / (1.0f + 1e-5f)) == lap - sign(lap)  for every |lap| <= 255 (lap/1.00001f lies
+// strictly between |lap|-1 and |lap|): the band needs no weight loads, no float conversion and no divide.
+template <bool TOP, bool FINAL, bool PURE>
 __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, const BlendArgs& a, int l, int x, int y,
                                           const bool valid[4], uint32_t cam_bits, int out[4][3], float ws[4])
 {
+    if (PURE) {
+        const CamDesc& c = cams[__builtin_ctz(cam_bits)];
+        const int lw = c.lw[l];
+        const int lx = x - c.ox[l], ly = y - c.oy[l];
+        uint32_t g[4];
+        uint32_t ubr[4] = {0, 0, 0, 0}, ug[4] = {0, 0, 0, 0};
+        if (TOP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                g[q] = valid[q] ? c.G[l][static_cast<uint32_t>(ly + (q >> 1)) * lw + lx + (q & 1)] : 0u;
+        } else {
+            const uint32_t off = static_cast<uint32_t>(ly) * lw + lx;
+            const uint2 g0 = *reinterpret_cast<const uint2*>(c.G[l] + off);
+            const uint2 g1 = *reinterpret_cast<const uint2*>(c.G[l] + off + lw);
+            uint32_t nb[3][3];
+            const int sw = c.lw[l + 1], sh = c.lh[l + 1];
+            int jm, jp, im, ip;
+            const int j = lx >> 1, i = ly >> 1;
+            up_idx(j, sw, jm, jp);
+            up_idx(i, sh, im, ip);
+            const uint32_t* __restrict__ gu = c.G[l + 1];
+            const uint32_t r0 = static_cast<uint32_t>(im) * sw, r1 = static_cast<uint32_t>(i) * sw,
+                           r2 = static_cast<uint32_t>(ip) * sw;
+            nb[0][0] = gu[r0 + jm]; nb[0][1] = gu[r0 + j]; nb[0][2] = gu[r0 + jp];
+            nb[1][0] = gu[r1 + jm]; nb[1][1] = gu[r1 + j]; nb[1][2] = gu[r1 + jp];
+            nb[2][0] = gu[r2 + jm]; nb[2][1] = gu[r2 + j]; nb[2][2] = gu[r2 + jp];
+            g[0] = g0.x; g[1] = g0.y; g[2] = g1.x; g[3] = g1.y;
+            pyrup_quad_packed(nb, ubr, ug);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int lb = static_cast<int>(g[q] & 0xFF) - static_cast<int>(ubr[q] & 0xFFFF);
+            const int lg = static_cast<int>((g[q] >> 8) & 0xFF) - static_cast<int>(ug[q]);
+            const int lr = static_cast<int>((g[q] >> 16) & 0xFF) - static_cast<int>(ubr[q] >> 16);
+            out[q][0] = lb - (lb > 0) + (lb < 0);
+            out[q][1] = lg - (lg > 0) + (lg < 0);
+            out[q][2] = lr - (lr > 0) + (lr < 0);
+            ws[q] = 1.f;
+        }
+        return;
+    }
     int acc[4][3];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { acc[q][0] = acc[q][1] = acc[q][2] = 0; ws[q] = 0.f; }
@@ -665,7 +772,7 @@ struct QuadIter {
 };
 
 // phase 1: normalised band of one coarse level into its LDS region
-template <bool TOP>
+template <bool TOP, bool PURE>
 __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int l, int tx, int ty,
                                            uint32_t cam_bits, uint2* __restrict__ lds)
 {
@@ -677,7 +784,7 @@ __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, con
         it.at(q, x, y, valid);
         int n[4][3];
         float ws[4];
-        band_quad<TOP, false>(cams, a, l, x, y, valid, cam_bits, n, ws);
+        band_quad<TOP, false, PURE>(cams, a, l, x, y, valid, cam_bits, n, ws);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (valid[k])
@@ -722,7 +829,7 @@ __device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx
 }
 
 // phase 3: level 0 band + pyrUp of collapsed level 1 -> crop, mask, convertTo(8U), panorama
-template <bool TOP>
+template <bool TOP, bool PURE>
 __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int tx, int ty,
                                             uint32_t cam_bits, const uint2* __restrict__ lds)
 {
@@ -741,7 +848,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
         it.at(q, x, y, valid);
         int n[4][3];
         float ws[4];
-        band_quad<TOP, true>(cams, a, 0, x, y, valid, cam_bits, n, ws);
+        band_quad<TOP, true, PURE>(cams, a, 0, x, y, valid, cam_bits, n, ws);
         int up[4][3];
         if (!TOP) pyrup_quad_lds(s_up, ur.x0, ur.y0, ur.x1 - ur.x0, a.cw[1], a.ch[1], x >> 1, y >> 1, up);
         uint32_t o8[4][3];
@@ -788,15 +895,23 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* lds = reinterpret_cast<uint2*>(smem);
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-    const uint32_t cam_bits = a.block_cams[blockIdx.x];
+    const uint32_t entry = a.block_cams[blockIdx.x];
+    const bool pure = (entry >> 31) != 0;                 // see band_quad: one camera, weight exactly 1 everywhere
+    const uint32_t cam_bits = entry & 0x7FFFFFFFu;
     const int top = a.nlev - 1;
     if (top == 0) {
-        final_level<true>(cams, a, tx, ty, cam_bits, lds);
+        if (pure) final_level<true, true>(cams, a, tx, ty, cam_bits, lds);
+        else final_level<true, false>(cams, a, tx, ty, cam_bits, lds);
         return;
     }
     // phase 1: every coarse band, independent of each other -> no barrier until all are in LDS
-    band_level<true>(cams, a, top, tx, ty, cam_bits, lds);
-    for (int l = top - 1; l >= 1; --l) band_level<false>(cams, a, l, tx, ty, cam_bits, lds);
+    if (pure) {
+        band_level<true, true>(cams, a, top, tx, ty, cam_bits, lds);
+        for (int l = top - 1; l >= 1; --l) band_level<false, true>(cams, a, l, tx, ty, cam_bits, lds);
+    } else {
+        band_level<true, false>(cams, a, top, tx, ty, cam_bits, lds);
+        for (int l = top - 1; l >= 1; --l) band_level<false, false>(cams, a, l, tx, ty, cam_bits, lds);
+    }
     __syncthreads();
     // phase 2: collapse coarse to fine (LDS only)
     if (a.dbg_C[top]) {
@@ -814,7 +929,8 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
         __syncthreads();
     }
     // phase 3
-    final_level<false>(cams, a, tx, ty, cam_bits, lds);
+    if (pure) final_level<false, true>(cams, a, tx, ty, cam_bits, lds);
+    else final_level<false, false>(cams, a, tx, ty, cam_bits, lds);
 }
 
 }  // namespace
@@ -836,12 +952,28 @@ void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4])
     out[0] = r.x0; out[1] = r.y0; out[2] = r.x1; out[3] = r.y1;
 }
 
-void launch_warp_pyr(const CamDesc* d_cams, int kind, const TileList& list, const FrameArgs& frames, hipStream_t s)
+size_t mb_warp_table_entries(int num_tiles) { return static_cast<size_t>(num_tiles) * A_LH * A_LW; }
+
+void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, uint2* d_table, hipStream_t s)
 {
     if (list.count <= 0) return;
-    if (kind == 0) hipLaunchKernelGGL(k_warp_pyr<0>, dim3(list.count), dim3(256), 0, s, d_cams, list, frames);
-    else if (kind == 1) hipLaunchKernelGGL(k_warp_pyr<1>, dim3(list.count), dim3(256), 0, s, d_cams, list, frames);
-    else hipLaunchKernelGGL(k_warp_pyr<2>, dim3(list.count), dim3(256), 0, s, d_cams, list, frames);
+    if (kind == 0) hipLaunchKernelGGL(k_warp_table<0>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table);
+    else if (kind == 1) hipLaunchKernelGGL(k_warp_table<1>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table);
+    else hipLaunchKernelGGL(k_warp_table<2>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table);
+}
+
+void launch_warp_pyr(const CamDesc* d_cams, int kind, const TileList& list, const FrameArgs& frames,
+                     const uint2* d_table, hipStream_t s)
+{
+    if (list.count <= 0) return;
+#define MST_LAUNCH_A(K, T) \
+    hipLaunchKernelGGL((k_warp_pyr<K, T>), dim3(list.count), dim3(256), 0, s, d_cams, list, frames, d_table)
+    if (d_table) {
+        if (kind == 0) MST_LAUNCH_A(0, true); else if (kind == 1) MST_LAUNCH_A(1, true); else MST_LAUNCH_A(2, true);
+    } else {
+        if (kind == 0) MST_LAUNCH_A(0, false); else if (kind == 1) MST_LAUNCH_A(1, false); else MST_LAUNCH_A(2, false);
+    }
+#undef MST_LAUNCH_A
 }
 
 void launch_pyr_chain(const CamDesc* d_cams, const TileList& list, int base, int k, hipStream_t s)

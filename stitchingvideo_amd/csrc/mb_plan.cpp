@@ -178,6 +178,25 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                     if (any) bits |= 1u << c;
                 }
             }
+            // "pure" tile (bit 31): exactly one camera, and over every level's region that camera's window covers
+            // the region and its weight is exactly 1.0f -> kernel C takes the integer-only band path
+            if (bits != 0 && (bits & (bits - 1)) == 0) {
+                int c = 0;
+                while (!(bits >> c & 1u)) ++c;
+                const CamDesc& d = desc[c];
+                bool pure = true;
+                for (int l = 0; l < nlev && pure; ++l) {
+                    int r[4];
+                    mb_blend_region(blend, tx, ty, l, r);
+                    const int x0 = r[0] - d.ox[l], y0 = r[1] - d.oy[l], x1 = r[2] - d.ox[l], y1 = r[3] - d.oy[l];
+                    if (x0 < 0 || y0 < 0 || x1 > d.lw[l] || y1 > d.lh[l]) { pure = false; break; }
+                    const std::vector<float>& w = weights[c][l];
+                    for (int y = y0; y < y1 && pure; ++y)
+                        for (int x = x0; x < x1; ++x)
+                            if (w[static_cast<size_t>(y) * d.lw[l] + x] != 1.0f) { pure = false; break; }
+                }
+                if (pure) bits |= 0x80000000u;
+            }
             plan.block_cams[static_cast<size_t>(ty) * plan.blend_tiles_x + tx] = bits;
         }
     int off = 0;
