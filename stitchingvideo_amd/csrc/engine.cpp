@@ -409,7 +409,8 @@ void Engine::update(const mst_calibration& calib)
         st->warp_list.count = static_cast<int32_t>(plan.warp_tiles.size());
         st->warp_list.first = 0;
         // frame-invariant backward map of every launched tile, in the order kernel A consumes it
-        if (std::getenv("MST_WARP_TABLE")) {     // tuning switch, see k_warp_pyr
+        const char* table_env = std::getenv("MST_WARP_TABLE");   // "0": evaluate the map per frame instead
+        if (!(table_env && table_env[0] == '0')) {
             st->warp_table = st->pool.alloc<uint2>(mb_warp_table_entries(st->warp_list.count));
             launch_warp_table(st->d_desc, cfg_.warp_kind, st->warp_list, st->warp_table, s);
             check_hip(hipGetLastError(), "k_warp_table");

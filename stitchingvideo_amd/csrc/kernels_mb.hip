@@ -60,6 +60,9 @@ __device__ __forceinline__ uint32_t pyrdown_finish(uint32_t vbr, uint32_t vg)
 #ifndef MST_A_PATCH
 #define MST_A_PATCH 0      // 1: border pixels in a separate patch pass; 0: inline (measured faster on MI355X)
 #endif
+#ifndef MST_ABLATE_A
+#define MST_ABLATE_A 0     // timing experiments only: 1 no gather, 2 no gain, 4 no pyrDown, 8 no map, 16 no blend math
+#endif
 constexpr int A_TW0 = 124, A_TH0 = MST_A_TH0;  // level-0 interior of a tile
 constexpr int A_LW = A_TW0 + 4, A_LH = A_TH0 + 4;   // with the 2-pixel pyrDown halo: 128 x 36
 constexpr int A_TW1 = A_TW0 / 2, A_TH1 = A_TH0 / 2; // level-1 outputs: 62 x 16
@@ -92,7 +95,7 @@ struct WarpConsts {           // per-camera scalars, copied out of the descripto
 };
 
 // The backward map of one destination pixel in the fixed-point form cv::remap uses, packed for the
-// per-calibration table:  x = sx (s16) | sy (s16) << 16,  y = fx | fy << 5 | fast << 10.
+// per-calibration table:  x = sx (s16) | sy (s16) << 16,  y = fx | fy << 6 | fast << 12  (fx, fy in 0..32).
 // The map is frame-invariant (the reference's driver caches xmap/ymap the same way, DRV:658-660,712-713), and
 // these kernels are bound by instruction issue, not by bytes: the table trades two IEEE divides, the trig
 // products and the cvRound logic per pixel per frame (~55 VALU instructions) for one coalesced 8-byte load.
@@ -113,48 +116,68 @@ __device__ __forceinline__ uint2 map_entry(const float kr[9], int src_w, int src
     if (KIND == 0 || Z > 0) { mx = X / Z; my = Y / Z; }
     else { mx = -1.f; my = -1.f; }
     const int fsx = cv_round(mx * 32.f), fsy = cv_round(my * 32.f);
-    const int sx = sat_s16(fsx >> 5), sy = sat_s16(fsy >> 5);
-    const uint32_t fast = static_cast<unsigned>(sx) < static_cast<unsigned>(src_w - 3) &&
-                          static_cast<unsigned>(sy) < static_cast<unsigned>(src_h - 1);
+    int sx = sat_s16(fsx >> 5), sy = sat_s16(fsy >> 5);
+    int fx = fsx & 31, fy = fsy & 31;
+    // fast = the 2x2 window lies inside the source and its two 12-byte reads stay inside the frame: they may
+    // run up to 8 bytes past the pixel pair, which is still this frame (next row) except on the last row
+    auto window_ok = [&](int x, int y) {
+        return x >= 0 && x < src_w - 1 && y >= 0 && y < src_h - 1 && (x < src_w - 3 || y < src_h - 2);
+    };
+    bool fast = window_ok(sx, sy);
+    if (!fast) {
+        // BORDER_REFLECT folds both taps of an axis onto neighbouring (or the same) source pixels, so the
+        // sample is again a 2x2 window with the two weights of the axis swapped or merged: the integer sum
+        // sum(v * wx * wy) is the same one remap forms.  Only windows that cannot be read with the 12-byte
+        // loads (the last pixels of the frame, one-pixel sources) stay on the per-tap path.
+        const int x0 = reflect<0>(sx, src_w), x1 = reflect<0>(sx + 1, src_w);
+        const int y0 = reflect<0>(sy, src_h), y1 = reflect<0>(sy + 1, src_h);
+        int xs = min(x0, x1), ys = min(y0, y1);
+        if (xs == src_w - 1) --xs;                  // both taps on the last pixel: window [len-2, len-1], all weight high
+        if (ys == src_h - 1) --ys;
+        const int wxl = (x0 == xs ? 32 - fx : 0) + (x1 == xs ? fx : 0);
+        const int wyl = (y0 == ys ? 32 - fy : 0) + (y1 == ys ? fy : 0);
+        if (window_ok(xs, ys)) {
+            sx = xs; sy = ys; fx = 32 - wxl; fy = 32 - wyl; fast = true;
+        }
+    }
     return make_uint2((static_cast<uint32_t>(sx) & 0xFFFFu) | (static_cast<uint32_t>(sy) << 16),
-                      static_cast<uint32_t>(fsx & 31) | static_cast<uint32_t>(fsy & 31) << 5 | fast << 10);
+                      static_cast<uint32_t>(fx) | static_cast<uint32_t>(fy) << 6 | static_cast<uint32_t>(fast) << 12);
 }
 
 // UNIFORM_ROW: every lane of the wave is on the same tile row (true in the main loop, not in the patch pass)
 template <bool UNIFORM_ROW = true>
 __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const uint2 e, const ColEntry& ce, const RowEntry& re,
-                                            const float H[A_GAIN_ROWS], int gmin, bool gain_in_regs, PixelFetch& f)
+                                            const float* s_gain, int gmin, bool gain_in_regs, PixelFetch& f)
 {
-    const int fx = e.y & 31, fy = (e.y >> 5) & 31;
+    const int fx = e.y & 63, fy = (e.y >> 6) & 63;
     f.sx = static_cast<int>(static_cast<short>(e.x & 0xFFFFu));
     f.sy = static_cast<int>(e.x) >> 16;
     f.w00 = (32 - fx) * (32 - fy) * 32; f.w01 = fx * (32 - fy) * 32;
     f.w10 = (32 - fx) * fy * 32;        f.w11 = fx * fy * 32;
-    f.fast = (e.y >> 10) & 1u;
-    if (MST_A_PATCH || f.fast) {
+    f.fast = (MST_ABLATE_A & 32) ? true : ((e.y >> 12) & 1u);
+    if (f.fast) {
         // Fast path = all four taps inside and 12 readable bytes from the aligned address below: the two
         // 6-byte pixel pairs come from aligned dword loads; the byte funnel shift happens at blend time.
-        // The loads are issued unconditionally from a clamped (always valid) address so that no branch sits
-        // between them and their use one iteration later; pixels off the fast path ignore them.
-        const int cx = min(max(f.sx, 0), k.src_w - 4), cy = min(max(f.sy, 0), k.src_h - 2);
-        const uint8_t* p0 = k.src + static_cast<uint32_t>(cy) * k.stride + static_cast<uint32_t>(cx) * 3u;
+        const uint8_t* p0 = k.src + static_cast<uint32_t>(f.sy) * k.stride + static_cast<uint32_t>(f.sx) * 3u;
         f.sh0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p0)) & 3u;
         const uint32_t* q0 = reinterpret_cast<const uint32_t*>(p0 - f.sh0);
         const uint8_t* p1 = p0 + k.stride;
         f.sh1 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p1)) & 3u;
         const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p1 - f.sh1);
+        if (MST_ABLATE_A & 1) {
+            f.a0 = f.sx; f.a1 = f.sy; f.a2 = f.sx ^ f.sy; f.c0 = f.sh0; f.c1 = f.sh1; f.c2 = f.sx + f.sy;
+        } else {
         f.a0 = q0[0]; f.a1 = q0[1]; f.a2 = q0[2];
         f.c0 = q1[0]; f.c1 = q1[1]; f.c2 = q1[2];
+        }
     }
     f.gain = k.gain;
-    if (k.expos == 2) {
+    if (!(MST_ABLATE_A & 2) && k.expos == 2) {
         float r0, r1;
         if (gain_in_regs) {
-            // the row is the same for every lane of the wave: scalar selects
-            int k0 = re.gy0 - gmin, k1 = re.gy1 - gmin;
-            if (UNIFORM_ROW) { k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1); }
-            r0 = k0 == 0 ? H[0] : (k0 == 1 ? H[1] : (k0 == 2 ? H[2] : H[3]));
-            r1 = k1 == 0 ? H[0] : (k1 == 1 ? H[1] : (k1 == 2 ? H[2] : H[3]));
+            // this column's horizontally interpolated gain rows sit in LDS (s_gain points at the column)
+            r0 = s_gain[(re.gy0 - gmin) * A_LW];
+            r1 = s_gain[(re.gy1 - gmin) * A_LW];
         } else {
             const float* g0 = k.gain_map + re.gy0 * k.gw;
             const float* g1 = k.gain_map + re.gy1 * k.gw;
@@ -171,7 +194,9 @@ template <bool SLOW>
 __device__ __forceinline__ uint32_t blend_pixel(const WarpConsts& k, const PixelFetch& f)
 {
     int b, g, r;
-    if (!SLOW) {
+    if ((MST_ABLATE_A & 16) && !SLOW) {
+        b = (f.a0 ^ f.c0) & 0xFF; g = (f.a1 ^ f.c1) & 0xFF; r = (f.a2 ^ f.c2 ^ f.w00 ^ f.w11 ^ f.w01 ^ f.w10) & 0xFF;
+    } else if (!SLOW) {
         const uint32_t lo0 = __builtin_amdgcn_alignbyte(f.a1, f.a0, f.sh0), hi0 = __builtin_amdgcn_alignbyte(f.a2, f.a1, f.sh0);
         const uint32_t lo1 = __builtin_amdgcn_alignbyte(f.c1, f.c0, f.sh1), hi1 = __builtin_amdgcn_alignbyte(f.c2, f.c1, f.sh1);
         b = ((lo0 & 0xFF) * f.w00 + (lo0 >> 24) * f.w01 + (lo1 & 0xFF) * f.w10 + (lo1 >> 24) * f.w11 + (1 << 14)) >> 15;
@@ -190,7 +215,7 @@ __device__ __forceinline__ uint32_t blend_pixel(const WarpConsts& k, const Pixel
         g = (p00[1] * f.w00 + p01[1] * f.w01 + p10[1] * f.w10 + p11[1] * f.w11 + (1 << 14)) >> 15;
         r = (p00[2] * f.w00 + p01[2] * f.w01 + p10[2] * f.w10 + p11[2] * f.w11 + (1 << 14)) >> 15;
     }
-    if (k.expos != 0) {
+    if (!(MST_ABLATE_A & 2) && k.expos != 0) {
         if (f.gain >= 8.0e6f) {
             b = apply_gain(b, f.gain); g = apply_gain(g, f.gain); r = apply_gain(r, f.gain);
         } else {
@@ -242,6 +267,7 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_l0[A_LH][A_LW];   // level-0 tile with halo, packed (18 KB)
     __shared__ RowEntry s_rows[A_LH];
+    __shared__ float s_gain_rows[A_GAIN_ROWS][A_LW];   // BlocksGainCompensator: HResizeLinear of the rows the tile spans
 
     const uint32_t t = list.tiles[blockIdx.x];
     const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
@@ -292,14 +318,17 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     gmin = __builtin_amdgcn_readfirstlane(gmin);
     gmax = __builtin_amdgcn_readfirstlane(gmax);
     const bool gain_in_regs = k.expos == 2 && (gmax - gmin) < A_GAIN_ROWS;
-    float H[A_GAIN_ROWS] = {0.f, 0.f, 0.f, 0.f};
     if (gain_in_regs) {
+        if (half == 0) {
 #pragma unroll
-        for (int i = 0; i < A_GAIN_ROWS; ++i) {
-            const float* g = k.gain_map + min(gmin + i, k.gh - 1) * k.gw;
-            H[i] = g[ce.gx0] * ce.gxw0 + g[ce.gx1] * ce.gxw1;
+            for (int i = 0; i < A_GAIN_ROWS; ++i) {
+                const float* g = k.gain_map + min(gmin + i, k.gh - 1) * k.gw;
+                s_gain_rows[i][col] = g[ce.gx0] * ce.gxw0 + g[ce.gx1] * ce.gxw1;
+            }
         }
+        __syncthreads();
     }
+    const float* H = &s_gain_rows[0][col];
 
     const int gx = lx0 + col;
     const bool col_interior = col >= 2 && col < A_LW - 2 && gx < bw;
@@ -321,6 +350,9 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
 #pragma unroll
     for (int i = 0; i < 9; ++i) kr[i] = USE_TABLE ? 0.f : c.kr[i];
     auto entry = [&](int row) -> uint2 {
+        if (MST_ABLATE_A & 8)
+            return make_uint2(static_cast<uint32_t>(col + 200) | static_cast<uint32_t>(row + 200) << 16,
+                              static_cast<uint32_t>((col * 7 + row * 3) & 31) | 4096u);
         return USE_TABLE ? tcol[row * A_LW] : map_entry<KIND>(kr, k.src_w, k.src_h, ce, s_rows[row]);
     };
     // table entries run two rows ahead of the gather, the gather one row ahead of the blend
@@ -349,7 +381,7 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
         fetch_pixel<false>(k, entry(row0 + it), ce, s_rows[row0 + it], H, gmin, gain_in_regs, fa);
         emit(row0 + it, blend_pixel<true>(k, fa));
     }
-    if (nlev < 2) return;
+    if (nlev < 2 || (MST_ABLATE_A & 4)) return;
     __syncthreads();
 
     // pyrDown straight from the LDS tile: output (j, i) reads rows 2i..2i+4, columns 2j..2j+4
