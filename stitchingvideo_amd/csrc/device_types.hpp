@@ -90,6 +90,7 @@ struct BlendArgs {
     uint8_t* pano; uint32_t pano_stride;
     uint8_t* pano_mask; uint32_t mask_stride;
     const uint32_t* block_cams;               // per block: bit i set = camera i has non-zero weight under the tile
+    const uint32_t* block_order;              // tile index (ty * tiles_x + tx) handled by block i
     int32_t tiles_x;
     int32_t lds_off[kMaxLevels];              // LDS offset (in pixels) of each level's region buffer
     int16_t* dbg_C[kMaxLevels];               // optional dump of the collapsed levels (MST_FLAG_DEBUG)

@@ -23,6 +23,8 @@
 // by HBM bytes or VALU issue, so they are shaped for occupancy (<= 20 KB LDS and <= 64 VGPRs per
 // block: 8 waves per SIMD) and for memory-level parallelism (the next pixel's gather is issued before
 // the current one is blended; all loads of a quad are issued before the first use).
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "kernels_common.hpp"
 
@@ -155,10 +157,13 @@ __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const uint2 e, 
     f.w00 = (32 - fx) * (32 - fy) * 32; f.w01 = fx * (32 - fy) * 32;
     f.w10 = (32 - fx) * fy * 32;        f.w11 = fx * fy * 32;
     f.fast = (MST_ABLATE_A & 32) ? true : ((e.y >> 12) & 1u);
-    if (f.fast) {
-        // Fast path = all four taps inside and 12 readable bytes from the aligned address below: the two
-        // 6-byte pixel pairs come from aligned dword loads; the byte funnel shift happens at blend time.
-        const uint8_t* p0 = k.src + static_cast<uint32_t>(f.sy) * k.stride + static_cast<uint32_t>(f.sx) * 3u;
+    {
+        // Fast path = a 2x2 window inside the source whose two 6-byte pixel pairs can be read as aligned dwords;
+        // the byte funnel shift happens at blend time.  The loads are issued unconditionally (pixels off the
+        // fast path read the frame's first bytes and ignore them): a branch here would put the register copies
+        // of its join -- and with them a wait for the data -- right behind the loads and serialise the loop.
+        const uint32_t ox = f.fast ? static_cast<uint32_t>(f.sx) : 0u, oy = f.fast ? static_cast<uint32_t>(f.sy) : 0u;
+        const uint8_t* p0 = k.src + oy * k.stride + ox * 3u;
         f.sh0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p0)) & 3u;
         const uint32_t* q0 = reinterpret_cast<const uint32_t*>(p0 - f.sh0);
         const uint8_t* p1 = p0 + k.stride;
@@ -167,24 +172,26 @@ __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const uint2 e, 
         if (MST_ABLATE_A & 1) {
             f.a0 = f.sx; f.a1 = f.sy; f.a2 = f.sx ^ f.sy; f.c0 = f.sh0; f.c1 = f.sh1; f.c2 = f.sx + f.sy;
         } else {
-        f.a0 = q0[0]; f.a1 = q0[1]; f.a2 = q0[2];
-        f.c0 = q1[0]; f.c1 = q1[1]; f.c2 = q1[2];
+            f.a0 = q0[0]; f.a1 = q0[1]; f.a2 = q0[2];
+            f.c0 = q1[0]; f.c1 = q1[1]; f.c2 = q1[2];
         }
     }
+    // exposure gain: k.gain is the camera's scalar gain (1 for "no compensation": uchar * 1.0f rounds to itself);
+    // with a block gain map the two horizontally interpolated map rows of this tile row come from LDS.  Kept
+    // branch-free: the reads are always issued (row index wrapped into the LDS table) and selected afterwards.
     f.gain = k.gain;
-    if (!(MST_ABLATE_A & 2) && k.expos == 2) {
-        float r0, r1;
-        if (gain_in_regs) {
-            // this column's horizontally interpolated gain rows sit in LDS (s_gain points at the column)
-            r0 = s_gain[(re.gy0 - gmin) * A_LW];
-            r1 = s_gain[(re.gy1 - gmin) * A_LW];
-        } else {
+    if (!(MST_ABLATE_A & 2)) {
+        const float r0 = s_gain[((re.gy0 - gmin) & (A_GAIN_ROWS - 1)) * A_LW];
+        const float r1 = s_gain[((re.gy1 - gmin) & (A_GAIN_ROWS - 1)) * A_LW];
+        const float g = r0 * re.gyw0 + r1 * re.gyw1;                      // VResizeLinear
+        f.gain = gain_in_regs ? g : f.gain;
+        if (k.expos == 2 && !gain_in_regs) {                               // tile spans more map rows than LDS holds
             const float* g0 = k.gain_map + re.gy0 * k.gw;
             const float* g1 = k.gain_map + re.gy1 * k.gw;
-            r0 = g0[ce.gx0] * ce.gxw0 + g0[ce.gx1] * ce.gxw1;       // HResizeLinear
-            r1 = g1[ce.gx0] * ce.gxw0 + g1[ce.gx1] * ce.gxw1;
+            const float q0 = g0[ce.gx0] * ce.gxw0 + g0[ce.gx1] * ce.gxw1;   // HResizeLinear
+            const float q1 = g1[ce.gx0] * ce.gxw0 + g1[ce.gx1] * ce.gxw1;
+            f.gain = q0 * re.gyw0 + q1 * re.gyw1;
         }
-        f.gain = r0 * re.gyw0 + r1 * re.gyw1;                        // VResizeLinear
     }
 }
 
@@ -215,7 +222,7 @@ __device__ __forceinline__ uint32_t blend_pixel(const WarpConsts& k, const Pixel
         g = (p00[1] * f.w00 + p01[1] * f.w01 + p10[1] * f.w10 + p11[1] * f.w11 + (1 << 14)) >> 15;
         r = (p00[2] * f.w00 + p01[2] * f.w01 + p10[2] * f.w10 + p11[2] * f.w11 + (1 << 14)) >> 15;
     }
-    if (!(MST_ABLATE_A & 2) && k.expos != 0) {
+    if (!(MST_ABLATE_A & 2)) {
         if (f.gain >= 8.0e6f) {
             b = apply_gain(b, f.gain); g = apply_gain(g, f.gain); r = apply_gain(r, f.gain);
         } else {
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
 
     WarpConsts k;
     k.src_w = c.src_w; k.src_h = c.src_h; k.expos = c.expos; k.gw = c.gw; k.gh = c.gh;
-    k.gain = c.gain; k.gain_map = c.gain_map;
+    k.gain = c.expos == 0 ? 1.f : c.gain; k.gain_map = c.gain_map;
     k.src = frames.ptr[cam]; k.stride = frames.stride[cam];
     // this tile's slice of the per-calibration map table: [row][col], one coalesced 8-byte load per pixel
     const uint2* __restrict__ tab = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW);
@@ -926,8 +933,9 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* lds = reinterpret_cast<uint2*>(smem);
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-    const uint32_t entry = a.block_cams[blockIdx.x];
+    const uint32_t tile = a.block_order[blockIdx.x];
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const uint32_t entry = a.block_cams[tile];
     const bool pure = (entry >> 31) != 0;                 // see band_quad: one camera, weight exactly 1 everywhere
     const uint32_t cam_bits = entry & 0x7FFFFFFFu;
     const int top = a.nlev - 1;
@@ -971,6 +979,13 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
 // launchers + host-side geometry helpers
 // ------------------------------------------------------------------------------------------------------
 
+// occupancy experiments: extra dynamic LDS per block (bytes) from the environment, 0 when unset
+static size_t tuning_env(const char* name)
+{
+    const char* v = std::getenv(name);
+    return v ? static_cast<size_t>(std::strtoul(v, nullptr, 10)) : 0;
+}
+
 void mb_tile_dims(int* a_tw0, int* a_th0, int* b_t, int* c_tw, int* c_th)
 {
     *a_tw0 = A_TW0; *a_th0 = A_TH0; *b_t = B_T; *c_tw = C_TW; *c_th = C_TH;
@@ -998,8 +1013,9 @@ void launch_warp_pyr(const CamDesc* d_cams, int kind, const TileList& list, cons
                      const uint2* d_table, hipStream_t s)
 {
     if (list.count <= 0) return;
+    static const size_t pad = tuning_env("MST_A_PAD_LDS");
 #define MST_LAUNCH_A(K, T) \
-    hipLaunchKernelGGL((k_warp_pyr<K, T>), dim3(list.count), dim3(256), 0, s, d_cams, list, frames, d_table)
+    hipLaunchKernelGGL((k_warp_pyr<K, T>), dim3(list.count), dim3(256), pad, s, d_cams, list, frames, d_table)
     if (d_table) {
         if (kind == 0) MST_LAUNCH_A(0, true); else if (kind == 1) MST_LAUNCH_A(1, true); else MST_LAUNCH_A(2, true);
     } else {
@@ -1017,7 +1033,8 @@ void launch_pyr_chain(const CamDesc* d_cams, const TileList& list, int base, int
 
 void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, size_t lds_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_blend, dim3(num_blocks), dim3(C_THREADS), lds_bytes, s, d_cams, a);
+    static const size_t pad = tuning_env("MST_C_PAD_LDS");
+    hipLaunchKernelGGL(k_blend, dim3(num_blocks), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
 }
 
 }  // namespace mst

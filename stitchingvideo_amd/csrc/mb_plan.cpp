@@ -199,6 +199,18 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
             }
             plan.block_cams[static_cast<size_t>(ty) * plan.blend_tiles_x + tx] = bits;
         }
+    // launch order: every canvas tile is resident at once on a 256-CU part, so the dispatcher's round-robin
+    // placement is the only load balancing there is -- hand out the expensive tiles (several cameras under the
+    // tile, float path) first so that they land on different CUs, then the single-camera integer-path tiles
+    plan.block_order.resize(plan.block_cams.size());
+    for (size_t i = 0; i < plan.block_order.size(); ++i) plan.block_order[i] = static_cast<uint32_t>(i);
+    auto cost = [&](uint32_t tile) {
+        const uint32_t e = plan.block_cams[tile];
+        const int cams_under = __builtin_popcount(e & 0x7FFFFFFFu);
+        return (e >> 31) ? 2 : 5 * cams_under;          // relative: integer path ~ 2, float path ~ 5 per camera
+    };
+    std::stable_sort(plan.block_order.begin(), plan.block_order.end(),
+                     [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
     int off = 0;
     for (int l = 1; l < nlev; ++l) {
         plan.lds_off[l] = off;
