@@ -460,6 +460,7 @@ void Engine::compose_device(const void* const* d_frames, const size_t* strides, 
     for (int i = 0; i < st->n; ++i) {
         if (!d_frames[i]) throw Error{MST_ERR_INVALID_ARG, "null frame pointer"};
         if (strides[i] < static_cast<size_t>(st->cams[i].src_w) * 3) throw Error{MST_ERR_INVALID_ARG, "frame stride too small"};
+        if (strides[i] >= (size_t{1} << 24)) throw Error{MST_ERR_INVALID_ARG, "frame stride must be below 16 MiB"};
         fa.ptr[i] = static_cast<const uint8_t*>(d_frames[i]);
         fa.stride[i] = strides[i];
     }
@@ -540,7 +541,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
     FrameArgs fa{};
     for (int i = 0; i < st->n; ++i) {
         if (!(camera_mask >> i & 1u)) continue;
-        if (!d_frames[i] || strides[i] < static_cast<size_t>(st->cams[i].src_w) * 3)
+        if (!d_frames[i] || strides[i] < static_cast<size_t>(st->cams[i].src_w) * 3 || strides[i] >= (size_t{1} << 24))
             throw Error{MST_ERR_INVALID_ARG, "bad frame for a camera in the mask"};
         fa.ptr[i] = static_cast<const uint8_t*>(d_frames[i]);
         fa.stride[i] = static_cast<uint32_t>(strides[i]);

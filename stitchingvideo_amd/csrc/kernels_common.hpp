@@ -18,6 +18,33 @@ namespace dev {
 
 constexpr float kWeightEps = 1e-5f;   // WEIGHT_EPS, blenders.cpp:50
 
+// Pointers read out of a descriptor are "generic" to the compiler, which then emits FLAT loads and stores:
+// those tick both memory counters, complete out of order with respect to LDS traffic, and force every later
+// wait to vmcnt(0) lgkmcnt(0) -- which serialises a software-pipelined loop.  Everything a descriptor points
+// at is device global memory, so the kernels say so.
+#define MST_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ T MST_GLOBAL* gp(T* p) { return (T MST_GLOBAL*)p; }
+
+// a trivially copyable object (size a multiple of 4) out of global memory
+template <typename T> __device__ __forceinline__ T load_global(const T* p)
+{
+    static_assert(sizeof(T) % 4 == 0, "dword-sized objects only");
+    T out;
+    const uint32_t MST_GLOBAL* s = (const uint32_t MST_GLOBAL*)p;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) d[i] = s[i];
+    return out;
+}
+template <typename T> __device__ __forceinline__ void store_global(T* p, const T& v)
+{
+    static_assert(sizeof(T) % 4 == 0, "dword-sized objects only");
+    uint32_t MST_GLOBAL* d = (uint32_t MST_GLOBAL*)p;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) d[i] = s[i];
+}
+
 // cvRound on x64 (cvtsd2si / cvtps2dq): round-half-even, 0x80000000 when unrepresentable
 __device__ __forceinline__ int cv_round(float v)
 {

@@ -24,6 +24,7 @@
 // block: 8 waves per SIMD) and for memory-level parallelism (the next pixel's gather is issued before
 // the current one is blended; all loads of a quad are issued before the first use).
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.hpp"
 #include "kernels_common.hpp"
@@ -82,7 +83,7 @@ __device__ __forceinline__ int apply_gain_bounded(int v, float g)
 struct PixelFetch {           // one pixel between "addresses issued" and "blended"
     uint32_t a0, a1, a2, c0, c1, c2;   // raw dwords covering the two 6-byte pixel pairs (fast path)
     uint32_t sh0, sh1;                 // byte offsets of the pairs inside those dwords
-    int w00, w01, w10, w11;            // 15-bit bilinear weights
+    uint32_t wx, wy0, wy1;             // bilinear weights: (32 - fx) | fx << 24, 32 - fy, fy
     int sx, sy;                        // integer source coordinate (slow path)
     float gain;
     bool fast;
@@ -92,8 +93,10 @@ struct WarpConsts {           // per-camera scalars, copied out of the descripto
     int src_w, src_h, expos, gw, gh;
     float gain;
     const float* gain_map;
-    const uint8_t* src;
-    uint32_t stride;
+    const uint8_t* src;                // frame base
+    const uint8_t* src_al;             // frame base rounded down to a dword boundary, src_lo2 bytes below src
+    uint32_t src_lo2;
+    uint32_t stride;                   // < 2^24 (checked by the engine): row offsets use the 24-bit multiplier
 };
 
 // The backward map of one destination pixel in the fixed-point form cv::remap uses, packed for the
@@ -146,16 +149,19 @@ __device__ __forceinline__ uint2 map_entry(const float kr[9], int src_w, int src
                       static_cast<uint32_t>(fx) | static_cast<uint32_t>(fy) << 6 | static_cast<uint32_t>(fast) << 12);
 }
 
-// UNIFORM_ROW: every lane of the wave is on the same tile row (true in the main loop, not in the patch pass)
-template <bool UNIFORM_ROW = true>
+// GAIN: how the exposure gain of the pixel is formed -- 0: the camera's scalar gain (1 for "no compensation":
+// uchar * 1.0f rounds to itself), 1: block gain map, horizontally interpolated rows of this tile in LDS,
+// 2: block gain map read from global memory (tile spans more map rows than the LDS table holds).
+// The caller picks the mode once per tile, so the loop body carries no uniform branch.
+template <int GAIN>
 __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const uint2 e, const ColEntry& ce, const RowEntry& re,
-                                            const float* s_gain, int gmin, bool gain_in_regs, PixelFetch& f)
+                                            const float* s_gain, PixelFetch& f)
 {
     const int fx = e.y & 63, fy = (e.y >> 6) & 63;
     f.sx = static_cast<int>(static_cast<short>(e.x & 0xFFFFu));
     f.sy = static_cast<int>(e.x) >> 16;
-    f.w00 = (32 - fx) * (32 - fy) * 32; f.w01 = fx * (32 - fy) * 32;
-    f.w10 = (32 - fx) * fy * 32;        f.w11 = fx * fy * 32;
+    f.wx = static_cast<uint32_t>(32 - fx) | static_cast<uint32_t>(fx) << 24;
+    f.wy0 = static_cast<uint32_t>(32 - fy); f.wy1 = static_cast<uint32_t>(fy);
     f.fast = (MST_ABLATE_A & 32) ? true : ((e.y >> 12) & 1u);
     {
         // Fast path = a 2x2 window inside the source whose two 6-byte pixel pairs can be read as aligned dwords;
@@ -163,12 +169,13 @@ __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const uint2 e, 
         // fast path read the frame's first bytes and ignore them): a branch here would put the register copies
         // of its join -- and with them a wait for the data -- right behind the loads and serialise the loop.
         const uint32_t ox = f.fast ? static_cast<uint32_t>(f.sx) : 0u, oy = f.fast ? static_cast<uint32_t>(f.sy) : 0u;
-        const uint8_t* p0 = k.src + oy * k.stride + ox * 3u;
-        f.sh0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p0)) & 3u;
-        const uint32_t* q0 = reinterpret_cast<const uint32_t*>(p0 - f.sh0);
-        const uint8_t* p1 = p0 + k.stride;
-        f.sh1 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p1)) & 3u;
-        const uint32_t* q1 = reinterpret_cast<const uint32_t*>(p1 - f.sh1);
+        // 32-bit byte offsets from the (uniform) dword-aligned frame base: scalar base + vector offset addressing
+        const uint32_t o0 = __umul24(oy, k.stride) + ox * 3u + k.src_lo2;
+        const uint32_t o1 = o0 + k.stride;
+        f.sh0 = o0 & 3u;
+        f.sh1 = o1 & 3u;
+        const uint32_t* q0 = reinterpret_cast<const uint32_t*>(k.src_al + (o0 & ~3u));
+        const uint32_t* q1 = reinterpret_cast<const uint32_t*>(k.src_al + (o1 & ~3u));
         if (MST_ABLATE_A & 1) {
             f.a0 = f.sx; f.a1 = f.sy; f.a2 = f.sx ^ f.sy; f.c0 = f.sh0; f.c1 = f.sh1; f.c2 = f.sx + f.sy;
         } else {
@@ -181,13 +188,13 @@ __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const uint2 e, 
     // branch-free: the reads are always issued (row index wrapped into the LDS table) and selected afterwards.
     f.gain = k.gain;
     if (!(MST_ABLATE_A & 2)) {
-        const float r0 = s_gain[((re.gy0 - gmin) & (A_GAIN_ROWS - 1)) * A_LW];
-        const float r1 = s_gain[((re.gy1 - gmin) & (A_GAIN_ROWS - 1)) * A_LW];
-        const float g = r0 * re.gyw0 + r1 * re.gyw1;                      // VResizeLinear
-        f.gain = gain_in_regs ? g : f.gain;
-        if (k.expos == 2 && !gain_in_regs) {                               // tile spans more map rows than LDS holds
-            const float* g0 = k.gain_map + re.gy0 * k.gw;
-            const float* g1 = k.gain_map + re.gy1 * k.gw;
+        if (GAIN == 1) {
+            // gy0/gy1 of the tile's row entries were rewritten to offsets into the LDS table
+            const float r0 = s_gain[re.gy0], r1 = s_gain[re.gy1];
+            f.gain = r0 * re.gyw0 + r1 * re.gyw1;                            // VResizeLinear
+        } else if (GAIN == 2) {
+            const float MST_GLOBAL* g0 = gp(k.gain_map) + re.gy0 * k.gw;
+            const float MST_GLOBAL* g1 = gp(k.gain_map) + re.gy1 * k.gw;
             const float q0 = g0[ce.gx0] * ce.gxw0 + g0[ce.gx1] * ce.gxw1;   // HResizeLinear
             const float q1 = g1[ce.gx0] * ce.gxw0 + g1[ce.gx1] * ce.gxw1;
             f.gain = q0 * re.gyw0 + q1 * re.gyw1;
@@ -197,33 +204,44 @@ __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const uint2 e, 
 
 // SLOW = the border path (per-tap BORDER_REFLECT, byte loads); the main loop only runs the fast form
 // and patches the few border pixels afterwards, so that no divergent load sits inside the pipeline.
-template <bool SLOW>
+// BIG = some gain of the tile is >= 8e6: use the general saturate_cast form (int overflow -> 0x80000000 -> 0).
+template <bool SLOW, bool BIG>
 __device__ __forceinline__ uint32_t blend_pixel(const WarpConsts& k, const PixelFetch& f)
 {
     int b, g, r;
     if ((MST_ABLATE_A & 16) && !SLOW) {
-        b = (f.a0 ^ f.c0) & 0xFF; g = (f.a1 ^ f.c1) & 0xFF; r = (f.a2 ^ f.c2 ^ f.w00 ^ f.w11 ^ f.w01 ^ f.w10) & 0xFF;
+        b = (f.a0 ^ f.c0) & 0xFF; g = (f.a1 ^ f.c1) & 0xFF; r = (f.a2 ^ f.c2 ^ f.wx ^ f.wy0 ^ f.wy1) & 0xFF;
     } else if (!SLOW) {
+        // cv::remap's fixed-point bilinear sum, separably: with wx in {32-fx, fx} and wy in {32-fy, fy},
+        // sum(v * wx * wy * 32) + 2^14 >> 15  ==  (sum_y wy * (sum_x wx * v)) + 512 >> 10  in exact integers.
+        // After the funnel shifts the pairs sit at fixed bytes (B0 G0 R0 B1 | G1 R1 . .), so one more constant
+        // shift per channel lines every channel up with the same byte-0 / byte-3 weight register for v_dot4.
         const uint32_t lo0 = __builtin_amdgcn_alignbyte(f.a1, f.a0, f.sh0), hi0 = __builtin_amdgcn_alignbyte(f.a2, f.a1, f.sh0);
         const uint32_t lo1 = __builtin_amdgcn_alignbyte(f.c1, f.c0, f.sh1), hi1 = __builtin_amdgcn_alignbyte(f.c2, f.c1, f.sh1);
-        b = ((lo0 & 0xFF) * f.w00 + (lo0 >> 24) * f.w01 + (lo1 & 0xFF) * f.w10 + (lo1 >> 24) * f.w11 + (1 << 14)) >> 15;
-        g = (((lo0 >> 8) & 0xFF) * f.w00 + (hi0 & 0xFF) * f.w01 + ((lo1 >> 8) & 0xFF) * f.w10 + (hi1 & 0xFF) * f.w11 +
-             (1 << 14)) >> 15;
-        r = (((lo0 >> 16) & 0xFF) * f.w00 + ((hi0 >> 8) & 0xFF) * f.w01 + ((lo1 >> 16) & 0xFF) * f.w10 +
-             ((hi1 >> 8) & 0xFF) * f.w11 + (1 << 14)) >> 15;
+        const uint32_t g0w = __builtin_amdgcn_alignbyte(hi0, lo0, 1), r0w = __builtin_amdgcn_alignbyte(hi0, lo0, 2);
+        const uint32_t g1w = __builtin_amdgcn_alignbyte(hi1, lo1, 1), r1w = __builtin_amdgcn_alignbyte(hi1, lo1, 2);
+        const uint32_t hb0 = __builtin_amdgcn_udot4(lo0, f.wx, 0u, false), hb1 = __builtin_amdgcn_udot4(lo1, f.wx, 0u, false);
+        const uint32_t hg0 = __builtin_amdgcn_udot4(g0w, f.wx, 0u, false), hg1 = __builtin_amdgcn_udot4(g1w, f.wx, 0u, false);
+        const uint32_t hr0 = __builtin_amdgcn_udot4(r0w, f.wx, 0u, false), hr1 = __builtin_amdgcn_udot4(r1w, f.wx, 0u, false);
+        b = static_cast<int>((__umul24(hb0, f.wy0) + __umul24(hb1, f.wy1) + 512u) >> 10);
+        g = static_cast<int>((__umul24(hg0, f.wy0) + __umul24(hg1, f.wy1) + 512u) >> 10);
+        r = static_cast<int>((__umul24(hr0, f.wy0) + __umul24(hr1, f.wy1) + 512u) >> 10);
     } else {
+        const int wx0 = static_cast<int>(f.wx & 0xFFu), wx1 = static_cast<int>(f.wx >> 24);
+        const int w00 = wx0 * static_cast<int>(f.wy0) * 32, w01 = wx1 * static_cast<int>(f.wy0) * 32;
+        const int w10 = wx0 * static_cast<int>(f.wy1) * 32, w11 = wx1 * static_cast<int>(f.wy1) * 32;
         const int x0 = reflect<0>(f.sx, k.src_w), x1 = reflect<0>(f.sx + 1, k.src_w);
         const int y0 = reflect<0>(f.sy, k.src_h), y1 = reflect<0>(f.sy + 1, k.src_h);
         const uint8_t* r0 = k.src + static_cast<uint32_t>(y0) * k.stride;
         const uint8_t* r1 = k.src + static_cast<uint32_t>(y1) * k.stride;
         const uint8_t* p00 = r0 + x0 * 3; const uint8_t* p01 = r0 + x1 * 3;
         const uint8_t* p10 = r1 + x0 * 3; const uint8_t* p11 = r1 + x1 * 3;
-        b = (p00[0] * f.w00 + p01[0] * f.w01 + p10[0] * f.w10 + p11[0] * f.w11 + (1 << 14)) >> 15;
-        g = (p00[1] * f.w00 + p01[1] * f.w01 + p10[1] * f.w10 + p11[1] * f.w11 + (1 << 14)) >> 15;
-        r = (p00[2] * f.w00 + p01[2] * f.w01 + p10[2] * f.w10 + p11[2] * f.w11 + (1 << 14)) >> 15;
+        b = (p00[0] * w00 + p01[0] * w01 + p10[0] * w10 + p11[0] * w11 + (1 << 14)) >> 15;
+        g = (p00[1] * w00 + p01[1] * w01 + p10[1] * w10 + p11[1] * w11 + (1 << 14)) >> 15;
+        r = (p00[2] * w00 + p01[2] * w01 + p10[2] * w10 + p11[2] * w11 + (1 << 14)) >> 15;
     }
     if (!(MST_ABLATE_A & 2)) {
-        if (f.gain >= 8.0e6f) {
+        if (BIG) {
             b = apply_gain(b, f.gain); g = apply_gain(g, f.gain); r = apply_gain(r, f.gain);
         } else {
             b = apply_gain_bounded(b, f.gain); g = apply_gain_bounded(g, f.gain); r = apply_gain_bounded(r, f.gain);
@@ -250,13 +268,13 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
     if (tid < A_LH) {
         const int by = reflect<1>(ly0 + tid, bh);
         const int ry = reflect<0>(by - c.top, c.roi_h);
-        s_rows[tid] = c.rows[ry];
+        s_rows[tid] = load_global(c.rows + ry);
     }
     const int col = tid & (A_LW - 1);
     const int half = tid >> 7;
     const int bx = reflect<1>(lx0 + col, bw);
     const int rx = reflect<0>(bx - c.left, c.roi_w);
-    const ColEntry ce = c.cols[rx];
+    const ColEntry ce = load_global(c.cols + rx);
     __syncthreads();
     uint2* __restrict__ out = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW) + col;
     for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
@@ -282,14 +300,16 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     const int bw = c.lw[0], bh = c.lh[0], nlev = c.nlev;
     const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;    // level-0 origin of the halo'd tile
     const int tid = threadIdx.x;
-    uint32_t* __restrict__ g0out = c.G[0];
-    uint32_t* __restrict__ g1out = c.G[1];
+    uint32_t MST_GLOBAL* __restrict__ g0out = gp(c.G[0]);
+    uint32_t MST_GLOBAL* __restrict__ g1out = gp(c.G[1]);
     const int lw1 = c.lw[1], lh1 = c.lh[1];
 
     WarpConsts k;
     k.src_w = c.src_w; k.src_h = c.src_h; k.expos = c.expos; k.gw = c.gw; k.gh = c.gh;
     k.gain = c.expos == 0 ? 1.f : c.gain; k.gain_map = c.gain_map;
     k.src = frames.ptr[cam]; k.stride = frames.stride[cam];
+    k.src_lo2 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(k.src)) & 3u;
+    k.src_al = k.src - k.src_lo2;
     // this tile's slice of the per-calibration map table: [row][col], one coalesced 8-byte load per pixel
     const uint2* __restrict__ tab = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW);
 
@@ -297,13 +317,13 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     if (tid < A_LH) {
         const int by = reflect<1>(ly0 + tid, bh);
         const int ry = reflect<0>(by - c.top, c.roi_h);
-        s_rows[tid] = c.rows[ry];
+        s_rows[tid] = load_global(c.rows + ry);
     }
     const int col = tid & (A_LW - 1);
     const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int bx = reflect<1>(lx0 + col, bw);
     const int rx = reflect<0>(bx - c.left, c.roi_w);
-    const ColEntry ce = c.cols[rx];
+    const ColEntry ce = load_global(c.cols + rx);
     __syncthreads();
 
     // BlocksGainCompensator's resize(gain_map): this column's horizontal interpolation of the few gain-map
@@ -324,16 +344,32 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     }
     gmin = __builtin_amdgcn_readfirstlane(gmin);
     gmax = __builtin_amdgcn_readfirstlane(gmax);
-    const bool gain_in_regs = k.expos == 2 && (gmax - gmin) < A_GAIN_ROWS;
-    if (gain_in_regs) {
-        if (half == 0) {
-#pragma unroll
-            for (int i = 0; i < A_GAIN_ROWS; ++i) {
-                const float* g = k.gain_map + min(gmin + i, k.gh - 1) * k.gw;
-                s_gain_rows[i][col] = g[ce.gx0] * ce.gxw0 + g[ce.gx1] * ce.gxw1;
+    // how this tile forms its gains (see fetch_pixel) and whether any of them can overflow the bounded rounding
+    int gain_mode = 0;
+    bool big = k.gain >= 8.0e6f;
+    if (k.expos == 2) {
+        if (gmax - gmin < A_GAIN_ROWS) {
+            gain_mode = 1;
+            __syncthreads();                // every wave has derived gmin/gmax from the row entries
+            if (tid < A_LH) {               // row entries now carry offsets into s_gain_rows instead of map rows
+                s_rows[tid].gy0 = (s_rows[tid].gy0 - gmin) * A_LW;
+                s_rows[tid].gy1 = (s_rows[tid].gy1 - gmin) * A_LW;
             }
+            bool col_big = false;
+            if (half == 0) {
+#pragma unroll
+                for (int i = 0; i < A_GAIN_ROWS; ++i) {
+                    const float MST_GLOBAL* g = gp(k.gain_map) + min(gmin + i, k.gh - 1) * k.gw;
+                    const float v = g[ce.gx0] * ce.gxw0 + g[ce.gx1] * ce.gxw1;
+                    s_gain_rows[i][col] = v;
+                    col_big |= v >= 4.0e6f;     // conservative: the vertical interpolation stays below 2x the rows
+                }
+            }
+            big = __syncthreads_or(col_big) != 0;
+        } else {
+            gain_mode = 2;
+            big = true;
         }
-        __syncthreads();
     }
     const float* H = &s_gain_rows[0][col];
 
@@ -350,8 +386,6 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
             g0out[static_cast<uint32_t>(gy) * bw + gx] = px;
     };
     const int row_last = row0 + A_ROWS_PER_THREAD - 1;
-    uint64_t slow_rows = 0;           // rows of this column that need the border path
-    PixelFetch fa, fb;
     const uint2* __restrict__ tcol = tab + col;
     float kr[9];
 #pragma unroll
@@ -362,31 +396,46 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
                               static_cast<uint32_t>((col * 7 + row * 3) & 31) | 4096u);
         return USE_TABLE ? tcol[row * A_LW] : map_entry<KIND>(kr, k.src_w, k.src_h, ce, s_rows[row]);
     };
-    // table entries run two rows ahead of the gather, the gather one row ahead of the blend
-    uint2 e0 = entry(row0), e1 = entry(row0 + 1);
-    fetch_pixel(k, e0, ce, s_rows[row0], H, gmin, gain_in_regs, fa);
-    for (int it = 0; it < A_ROWS_PER_THREAD; it += 2) {
-        const int row = row0 + it;
-        e0 = entry(min(row + 2, row_last));
-        fetch_pixel(k, e1, ce, s_rows[row + 1], H, gmin, gain_in_regs, fb);
-        e1 = entry(min(row + 3, row_last));
-#if MST_A_PATCH
-        slow_rows |= static_cast<uint64_t>(!fa.fast) << it;
-        emit(row, blend_pixel<false>(k, fa));
-        fetch_pixel(k, e0, ce, s_rows[min(row + 2, row_last)], H, gmin, gain_in_regs, fa);
-        slow_rows |= static_cast<uint64_t>(!fb.fast) << (it + 1);
-        emit(row + 1, blend_pixel<false>(k, fb));
-#else
-        emit(row, fa.fast ? blend_pixel<false>(k, fa) : blend_pixel<true>(k, fa));
-        fetch_pixel(k, e0, ce, s_rows[min(row + 2, row_last)], H, gmin, gain_in_regs, fa);
-        emit(row + 1, fb.fast ? blend_pixel<false>(k, fb) : blend_pixel<true>(k, fb));
-#endif
-    }
-    while (slow_rows) {               // rare: source taps that touch the frame border
-        const int it = __builtin_ctzll(slow_rows);
-        slow_rows &= slow_rows - 1;
-        fetch_pixel<false>(k, entry(row0 + it), ce, s_rows[row0 + it], H, gmin, gain_in_regs, fa);
-        emit(row0 + it, blend_pixel<true>(k, fa));
+    // Table entries run two rows ahead of the gather, the gather one row ahead of the blend.  The loop body is
+    // one basic block (no uniform branch on the gain mode, no divergent branch for border pixels: those are
+    // redone after the loop), so the scheduler is free to hoist the loads of both pixels.
+    auto run = [&](auto gain_tag, auto big_tag) {
+        constexpr int GM = decltype(gain_tag)::value;
+        constexpr bool BG = decltype(big_tag)::value;
+        static_assert(A_ROWS_PER_THREAD <= 32, "slow_rows is a 32-bit mask");
+        PixelFetch fa, fb;
+        uint32_t slow_rows = 0;           // rows of this column that need the per-tap border path
+        uint2 e0 = entry(row0), e1 = entry(row0 + 1);
+        fetch_pixel<GM>(k, e0, ce, s_rows[row0], H, fa);
+        // fully unrolled: a back edge would carry the in-flight gather registers through copies, and a copy of
+        // a register that is still being loaded is a wait for the load
+#pragma unroll
+        for (int it = 0; it < A_ROWS_PER_THREAD; it += 2) {
+            const int row = row0 + it;
+            e0 = entry(min(row + 2, row_last));
+            fetch_pixel<GM>(k, e1, ce, s_rows[row + 1], H, fb);
+            e1 = entry(min(row + 3, row_last));
+            slow_rows |= static_cast<uint32_t>(!fa.fast) << it;
+            emit(row, blend_pixel<false, BG>(k, fa));
+            fetch_pixel<GM>(k, e0, ce, s_rows[min(row + 2, row_last)], H, fa);
+            slow_rows |= static_cast<uint32_t>(!fb.fast) << (it + 1);
+            emit(row + 1, blend_pixel<false, BG>(k, fb));
+        }
+        while (slow_rows) {               // rare: windows at the very end of the frame, one-pixel sources
+            const int it = __builtin_ctz(slow_rows);
+            slow_rows &= slow_rows - 1;
+            fetch_pixel<GM>(k, entry(row0 + it), ce, s_rows[row0 + it], H, fa);
+            emit(row0 + it, blend_pixel<true, BG>(k, fa));
+        }
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    if (gain_mode == 1) {
+        if (big) run(std::integral_constant<int, 1>{}, Yes{}); else run(std::integral_constant<int, 1>{}, No{});
+    } else if (gain_mode == 2) {
+        run(std::integral_constant<int, 2>{}, Yes{});
+    } else {
+        if (big) run(std::integral_constant<int, 0>{}, Yes{}); else run(std::integral_constant<int, 0>{}, No{});
     }
     if (nlev < 2 || (MST_ABLATE_A & 4)) return;
     __syncthreads();
@@ -453,7 +502,7 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
     // load the base region (coordinates outside the image are never referenced: taps are reflected first)
     {
         const int w = c.lw[base], h = c.lh[base];
-        const uint32_t* __restrict__ g = c.G[base];
+        const uint32_t MST_GLOBAL* __restrict__ g = gp(c.G[base]);
         constexpr int n0 = e[0] * e[0];
         constexpr int kBatch = (n0 + B_THREADS - 1) / B_THREADS;       // 6 independent loads per thread
         uint32_t v[kBatch];
@@ -481,7 +530,7 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
         const int dw = c.lw[base + j + 1], dh = c.lh[base + j + 1];  // destination level size
         const uint32_t* __restrict__ s = s_all + offs[j];
         uint32_t* __restrict__ d = (j + 1 < B_KMAX) ? s_all + offs[j + 1] : nullptr;
-        uint32_t* __restrict__ gout = c.G[base + j + 1];
+        uint32_t MST_GLOBAL* __restrict__ gout = gp(c.G[base + j + 1]);
         constexpr int dummy = 0; (void)dummy;
         const int en = e[j + 1], es = e[j];
         // interior of this tile at the destination level
@@ -655,18 +704,18 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
         if (TOP) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                g[q] = valid[q] ? c.G[l][static_cast<uint32_t>(ly + (q >> 1)) * lw + lx + (q & 1)] : 0u;
+                g[q] = valid[q] ? gp(c.G[l])[static_cast<uint32_t>(ly + (q >> 1)) * lw + lx + (q & 1)] : 0u;
         } else {
             const uint32_t off = static_cast<uint32_t>(ly) * lw + lx;
-            const uint2 g0 = *reinterpret_cast<const uint2*>(c.G[l] + off);
-            const uint2 g1 = *reinterpret_cast<const uint2*>(c.G[l] + off + lw);
+            const uint2 g0 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off));
+            const uint2 g1 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off + lw));
             uint32_t nb[3][3];
             const int sw = c.lw[l + 1], sh = c.lh[l + 1];
             int jm, jp, im, ip;
             const int j = lx >> 1, i = ly >> 1;
             up_idx(j, sw, jm, jp);
             up_idx(i, sh, im, ip);
-            const uint32_t* __restrict__ gu = c.G[l + 1];
+            const uint32_t MST_GLOBAL* __restrict__ gu = gp(c.G[l + 1]);
             const uint32_t r0 = static_cast<uint32_t>(im) * sw, r1 = static_cast<uint32_t>(i) * sw,
                            r2 = static_cast<uint32_t>(ip) * sw;
             nb[0][0] = gu[r0 + jm]; nb[0][1] = gu[r0 + j]; nb[0][2] = gu[r0 + jp];
@@ -712,8 +761,8 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
                 w[q] = 0.f;
                 g[q] = 0u;
                 if (in) {
-                    w[q] = FINAL ? static_cast<float>(c.mask_b[off]) * a.alpha + 0.f : c.W[l][off];
-                    g[q] = c.G[l][off];
+                    w[q] = FINAL ? static_cast<float>(gp(c.mask_b)[off]) * a.alpha + 0.f : gp(c.W[l])[off];
+                    g[q] = gp(c.G[l])[off];
                     any = true;
                 }
             }
@@ -729,21 +778,21 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
             float2 w0 = make_float2(0.f, 0.f), w1 = w0;
             if (FINAL) {
                 // level-0 weight = mask.convertTo(32F, 1/255) with BORDER_CONSTANT 0 around the roi (mask_b)
-                m01 = static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(c.mask_b + off)) |
-                      static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(c.mask_b + off + lw)) << 16;
+                m01 = static_cast<uint32_t>(*(const uint16_t MST_GLOBAL*)(gp(c.mask_b) + off)) |
+                      static_cast<uint32_t>(*(const uint16_t MST_GLOBAL*)(gp(c.mask_b) + off + lw)) << 16;
             } else {
-                w0 = *reinterpret_cast<const float2*>(c.W[l] + off);
-                w1 = *reinterpret_cast<const float2*>(c.W[l] + off + lw);
+                w0 = load_global(reinterpret_cast<const float2*>(c.W[l] + off));
+                w1 = load_global(reinterpret_cast<const float2*>(c.W[l] + off + lw));
             }
-            const uint2 g0 = *reinterpret_cast<const uint2*>(c.G[l] + off);
-            const uint2 g1 = *reinterpret_cast<const uint2*>(c.G[l] + off + lw);
+            const uint2 g0 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off));
+            const uint2 g1 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off + lw));
             {
                 const int sw = c.lw[l + 1], sh = c.lh[l + 1];
                 int jm, jp, im, ip;
                 const int j = lx >> 1, i = ly >> 1;
                 up_idx(j, sw, jm, jp);
                 up_idx(i, sh, im, ip);
-                const uint32_t* __restrict__ gu = c.G[l + 1];
+                const uint32_t MST_GLOBAL* __restrict__ gu = gp(c.G[l + 1]);
                 const uint32_t r0 = static_cast<uint32_t>(im) * sw, r1 = static_cast<uint32_t>(i) * sw,
                                r2 = static_cast<uint32_t>(ip) * sw;
                 nb[0][0] = gu[r0 + jm]; nb[0][1] = gu[r0 + j]; nb[0][2] = gu[r0 + jp];
