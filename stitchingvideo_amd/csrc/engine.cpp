@@ -465,6 +465,8 @@ void Engine::compose_device(const void* const* d_frames, const size_t* strides, 
         fa.stride[i] = strides[i];
     }
     if (pano_stride < static_cast<size_t>(st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
+    if (pano_stride >= (size_t{1} << 24) || mask_stride >= (size_t{1} << 24))
+        throw Error{MST_ERR_INVALID_ARG, "panorama and mask strides must be below 16 MiB"};
     if (d_mask && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
     uint8_t* pano = static_cast<uint8_t*>(d_pano);
     uint8_t* pmask = static_cast<uint8_t*>(d_mask);
@@ -576,6 +578,8 @@ void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_stage_canvas before a successful mst_update"};
     if (st->blend_kind != MST_BLEND_MULTI_BAND) throw Error{MST_ERR_INVALID_ARG, "stage calls exist for multi-band only"};
     if (!d_pano || pano_stride < static_cast<size_t>(st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "bad panorama buffer"};
+    if (pano_stride >= (size_t{1} << 24) || mask_stride >= (size_t{1} << 24))
+        throw Error{MST_ERR_INVALID_ARG, "panorama and mask strides must be below 16 MiB"};
     if (d_mask && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
     hipStream_t s = stream ? stream : stream_;
     BlendArgs ba = st->blend;

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
         s_l0[row][col] = px;
         const int gy = ly0 + row;
         if (col_interior && row >= 2 && row < A_LH - 2 && gy < bh)
-            g0out[static_cast<uint32_t>(gy) * bw + gx] = px;
+            g0out[__umul24(gy, bw) + gx] = px;
     };
     const int row_last = row0 + A_ROWS_PER_THREAD - 1;
     const uint2* __restrict__ tcol = tab + col;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
             vbr += wy * hbr;
             vg += wy * hg;
         }
-        g1out[static_cast<uint32_t>(y1 + i) * lw1 + x1 + j] = pyrdown_finish(vbr, vg);
+        g1out[__umul24(y1 + i, lw1) + x1 + j] = pyrdown_finish(vbr, vg);
     }
 }
 
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
             v[u] = 0;
             if (idx < n0 && static_cast<unsigned>(gx) < static_cast<unsigned>(w) &&
                 static_cast<unsigned>(gy) < static_cast<unsigned>(h))
-                v[u] = g[static_cast<uint32_t>(gy) * w + gx];
+                v[u] = g[__umul24(gy, w) + gx];
         }
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
                 }
 #pragma unroll
                 for (int ky = 0; ky < 5; ++ky) {
-                    const uint32_t* r = s + yi[ky] * es;
+                    const uint32_t* r = s + __mul24(yi[ky], es);
                     uint32_t hbr, hg;
                     tap5(r[xi[0]], r[xi[1]], r[xi[2]], r[xi[3]], r[xi[4]], hbr, hg);
                     const uint32_t wy = (ky == 2) ? 6u : ((ky == 1 || ky == 3) ? 4u : 1u);
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
             const uint32_t v = pyrdown_finish(vbr, vg);
             if (d && j + 1 < k) d[idx] = v;
             if (ox >= ix0 && ox < ix0 + isz && oy >= iy0 && oy < iy0 + isz)
-                gout[static_cast<uint32_t>(oy) * dw + ox] = v;
+                gout[__umul24(oy, dw) + ox] = v;
         }
         __syncthreads();
     }
@@ -587,7 +587,10 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
 #define MST_C_TH 64        // 128x64 canvas tiles: 84.5 us vs 87.8 us for 128x32 (C3, MI355X)
 #endif
 constexpr int C_TW = 128, C_TH = MST_C_TH;
-constexpr int C_THREADS = 256;
+#ifndef MST_C_THREADS
+#define MST_C_THREADS 256
+#endif
+constexpr int C_THREADS = MST_C_THREADS;
 
 struct Region { int x0, y0, x1, y1; };
 
@@ -660,7 +663,7 @@ __device__ __forceinline__ void pyrup_quad_lds(const uint2* __restrict__ s, int 
     int he[3][3], ho[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        const uint2* p = s + rows[r] * pitch;
+        const uint2* p = s + __mul24(rows[r], pitch);
         const uint2 a = p[c0], b = p[c1], c = p[c2];
         const int av[3] = {s16_lo(a.x), s16_hi(a.x), s16_lo(a.y)};
         const int bv[3] = {s16_lo(b.x), s16_hi(b.x), s16_lo(b.y)};
@@ -704,9 +707,9 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
         if (TOP) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                g[q] = valid[q] ? gp(c.G[l])[static_cast<uint32_t>(ly + (q >> 1)) * lw + lx + (q & 1)] : 0u;
+                g[q] = valid[q] ? gp(c.G[l])[__umul24(ly + (q >> 1), lw) + lx + (q & 1)] : 0u;
         } else {
-            const uint32_t off = static_cast<uint32_t>(ly) * lw + lx;
+            const uint32_t off = __umul24(ly, lw) + lx;
             const uint2 g0 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off));
             const uint2 g1 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off + lw));
             uint32_t nb[3][3];
@@ -716,8 +719,8 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
             up_idx(j, sw, jm, jp);
             up_idx(i, sh, im, ip);
             const uint32_t MST_GLOBAL* __restrict__ gu = gp(c.G[l + 1]);
-            const uint32_t r0 = static_cast<uint32_t>(im) * sw, r1 = static_cast<uint32_t>(i) * sw,
-                           r2 = static_cast<uint32_t>(ip) * sw;
+            const uint32_t r0 = __umul24(im, sw), r1 = __umul24(i, sw),
+                           r2 = __umul24(ip, sw);
             nb[0][0] = gu[r0 + jm]; nb[0][1] = gu[r0 + j]; nb[0][2] = gu[r0 + jp];
             nb[1][0] = gu[r1 + jm]; nb[1][1] = gu[r1 + j]; nb[1][2] = gu[r1 + jp];
             nb[2][0] = gu[r2 + jm]; nb[2][1] = gu[r2 + j]; nb[2][2] = gu[r2 + jp];
@@ -757,7 +760,7 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
                 const int px = lx + (q & 1), py = ly + (q >> 1);
                 const bool in = valid[q] && static_cast<unsigned>(px) < static_cast<unsigned>(lw) &&
                                 static_cast<unsigned>(py) < static_cast<unsigned>(lh);
-                const uint32_t off = static_cast<uint32_t>(py) * lw + px;
+                const uint32_t off = __umul24(py, lw) + px;
                 w[q] = 0.f;
                 g[q] = 0u;
                 if (in) {
@@ -772,7 +775,7 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
             const bool inside = static_cast<unsigned>(lx) < static_cast<unsigned>(lw) &&
                                 static_cast<unsigned>(ly) < static_cast<unsigned>(lh);
             if (!inside) continue;
-            const uint32_t off = static_cast<uint32_t>(ly) * lw + lx;
+            const uint32_t off = __umul24(ly, lw) + lx;
             // issue every load of this camera before the first use: weights, Gaussian quad, pyrUp sources
             uint32_t m01 = 0;
             float2 w0 = make_float2(0.f, 0.f), w1 = w0;
@@ -793,8 +796,8 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
                 up_idx(j, sw, jm, jp);
                 up_idx(i, sh, im, ip);
                 const uint32_t MST_GLOBAL* __restrict__ gu = gp(c.G[l + 1]);
-                const uint32_t r0 = static_cast<uint32_t>(im) * sw, r1 = static_cast<uint32_t>(i) * sw,
-                               r2 = static_cast<uint32_t>(ip) * sw;
+                const uint32_t r0 = __umul24(im, sw), r1 = __umul24(i, sw),
+                               r2 = __umul24(ip, sw);
                 nb[0][0] = gu[r0 + jm]; nb[0][1] = gu[r0 + j]; nb[0][2] = gu[r0 + jp];
                 nb[1][0] = gu[r1 + jm]; nb[1][1] = gu[r1 + j]; nb[1][2] = gu[r1 + jp];
                 nb[2][0] = gu[r2 + jm]; nb[2][1] = gu[r2 + j]; nb[2][2] = gu[r2 + jp];
@@ -840,6 +843,9 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
     }
 }
 
+#ifndef MST_ABLATE_C
+#define MST_ABLATE_C 0     // timing experiments only: 1 no coarse bands, 2 no collapse, 4 no final pyrUp, 8 no final band,
+#endif                     // 16 no panorama stores, 32 every tile on the single-camera integer path
 struct QuadIter {
     Region r;
     int rw, qw, nq;
@@ -851,7 +857,7 @@ struct QuadIter {
     }
     __device__ __forceinline__ void at(int q, int& x, int& y, bool valid[4]) const
     {
-        const int qy = q / qw, qx = q - qy * qw;
+        const int qy = q / qw, qx = q - __mul24(qy, qw);
         x = r.x0 + 2 * qx;
         y = r.y0 + 2 * qy;
 #pragma unroll
@@ -872,11 +878,15 @@ __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, con
         it.at(q, x, y, valid);
         int n[4][3];
         float ws[4];
-        band_quad<TOP, false, PURE>(cams, a, l, x, y, valid, cam_bits, n, ws);
+        if (MST_ABLATE_C & 1) {
+            for (int k = 0; k < 4; ++k) n[k][0] = n[k][1] = n[k][2] = x + y + k;
+        } else {
+            band_quad<TOP, false, PURE>(cams, a, l, x, y, valid, cam_bits, n, ws);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (valid[k])
-                s_out[(y + (k >> 1) - it.r.y0) * it.rw + (x + (k & 1) - it.r.x0)] = pack3(n[k][0], n[k][1], n[k][2]);
+                s_out[__mul24(y + (k >> 1) - it.r.y0, it.rw) + (x + (k & 1) - it.r.x0)] = pack3(n[k][0], n[k][1], n[k][2]);
     }
 }
 
@@ -906,7 +916,7 @@ __device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx
         for (int k = 0; k < 4; ++k) {
             if (!valid[k]) continue;
             const int px = x + (k & 1), py = y + (k >> 1);
-            uint2* p = s_io + (py - it.r.y0) * it.rw + (px - it.r.x0);
+            uint2* p = s_io + __mul24(py - it.r.y0, it.rw) + (px - it.r.x0);
             const uint2 n = *p;
             const int v[3] = {sat_s16(up[k][0] + s16_lo(n.x)), sat_s16(up[k][1] + s16_hi(n.x)),
                               sat_s16(up[k][2] + s16_lo(n.y))};           // cv::add saturates
@@ -936,9 +946,15 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
         it.at(q, x, y, valid);
         int n[4][3];
         float ws[4];
-        band_quad<TOP, true, PURE>(cams, a, 0, x, y, valid, cam_bits, n, ws);
+        if (MST_ABLATE_C & 8) {
+            for (int k = 0; k < 4; ++k) { n[k][0] = n[k][1] = n[k][2] = x + y + k; ws[k] = 1.f; }
+        } else {
+            band_quad<TOP, true, PURE>(cams, a, 0, x, y, valid, cam_bits, n, ws);
+        }
         int up[4][3];
-        if (!TOP) pyrup_quad_lds(s_up, ur.x0, ur.y0, ur.x1 - ur.x0, a.cw[1], a.ch[1], x >> 1, y >> 1, up);
+        if (MST_ABLATE_C & 4) {
+            for (int k = 0; k < 4; ++k) up[k][0] = up[k][1] = up[k][2] = x - y + k;
+        } else if (!TOP) pyrup_quad_lds(s_up, ur.x0, ur.y0, ur.x1 - ur.x0, a.cw[1], a.ch[1], x >> 1, y >> 1, up);
         uint32_t o8[4][3];
         bool m[4];
 #pragma unroll
@@ -954,7 +970,8 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
         for (int ry = 0; ry < 2; ++ry) {
             const int py = y + ry;
             if (py >= a.final_h || !valid[2 * ry]) continue;                     // crop to dst_roi_final_
-            uint8_t* o = a.pano + static_cast<uint32_t>(py) * a.pano_stride + x * 3;
+            if ((MST_ABLATE_C & 16) && o8[2 * ry][0] != 77777u) continue;
+            uint8_t* o = a.pano + __umul24(py, a.pano_stride) + x * 3;
             const uint32_t* p0 = o8[2 * ry];
             const uint32_t* p1 = o8[2 * ry + 1];
             const bool both = valid[2 * ry + 1] && x + 1 < a.final_w;
@@ -969,7 +986,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
                     if (both) { o[3] = static_cast<uint8_t>(p1[0]); o[4] = static_cast<uint8_t>(p1[1]); o[5] = static_cast<uint8_t>(p1[2]); }
                 }
                 if (a.pano_mask) {
-                    uint8_t* om = a.pano_mask + static_cast<uint32_t>(py) * a.mask_stride + x;
+                    uint8_t* om = a.pano_mask + __umul24(py, a.mask_stride) + x;
                     om[0] = m[2 * ry] ? 255 : 0;
                     if (both) om[1] = m[2 * ry + 1] ? 255 : 0;
                 }
@@ -985,7 +1002,7 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
     const uint32_t tile = a.block_order[blockIdx.x];
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const uint32_t entry = a.block_cams[tile];
-    const bool pure = (entry >> 31) != 0;                 // see band_quad: one camera, weight exactly 1 everywhere
+    const bool pure = (MST_ABLATE_C & 32) ? true : (entry >> 31) != 0;   // see band_quad: one camera, weight exactly 1 everywhere
     const uint32_t cam_bits = entry & 0x7FFFFFFFu;
     const int top = a.nlev - 1;
     if (top == 0) {
@@ -1014,7 +1031,7 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
         }
     }
     for (int l = top - 1; l >= 1; --l) {
-        collapse_level(a, l, tx, ty, lds);
+        if (!(MST_ABLATE_C & 2)) collapse_level(a, l, tx, ty, lds);
         __syncthreads();
     }
     // phase 3

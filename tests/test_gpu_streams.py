@@ -97,3 +97,42 @@ def test_camera_sharded_stages_match_oracle():
     torch.cuda.synchronize()
     assert np.array_equal(pano2.cpu().numpy(), opano)
     e0.close(); e1.close()
+
+
+@pytest.mark.parametrize("blend", ["multiband", "feather", "no"])
+def test_unaligned_frames_and_odd_strides(blend):
+    """Frame bases at every byte alignment, row strides that are not multiples of four, and an odd-stride
+    panorama: the kernels address sources through a dword-aligned base plus byte offsets and use paired
+    byte stores only when the panorama rows allow it."""
+    import torch
+    cfg = rigmod.scaled_config("C3", 8)
+    cfg["blend"] = blend
+    rig = rigmod.build_rig(cfg)
+    eng = H.make_engine(rig)
+    _, _, cw, ch = eng.canvas()
+    dev = torch.device("cuda", 0)
+    host = rigmod.frames_for(rig, 3)
+    ptrs, strides, keep = [], [], []
+    for i, f in enumerate(host):
+        h, w, _ = f.shape
+        stride = 3 * w + (5, 1, 7, 3, 2, 6)[i % 6]
+        off = i % 4
+        buf = torch.zeros(off + stride * h + 16, dtype=torch.uint8, device=dev)
+        rows = buf[off:off + stride * h].view(h, stride)
+        rows[:, :3 * w] = torch.from_numpy(f.reshape(h, 3 * w)).to(dev)
+        keep.append(buf)
+        ptrs.append(buf.data_ptr() + off)
+        strides.append(stride)
+    pstride = 3 * cw + 5
+    pbuf = torch.zeros(1 + pstride * ch + 16, dtype=torch.uint8, device=dev)
+    mstride = cw + 3
+    mbuf = torch.zeros(1 + mstride * ch + 16, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng.compose_device(ptrs, strides, pbuf.data_ptr() + 1, pstride, mbuf.data_ptr() + 1, mstride)
+    eng.synchronize()
+    pano = pbuf[1:1 + pstride * ch].view(ch, pstride)[:, :3 * cw].reshape(ch, cw, 3).cpu().numpy()
+    mask = mbuf[1:1 + mstride * ch].view(ch, mstride)[:, :cw].cpu().numpy()
+    _, opano, omask = H.oracle_compose(rig, host)
+    assert np.array_equal(pano, opano)
+    assert np.array_equal(mask, omask)
+    eng.close()
