@@ -485,14 +485,20 @@ void Engine::compose_device(const void* const* d_frames, const size_t* strides, 
             check_hip(hipStreamWaitEvent(sf, ev_canvas_done_[slot], 0), "hipStreamWaitEvent");
         launch_warp_pyr(desc, cfg_.warp_kind, st->warp_list, fa, st->warp_table, sf);
         mark("k_warp_pyr");
-        for (size_t i = 0; i < st->chain_lists.size(); ++i) {
-            launch_pyr_chain(desc, st->chain_lists[i], st->plan.chain[i].base, st->plan.chain[i].k, sf);
-            mark("k_pyr_chain");
-        }
-        if (overlap) {
+        // where the frame crosses from the front stream to the caller's stream: after the warp kernel (the small
+        // pyramid-chain launches then fill in beside the next frame's warp) or after the chain
+        static const bool split_after_warp = [] { const char* v = std::getenv("MST_OVERLAP_SPLIT"); return v && v[0] == '1'; }();
+        auto cross = [&] {
             check_hip(hipEventRecord(ev_front_done_[slot], sf), "hipEventRecord");
             check_hip(hipStreamWaitEvent(s, ev_front_done_[slot], 0), "hipStreamWaitEvent");
+        };
+        if (overlap && split_after_warp) cross();
+        hipStream_t sc = (overlap && !split_after_warp) ? sf : s;
+        for (size_t i = 0; i < st->chain_lists.size(); ++i) {
+            launch_pyr_chain(desc, st->chain_lists[i], st->plan.chain[i].base, st->plan.chain[i].k, sc);
+            mark("k_pyr_chain");
         }
+        if (overlap && !split_after_warp) cross();
         BlendArgs ba = st->blend;
         ba.pano = pano; ba.pano_stride = static_cast<uint32_t>(pano_stride);
         ba.pano_mask = pmask; ba.mask_stride = static_cast<uint32_t>(mask_stride);

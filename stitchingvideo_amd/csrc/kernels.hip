@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_weight_level0(const CamDesc* __restrict
     float w = 0.f;
     if (static_cast<unsigned>(rx) < static_cast<unsigned>(c.roi_w) &&
         static_cast<unsigned>(ry) < static_cast<unsigned>(c.roi_h))
-        w = static_cast<float>(c.mask[static_cast<size_t>(ry) * c.roi_w + rx]) * alpha + 0.f;
+        w = static_cast<float>(gp(c.mask)[static_cast<size_t>(ry) * c.roi_w + rx]) * alpha + 0.f;
     w0[static_cast<size_t>(y) * bw + x] = w;
 }
 
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_border_mask(const CamDesc* __restrict__
     uint8_t m = 0;
     if (static_cast<unsigned>(rx) < static_cast<unsigned>(c.roi_w) &&
         static_cast<unsigned>(ry) < static_cast<unsigned>(c.roi_h))
-        m = c.mask[static_cast<size_t>(ry) * c.roi_w + rx];
+        m = gp(c.mask)[static_cast<size_t>(ry) * c.roi_w + rx];
     out[static_cast<size_t>(y) * bw + x] = m;
 }
 
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_band_weight_sum(const CamDesc* __restri
         const int lx = x - c.ox[level], ly = y - c.oy[level];
         if (static_cast<unsigned>(lx) < static_cast<unsigned>(c.lw[level]) &&
             static_cast<unsigned>(ly) < static_cast<unsigned>(c.lh[level]))
-            acc += c.W[level][static_cast<size_t>(ly) * c.lw[level] + lx];
+            acc += gp(c.W[level])[static_cast<size_t>(ly) * c.lw[level] + lx];
     }
     ws[static_cast<size_t>(y) * cw + x] = acc;
 }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_feather_weight_sum(const CamDesc* __res
         const int lx = x - c.corner_x, ly = y - c.corner_y;
         if (static_cast<unsigned>(lx) < static_cast<unsigned>(c.roi_w) &&
             static_cast<unsigned>(ly) < static_cast<unsigned>(c.roi_h))
-            acc += c.feather_w[static_cast<size_t>(ly) * c.roi_w + lx];
+            acc += gp(c.feather_w)[static_cast<size_t>(ly) * c.roi_w + lx];
     }
     ws[static_cast<size_t>(y) * cw + x] = acc;
 }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_feather_compose(const CamDesc* __restri
         if (static_cast<unsigned>(lx) >= static_cast<unsigned>(c.roi_w) ||
             static_cast<unsigned>(ly) >= static_cast<unsigned>(c.roi_h))
             continue;
-        const float w = c.feather_w[static_cast<size_t>(ly) * c.roi_w + lx];
+        const float w = gp(c.feather_w)[static_cast<size_t>(ly) * c.roi_w + lx];
         if (w == 0.f) continue;
         int v[3];
         warped_pixel(c, frames.ptr[i], frames.stride[i], lx, ly, v);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_paste_compose(const CamDesc* __restrict
         if (static_cast<unsigned>(lx) >= static_cast<unsigned>(c.roi_w) ||
             static_cast<unsigned>(ly) >= static_cast<unsigned>(c.roi_h))
             continue;
-        const int mv = c.mask[static_cast<size_t>(ly) * c.roi_w + lx];
+        const int mv = gp(c.mask)[static_cast<size_t>(ly) * c.roi_w + lx];
         mask_or |= mv;
         if (mv) { owner = i; olx = lx; oly = ly; }
     }

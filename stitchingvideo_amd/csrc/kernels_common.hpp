@@ -79,8 +79,8 @@ __device__ __forceinline__ int reflect(int p, int len)
 // ---- backward map (generic form, table per axis) -------------------------------------------------
 __device__ __forceinline__ void backward_map(const CamDesc& c, int x, int y, float& mx, float& my)
 {
-    const float ca = c.col_a[x];
-    const float ra = c.row_a[y];
+    const float ca = gp(c.col_a)[x];
+    const float ra = gp(c.row_a)[y];
     float X, Y, Z;
     if (c.kind == 0) {
         const float omt = c.one_minus_t2;
@@ -92,10 +92,10 @@ __device__ __forceinline__ void backward_map(const CamDesc& c, int x, int y, flo
         return;
     }
     float x_, y_, z_;
-    const float cb = c.col_b[x];
+    const float cb = gp(c.col_b)[x];
     if (c.kind == 1) {
         x_ = ra * ca;
-        y_ = c.row_b[y];
+        y_ = gp(c.row_b)[y];
         z_ = ra * cb;
     } else {
         x_ = ca;
@@ -169,11 +169,11 @@ __device__ __forceinline__ void sample_linear_reflect_c3(const uint8_t* __restri
 __device__ __forceinline__ float gain_at(const CamDesc& c, int x, int y)
 {
     if (c.expos == 2) {
-        const int x0 = c.gx0[x], x1 = c.gx1[x];
-        const float a0 = c.gxw0[x], a1 = c.gxw1[x];
-        const float* g0 = c.gain_map + c.gy0[y] * c.gw;
-        const float* g1 = c.gain_map + c.gy1[y] * c.gw;
-        const float b0 = c.gyw0[y], b1 = c.gyw1[y];
+        const int x0 = gp(c.gx0)[x], x1 = gp(c.gx1)[x];
+        const float a0 = gp(c.gxw0)[x], a1 = gp(c.gxw1)[x];
+        const float MST_GLOBAL* g0 = gp(c.gain_map) + gp(c.gy0)[y] * c.gw;
+        const float MST_GLOBAL* g1 = gp(c.gain_map) + gp(c.gy1)[y] * c.gw;
+        const float b0 = gp(c.gyw0)[y], b1 = gp(c.gyw1)[y];
         const float r0 = g0[x0] * a0 + g0[x1] * a1;    // HResizeLinear
         const float r1 = g1[x0] * a0 + g1[x1] * a1;
         return r0 * b0 + r1 * b1;                      // VResizeLinear

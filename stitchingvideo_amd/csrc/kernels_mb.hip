@@ -469,7 +469,10 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
 // barrier-separated phases in too few resident blocks (36-67 us); 2-deep launches with many threads per
 // tile keep the per-thread instruction stream short, which is what bounds these small kernels.
 constexpr int B_T = 64;                         // base-level interior of a tile
-constexpr int B_THREADS = 1024;
+#ifndef MST_B_THREADS
+#define MST_B_THREADS 1024
+#endif
+constexpr int B_THREADS = MST_B_THREADS;
 constexpr int B_KMAX = 2;
 constexpr int B_E0 = 73, B_E1 = 35;             // region extents for a full k = 2 chain (e2 = 16)
 
