@@ -4,17 +4,19 @@
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
 A step is one pass of the per-frame hot path (warp -> exposure gain -> Laplacian multi-band blend
--> 8-bit panorama) over one set of N_cam synthetic frames that is already resident in HBM.  The
-workload at every N is BASELINE config C3: 6x1920x1080 streams, spherical warp, block gains,
-5-band multi-band blend, canvas 7852x1020.
+-> 8-bit panorama) over one batch of --batch (default 8) sets of N_cam synthetic frames that are already
+resident in HBM: every kernel of the path is launched once per step over all frame sets of the batch
+(mst_compose_device_batch) and `value` counts panoramas, i.e. steps x batch.  --batch 1 is one frame set
+per launch sequence (with frame pipelining unless --no-overlap).  The workload at every N is BASELINE
+config C3: 6x1920x1080 streams, spherical warp, block gains, 5-band multi-band blend, canvas 7852x1020.
 
 N > 1 shards *frames*: every rank owns the full calibration and stitches its own stream of frame
 sets (independent panoramas, no data-path collective) -> "scaling": "weak".
 
 Extra objects on the JSON line:
-  roofline      HBM roofline of the frame: algorithmic bytes 3*(N_cam*W*H + Wc*Hc)
-                over the measured per-frame device time; per-kernel times come from HIP events
-                recorded between launches on the compose stream (mst_compose_profile).
+  roofline      HBM roofline of a step: algorithmic bytes 3*(N_cam*W*H + Wc*Hc) per frame set
+                x batch over the measured device time of the step; per-kernel times come from HIP events
+                recorded between launches on the compose stream (mst_compose_profile_batch).
   cpu_baseline  the CPU oracle (oracle/, a port of the reference arithmetic) timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -39,6 +41,8 @@ def parse_args():
     ap.add_argument("--frame-sets", type=int, default=3, help="distinct synthetic frame sets cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap consecutive frames (latency mode)")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="frame sets per step (mst_compose_device_batch); 1 = one frame set per launch sequence")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = sized to ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = min(host cores, 32))")
     return ap.parse_args()
@@ -87,26 +91,39 @@ def main():
     n_cam = len(rig["cameras"])
     # throughput mode: frame t+1's per-camera kernels overlap frame t's canvas kernel (frames are resident in
     # HBM before each call, as MST_FLAG_OVERLAP_FRAMES requires); --no-overlap keeps one stream
+    batch = max(1, min(args.batch, 8))
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
-                           overlap_frames=not args.no_overlap and blend == "multiband")
+                           overlap_frames=not args.no_overlap and blend == "multiband" and batch == 1,
+                           max_batch=batch)
     eng.update(rig["scale"], rig["cameras"])
     cx, cy, cw, ch = eng.canvas()
 
     # frames resident in HBM: a few distinct sets, each rank its own (frame index offset by rank)
     dev = torch.device("cuda", local_rank)
     host_sets, dev_sets = [], []
-    for s in range(args.frame_sets):
+    n_sets = max(args.frame_sets, batch)
+    for s in range(n_sets):
         fr = rigmod.frames_for(rig, frame_index=sharding_mod.global_frame_index(rank, world, s))
         host_sets.append(fr)
         dev_sets.append([torch.from_numpy(f).to(dev) for f in fr])
-    pano = torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev)
+    panos = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(batch)]
+    pano = panos[0]
     # a real (non-null) stream, made torch's current one, so torch.cuda.Event brackets the launches
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
-    calls = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),
-                                  pano.stride(0), stream=stream) for ds in dev_sets]
+    # a step = one batch of `batch` frame sets through one launch sequence (consecutive sets, rotating start)
+    def tables(first):
+        sets = [dev_sets[(first + k) % n_sets] for k in range(batch)]
+        return [[t.data_ptr() for t in ds] for ds in sets], [[t.stride(0) for t in ds] for ds in sets]
+
+    if batch == 1:
+        calls = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),
+                                      pano.stride(0), stream=stream) for ds in dev_sets]
+    else:
+        calls = [eng.make_device_batch_call(*tables(first), [p.data_ptr() for p in panos], pano.stride(0),
+                                            stream=stream) for first in range(n_sets)]
 
     def barrier():
         if world > 1:
@@ -138,17 +155,16 @@ def main():
         acc = {}
         order = []
         for i in range(reps):
-            ds = dev_sets[i % len(dev_sets)]
-            st = eng.profile_stages([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),
-                                    pano.stride(0), stream=stream)
+            st = eng.profile_stages_batch(*tables(i % n_sets), [p.data_ptr() for p in panos], pano.stride(0),
+                                          stream=stream)
             for name, ms in st:
                 if name not in acc:
                     acc[name] = [0.0, 0]
                     order.append(name)
                 acc[name][0] += ms
                 acc[name][1] += 1
-        kernels = [{"name": k, "launches_per_frame": acc[k][1] // reps, "avg_ms": round(acc[k][0] / acc[k][1], 5),
-                    "ms_per_frame": round(acc[k][0] / reps, 5)} for k in order]
+        kernels = [{"name": k, "launches_per_step": acc[k][1] // reps, "avg_ms": round(acc[k][0] / acc[k][1], 5),
+                    "ms_per_frame": round(acc[k][0] / reps / batch, 5)} for k in order]
         dominant = max(kernels, key=lambda k: k["ms_per_frame"]) if kernels else None
 
         ms_per_step = wall * 1000.0 / args.steps
@@ -159,10 +175,11 @@ def main():
             traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.config]["bytes_per_frame"]
         except (OSError, KeyError, ValueError):
             pass
-        achieved = alg_bytes / (dev_ms_per_step * 1e-3) / 1e9
+        # one step = one launch of every kernel over `batch` frame sets: algorithmic bytes per launch = batch x frame
+        achieved = alg_bytes * batch / (dev_ms_per_step * 1e-3) / 1e9
         out = {
             "metric": "stitched panorama frames/sec, 6x1080p->360deg canvas",
-            "value": round(sharding.aggregate_throughput(world, args.steps, wall), 3),
+            "value": round(sharding.aggregate_throughput(world, args.steps * batch, wall), 3),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -175,12 +192,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d BGR8 streams, %s warp, gain_blocks, %s blend (5 bands), canvas %dx%d"
                                    % (args.config, n_cam, rig["size"][0], rig["size"][1], rig["warp"], blend, cw, ch),
-                       "frames_resident_in_hbm": True, "parallelism": "frames sharded over %d rank(s), no collective" % world},
+                       "frames_resident_in_hbm": True, "frame_sets_per_step": batch,
+                       "parallelism": "frames sharded over %d rank(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic * batch if traffic else None,
                          "algorithmic_bytes_per_frame": alg_bytes,
-                         "device_ms_per_frame": round(dev_ms_per_step, 5),
-                         "scope": "whole frame (%d launches)" % sum(k["launches_per_frame"] for k in kernels),
+                         "algorithmic_bytes_per_launch": alg_bytes * batch,
+                         "device_ms_per_frame": round(dev_ms_per_step / batch, 5),
+                         "scope": "whole step (%d launches over %d frame sets)"
+                                  % (sum(k["launches_per_step"] for k in kernels), batch),
                          "dominant_kernel": dominant, "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -86,6 +86,7 @@ extern "C" {
                                       the panorama of that call is complete.  Multi-band only; not with MST_FLAG_DEBUG. */
 
 #define MST_MAX_CAMERAS 16
+#define MST_MAX_BATCH 8
 #define MST_MAX_BANDS   10
 
 typedef struct mst_engine mst_engine;
@@ -101,6 +102,8 @@ typedef struct mst_config {
     int32_t  device;             /* HIP device ordinal */
     uint32_t flags;              /* MST_FLAG_* */
     float    upblack, downblack, leftblack, rightblack;   /* DRV:47 crop margins (LUT path) */
+    int32_t  max_batch;          /* frame sets per mst_compose_device_batch call, 0/1 = none, <= MST_MAX_BATCH;
+                                  * multi-band keeps one set of Gaussian pyramids per frame set of a batch */
 } mst_config;
 
 typedef struct mst_camera {
@@ -155,6 +158,15 @@ int  mst_compose(mst_engine *e, const uint8_t *const *frames, const size_t *fram
 int  mst_compose_device(mst_engine *e, const void *const *d_frames, const size_t *frame_strides,
                         void *d_pano, size_t pano_stride, void *d_pano_mask, size_t pano_mask_stride,
                         void *stream);
+/* Throughput mode: `count` independent frame sets (1 <= count <= mst_config.max_batch) through one launch
+ * sequence -- every kernel of the path runs once over all sets, which amortises the launch boundaries and fills
+ * the chip during the small pyramid-chain launches.  The reference stitches one frame set per StitchingAll()
+ * call (DRV:724-770); results are exactly those of `count` mst_compose_device calls.  d_frames / frame_strides
+ * hold count * num_cameras entries (frame set f, camera i at f * num_cameras + i); d_panos (and d_pano_masks,
+ * or NULL) hold one pointer per frame set, all with the same strides. */
+int  mst_compose_device_batch(mst_engine *e, int count, const void *const *d_frames, const size_t *frame_strides,
+                              void *const *d_panos, size_t pano_stride, void *const *d_pano_masks,
+                              size_t pano_mask_stride, void *stream);
 int  mst_synchronize(mst_engine *e);
 /* One frame of mst_compose_device with a HIP event recorded on `stream` between consecutive
  * kernel launches: the counterpart of the reference's getTickCount() brackets
@@ -163,6 +175,10 @@ int  mst_synchronize(mst_engine *e);
 int  mst_compose_profile(mst_engine *e, const void *const *d_frames, const size_t *frame_strides,
                          void *d_pano, size_t pano_stride, void *stream, int max_stages,
                          char (*names)[32], float *stage_ms, int *num_stages);
+/* the same for one mst_compose_device_batch call */
+int  mst_compose_profile_batch(mst_engine *e, int count, const void *const *d_frames, const size_t *frame_strides,
+                               void *const *d_panos, size_t pano_stride, void *stream, int max_stages,
+                               char (*names)[32], float *stage_ms, int *num_stages);
 
 /* ---- camera streams sharded over GPUs (multi-band only) ---------------------------------------
  * The reference runs its per-camera work under `#pragma omp parallel for` over cameras (DRV:736,748) and

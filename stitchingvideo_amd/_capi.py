@@ -26,7 +26,8 @@ DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, 
 
 EXPORTS = [
     "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_canvas", "mst_camera_roi",
-    "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_profile", "mst_synchronize", "mst_warp_roi",
+    "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_device_batch", "mst_compose_profile",
+    "mst_compose_profile_batch", "mst_synchronize", "mst_warp_roi",
     "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
     "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
     "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame",
@@ -38,7 +39,7 @@ class Config(C.Structure):
                 ("blend_kind", C.c_int32), ("num_bands", C.c_int32), ("feather_sharpness", C.c_float),
                 ("expos_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("upblack", C.c_float), ("downblack", C.c_float), ("leftblack", C.c_float),
-                ("rightblack", C.c_float)]
+                ("rightblack", C.c_float), ("max_batch", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -100,6 +101,12 @@ def load():
     L.mst_compose_device.restype = C.c_int
     L.mst_compose_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), vp, C.c_size_t, vp,
                                      C.c_size_t, vp]
+    L.mst_compose_device_batch.restype = C.c_int
+    L.mst_compose_device_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
+                                           C.c_size_t, C.POINTER(vp), C.c_size_t, vp]
+    L.mst_compose_profile_batch.restype = C.c_int
+    L.mst_compose_profile_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
+                                            C.c_size_t, vp, C.c_int, vp, fp, ip]
     L.mst_synchronize.restype = C.c_int
     L.mst_synchronize.argtypes = [vp]
     L.mst_stage_cameras.restype = C.c_int

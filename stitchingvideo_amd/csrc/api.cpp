@@ -85,6 +85,8 @@ int mst_create(const mst_config* cfg, mst_engine** out)
                 "MST_FLAG_DRIVER_LUT requires MST_BLEND_NO");
         require(!(cfg->flags & MST_FLAG_OVERLAP_FRAMES) || !(cfg->flags & MST_FLAG_DEBUG),
                 "MST_FLAG_OVERLAP_FRAMES cannot be combined with MST_FLAG_DEBUG");
+        require(cfg->max_batch >= 0 && cfg->max_batch <= MST_MAX_BATCH, "max_batch out of range");
+        static_assert(MST_MAX_BATCH == mst::kMaxBatch, "public and device batch limits differ");
         created = new mst_engine(*cfg);
         created->impl.init();
     });
@@ -166,16 +168,36 @@ int mst_compose_device(mst_engine* e, const void* const* d_frames, const size_t*
     });
 }
 
+int mst_compose_device_batch(mst_engine* e, int count, const void* const* d_frames, const size_t* frame_strides,
+                             void* const* d_panos, size_t pano_stride, void* const* d_pano_masks,
+                             size_t pano_mask_stride, void* stream)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] {
+        e->impl.compose_batch(count, d_frames, frame_strides, d_panos, pano_stride, d_pano_masks, pano_mask_stride,
+                              static_cast<hipStream_t>(stream));
+    });
+}
+
 int mst_compose_profile(mst_engine* e, const void* const* d_frames, const size_t* frame_strides, void* d_pano,
                         size_t pano_stride, void* stream, int max_stages, char (*names)[32], float* stage_ms,
                         int* num_stages)
+{
+    void* panos[1] = {d_pano};
+    return mst_compose_profile_batch(e, 1, d_frames, frame_strides, panos, pano_stride, stream, max_stages, names,
+                                     stage_ms, num_stages);
+}
+
+int mst_compose_profile_batch(mst_engine* e, int count, const void* const* d_frames, const size_t* frame_strides,
+                              void* const* d_panos, size_t pano_stride, void* stream, int max_stages,
+                              char (*names)[32], float* stage_ms, int* num_stages)
 {
     if (!e) return MST_ERR_INVALID_ARG;
     return guarded(e, [&] {
         require(max_stages >= 0 && num_stages != nullptr, "bad stage buffer");
         mst::StageTimer timer;
-        e->impl.compose_device(d_frames, frame_strides, d_pano, pano_stride, nullptr, 0,
-                               static_cast<hipStream_t>(stream), &timer);
+        e->impl.compose_batch(count, d_frames, frame_strides, d_panos, pano_stride, nullptr, 0,
+                              static_cast<hipStream_t>(stream), &timer);
         std::vector<std::pair<std::string, float>> stages;
         timer.collect(stages);
         *num_stages = static_cast<int>(stages.size());

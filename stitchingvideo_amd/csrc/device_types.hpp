@@ -73,6 +73,13 @@ struct FrameArgs {                 // per-frame source pointers, passed by value
     uint32_t stride[kMaxCams];
 };
 
+// Frame sets of one batched launch (mst_compose_device_batch): set f is handled by the blocks with
+// blockIdx.y == f, against the f-th copy of the camera descriptors (own Gaussian pyramids).
+constexpr int kMaxBatch = 8;
+struct FrameBatch {
+    FrameArgs f[kMaxBatch];
+};
+
 struct CanvasDesc {
     int32_t n_cams;
     int32_t nlev;
@@ -87,8 +94,8 @@ struct BlendArgs {
     int32_t nlev, n_cams;
     int32_t cw[kMaxLevels], ch[kMaxLevels];   // padded canvas pyramid level sizes
     int32_t final_w, final_h;                 // dst_roi_final_
-    uint8_t* pano; uint32_t pano_stride;
-    uint8_t* pano_mask; uint32_t mask_stride;
+    uint8_t* pano[kMaxBatch]; uint32_t pano_stride;          // one panorama (and optional mask) per frame set
+    uint8_t* pano_mask[kMaxBatch]; uint32_t mask_stride;
     const uint32_t* block_cams;               // per block: bit i set = camera i has non-zero weight under the tile
     const uint32_t* block_order;              // tile index (ty * tiles_x + tx) handled by block i
     int32_t tiles_x;

@@ -360,20 +360,24 @@ void Engine::update(const mst_calibration& calib)
             mask_b[i] = st->pool.alloc<uint8_t>(static_cast<size_t>(d.lw[0]) * d.lh[0] + 16);
             d.mask_b = mask_b[i];
         }
-        st->d_desc = st->pool.upload(st->desc, s);
-        if (cfg_.flags & MST_FLAG_OVERLAP_FRAMES) {
-            // second set of Gaussian pyramids: frame t+1's per-camera kernels write it while frame t's
-            // canvas kernel still reads the first
-            std::vector<CamDesc> alt = st->desc;
-            for (int i = 0; i < n; ++i)
+        // Descriptor sets: set 0 owns the pyramids above; frame pipelining (MST_FLAG_OVERLAP_FRAMES) needs a second
+        // set of Gaussian pyramids (frame t+1's per-camera kernels write it while frame t's canvas kernel still
+        // reads the first), batched launches (mst_config.max_batch) one per frame set of a batch.
+        st->num_sets = std::max(1, std::min<int>(cfg_.max_batch, kMaxBatch));
+        if (cfg_.flags & MST_FLAG_OVERLAP_FRAMES) st->num_sets = std::max(st->num_sets, 2);
+        std::vector<CamDesc> sets = st->desc;
+        for (int k = 1; k < st->num_sets; ++k)
+            for (int i = 0; i < n; ++i) {
+                CamDesc d = st->desc[i];
                 for (int l = 0; l <= nb; ++l) {
-                    const size_t px = static_cast<size_t>(alt[i].lw[l]) * alt[i].lh[l];
-                    alt[i].G[l] = st->pool.alloc<uint32_t>(px);
-                    check_hip(hipMemsetAsync(alt[i].G[l], 0, px * sizeof(uint32_t), s), "hipMemsetAsync");
+                    const size_t px = static_cast<size_t>(d.lw[l]) * d.lh[l];
+                    d.G[l] = st->pool.alloc<uint32_t>(px);
+                    check_hip(hipMemsetAsync(d.G[l], 0, px * sizeof(uint32_t), s), "hipMemsetAsync");
                 }
-            st->d_desc_alt = st->pool.upload(alt, s);
-            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
-        }
+                sets.push_back(d);
+            }
+        st->d_desc = st->pool.upload(sets, s);
+        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");     // `sets` is pageable and local
         for (int i = 0; i < n; ++i) {
             const CamDesc& d = st->desc[i];
             launch_border_mask(st->d_desc, i, mask_b[i], d.lw[0], d.lh[0], s);
@@ -451,39 +455,61 @@ void Engine::update(const mst_calibration& calib)
 void Engine::compose_device(const void* const* d_frames, const size_t* strides, void* d_pano, size_t pano_stride,
                             void* d_mask, size_t mask_stride, hipStream_t stream, StageTimer* timer)
 {
+    void* panos[1] = {d_pano};
+    void* masks[1] = {d_mask};
+    compose_batch(1, d_frames, strides, panos, pano_stride, d_mask ? masks : nullptr, mask_stride, stream, timer);
+}
+
+void Engine::compose_batch(int count, const void* const* d_frames, const size_t* strides, void* const* d_panos,
+                           size_t pano_stride, void* const* d_masks, size_t mask_stride, hipStream_t stream,
+                           StageTimer* timer)
+{
     select_device(cfg_.device);
     std::shared_ptr<CalibState> st = state();
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
-    if (!d_frames || !strides || !d_pano) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama pointer"};
+    if (!d_frames || !strides || !d_panos) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama table"};
+    if (count < 1 || count > kMaxBatch) throw Error{MST_ERR_INVALID_ARG, "batch size out of range"};
+    if (st->blend_kind == MST_BLEND_MULTI_BAND && count > 1 && count > st->num_sets)
+        throw Error{MST_ERR_INVALID_ARG, "batch larger than mst_config.max_batch"};
     hipStream_t s = stream ? stream : stream_;
-    FrameArgs fa{};
-    for (int i = 0; i < st->n; ++i) {
-        if (!d_frames[i]) throw Error{MST_ERR_INVALID_ARG, "null frame pointer"};
-        if (strides[i] < static_cast<size_t>(st->cams[i].src_w) * 3) throw Error{MST_ERR_INVALID_ARG, "frame stride too small"};
-        if (strides[i] >= (size_t{1} << 24)) throw Error{MST_ERR_INVALID_ARG, "frame stride must be below 16 MiB"};
-        fa.ptr[i] = static_cast<const uint8_t*>(d_frames[i]);
-        fa.stride[i] = strides[i];
-    }
+    FrameBatch fb{};
+    for (int f = 0; f < count; ++f)
+        for (int i = 0; i < st->n; ++i) {
+            const void* p = d_frames[f * st->n + i];
+            const size_t stride = strides[f * st->n + i];
+            if (!p) throw Error{MST_ERR_INVALID_ARG, "null frame pointer"};
+            if (stride < static_cast<size_t>(st->cams[i].src_w) * 3) throw Error{MST_ERR_INVALID_ARG, "frame stride too small"};
+            if (stride >= (size_t{1} << 24)) throw Error{MST_ERR_INVALID_ARG, "frame stride must be below 16 MiB"};
+            fb.f[f].ptr[i] = static_cast<const uint8_t*>(p);
+            fb.f[f].stride[i] = static_cast<uint32_t>(stride);
+        }
     if (pano_stride < static_cast<size_t>(st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
     if (pano_stride >= (size_t{1} << 24) || mask_stride >= (size_t{1} << 24))
         throw Error{MST_ERR_INVALID_ARG, "panorama and mask strides must be below 16 MiB"};
-    if (d_mask && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
-    uint8_t* pano = static_cast<uint8_t*>(d_pano);
-    uint8_t* pmask = static_cast<uint8_t*>(d_mask);
+    if (d_masks && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
+    for (int f = 0; f < count; ++f)
+        if (!d_panos[f]) throw Error{MST_ERR_INVALID_ARG, "null panorama pointer"};
 
     auto mark = [&](const char* name) { if (timer) timer->mark(name, s); };
     if (timer) timer->begin(s);
     if (st->blend_kind == MST_BLEND_MULTI_BAND) {
-        // Frame pipelining: the per-camera kernels (A, B) of this frame go to front_stream_ and only wait for the
-        // canvas kernel that last read this pyramid set (two frames ago); the canvas kernel (C) stays on the
-        // caller's stream behind them.  Frame t+1's A/B therefore overlap frame t's C.
-        const bool overlap = st->d_desc_alt != nullptr && timer == nullptr && !in_host_compose_;
+        // Frame pipelining (single frame sets only): the per-camera kernels (A, B) of this frame go to front_stream_
+        // and only wait for the canvas kernel that last read this pyramid set (two frames ago); the canvas kernel
+        // (C) stays on the caller's stream behind them.  Frame t+1's A/B therefore overlap frame t's C.
+        const bool overlap = count == 1 && (cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && st->num_sets >= 2 &&
+                             timer == nullptr && !in_host_compose_;
         const int slot = overlap ? static_cast<int>(frame_counter_++ & 1u) : 0;
-        const CamDesc* desc = slot ? st->d_desc_alt : st->d_desc;
+        const CamDesc* desc = st->d_desc + static_cast<size_t>(slot) * st->n;
         hipStream_t sf = overlap ? front_stream_ : s;
         if (overlap && canvas_pending_[slot])
             check_hip(hipStreamWaitEvent(sf, ev_canvas_done_[slot], 0), "hipStreamWaitEvent");
-        launch_warp_pyr(desc, cfg_.warp_kind, st->warp_list, fa, st->warp_table, sf);
+        if (!overlap)          // a batch (or a timed frame) re-uses the sets an earlier pipelined frame may still read
+            for (int k = 0; k < 2; ++k)
+                if (canvas_pending_[k]) {
+                    check_hip(hipStreamWaitEvent(s, ev_canvas_done_[k], 0), "hipStreamWaitEvent");
+                    canvas_pending_[k] = false;
+                }
+        launch_warp_pyr(desc, st->n, cfg_.warp_kind, st->warp_list, fb, count, st->warp_table, sf);
         mark("k_warp_pyr");
         // where the frame crosses from the front stream to the caller's stream: after the warp kernel (the small
         // pyramid-chain launches then fill in beside the next frame's warp) or after the chain
@@ -495,28 +521,38 @@ void Engine::compose_device(const void* const* d_frames, const size_t* strides, 
         if (overlap && split_after_warp) cross();
         hipStream_t sc = (overlap && !split_after_warp) ? sf : s;
         for (size_t i = 0; i < st->chain_lists.size(); ++i) {
-            launch_pyr_chain(desc, st->chain_lists[i], st->plan.chain[i].base, st->plan.chain[i].k, sc);
+            launch_pyr_chain(desc, st->n, st->chain_lists[i], st->plan.chain[i].base, st->plan.chain[i].k, count, sc);
             mark("k_pyr_chain");
         }
         if (overlap && !split_after_warp) cross();
         BlendArgs ba = st->blend;
-        ba.pano = pano; ba.pano_stride = static_cast<uint32_t>(pano_stride);
-        ba.pano_mask = pmask; ba.mask_stride = static_cast<uint32_t>(mask_stride);
-        launch_blend(desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, st->plan.lds_bytes, s);
+        for (int f = 0; f < count; ++f) {
+            ba.pano[f] = static_cast<uint8_t*>(d_panos[f]);
+            ba.pano_mask[f] = d_masks ? static_cast<uint8_t*>(d_masks[f]) : nullptr;
+        }
+        ba.pano_stride = static_cast<uint32_t>(pano_stride);
+        ba.mask_stride = static_cast<uint32_t>(mask_stride);
+        launch_blend(desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, count, st->plan.lds_bytes, s);
         mark("k_blend");
         if (overlap) {
             check_hip(hipEventRecord(ev_canvas_done_[slot], s), "hipEventRecord");
             canvas_pending_[slot] = true;
         }
-    } else if (st->blend_kind == MST_BLEND_FEATHER) {
-        launch_feather_compose(st->d_desc, st->n, fa, st->d_feather_ws, st->canvas.width, st->canvas.height, pano,
-                               pano_stride, pmask, mask_stride, s);
-        mark("k_feather_compose");
     } else {
-        launch_paste_compose(st->d_desc, st->n, fa, st->canvas.width, st->canvas.height, st->crop_x, st->crop_y,
-                             st->out_w, st->out_h, (cfg_.flags & MST_FLAG_DRIVER_LUT) ? 1 : 0, pano, pano_stride,
-                             pmask, mask_stride, s);
-        mark("k_paste_compose");
+        for (int f = 0; f < count; ++f) {
+            uint8_t* pano = static_cast<uint8_t*>(d_panos[f]);
+            uint8_t* pmask = d_masks ? static_cast<uint8_t*>(d_masks[f]) : nullptr;
+            if (st->blend_kind == MST_BLEND_FEATHER) {
+                launch_feather_compose(st->d_desc, st->n, fb.f[f], st->d_feather_ws, st->canvas.width, st->canvas.height,
+                                       pano, pano_stride, pmask, mask_stride, s);
+                mark("k_feather_compose");
+            } else {
+                launch_paste_compose(st->d_desc, st->n, fb.f[f], st->canvas.width, st->canvas.height, st->crop_x,
+                                     st->crop_y, st->out_w, st->out_h, (cfg_.flags & MST_FLAG_DRIVER_LUT) ? 1 : 0, pano,
+                                     pano_stride, pmask, mask_stride, s);
+                mark("k_paste_compose");
+            }
+        }
     }
     check_hip(hipGetLastError(), "compose kernels");
     std::lock_guard<std::mutex> lk(mu_);
@@ -546,7 +582,8 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
     if (st->blend_kind != MST_BLEND_MULTI_BAND) throw Error{MST_ERR_INVALID_ARG, "stage calls exist for multi-band only"};
     if (!d_frames || !strides) throw Error{MST_ERR_INVALID_ARG, "null frame table"};
     hipStream_t s = stream ? stream : stream_;
-    FrameArgs fa{};
+    FrameBatch fb{};
+    FrameArgs& fa = fb.f[0];
     for (int i = 0; i < st->n; ++i) {
         if (!(camera_mask >> i & 1u)) continue;
         if (!d_frames[i] || strides[i] < static_cast<size_t>(st->cams[i].src_w) * 3 || strides[i] >= (size_t{1} << 24))
@@ -561,7 +598,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
         tl.tiles = st->warp_list.tiles + plan.warp_cam_start[i];
         tl.count = plan.warp_cam_start[i + 1] - plan.warp_cam_start[i];
         tl.first = plan.warp_cam_start[i];
-        launch_warp_pyr(st->d_desc, cfg_.warp_kind, tl, fa, st->warp_table, s);
+        launch_warp_pyr(st->d_desc, st->n, cfg_.warp_kind, tl, fb, 1, st->warp_table, s);
     }
     for (size_t k = 0; k < st->chain_lists.size(); ++k)
         for (int i = 0; i < st->n; ++i) {
@@ -570,7 +607,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
             tl.tiles = st->chain_lists[k].tiles + plan.chain[k].cam_start[i];
             tl.count = plan.chain[k].cam_start[i + 1] - plan.chain[k].cam_start[i];
             tl.first = plan.chain[k].cam_start[i];
-            launch_pyr_chain(st->d_desc, tl, plan.chain[k].base, plan.chain[k].k, s);
+            launch_pyr_chain(st->d_desc, st->n, tl, plan.chain[k].base, plan.chain[k].k, 1, s);
         }
     check_hip(hipGetLastError(), "camera stage kernels");
     std::lock_guard<std::mutex> lk(mu_);
@@ -589,9 +626,9 @@ void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t
     if (d_mask && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
     hipStream_t s = stream ? stream : stream_;
     BlendArgs ba = st->blend;
-    ba.pano = static_cast<uint8_t*>(d_pano); ba.pano_stride = static_cast<uint32_t>(pano_stride);
-    ba.pano_mask = static_cast<uint8_t*>(d_mask); ba.mask_stride = static_cast<uint32_t>(mask_stride);
-    launch_blend(st->d_desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, st->plan.lds_bytes, s);
+    ba.pano[0] = static_cast<uint8_t*>(d_pano); ba.pano_stride = static_cast<uint32_t>(pano_stride);
+    ba.pano_mask[0] = static_cast<uint8_t*>(d_mask); ba.mask_stride = static_cast<uint32_t>(mask_stride);
+    launch_blend(st->d_desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, 1, st->plan.lds_bytes, s);
     check_hip(hipGetLastError(), "canvas stage kernel");
     std::lock_guard<std::mutex> lk(mu_);
     in_flight_ = std::move(st);

@@ -56,8 +56,8 @@ struct CalibState {
     int blend_kind = 0;
     std::vector<CameraSetup> cams;
     std::vector<CamDesc> desc;      // host copy of the device array
-    CamDesc* d_desc = nullptr;
-    CamDesc* d_desc_alt = nullptr;  // same cameras, second set of Gaussian pyramids (frame pipelining)
+    CamDesc* d_desc = nullptr;      // num_sets copies back to back: same cameras, own Gaussian pyramids per set
+    int num_sets = 1;               // (frame pipelining uses sets 0/1, a batched launch set f for frame set f)
     std::vector<uint32_t*> pyr_base;   // per camera: the contiguous Gaussian pyramid block (first set)
     std::vector<size_t> pyr_bytes;
     Rect canvas;                    // resultRoi(corners, sizes)
@@ -98,6 +98,10 @@ public:
     void update(const mst_calibration& calib);         // throws Error
     void compose_device(const void* const* d_frames, const size_t* strides, void* d_pano, size_t pano_stride,
                         void* d_mask, size_t mask_stride, hipStream_t stream, StageTimer* timer = nullptr);
+    // `count` frame sets (frame set f's camera i at index f * n + i) -> `count` panoramas, one launch sequence
+    void compose_batch(int count, const void* const* d_frames, const size_t* strides, void* const* d_panos,
+                       size_t pano_stride, void* const* d_masks, size_t mask_stride, hipStream_t stream,
+                       StageTimer* timer = nullptr);
     void compose_host(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride,
                       uint8_t* pano_mask, size_t mask_stride);
     void stage_cameras(uint32_t camera_mask, const void* const* d_frames, const size_t* strides, hipStream_t stream);

@@ -28,10 +28,11 @@ void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4]);
 size_t mb_warp_table_entries(int num_tiles);                                         // uint2 entries for `num_tiles` tiles
 void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, uint2* d_table, hipStream_t s);
 // d_table == nullptr: evaluate the backward map in the kernel (default); else read it from the table
-void launch_warp_pyr(const CamDesc* d_cams, int kind, const TileList& list, const FrameArgs& frames,
-                     const uint2* d_table, hipStream_t s);
-void launch_pyr_chain(const CamDesc* d_cams, const TileList& list, int base, int k, hipStream_t s);
-void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, size_t lds_bytes, hipStream_t s);
+// `batch` frame sets per launch (grid.y): set f uses frames.f[f] and the descriptors d_cams[f * n_cams ...]
+void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
+                     int batch, const uint2* d_table, hipStream_t s);
+void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s);
+void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int batch, size_t lds_bytes, hipStream_t s);
 
 // ---- per-frame hot path: feather / paste (fully fused: warp + gain + blend in one kernel) ----
 void launch_feather_compose(const CamDesc* d_cams, int n_cams, const FrameArgs& frames, const float* d_ws,

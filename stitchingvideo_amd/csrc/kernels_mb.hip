@@ -287,9 +287,12 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
 // instructions, one more dependent load per pixel).  Measured on MI355X (C3): 81.5 us with the table vs
 // 76 us without while the gather comes from global memory, so the default evaluates the map in place.
 template <int KIND, bool USE_TABLE>
-__global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ cams, TileList list, FrameArgs frames,
-                                                  const uint2* __restrict__ table)
+__global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ cams_all, TileList list, FrameBatch batch,
+                                                  const uint2* __restrict__ table, int n_cams)
 {
+    // blockIdx.y = frame set of a batched launch: its own frames and its own copy of the descriptors (pyramids)
+    const CamDesc* __restrict__ cams = cams_all + blockIdx.y * n_cams;
+    const FrameArgs& frames = batch.f[blockIdx.y];
     __shared__ __attribute__((aligned(16))) uint32_t s_l0[A_LH][A_LW];   // level-0 tile with halo, packed (18 KB)
     __shared__ RowEntry s_rows[A_LH];
     __shared__ float s_gain_rows[A_GAIN_ROWS][A_LW];   // BlocksGainCompensator: HResizeLinear of the rows the tile spans
@@ -477,8 +480,10 @@ constexpr int B_KMAX = 2;
 constexpr int B_E0 = 73, B_E1 = 35;             // region extents for a full k = 2 chain (e2 = 16)
 
 template <int K>
-__global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restrict__ cams, TileList list, int base)
+__global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restrict__ cams_all, TileList list, int base,
+                                                         int n_cams)
 {
+    const CamDesc* __restrict__ cams = cams_all + blockIdx.y * n_cams;
     constexpr int k = K;
     // regions of levels base and base+1, back to back (21.3 + 4.9 KB)
     constexpr int kOff1 = B_E0 * B_E0;
@@ -932,7 +937,8 @@ __device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx
 // phase 3: level 0 band + pyrUp of collapsed level 1 -> crop, mask, convertTo(8U), panorama
 template <bool TOP, bool PURE>
 __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int tx, int ty,
-                                            uint32_t cam_bits, const uint2* __restrict__ lds)
+                                            uint32_t cam_bits, const uint2* __restrict__ lds, uint8_t* __restrict__ pano,
+                                            uint8_t* __restrict__ pano_mask)
 {
     const QuadIter it(blend_region(a, tx, ty, 0));
     Region ur = it.r;
@@ -942,7 +948,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
         s_up = lds + a.lds_off[1];
     }
     // two bytes per store when the panorama rows allow it (even base and stride)
-    const bool pair_stores = ((reinterpret_cast<uintptr_t>(a.pano) | a.pano_stride) & 1u) == 0;
+    const bool pair_stores = ((reinterpret_cast<uintptr_t>(pano) | a.pano_stride) & 1u) == 0;
     for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
         int x, y;
         bool valid[4];
@@ -974,7 +980,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
             const int py = y + ry;
             if (py >= a.final_h || !valid[2 * ry]) continue;                     // crop to dst_roi_final_
             if ((MST_ABLATE_C & 16) && o8[2 * ry][0] != 77777u) continue;
-            uint8_t* o = a.pano + __umul24(py, a.pano_stride) + x * 3;
+            uint8_t* o = pano + __umul24(py, a.pano_stride) + x * 3;
             const uint32_t* p0 = o8[2 * ry];
             const uint32_t* p1 = o8[2 * ry + 1];
             const bool both = valid[2 * ry + 1] && x + 1 < a.final_w;
@@ -988,8 +994,8 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
                     o[0] = static_cast<uint8_t>(p0[0]); o[1] = static_cast<uint8_t>(p0[1]); o[2] = static_cast<uint8_t>(p0[2]);
                     if (both) { o[3] = static_cast<uint8_t>(p1[0]); o[4] = static_cast<uint8_t>(p1[1]); o[5] = static_cast<uint8_t>(p1[2]); }
                 }
-                if (a.pano_mask) {
-                    uint8_t* om = a.pano_mask + __umul24(py, a.mask_stride) + x;
+                if (pano_mask) {
+                    uint8_t* om = pano_mask + __umul24(py, a.mask_stride) + x;
                     om[0] = m[2 * ry] ? 255 : 0;
                     if (both) om[1] = m[2 * ry + 1] ? 255 : 0;
                 }
@@ -998,8 +1004,11 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
     }
 }
 
-__global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__ cams, BlendArgs a)
+__global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__ cams_all, BlendArgs a)
 {
+    const CamDesc* __restrict__ cams = cams_all + blockIdx.y * a.n_cams;
+    uint8_t* __restrict__ pano = a.pano[blockIdx.y];
+    uint8_t* __restrict__ pano_mask = a.pano_mask[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* lds = reinterpret_cast<uint2*>(smem);
     const uint32_t tile = a.block_order[blockIdx.x];
@@ -1009,8 +1018,8 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
     const uint32_t cam_bits = entry & 0x7FFFFFFFu;
     const int top = a.nlev - 1;
     if (top == 0) {
-        if (pure) final_level<true, true>(cams, a, tx, ty, cam_bits, lds);
-        else final_level<true, false>(cams, a, tx, ty, cam_bits, lds);
+        if (pure) final_level<true, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
+        else final_level<true, false>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
         return;
     }
     // phase 1: every coarse band, independent of each other -> no barrier until all are in LDS
@@ -1038,8 +1047,8 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
         __syncthreads();
     }
     // phase 3
-    if (pure) final_level<false, true>(cams, a, tx, ty, cam_bits, lds);
-    else final_level<false, false>(cams, a, tx, ty, cam_bits, lds);
+    if (pure) final_level<false, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
+    else final_level<false, false>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
 }
 
 }  // namespace
@@ -1078,13 +1087,13 @@ void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, ui
     else hipLaunchKernelGGL(k_warp_table<2>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table);
 }
 
-void launch_warp_pyr(const CamDesc* d_cams, int kind, const TileList& list, const FrameArgs& frames,
-                     const uint2* d_table, hipStream_t s)
+void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
+                     int batch, const uint2* d_table, hipStream_t s)
 {
-    if (list.count <= 0) return;
+    if (list.count <= 0 || batch <= 0) return;
     static const size_t pad = tuning_env("MST_A_PAD_LDS");
 #define MST_LAUNCH_A(K, T) \
-    hipLaunchKernelGGL((k_warp_pyr<K, T>), dim3(list.count), dim3(256), pad, s, d_cams, list, frames, d_table)
+    hipLaunchKernelGGL((k_warp_pyr<K, T>), dim3(list.count, batch), dim3(256), pad, s, d_cams, list, frames, d_table, n_cams)
     if (d_table) {
         if (kind == 0) MST_LAUNCH_A(0, true); else if (kind == 1) MST_LAUNCH_A(1, true); else MST_LAUNCH_A(2, true);
     } else {
@@ -1093,17 +1102,17 @@ void launch_warp_pyr(const CamDesc* d_cams, int kind, const TileList& list, cons
 #undef MST_LAUNCH_A
 }
 
-void launch_pyr_chain(const CamDesc* d_cams, const TileList& list, int base, int k, hipStream_t s)
+void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s)
 {
-    if (list.count <= 0 || k <= 0) return;
-    if (k == 1) hipLaunchKernelGGL(k_pyr_chain<1>, dim3(list.count), dim3(B_THREADS), 0, s, d_cams, list, base);
-    else hipLaunchKernelGGL(k_pyr_chain<2>, dim3(list.count), dim3(B_THREADS), 0, s, d_cams, list, base);
+    if (list.count <= 0 || k <= 0 || batch <= 0) return;
+    if (k == 1) hipLaunchKernelGGL(k_pyr_chain<1>, dim3(list.count, batch), dim3(B_THREADS), 0, s, d_cams, list, base, n_cams);
+    else hipLaunchKernelGGL(k_pyr_chain<2>, dim3(list.count, batch), dim3(B_THREADS), 0, s, d_cams, list, base, n_cams);
 }
 
-void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, size_t lds_bytes, hipStream_t s)
+void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int batch, size_t lds_bytes, hipStream_t s)
 {
     static const size_t pad = tuning_env("MST_C_PAD_LDS");
-    hipLaunchKernelGGL(k_blend, dim3(num_blocks), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
+    hipLaunchKernelGGL(k_blend, dim3(num_blocks, batch), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
 }
 
 }  // namespace mst

@@ -152,7 +152,7 @@ class PanoramaEngine:
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
                  feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False,
-                 overlap_frames=False):
+                 overlap_frames=False, max_batch=0):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -167,6 +167,7 @@ class PanoramaEngine:
         cfg.flags = (capi.FLAG_DRIVER_LUT if driver_lut else 0) | (capi.FLAG_DEBUG if debug else 0) | \
             (capi.FLAG_OVERLAP_FRAMES if overlap_frames else 0)
         cfg.upblack, cfg.downblack, cfg.leftblack, cfg.rightblack = crop
+        cfg.max_batch = max_batch
         self.num_cameras = num_cameras
         self.device = device
         capi.check(self._L.mst_create(C.byref(cfg), C.byref(self._h)))
@@ -261,6 +262,49 @@ class PanoramaEngine:
             if rc:
                 self._check(rc)
         return call
+
+    def _batch_tables(self, frame_ptrs, frame_strides, pano_ptrs, mask_ptrs):
+        count = len(pano_ptrs)
+        flat_p = [p for fs in frame_ptrs for p in fs]
+        flat_s = [s for fs in frame_strides for s in fs]
+        if len(flat_p) != count * self.num_cameras or len(flat_s) != len(flat_p):
+            raise ValueError("need num_cameras frame pointers and strides per frame set")
+        ptrs = (C.c_void_p * len(flat_p))(*flat_p)
+        strides = (C.c_size_t * len(flat_s))(*flat_s)
+        panos = (C.c_void_p * count)(*pano_ptrs)
+        masks = (C.c_void_p * count)(*mask_ptrs) if mask_ptrs else None
+        return count, ptrs, strides, panos, masks
+
+    def compose_device_batch(self, frame_ptrs, frame_strides, pano_ptrs, pano_stride, mask_ptrs=None, mask_stride=0,
+                             stream=None):
+        """len(pano_ptrs) frame sets (lists of per-camera device pointers / strides) -> that many panoramas,
+        one launch sequence (needs max_batch >= the count at construction)."""
+        count, ptrs, strides, panos, masks = self._batch_tables(frame_ptrs, frame_strides, pano_ptrs, mask_ptrs)
+        self._check(self._L.mst_compose_device_batch(self._h, count, ptrs, strides, panos, pano_stride, masks,
+                                                     mask_stride, stream))
+
+    def make_device_batch_call(self, frame_ptrs, frame_strides, pano_ptrs, pano_stride, mask_ptrs=None, mask_stride=0,
+                               stream=None):
+        """Pre-marshalled compose_device_batch; returns a zero-argument callable (for tight frame loops)."""
+        count, ptrs, strides, panos, masks = self._batch_tables(frame_ptrs, frame_strides, pano_ptrs, mask_ptrs)
+        f, h, stream = self._L.mst_compose_device_batch, self._h, C.c_void_p(stream)
+
+        def call():
+            rc = f(h, count, ptrs, strides, panos, pano_stride, masks, mask_stride, stream)
+            if rc:
+                self._check(rc)
+        return call
+
+    def profile_stages_batch(self, frame_ptrs, frame_strides, pano_ptrs, pano_stride, stream=None, max_stages=64):
+        """One batched launch sequence with a HIP event between consecutive launches -> [(kernel name, ms), ...]."""
+        count, ptrs, strides, panos, _ = self._batch_tables(frame_ptrs, frame_strides, pano_ptrs, None)
+        names = ((C.c_char * 32) * max_stages)()
+        ms = (C.c_float * max_stages)()
+        num = C.c_int()
+        self._check(self._L.mst_compose_profile_batch(self._h, count, ptrs, strides, panos, pano_stride, stream,
+                                                      max_stages, C.cast(names, C.c_void_p), ms, C.byref(num)))
+        k = min(num.value, max_stages)
+        return [(names[i].value.decode(), float(ms[i])) for i in range(k)]
 
     # ---- camera streams sharded over GPUs: per-camera stage, pyramid hand-off, canvas stage ----
     def stage_cameras(self, cameras, frame_ptrs, frame_strides, stream=None):

@@ -136,3 +136,45 @@ def test_unaligned_frames_and_odd_strides(blend):
     assert np.array_equal(pano, opano)
     assert np.array_equal(mask, omask)
     eng.close()
+
+
+@pytest.mark.parametrize("blend,count", [("multiband", 4), ("multiband", 3), ("feather", 2)])
+def test_batched_launch_matches_oracle(blend, count):
+    """mst_compose_device_batch: `count` frame sets through one launch sequence, each against the oracle;
+    a second, smaller batch and a single frame afterwards re-use the pyramid sets."""
+    import torch
+    cfg = rigmod.scaled_config("C3", 8)
+    cfg["blend"] = blend
+    rig = rigmod.build_rig(cfg)
+    eng = H.make_engine(rig, max_batch=4)
+    _, _, cw, ch = eng.canvas()
+    dev = torch.device("cuda", 0)
+    host = [rigmod.frames_for(rig, i) for i in range(count)]
+    dfr = [[torch.from_numpy(f).to(dev) for f in fr] for fr in host]
+    panos = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(count)]
+    masks = [torch.zeros((ch, cw), dtype=torch.uint8, device=dev) for _ in range(count)]
+    torch.cuda.synchronize()
+    ptrs = [[t.data_ptr() for t in fr] for fr in dfr]
+    strides = [[t.stride(0) for t in fr] for fr in dfr]
+    eng.compose_device_batch(ptrs, strides, [p.data_ptr() for p in panos], panos[0].stride(0),
+                             [m.data_ptr() for m in masks], masks[0].stride(0))
+    eng.synchronize()
+    expect = [H.oracle_compose(rig, host[i]) for i in range(count)]
+    for i in range(count):
+        assert np.array_equal(panos[i].cpu().numpy(), expect[i][1]), "frame set %d" % i
+        assert np.array_equal(masks[i].cpu().numpy(), expect[i][2]), "frame set %d mask" % i
+    # reversed order in a batch of two, then a plain single frame
+    for p in panos:
+        p.zero_()
+    eng.compose_device_batch([ptrs[1], ptrs[0]], [strides[1], strides[0]], [panos[0].data_ptr(), panos[1].data_ptr()],
+                             panos[0].stride(0))
+    eng.compose_device(ptrs[count - 1], strides[count - 1], panos[2 % count].data_ptr(), panos[0].stride(0))
+    eng.synchronize()
+    assert np.array_equal(panos[0].cpu().numpy(), expect[1][1])
+    if count > 2:
+        assert np.array_equal(panos[1].cpu().numpy(), expect[0][1])
+        assert np.array_equal(panos[2].cpu().numpy(), expect[count - 1][1])
+    if blend == "multiband":           # one pyramid set per frame set: max_batch bounds the batch
+        with pytest.raises(Exception):
+            eng.compose_device_batch([ptrs[0]] * 5, [strides[0]] * 5, [panos[0].data_ptr()] * 5, panos[0].stride(0))
+    eng.close()

@@ -8,6 +8,6 @@ for setting in "$@"; do
   env $setting MST_VERBOSE=1 python bench.py --steps 100 --warmup 10 --no-cpu-baseline $BENCH_ARGS 2> /tmp/bench_env.err | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.readline())
-print(d['value'], [(k['name'],k['launches_per_frame'],round(k['ms_per_frame']*1000,1)) for k in d['roofline']['kernels']])"
+print(d['value'], [(k['name'],k['launches_per_step'],round(k['ms_per_frame']*1000,1)) for k in d['roofline']['kernels']])"
   grep -h "mi355stitch" /tmp/bench_env.err | sort | uniq | head -3
 done

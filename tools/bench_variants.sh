@@ -9,5 +9,5 @@ for lib in stitchingvideo_amd/libmi355stitch_*.so; do
   MST_LIB=$PWD/$lib python bench.py --steps 100 --warmup 10 --no-cpu-baseline $BENCH_ARGS | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.readline())
-print(d['value'], [(k['name'],k['launches_per_frame'],round(k['ms_per_frame']*1000,1)) for k in d['roofline']['kernels']])"
+print(d['value'], [(k['name'],k['launches_per_step'],round(k['ms_per_frame']*1000,1)) for k in d['roofline']['kernels']])"
 done
