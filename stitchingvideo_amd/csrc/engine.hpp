@@ -67,7 +67,8 @@ struct CalibState {
     CanvasDesc cv{};
     MbPlanHost plan;                    // work lists of the fused kernels (host copy, for introspection)
     TileList warp_list{};               // kernel A
-    uint2* warp_table = nullptr;        // per-tile backward-map table (frame-invariant), see kernels_mb.hip
+    uint32_t* warp_table = nullptr;     // per-tile backward-map table (frame-invariant), see kernels_mb.hip
+    int2* warp_table_base = nullptr;    // per tile: the source coordinate its table entries are relative to
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step
     BlendArgs blend{};                  // kernel C (pano pointers filled per frame)
     // feather

@@ -99,13 +99,39 @@ struct WarpConsts {           // per-camera scalars, copied out of the descripto
     uint32_t stride;                   // < 2^24 (checked by the engine): row offsets use the 24-bit multiplier
 };
 
-// The backward map of one destination pixel in the fixed-point form cv::remap uses, packed for the
-// per-calibration table:  x = sx (s16) | sy (s16) << 16,  y = fx | fy << 6 | fast << 12  (fx, fy in 0..32).
-// The map is frame-invariant (the reference's driver caches xmap/ymap the same way, DRV:658-660,712-713), and
-// these kernels are bound by instruction issue, not by bytes: the table trades two IEEE divides, the trig
-// products and the cvRound logic per pixel per frame (~55 VALU instructions) for one coalesced 8-byte load.
+// The backward map of one destination pixel in the fixed-point form cv::remap uses: integer source
+// coordinate of the 2x2 window, 5-bit fractions (0..32 after border folding), and whether the window can be
+// read with the two 12-byte loads.
+struct MapPx {
+    int sx, sy, fx, fy;
+    bool fast;
+};
+
+// The map is frame-invariant (the reference's driver caches xmap/ymap the same way, DRV:658-660,712-713), so it
+// is tabulated once per calibration: that trades two IEEE divides, the rotation products and the cvRound logic
+// per pixel per frame (~55 VALU instructions) for one coalesced 4-byte load.  Table entry, relative to the
+// tile's smallest window coordinate (bx, by):  dx | dy << 10 | fx << 19 | fy << 25 | fast << 31; a window
+// further than 1023 x 511 from that corner (extreme stretch) is simply left to the per-tap path, which
+// re-evaluates the map.
+__device__ __forceinline__ uint32_t pack_map(const MapPx& m, int bx, int by)
+{
+    const uint32_t dx = static_cast<uint32_t>(m.sx - bx), dy = static_cast<uint32_t>(m.sy - by);
+    const bool ok = m.fast && dx < 1024u && dy < 512u;
+    return ok ? (dx | dy << 10 | static_cast<uint32_t>(m.fx) << 19 | static_cast<uint32_t>(m.fy) << 25 | 1u << 31) : 0u;
+}
+__device__ __forceinline__ MapPx unpack_map(uint32_t e, int bx, int by)
+{
+    MapPx m;
+    m.sx = bx + static_cast<int>(e & 1023u);
+    m.sy = by + static_cast<int>((e >> 10) & 511u);
+    m.fx = static_cast<int>((e >> 19) & 63u);
+    m.fy = static_cast<int>((e >> 25) & 63u);
+    m.fast = (e >> 31) != 0;
+    return m;
+}
+
 template <int KIND>
-__device__ __forceinline__ uint2 map_entry(const float kr[9], int src_w, int src_h, const ColEntry& ce, const RowEntry& re)
+__device__ __forceinline__ MapPx map_px(const float kr[9], int src_w, int src_h, const ColEntry& ce, const RowEntry& re)
 {
     float X, Y, Z, mx, my;
     if (KIND == 1) {
@@ -145,8 +171,9 @@ __device__ __forceinline__ uint2 map_entry(const float kr[9], int src_w, int src
             sx = xs; sy = ys; fx = 32 - wxl; fy = 32 - wyl; fast = true;
         }
     }
-    return make_uint2((static_cast<uint32_t>(sx) & 0xFFFFu) | (static_cast<uint32_t>(sy) << 16),
-                      static_cast<uint32_t>(fx) | static_cast<uint32_t>(fy) << 6 | static_cast<uint32_t>(fast) << 12);
+    MapPx m;
+    m.sx = sx; m.sy = sy; m.fx = fx; m.fy = fy; m.fast = fast;
+    return m;
 }
 
 // GAIN: how the exposure gain of the pixel is formed -- 0: the camera's scalar gain (1 for "no compensation":
@@ -154,15 +181,15 @@ __device__ __forceinline__ uint2 map_entry(const float kr[9], int src_w, int src
 // 2: block gain map read from global memory (tile spans more map rows than the LDS table holds).
 // The caller picks the mode once per tile, so the loop body carries no uniform branch.
 template <int GAIN>
-__device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const uint2 e, const ColEntry& ce, const RowEntry& re,
+__device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const MapPx& e, const ColEntry& ce, const RowEntry& re,
                                             const float* s_gain, PixelFetch& f)
 {
-    const int fx = e.y & 63, fy = (e.y >> 6) & 63;
-    f.sx = static_cast<int>(static_cast<short>(e.x & 0xFFFFu));
-    f.sy = static_cast<int>(e.x) >> 16;
+    const int fx = e.fx, fy = e.fy;
+    f.sx = e.sx;
+    f.sy = e.sy;
     f.wx = static_cast<uint32_t>(32 - fx) | static_cast<uint32_t>(fx) << 24;
     f.wy0 = static_cast<uint32_t>(32 - fy); f.wy1 = static_cast<uint32_t>(fy);
-    f.fast = (MST_ABLATE_A & 32) ? true : ((e.y >> 12) & 1u);
+    f.fast = (MST_ABLATE_A & 32) ? true : e.fast;
     {
         // Fast path = a 2x2 window inside the source whose two 6-byte pixel pairs can be read as aligned dwords;
         // the byte funnel shift happens at blend time.  The loads are issued unconditionally (pixels off the
@@ -251,11 +278,13 @@ __device__ __forceinline__ uint32_t blend_pixel(const WarpConsts& k, const Pixel
 }
 
 // Per-calibration: the backward map of every pixel of every launched tile, in the tile/row/column order in
-// which k_warp_pyr's threads consume it.
+// which k_warp_pyr's threads consume it, relative to the tile's smallest window coordinate (tile_base).
 template <int KIND>
-__global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ cams, TileList list, uint2* __restrict__ table)
+__global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ cams, TileList list,
+                                                    uint32_t* __restrict__ table, int2* __restrict__ tile_base)
 {
     __shared__ RowEntry s_rows[A_LH];
+    __shared__ int s_min[2];
     const uint32_t t = list.tiles[blockIdx.x];
     const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
@@ -270,16 +299,26 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
         const int ry = reflect<0>(by - c.top, c.roi_h);
         s_rows[tid] = load_global(c.rows + ry);
     }
+    if (tid == 0) { s_min[0] = INT_MAX; s_min[1] = INT_MAX; }
     const int col = tid & (A_LW - 1);
     const int half = tid >> 7;
     const int bx = reflect<1>(lx0 + col, bw);
     const int rx = reflect<0>(bx - c.left, c.roi_w);
     const ColEntry ce = load_global(c.cols + rx);
     __syncthreads();
-    uint2* __restrict__ out = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW) + col;
+    int x_lo = INT_MAX, y_lo = INT_MAX;
+    for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
+        const MapPx m = map_px<KIND>(kr, c.src_w, c.src_h, ce, s_rows[half * A_ROWS_PER_THREAD + it]);
+        if (m.fast) { x_lo = min(x_lo, m.sx); y_lo = min(y_lo, m.sy); }
+    }
+    if (x_lo != INT_MAX) { atomicMin(&s_min[0], x_lo); atomicMin(&s_min[1], y_lo); }
+    __syncthreads();
+    const int tbx = s_min[0] == INT_MAX ? 0 : s_min[0], tby = s_min[1] == INT_MAX ? 0 : s_min[1];
+    if (tid == 0) tile_base[list.first + blockIdx.x] = make_int2(tbx, tby);
+    uint32_t* __restrict__ out = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW) + col;
     for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
         const int row = half * A_ROWS_PER_THREAD + it;
-        out[row * A_LW] = map_entry<KIND>(kr, c.src_w, c.src_h, ce, s_rows[row]);
+        out[row * A_LW] = pack_map(map_px<KIND>(kr, c.src_w, c.src_h, ce, s_rows[row]), tbx, tby);
     }
 }
 
@@ -288,7 +327,8 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
 // 76 us without while the gather comes from global memory, so the default evaluates the map in place.
 template <int KIND, bool USE_TABLE>
 __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ cams_all, TileList list, FrameBatch batch,
-                                                  const uint2* __restrict__ table, int n_cams)
+                                                  const uint32_t* __restrict__ table, const int2* __restrict__ tile_base,
+                                                  int n_cams)
 {
     // blockIdx.y = frame set of a batched launch: its own frames and its own copy of the descriptors (pyramids)
     const CamDesc* __restrict__ cams = cams_all + blockIdx.y * n_cams;
@@ -314,7 +354,12 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     k.src_lo2 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(k.src)) & 3u;
     k.src_al = k.src - k.src_lo2;
     // this tile's slice of the per-calibration map table: [row][col], one coalesced 8-byte load per pixel
-    const uint2* __restrict__ tab = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW);
+    const uint32_t* __restrict__ tab = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW);
+    int tbx = 0, tby = 0;
+    if (USE_TABLE) {
+        const int2 tb = tile_base[list.first + blockIdx.x];
+        tbx = tb.x; tby = tb.y;
+    }
 
     // per tile row: pyrDown's REFLECT_101 into the bordered image, then copyMakeBorder's REFLECT into the roi
     if (tid < A_LH) {
@@ -389,15 +434,17 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
             g0out[__umul24(gy, bw) + gx] = px;
     };
     const int row_last = row0 + A_ROWS_PER_THREAD - 1;
-    const uint2* __restrict__ tcol = tab + col;
+    const uint32_t* __restrict__ tcol = tab + col;
     float kr[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) kr[i] = USE_TABLE ? 0.f : c.kr[i];
-    auto entry = [&](int row) -> uint2 {
-        if (MST_ABLATE_A & 8)
-            return make_uint2(static_cast<uint32_t>(col + 200) | static_cast<uint32_t>(row + 200) << 16,
-                              static_cast<uint32_t>((col * 7 + row * 3) & 31) | 4096u);
-        return USE_TABLE ? tcol[row * A_LW] : map_entry<KIND>(kr, k.src_w, k.src_h, ce, s_rows[row]);
+    for (int i = 0; i < 9; ++i) kr[i] = c.kr[i];
+    auto entry = [&](int row) -> MapPx {
+        if (MST_ABLATE_A & 8) {
+            MapPx m;
+            m.sx = col + 200; m.sy = row + 200; m.fx = (col * 7) & 31; m.fy = (row * 3) & 31; m.fast = true;
+            return m;
+        }
+        return USE_TABLE ? unpack_map(tcol[row * A_LW], tbx, tby) : map_px<KIND>(kr, k.src_w, k.src_h, ce, s_rows[row]);
     };
     // Table entries run two rows ahead of the gather, the gather one row ahead of the blend.  The loop body is
     // one basic block (no uniform branch on the gain mode, no divergent branch for border pixels: those are
@@ -408,7 +455,7 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
         static_assert(A_ROWS_PER_THREAD <= 32, "slow_rows is a 32-bit mask");
         PixelFetch fa, fb;
         uint32_t slow_rows = 0;           // rows of this column that need the per-tap border path
-        uint2 e0 = entry(row0), e1 = entry(row0 + 1);
+        MapPx e0 = entry(row0), e1 = entry(row0 + 1);
         fetch_pixel<GM>(k, e0, ce, s_rows[row0], H, fa);
         // fully unrolled: a back edge would carry the in-flight gather registers through copies, and a copy of
         // a register that is still being loaded is a wait for the load
@@ -427,7 +474,8 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
         while (slow_rows) {               // rare: windows at the very end of the frame, one-pixel sources
             const int it = __builtin_ctz(slow_rows);
             slow_rows &= slow_rows - 1;
-            fetch_pixel<GM>(k, entry(row0 + it), ce, s_rows[row0 + it], H, fa);
+            // (the table does not keep coordinates of windows it cannot address: evaluate the map)
+            fetch_pixel<GM>(k, map_px<KIND>(kr, k.src_w, k.src_h, ce, s_rows[row0 + it]), ce, s_rows[row0 + it], H, fa);
             emit(row0 + it, blend_pixel<true, BG>(k, fa));
         }
     };
@@ -1079,21 +1127,22 @@ void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4])
 
 size_t mb_warp_table_entries(int num_tiles) { return static_cast<size_t>(num_tiles) * A_LH * A_LW; }
 
-void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, uint2* d_table, hipStream_t s)
+void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, int2* d_tile_base,
+                       hipStream_t s)
 {
     if (list.count <= 0) return;
-    if (kind == 0) hipLaunchKernelGGL(k_warp_table<0>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table);
-    else if (kind == 1) hipLaunchKernelGGL(k_warp_table<1>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table);
-    else hipLaunchKernelGGL(k_warp_table<2>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table);
+#define MST_LAUNCH_T(K) hipLaunchKernelGGL(k_warp_table<K>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table, d_tile_base)
+    if (kind == 0) MST_LAUNCH_T(0); else if (kind == 1) MST_LAUNCH_T(1); else MST_LAUNCH_T(2);
+#undef MST_LAUNCH_T
 }
 
 void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
-                     int batch, const uint2* d_table, hipStream_t s)
+                     int batch, const uint32_t* d_table, const int2* d_tile_base, hipStream_t s)
 {
     if (list.count <= 0 || batch <= 0) return;
     static const size_t pad = tuning_env("MST_A_PAD_LDS");
 #define MST_LAUNCH_A(K, T) \
-    hipLaunchKernelGGL((k_warp_pyr<K, T>), dim3(list.count, batch), dim3(256), pad, s, d_cams, list, frames, d_table, n_cams)
+    hipLaunchKernelGGL((k_warp_pyr<K, T>), dim3(list.count, batch), dim3(256), pad, s, d_cams, list, frames, d_table, d_tile_base, n_cams)
     if (d_table) {
         if (kind == 0) MST_LAUNCH_A(0, true); else if (kind == 1) MST_LAUNCH_A(1, true); else MST_LAUNCH_A(2, true);
     } else {
