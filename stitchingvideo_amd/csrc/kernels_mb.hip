@@ -708,19 +708,13 @@ __device__ __forceinline__ uint2 pack3(int c0, int c1, int c2)
 
 // pyrUp of the collapsed coarser level held in LDS (signed shorts) around coarse pixel (j, i) given in
 // level coordinates; rx0/ry0/pitch describe the LDS region.  out[q][ch], already (v + 32) >> 6 and saturated.
-__device__ __forceinline__ void pyrup_quad_lds(const uint2* __restrict__ s, int rx0, int ry0, int pitch, int sw, int sh,
-                                               int j, int i, int out[4][3])
+// (the arithmetic, on a 3x3 neighbourhood already in registers)
+__device__ __forceinline__ void pyrup_quad_s16(const uint2 v[3][3], int out[4][3])
 {
-    int jm, jp, im, ip;
-    up_idx(j, sw, jm, jp);
-    up_idx(i, sh, im, ip);
-    const int rows[3] = {im - ry0, i - ry0, ip - ry0};
-    const int c0 = jm - rx0, c1 = j - rx0, c2 = jp - rx0;
     int he[3][3], ho[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        const uint2* p = s + __mul24(rows[r], pitch);
-        const uint2 a = p[c0], b = p[c1], c = p[c2];
+        const uint2 a = v[r][0], b = v[r][1], c = v[r][2];
         const int av[3] = {s16_lo(a.x), s16_hi(a.x), s16_lo(a.y)};
         const int bv[3] = {s16_lo(b.x), s16_hi(b.x), s16_lo(b.y)};
         const int cv[3] = {s16_lo(c.x), s16_hi(c.x), s16_lo(c.y)};
@@ -737,6 +731,23 @@ __device__ __forceinline__ void pyrup_quad_lds(const uint2* __restrict__ s, int 
         out[2][ch] = sat_s16((4 * (he[1][ch] + he[2][ch]) + 32) >> 6);
         out[3][ch] = sat_s16((4 * (ho[1][ch] + ho[2][ch]) + 32) >> 6);
     }
+}
+
+__device__ __forceinline__ void pyrup_quad_lds(const uint2* __restrict__ s, int rx0, int ry0, int pitch, int sw, int sh,
+                                               int j, int i, int out[4][3])
+{
+    int jm, jp, im, ip;
+    up_idx(j, sw, jm, jp);
+    up_idx(i, sh, im, ip);
+    const int rows[3] = {im - ry0, i - ry0, ip - ry0};
+    const int c0 = jm - rx0, c1 = j - rx0, c2 = jp - rx0;
+    uint2 v[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint2* p = s + __mul24(rows[r], pitch);
+        v[r][0] = p[c0]; v[r][1] = p[c1]; v[r][2] = p[c2];
+    }
+    pyrup_quad_s16(v, out);
 }
 
 // The normalised band of one 2x2 quad of canvas level `l` at even coordinates (x, y): the weighted sum over
@@ -982,6 +993,115 @@ __device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx
     }
 }
 
+// crop to dst_roi_final_, mask, convertTo(8U) results of one quad -> panorama (+ optional mask plane)
+__device__ __forceinline__ void store_quad(const BlendArgs& a, uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask,
+                                           int x, int y, const bool valid[4], const uint32_t o8[4][3], const bool m[4],
+                                           bool pair_stores)
+{
+#pragma unroll
+    for (int ry = 0; ry < 2; ++ry) {
+        const int py = y + ry;
+        if (py >= a.final_h || !valid[2 * ry]) continue;                     // crop to dst_roi_final_
+        if ((MST_ABLATE_C & 16) && o8[2 * ry][0] != 77777u) continue;
+        uint8_t* o = pano + __umul24(py, a.pano_stride) + x * 3;
+        const uint32_t* p0 = o8[2 * ry];
+        const uint32_t* p1 = o8[2 * ry + 1];
+        const bool both = valid[2 * ry + 1] && x + 1 < a.final_w;
+        if (x < a.final_w) {
+            if (both && pair_stores) {
+                uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
+                o16[0] = static_cast<uint16_t>(p0[0] | p0[1] << 8);
+                o16[1] = static_cast<uint16_t>(p0[2] | p1[0] << 8);
+                o16[2] = static_cast<uint16_t>(p1[1] | p1[2] << 8);
+            } else {
+                o[0] = static_cast<uint8_t>(p0[0]); o[1] = static_cast<uint8_t>(p0[1]); o[2] = static_cast<uint8_t>(p0[2]);
+                if (both) { o[3] = static_cast<uint8_t>(p1[0]); o[4] = static_cast<uint8_t>(p1[1]); o[5] = static_cast<uint8_t>(p1[2]); }
+            }
+            if (pano_mask) {
+                uint8_t* om = pano_mask + __umul24(py, a.mask_stride) + x;
+                om[0] = m[2 * ry] ? 255 : 0;
+                if (both) om[1] = m[2 * ry + 1] ? 255 : 0;
+            }
+        }
+    }
+}
+
+// phase 3 for a tile that is pure (see band_quad), not the top level, covers a whole C_TW x C_TH region and lies
+// inside the final crop: every quad is valid, the quad columns are fixed per thread, and the trip count is a
+// compile-time constant -- so the loop is fully unrolled with the loads of the next quad (Gaussian quad, 3x3
+// pyrUp sources from global memory, 3x3 collapsed level-1 values from LDS) issued before the current quad is
+// evaluated, and no validity predicate or per-quad index division is left.
+__device__ __forceinline__ void final_level_pure_full(const CamDesc* __restrict__ cams, const BlendArgs& a, int tx, int ty,
+                                                      uint32_t cam_bits, const uint2* __restrict__ lds,
+                                                      uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask)
+{
+    static_assert(C_TW == 128 && (C_TW / 2) * (C_TH / 2) % C_THREADS == 0, "thread <-> quad column mapping");
+    constexpr int kIters = (C_TW / 2) * (C_TH / 2) / C_THREADS;
+    constexpr int kRowStep = 2 * C_THREADS / (C_TW / 2);        // canvas rows between two quads of a thread
+    const Region r = blend_region(a, tx, ty, 0);
+    const Region ur = blend_region(a, tx, ty, 1);
+    const uint2* s_up = lds + a.lds_off[1];
+    const int upitch = ur.x1 - ur.x0;
+    const CamDesc& c = cams[__builtin_ctz(cam_bits)];
+    const int lw = c.lw[0], sw = c.lw[1], sh = c.lh[1];
+    const int x = r.x0 + 2 * static_cast<int>(threadIdx.x & (C_TW / 2 - 1));
+    const int y0 = r.y0 + 2 * static_cast<int>(threadIdx.x / (C_TW / 2));
+    const int lx = x - c.ox[0];
+    int jm, jp, cjm, cjp;
+    const int j = lx >> 1, cj = x >> 1;
+    up_idx(j, sw, jm, jp);
+    up_idx(cj, a.cw[1], cjm, cjp);
+    const int uc[3] = {cjm - ur.x0, cj - ur.x0, cjp - ur.x0};
+    const uint32_t MST_GLOBAL* __restrict__ g0p = gp(c.G[0]);
+    const uint32_t MST_GLOBAL* __restrict__ g1p = gp(c.G[1]);
+    const bool pair_stores = ((reinterpret_cast<uintptr_t>(pano) | a.pano_stride) & 1u) == 0;
+
+    struct Stage { uint32_t g[4]; uint32_t nb[3][3]; uint2 u[3][3]; };
+    auto load = [&](Stage& st, int y) {
+        const int ly = y - c.oy[0];
+        const uint32_t off = __umul24(ly, lw) + lx;
+        st.g[0] = g0p[off]; st.g[1] = g0p[off + 1]; st.g[2] = g0p[off + lw]; st.g[3] = g0p[off + lw + 1];
+        int im, ip, cim, cip;
+        const int i = ly >> 1, ci = y >> 1;
+        up_idx(i, sh, im, ip);
+        up_idx(ci, a.ch[1], cim, cip);
+        const int rr[3] = {__mul24(im, sw), __mul24(i, sw), __mul24(ip, sw)};
+        const int ur_[3] = {__mul24(cim - ur.y0, upitch), __mul24(ci - ur.y0, upitch), __mul24(cip - ur.y0, upitch)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            st.nb[k][0] = g1p[rr[k] + jm]; st.nb[k][1] = g1p[rr[k] + j]; st.nb[k][2] = g1p[rr[k] + jp];
+            st.u[k][0] = s_up[ur_[k] + uc[0]]; st.u[k][1] = s_up[ur_[k] + uc[1]]; st.u[k][2] = s_up[ur_[k] + uc[2]];
+        }
+    };
+    auto finish = [&](const Stage& st, int y) {
+        uint32_t ubr[4], ug[4];
+        pyrup_quad_packed(st.nb, ubr, ug);
+        int up[4][3];
+        pyrup_quad_s16(st.u, up);
+        uint32_t o8[4][3];
+        const bool all[4] = {true, true, true, true};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int lb = static_cast<int>(st.g[q] & 0xFF) - static_cast<int>(ubr[q] & 0xFFFF);
+            const int lg = static_cast<int>((st.g[q] >> 8) & 0xFF) - static_cast<int>(ug[q]);
+            const int lr = static_cast<int>((st.g[q] >> 16) & 0xFF) - static_cast<int>(ubr[q] >> 16);
+            const int n[3] = {lb - (lb > 0) + (lb < 0), lg - (lg > 0) + (lg < 0), lr - (lr > 0) + (lr < 0)};
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) o8[q][ch] = static_cast<uint32_t>(sat_u8(sat_s16(up[q][ch] + n[ch])));
+        }
+        store_quad(a, pano, pano_mask, x, y, all, o8, all, pair_stores);
+    };
+    Stage sa, sb;
+    load(sa, y0);
+#pragma unroll
+    for (int it = 0; it < kIters; it += 2) {
+        if (it + 1 < kIters) load(sb, y0 + (it + 1) * kRowStep);
+        finish(sa, y0 + it * kRowStep);
+        if (it + 2 < kIters) load(sa, y0 + (it + 2) * kRowStep);
+        if (it + 1 < kIters) finish(sb, y0 + (it + 1) * kRowStep);
+    }
+}
+
 // phase 3: level 0 band + pyrUp of collapsed level 1 -> crop, mask, convertTo(8U), panorama
 template <bool TOP, bool PURE>
 __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int tx, int ty,
@@ -1023,32 +1143,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
                 o8[k][ch] = m[k] ? static_cast<uint32_t>(sat_u8(v)) : 0u;
             }
         }
-#pragma unroll
-        for (int ry = 0; ry < 2; ++ry) {
-            const int py = y + ry;
-            if (py >= a.final_h || !valid[2 * ry]) continue;                     // crop to dst_roi_final_
-            if ((MST_ABLATE_C & 16) && o8[2 * ry][0] != 77777u) continue;
-            uint8_t* o = pano + __umul24(py, a.pano_stride) + x * 3;
-            const uint32_t* p0 = o8[2 * ry];
-            const uint32_t* p1 = o8[2 * ry + 1];
-            const bool both = valid[2 * ry + 1] && x + 1 < a.final_w;
-            if (x < a.final_w) {
-                if (both && pair_stores) {
-                    uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
-                    o16[0] = static_cast<uint16_t>(p0[0] | p0[1] << 8);
-                    o16[1] = static_cast<uint16_t>(p0[2] | p1[0] << 8);
-                    o16[2] = static_cast<uint16_t>(p1[1] | p1[2] << 8);
-                } else {
-                    o[0] = static_cast<uint8_t>(p0[0]); o[1] = static_cast<uint8_t>(p0[1]); o[2] = static_cast<uint8_t>(p0[2]);
-                    if (both) { o[3] = static_cast<uint8_t>(p1[0]); o[4] = static_cast<uint8_t>(p1[1]); o[5] = static_cast<uint8_t>(p1[2]); }
-                }
-                if (pano_mask) {
-                    uint8_t* om = pano_mask + __umul24(py, a.mask_stride) + x;
-                    om[0] = m[2 * ry] ? 255 : 0;
-                    if (both) om[1] = m[2 * ry + 1] ? 255 : 0;
-                }
-            }
-        }
+        store_quad(a, pano, pano_mask, x, y, valid, o8, m, pair_stores);
     }
 }
 
@@ -1095,7 +1190,10 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
         __syncthreads();
     }
     // phase 3
-    if (pure) final_level<false, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
+    const Region r0 = blend_region(a, tx, ty, 0);
+    const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
+    if (pure && full && !(MST_ABLATE_C & 64)) final_level_pure_full(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
+    else if (pure) final_level<false, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
     else final_level<false, false>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
 }
 
