@@ -843,17 +843,25 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
                                 static_cast<unsigned>(ly) < static_cast<unsigned>(lh);
             if (!inside) continue;
             const uint32_t off = __umul24(ly, lw) + lx;
-            // issue every load of this camera before the first use: weights, Gaussian quad, pyrUp sources
-            uint32_t m01 = 0;
-            float2 w0 = make_float2(0.f, 0.f), w1 = w0;
+            // weights first: a camera whose four weights are zero here contributes short(v * 0.f) == 0 and its
+            // Gaussian quad and pyrUp sources need not be fetched at all (in a seam tile that is about half of
+            // the camera/quad pairs); the remaining loads are all issued before the first use
             if (FINAL) {
                 // level-0 weight = mask.convertTo(32F, 1/255) with BORDER_CONSTANT 0 around the roi (mask_b)
-                m01 = static_cast<uint32_t>(*(const uint16_t MST_GLOBAL*)(gp(c.mask_b) + off)) |
-                      static_cast<uint32_t>(*(const uint16_t MST_GLOBAL*)(gp(c.mask_b) + off + lw)) << 16;
+                const uint32_t m01 = static_cast<uint32_t>(*(const uint16_t MST_GLOBAL*)(gp(c.mask_b) + off)) |
+                                     static_cast<uint32_t>(*(const uint16_t MST_GLOBAL*)(gp(c.mask_b) + off + lw)) << 16;
+                w[0] = static_cast<float>(m01 & 0xFF) * a.alpha + 0.f;
+                w[1] = static_cast<float>((m01 >> 8) & 0xFF) * a.alpha + 0.f;
+                w[2] = static_cast<float>((m01 >> 16) & 0xFF) * a.alpha + 0.f;
+                w[3] = static_cast<float>(m01 >> 24) * a.alpha + 0.f;
             } else {
-                w0 = load_global(reinterpret_cast<const float2*>(c.W[l] + off));
-                w1 = load_global(reinterpret_cast<const float2*>(c.W[l] + off + lw));
+                const float2 w0 = load_global(reinterpret_cast<const float2*>(c.W[l] + off));
+                const float2 w1 = load_global(reinterpret_cast<const float2*>(c.W[l] + off + lw));
+                w[0] = w0.x; w[1] = w0.y; w[2] = w1.x; w[3] = w1.y;
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (!valid[q]) w[q] = 0.f;
+            if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;   // also adds nothing to ws
             const uint2 g0 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off));
             const uint2 g1 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off + lw));
             {
@@ -869,16 +877,6 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
                 nb[1][0] = gu[r1 + jm]; nb[1][1] = gu[r1 + j]; nb[1][2] = gu[r1 + jp];
                 nb[2][0] = gu[r2 + jm]; nb[2][1] = gu[r2 + j]; nb[2][2] = gu[r2 + jp];
             }
-            if (FINAL) {
-                w[0] = static_cast<float>(m01 & 0xFF) * a.alpha + 0.f;
-                w[1] = static_cast<float>((m01 >> 8) & 0xFF) * a.alpha + 0.f;
-                w[2] = static_cast<float>((m01 >> 16) & 0xFF) * a.alpha + 0.f;
-                w[3] = static_cast<float>(m01 >> 24) * a.alpha + 0.f;
-            } else {
-                w[0] = w0.x; w[1] = w0.y; w[2] = w1.x; w[3] = w1.y;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (!valid[q]) w[q] = 0.f;
             g[0] = g0.x; g[1] = g0.y; g[2] = g1.x; g[3] = g1.y;
         }
 #pragma unroll
@@ -900,13 +898,25 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
         }
     }
 
+    // normalizeUsingWeightMap: static_cast<short>(v / (w + eps)); |v / d| < 2^31 always (d >= 1e-5).
+    // Where the weights sum to exactly 1.0f (most pixels away from a seam, and every covered pixel at level 0
+    // with 0/255 masks) the accumulator is an integer with |v| <= 255 (non-negative weights summing to 1 times
+    // Laplacians within +-255) and short(v / 1.00001f) == v - sign(v), the identity of the single-camera path;
+    // where they sum to 0 the accumulator is 0 and so is the quotient.  Only the remaining pixels divide.
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float d = ws[q] + kWeightEps;
+        const bool unit = ws[q] == 1.0f || ws[q] == 0.f;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-            // normalizeUsingWeightMap: static_cast<short>(v / (w + eps)); |v / d| < 2^31 always (d >= 1e-5)
-            out[q][ch] = wrap_s16(static_cast<int>(static_cast<float>(acc[q][ch]) / d));
+        for (int ch = 0; ch < 3; ++ch) {
+            const int v = acc[q][ch];
+            out[q][ch] = v - (v > 0) + (v < 0);
+        }
+        if (!unit) {
+            const float d = ws[q] + kWeightEps;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                out[q][ch] = wrap_s16(static_cast<int>(static_cast<float>(acc[q][ch]) / d));
+        }
     }
 }
 
