@@ -967,6 +967,55 @@ __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, con
     }
 }
 
+// phase 1 for all coarse levels at once.  The levels above 1 hold only a few dozen quads per tile, so looping
+// over them one after the other leaves most of the block idle while each level's load -> band chain runs its
+// course, five times in a row.  Here the quads of every level form one index space cut into 64-quad chunks
+// (coarsest level first); the waves of the block take chunks round-robin, so the levels are in flight together.
+// The level of a chunk is wave-uniform, which keeps every descriptor access scalar.
+template <bool PURE>
+__device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, const BlendArgs& a, int top, int tx, int ty,
+                                            uint32_t cam_bits, uint2* __restrict__ lds)
+{
+    constexpr int kWaves = C_THREADS / 64;
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    int nch[kMaxLevels];          // chunks per level; only ever indexed by unrolled constants
+    int total = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxLevels; ++k) {
+        nch[k] = k <= top ? (QuadIter(blend_region(a, tx, ty, k)).nq + 63) >> 6 : 0;
+        total += nch[k];
+    }
+    for (int chunk = wave; chunk < total; chunk += kWaves) {
+        int l = 0, first = 0, acc = 0;
+#pragma unroll
+        for (int k = kMaxLevels - 1; k >= 1; --k) {
+            if (l == 0 && chunk < acc + nch[k]) { l = k; first = acc; }
+            acc += nch[k];
+        }
+        const QuadIter it(blend_region(a, tx, ty, l));
+        uint2* s_out = lds + a.lds_off[l];
+        const int q = ((chunk - first) << 6) + lane;
+        if (q >= it.nq) continue;
+        int x, y;
+        bool valid[4];
+        it.at(q, x, y, valid);
+        int n[4][3];
+        float ws[4];
+        if (MST_ABLATE_C & 1) {
+            for (int k = 0; k < 4; ++k) n[k][0] = n[k][1] = n[k][2] = x + y + k;
+        } else if (l == top) {
+            band_quad<true, false, PURE>(cams, a, l, x, y, valid, cam_bits, n, ws);
+        } else {
+            band_quad<false, false, PURE>(cams, a, l, x, y, valid, cam_bits, n, ws);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (valid[k])
+                s_out[__mul24(y + (k >> 1) - it.r.y0, it.rw) + (x + (k & 1) - it.r.x0)] = pack3(n[k][0], n[k][1], n[k][2]);
+    }
+}
+
 __device__ __forceinline__ void dump_level(const BlendArgs& a, int l, int px, int py, const int v[3])
 {
     const uint32_t plane = static_cast<uint32_t>(a.cw[l]) * a.ch[l];
@@ -1176,12 +1225,18 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
         return;
     }
     // phase 1: every coarse band, independent of each other -> no barrier until all are in LDS
-    if (pure) {
-        band_level<true, true>(cams, a, top, tx, ty, cam_bits, lds);
-        for (int l = top - 1; l >= 1; --l) band_level<false, true>(cams, a, l, tx, ty, cam_bits, lds);
+    if (MST_ABLATE_C & 128) {
+        if (pure) {
+            band_level<true, true>(cams, a, top, tx, ty, cam_bits, lds);
+            for (int l = top - 1; l >= 1; --l) band_level<false, true>(cams, a, l, tx, ty, cam_bits, lds);
+        } else {
+            band_level<true, false>(cams, a, top, tx, ty, cam_bits, lds);
+            for (int l = top - 1; l >= 1; --l) band_level<false, false>(cams, a, l, tx, ty, cam_bits, lds);
+        }
+    } else if (pure) {
+        band_levels<true>(cams, a, top, tx, ty, cam_bits, lds);
     } else {
-        band_level<true, false>(cams, a, top, tx, ty, cam_bits, lds);
-        for (int l = top - 1; l >= 1; --l) band_level<false, false>(cams, a, l, tx, ty, cam_bits, lds);
+        band_levels<false>(cams, a, top, tx, ty, cam_bits, lds);
     }
     __syncthreads();
     // phase 2: collapse coarse to fine (LDS only)
