@@ -54,6 +54,19 @@ __device__ __forceinline__ uint32_t pyrdown_finish(uint32_t vbr, uint32_t vg)
     return (((vbr + 0x00800080u) >> 8) & 0x00FF00FFu) | (((vg + 128u) >> 8) << 8);
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (each XCD has its own L2), so block b works on list entry
+// xcd_run_index(b, n): XCD k = b % 8 walks one contiguous run of the list, and tiles that are neighbours in the
+// image (shared source rows, shared pyramid halos) meet in one L2.  A bijection on [0, n) for every n.
+__device__ __forceinline__ int xcd_run_index(int b, int n)
+{
+#if defined(MST_NO_XCD_SWIZZLE)
+    return b;
+#else
+    const int q = n >> 3, r = n & 7, k = b & 7, j = b >> 3;
+    return k * q + min(k, r) + j;
+#endif
+}
+
 // ======================================================================================================
 // A: warp + gain -> level 0 (LDS + global) -> pyrDown -> level 1
 // ======================================================================================================
@@ -337,7 +350,8 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     __shared__ RowEntry s_rows[A_LH];
     __shared__ float s_gain_rows[A_GAIN_ROWS][A_LW];   // BlocksGainCompensator: HResizeLinear of the rows the tile spans
 
-    const uint32_t t = list.tiles[blockIdx.x];
+    const int li = xcd_run_index(blockIdx.x, list.count);       // position in the tile list
+    const uint32_t t = list.tiles[li];
     const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
     const int bw = c.lw[0], bh = c.lh[0], nlev = c.nlev;
@@ -354,10 +368,10 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     k.src_lo2 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(k.src)) & 3u;
     k.src_al = k.src - k.src_lo2;
     // this tile's slice of the per-calibration map table: [row][col], one coalesced 8-byte load per pixel
-    const uint32_t* __restrict__ tab = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW);
+    const uint32_t* __restrict__ tab = table + static_cast<size_t>(list.first + li) * (A_LH * A_LW);
     int tbx = 0, tby = 0;
     if (USE_TABLE) {
-        const int2 tb = tile_base[list.first + blockIdx.x];
+        const int2 tb = tile_base[list.first + li];
         tbx = tb.x; tby = tb.y;
     }
 
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
     __shared__ uint32_t s_all[kOff1 + B_E1 * B_E1];
     uint32_t* const s_e0 = s_all;
 
-    const uint32_t t = list.tiles[blockIdx.x];
+    const uint32_t t = list.tiles[xcd_run_index(blockIdx.x, list.count)];
     const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
     const int tid = threadIdx.x;
