@@ -118,6 +118,13 @@ typedef struct mst_camera {
                                              exactly the warpRoi() size of this camera */
     int32_t  mask_width, mask_height;
     size_t   mask_stride;                 /* bytes */
+    /* Optional lens-undistort pre-pass (the driver's mapEye1/mapEye2, DRV:232,741): fixed-point maps as
+     * initUndistortRectifyMap(..., CV_16SC2, map1, map2) / mst_init_undistort_rectify_map produce them,
+     * src_height x src_width, tightly packed.  Both NULL: the frames are used as they come.  When set,
+     * every compose call first runs remap(frame, undistorted, map1, map2, INTER_LINEAR) for this camera into
+     * an engine-owned buffer and warps that. */
+    const int16_t  *undistort_map1;       /* CV_16SC2: (x, y) integer source coordinate per pixel */
+    const uint16_t *undistort_map2;       /* CV_16UC1: (fy << 5) | fx */
 } mst_camera;
 
 typedef struct mst_calibration {
@@ -205,6 +212,15 @@ int  mst_build_maps(int device, int warp_kind, float scale, const float K[9], co
  * derive calibration inputs such as all-255 warped masks where no GPU is present. */
 int  mst_build_maps_host(int warp_kind, float scale, const float K[9], const float R[9],
                          const float T[3], int src_width, int src_height, float *xmap, float *ymap);
+/* cv::initUndistortRectifyMap(K, dist, R, newK, Size(width, height), CV_16SC2, map1, map2) as RunTestEyeFishMap calls
+ * it (DRV:201-238); host only.  K, newK: 3x3 row-major doubles; R: 3x3 or NULL (identity); dist: 0, 4, 5 or 8
+ * coefficients (k1 k2 p1 p2 [k3 [k4 k5 k6]]).  map1: height x width x 2 shorts, map2: height x width ushorts. */
+int  mst_init_undistort_rectify_map(const double K[9], const double *dist, int num_dist, const double R[9],
+                                    const double newK[9], int width, int height, int16_t *map1, uint16_t *map2);
+/* remap(src, dst, map1, map2, INTER_LINEAR) for a CV_8UC3 host image with such maps (default constant border,
+ * DRV:741); dst has the size of src. */
+int  mst_remap_fixed(int device, const uint8_t *src, int width, int height, size_t src_stride,
+                     const int16_t *map1, const uint16_t *map2, uint8_t *dst, size_t dst_stride);
 /* RotationWarper::warp for CV_8UC1 / CV_8UC3 host images; dst is the warpRoi() size.
  * interp/border: (LINEAR, REFLECT) for images, (NEAREST, CONSTANT) for masks. */
 int  mst_warp(int device, int warp_kind, float scale, const float K[9], const float R[9],

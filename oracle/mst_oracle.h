@@ -92,6 +92,16 @@ mo_rect mo_warp_8u(int kind, float scale, const float K[9], const float R[9], co
                    int interp, int border_type, uint8_t *dst);
 const int16_t *mo_bilinear_tab_i(void);   /* [1024][4] fixed-point weights, for KATs */
 
+/* ---- lens undistort (a22): initUndistortRectifyMap(CV_16SC2) + remap with fixed-point maps ------ */
+/* K, newK: 3x3 row-major CV_64F; dist: 0, 4, 5 or 8 coefficients (k1 k2 p1 p2 [k3 [k4 k5 k6]]); R: 3x3 or NULL
+ * (identity).  map1: height x width x 2 shorts, map2: height x width ushorts, tightly packed.  -1 on a bad shape. */
+int mo_init_undistort_rectify_map(const double K[9], const double *dist, int ndist, const double *R,
+                                  const double newK[9], int width, int height, int16_t *map1, uint16_t *map2);
+/* remap(src, dst, map1, map2, INTER_LINEAR) with the default BORDER_CONSTANT / Scalar() border (DRV:741) */
+void mo_remap_8u_fixed(const uint8_t *src, int sw, int sh, size_t sstride, int cn,
+                       uint8_t *dst, int dw, int dh, size_t dstride,
+                       const int16_t *map1, const uint16_t *map2);
+
 /* ---- exposure (a7) ---------------------------------------------------------- */
 void mo_resize_linear_32f(const float *src, int sw, int sh, float *dst, int dw, int dh);
 void mo_blocks_gain_apply(uint8_t *img, int w, int h, size_t stride,

@@ -6,7 +6,9 @@ warper / exposure-compensator / frame-loop interfaces plus the synthetic-rig inp
 """
 from . import _capi as capi  # noqa: F401
 from .engine import (BlocksGainCompensator, CylindricalWarper, GainCompensator, PanoramaEngine,  # noqa: F401
-                     PlaneWarper, RotationWarper, SphericalWarper, multiband_geometry, synth_frame)
+                     PlaneWarper, RotationWarper, SphericalWarper, init_undistort_rectify_map, multiband_geometry,
+                     remap_fixed, synth_frame)
 
 __all__ = ["capi", "PanoramaEngine", "RotationWarper", "PlaneWarper", "SphericalWarper", "CylindricalWarper",
-           "GainCompensator", "BlocksGainCompensator", "multiband_geometry", "synth_frame"]
+           "GainCompensator", "BlocksGainCompensator", "multiband_geometry", "synth_frame",
+           "init_undistort_rectify_map", "remap_fixed"]

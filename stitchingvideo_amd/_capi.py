@@ -5,6 +5,7 @@ There is no Python or CPU fallback; if the shared object is missing the import f
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MST_LIB") or os.path.join(_HERE, "libmi355stitch.so")   # MST_LIB: tuning variants
@@ -30,6 +31,7 @@ EXPORTS = [
     "mst_compose_profile_batch", "mst_synchronize", "mst_warp_roi",
     "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
     "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
+    "mst_init_undistort_rectify_map", "mst_remap_fixed",
     "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame",
 ]
 
@@ -47,7 +49,7 @@ class Camera(C.Structure):
                 ("R", C.c_float * 9), ("T", C.c_float * 3), ("gain_map", C.c_void_p),
                 ("gain_w", C.c_int32), ("gain_h", C.c_int32), ("gain", C.c_float),
                 ("mask", C.c_void_p), ("mask_width", C.c_int32), ("mask_height", C.c_int32),
-                ("mask_stride", C.c_size_t)]
+                ("mask_stride", C.c_size_t), ("undistort_map1", C.c_void_p), ("undistort_map2", C.c_void_p)]
 
 
 class Calibration(C.Structure):
@@ -80,6 +82,15 @@ def load():
         raise ImportError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C stitchingvideo_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    # PyTorch's ROCm wheel ships its own HIP runtime under the soname this library links; the copy that is loaded
+    # first serves the whole process, and torch only finds its GPUs with its own.  A process that will also use
+    # torch (tests, bench.py, the sharded launcher) therefore needs torch loaded before this library.
+    import importlib.util
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # a broken torch install must not take the engine down with it
+            pass
     L = C.CDLL(LIB_PATH)
     fp, vp, ip = C.POINTER(C.c_float), C.c_void_p, C.POINTER(C.c_int)
     L.mst_create.restype = C.c_int
@@ -107,6 +118,10 @@ def load():
     L.mst_compose_profile_batch.restype = C.c_int
     L.mst_compose_profile_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                             C.c_size_t, vp, C.c_int, vp, fp, ip]
+    L.mst_init_undistort_rectify_map.restype = C.c_int
+    L.mst_init_undistort_rectify_map.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.mst_remap_fixed.restype = C.c_int
+    L.mst_remap_fixed.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_size_t, vp, vp, vp, C.c_size_t]
     L.mst_synchronize.restype = C.c_int
     L.mst_synchronize.argtypes = [vp]
     L.mst_stage_cameras.restype = C.c_int

@@ -328,6 +328,47 @@ int mst_warp(int device, int warp_kind, float scale, const float K[9], const flo
     });
 }
 
+int mst_init_undistort_rectify_map(const double K[9], const double* dist, int num_dist, const double R[9],
+                                   const double newK[9], int width, int height, int16_t* map1, uint16_t* map2)
+{
+    return guarded(nullptr, [&] {
+        require(K && newK && map1 && map2, "null matrix or map pointer");
+        require(width > 0 && height > 0, "bad map size");
+        require(num_dist == 0 || dist != nullptr, "null distortion coefficients");
+        require(mst::init_undistort_rectify_map(K, dist, num_dist, R, newK, width, height, map1, map2),
+                "distortion coefficients must be 0, 4, 5 or 8 values");
+    });
+}
+
+int mst_remap_fixed(int device, const uint8_t* src, int width, int height, size_t src_stride, const int16_t* map1,
+                    const uint16_t* map2, uint8_t* dst, size_t dst_stride)
+{
+    return guarded(nullptr, [&] {
+        require(src && dst && map1 && map2, "null image or map pointer");
+        require(width > 0 && height > 0, "bad image size");
+        const size_t row = static_cast<size_t>(width) * 3;
+        require(src_stride >= row && dst_stride >= row && row < (size_t{1} << 24), "bad stride");
+        mst::select_device(device);
+        StageCtx ctx;
+        mst::check_hip(hipStreamCreate(&ctx.s), "hipStreamCreate");
+        const size_t px = static_cast<size_t>(width) * height;
+        mst::UndistortCam u{ctx.pool.upload(map1, px * 2, ctx.s), ctx.pool.upload(map2, px, ctx.s), width, height};
+        mst::UndistortCam* d_u = ctx.pool.upload(&u, 1, ctx.s);
+        uint8_t* d_src = ctx.pool.alloc<uint8_t>(row * height);
+        uint8_t* d_dst = ctx.pool.alloc<uint8_t>(row * height);
+        mst::check_hip(hipMemcpy2DAsync(d_src, row, src, src_stride, row, height, hipMemcpyHostToDevice, ctx.s),
+                       "hipMemcpy2DAsync");
+        mst::FrameBatch fs{}, fd{};
+        fs.f[0].ptr[0] = d_src; fs.f[0].stride[0] = static_cast<uint32_t>(row);
+        fd.f[0].ptr[0] = d_dst; fd.f[0].stride[0] = static_cast<uint32_t>(row);
+        mst::launch_remap_fixed(d_u, 1, width, height, fs, fd, 1, ctx.s);
+        mst::check_hip(hipGetLastError(), "k_remap_fixed");
+        mst::check_hip(hipMemcpy2DAsync(dst, dst_stride, d_dst, row, row, height, hipMemcpyDeviceToHost, ctx.s),
+                       "hipMemcpy2DAsync");
+        mst::check_hip(hipStreamSynchronize(ctx.s), "hipStreamSynchronize");
+    });
+}
+
 int mst_exposure_apply(int device, int expos_kind, uint8_t* image, int width, int height, size_t stride,
                        const float* gain_map, int gain_w, int gain_h, float gain)
 {

@@ -89,6 +89,14 @@ struct CanvasDesc {
     int32_t final_w, final_h;      // dst_roi_final_ (un-padded)
 };
 
+// Lens-undistort pre-pass: per camera the fixed-point maps of initUndistortRectifyMap(CV_16SC2).
+// map1 == nullptr: the camera's frames are used as they come.
+struct UndistortCam {
+    const int16_t* map1;           // src_h x src_w x 2: integer source coordinate (x, y)
+    const uint16_t* map2;          // src_h x src_w: (fy << 5) | fx
+    int32_t w, h;                  // frame size (the maps are frame-sized: the reference undistorts in place size)
+};
+
 // Arguments of the fused canvas kernel (k_blend), passed by value.
 struct BlendArgs {
     int32_t nlev, n_cams;

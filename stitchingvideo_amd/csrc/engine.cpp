@@ -57,6 +57,9 @@ template CamDesc* DevicePool::upload<CamDesc>(const CamDesc*, size_t, hipStream_
 template ColEntry* DevicePool::upload<ColEntry>(const ColEntry*, size_t, hipStream_t);
 template RowEntry* DevicePool::upload<RowEntry>(const RowEntry*, size_t, hipStream_t);
 template uint32_t* DevicePool::upload<uint32_t>(const uint32_t*, size_t, hipStream_t);
+template int16_t* DevicePool::upload<int16_t>(const int16_t*, size_t, hipStream_t);
+template uint16_t* DevicePool::upload<uint16_t>(const uint16_t*, size_t, hipStream_t);
+template UndistortCam* DevicePool::upload<UndistortCam>(const UndistortCam*, size_t, hipStream_t);
 
 CalibState::~CalibState()
 {
@@ -299,6 +302,31 @@ void Engine::update(const mst_calibration& calib)
         check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
     }
 
+    // frame sets in flight: one per frame set of a batch, two for frame pipelining
+    st->num_sets = std::max(1, std::min<int>(cfg_.max_batch, kMaxBatch));
+    if ((cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && cfg_.blend_kind == MST_BLEND_MULTI_BAND) st->num_sets = std::max(st->num_sets, 2);
+
+    // optional lens-undistort maps (DRV:232): uploaded once, applied to every frame before the warp
+    st->ucams.assign(n, UndistortCam{nullptr, nullptr, 0, 0});
+    st->undist_frames.assign(static_cast<size_t>(st->num_sets) * n, nullptr);
+    for (int i = 0; i < n; ++i) {
+        const mst_camera& c = calib.cameras[i];
+        if (!c.undistort_map1 && !c.undistort_map2) continue;
+        if (!c.undistort_map1 || !c.undistort_map2) throw Error{MST_ERR_INVALID_ARG, "undistort maps come in pairs"};
+        const size_t px = static_cast<size_t>(c.src_width) * c.src_height;
+        UndistortCam& u = st->ucams[i];
+        u.map1 = st->pool.upload(c.undistort_map1, px * 2, s);
+        u.map2 = st->pool.upload(c.undistort_map2, px, s);
+        u.w = c.src_width; u.h = c.src_height;
+        st->any_undistort = true;
+        st->undist_max_w = std::max(st->undist_max_w, u.w);
+        st->undist_max_h = std::max(st->undist_max_h, u.h);
+        for (int k = 0; k < st->num_sets; ++k)
+            st->undist_frames[static_cast<size_t>(k) * n + i] = st->pool.alloc<uint8_t>(px * 3 + 16);
+        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");      // the caller's maps are only borrowed
+    }
+    if (st->any_undistort) st->d_ucams = st->pool.upload(st->ucams, s);
+
     st->canvas = result_roi(rois);
     for (int i = 0; i < n; ++i) {
         st->desc[i].corner_x = rois[i].x - st->canvas.x;
@@ -363,8 +391,6 @@ void Engine::update(const mst_calibration& calib)
         // Descriptor sets: set 0 owns the pyramids above; frame pipelining (MST_FLAG_OVERLAP_FRAMES) needs a second
         // set of Gaussian pyramids (frame t+1's per-camera kernels write it while frame t's canvas kernel still
         // reads the first), batched launches (mst_config.max_batch) one per frame set of a batch.
-        st->num_sets = std::max(1, std::min<int>(cfg_.max_batch, kMaxBatch));
-        if (cfg_.flags & MST_FLAG_OVERLAP_FRAMES) st->num_sets = std::max(st->num_sets, 2);
         std::vector<CamDesc> sets = st->desc;
         for (int k = 1; k < st->num_sets; ++k)
             for (int i = 0; i < n; ++i) {
@@ -470,7 +496,7 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
     if (!d_frames || !strides || !d_panos) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama table"};
     if (count < 1 || count > kMaxBatch) throw Error{MST_ERR_INVALID_ARG, "batch size out of range"};
-    if (st->blend_kind == MST_BLEND_MULTI_BAND && count > 1 && count > st->num_sets)
+    if ((st->blend_kind == MST_BLEND_MULTI_BAND || st->any_undistort) && count > 1 && count > st->num_sets)
         throw Error{MST_ERR_INVALID_ARG, "batch larger than mst_config.max_batch"};
     hipStream_t s = stream ? stream : stream_;
     FrameBatch fb{};
@@ -493,6 +519,21 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
 
     auto mark = [&](const char* name) { if (timer) timer->mark(name, s); };
     if (timer) timer->begin(s);
+    // lens-undistort pre-pass: remap the caller's frames into the engine's buffers of frame sets first_set.. and
+    // point the frame table at them (cameras without maps keep the caller's frames)
+    auto undistort = [&](int first_set, hipStream_t on) {
+        if (!st->any_undistort) return;
+        FrameBatch ub = fb;
+        for (int f = 0; f < count; ++f)
+            for (int i = 0; i < st->n; ++i)
+                if (uint8_t* buf = st->undist_frames[static_cast<size_t>(first_set + f) * st->n + i]) {
+                    ub.f[f].ptr[i] = buf;
+                    ub.f[f].stride[i] = static_cast<uint32_t>(st->cams[i].src_w) * 3u;
+                }
+        launch_remap_fixed(st->d_ucams, st->n, st->undist_max_w, st->undist_max_h, fb, ub, count, on);
+        if (timer) timer->mark("k_remap_fixed", on);
+        fb = ub;
+    };
     if (st->blend_kind == MST_BLEND_MULTI_BAND) {
         // Frame pipelining (single frame sets only): the per-camera kernels (A, B) of this frame go to front_stream_
         // and only wait for the canvas kernel that last read this pyramid set (two frames ago); the canvas kernel
@@ -510,6 +551,7 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
                     check_hip(hipStreamWaitEvent(s, ev_canvas_done_[k], 0), "hipStreamWaitEvent");
                     canvas_pending_[k] = false;
                 }
+        undistort(slot, sf);
         launch_warp_pyr(desc, st->n, cfg_.warp_kind, st->warp_list, fb, count, st->warp_table, st->warp_table_base, sf);
         mark("k_warp_pyr");
         // where the frame crosses from the front stream to the caller's stream: after the warp kernel (the small
@@ -540,6 +582,7 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
             canvas_pending_[slot] = true;
         }
     } else {
+        undistort(0, s);
         for (int f = 0; f < count; ++f) {
             uint8_t* pano = static_cast<uint8_t*>(d_panos[f]);
             uint8_t* pmask = d_masks ? static_cast<uint8_t*>(d_masks[f]) : nullptr;
@@ -591,6 +634,16 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
             throw Error{MST_ERR_INVALID_ARG, "bad frame for a camera in the mask"};
         fa.ptr[i] = static_cast<const uint8_t*>(d_frames[i]);
         fa.stride[i] = static_cast<uint32_t>(strides[i]);
+    }
+    if (st->any_undistort) {            // lens-undistort pre-pass for the cameras of this call (frame set 0)
+        FrameBatch ub = fb;
+        for (int i = 0; i < st->n; ++i)
+            if (uint8_t* buf = (camera_mask >> i & 1u) ? st->undist_frames[i] : nullptr) {
+                ub.f[0].ptr[i] = buf;
+                ub.f[0].stride[i] = static_cast<uint32_t>(st->cams[i].src_w) * 3u;
+            }
+        launch_remap_fixed(st->d_ucams, st->n, st->undist_max_w, st->undist_max_h, fb, ub, 1, s);
+        fb = ub;
     }
     const MbPlanHost& plan = st->plan;
     for (int i = 0; i < st->n; ++i) {

@@ -67,6 +67,12 @@ struct CalibState {
     CanvasDesc cv{};
     MbPlanHost plan;                    // work lists of the fused kernels (host copy, for introspection)
     TileList warp_list{};               // kernel A
+    // lens-undistort pre-pass (optional per camera)
+    std::vector<UndistortCam> ucams;    // host copy (device map pointers)
+    UndistortCam* d_ucams = nullptr;
+    bool any_undistort = false;
+    int undist_max_w = 0, undist_max_h = 0;
+    std::vector<uint8_t*> undist_frames;   // num_sets x n engine-owned undistorted frames (nullptr: camera has no maps)
     uint32_t* warp_table = nullptr;     // per-tile backward-map table (frame-invariant), see kernels_mb.hip
     int2* warp_table_base = nullptr;    // per tile: the source coordinate its table entries are relative to
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step

@@ -329,4 +329,72 @@ BandGeometry multiband_feed_geometry(const Rect& roi, int num_bands, const Rect&
     return g;
 }
 
+// ---- lens undistortion maps -------------------------------------------------------------------------
+// OpenCV 2.4.11 imgproc/undistort.cpp (not vendored by the reference; restated from the published algorithm):
+// the inverse of newK * R in closed form (cv::invert on a 3x3 CV_64F: reciprocal determinant times adjugate),
+// the normalised ray advanced incrementally along each row, the radial/tangential model in double, and the
+// CV_16SC2 fixed-point split cvRound(u * 32) -> (>> 5, & 31).
+namespace {
+double round_half_even_to_int(double v, bool& ok)
+{
+    const double r = std::nearbyint(v);             // default rounding mode: to nearest, ties to even (cvtsd2si)
+    ok = r >= -2147483648.0 && r <= 2147483647.0;
+    return r;
+}
+int cv_round64(double v)
+{
+    bool ok;
+    const double r = round_half_even_to_int(v, ok);
+    return ok ? static_cast<int>(r) : INT_MIN;      // the x64 conversion's "integer indefinite"
+}
+}  // namespace
+
+bool init_undistort_rectify_map(const double K[9], const double* dist, int ndist, const double* R, const double newK[9],
+                                int width, int height, int16_t* map1, uint16_t* map2)
+{
+    if (!(ndist == 0 || ndist == 4 || ndist == 5 || ndist == 8)) return false;
+    double m[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            if (!R) { m[3 * i + j] = newK[3 * i + j]; continue; }
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += newK[3 * i + k] * R[3 * k + j];
+            m[3 * i + j] = acc;
+        }
+    double ir[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+                 m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (det != 0.) {
+        det = 1. / det;
+        ir[0] = (m[4] * m[8] - m[5] * m[7]) * det; ir[1] = (m[2] * m[7] - m[1] * m[8]) * det;
+        ir[2] = (m[1] * m[5] - m[2] * m[4]) * det; ir[3] = (m[5] * m[6] - m[3] * m[8]) * det;
+        ir[4] = (m[0] * m[8] - m[2] * m[6]) * det; ir[5] = (m[2] * m[3] - m[0] * m[5]) * det;
+        ir[6] = (m[3] * m[7] - m[4] * m[6]) * det; ir[7] = (m[1] * m[6] - m[0] * m[7]) * det;
+        ir[8] = (m[0] * m[4] - m[1] * m[3]) * det;
+    }
+    const double u0 = K[2], v0 = K[5], fx = K[0], fy = K[4];
+    const double k1 = ndist > 0 ? dist[0] : 0., k2 = ndist > 1 ? dist[1] : 0.;
+    const double p1 = ndist > 2 ? dist[2] : 0., p2 = ndist > 3 ? dist[3] : 0.;
+    const double k3 = ndist >= 5 ? dist[4] : 0.;
+    const double k4 = ndist >= 8 ? dist[5] : 0., k5 = ndist >= 8 ? dist[6] : 0., k6 = ndist >= 8 ? dist[7] : 0.;
+    for (int i = 0; i < height; ++i) {
+        int16_t* m1 = map1 + static_cast<size_t>(i) * width * 2;
+        uint16_t* m2 = map2 + static_cast<size_t>(i) * width;
+        double xr = i * ir[1] + ir[2], yr = i * ir[4] + ir[5], wr = i * ir[7] + ir[8];
+        for (int j = 0; j < width; ++j, xr += ir[0], yr += ir[3], wr += ir[6]) {
+            const double w = 1. / wr, x = xr * w, y = yr * w;
+            const double x2 = x * x, y2 = y * y;
+            const double r2 = x2 + y2, xy2 = 2 * x * y;
+            const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+            const double u = fx * (x * kr + p1 * xy2 + p2 * (r2 + 2 * x2)) + u0;
+            const double v = fy * (y * kr + p1 * (r2 + 2 * y2) + p2 * xy2) + v0;
+            const int iu = cv_round64(u * 32), iv = cv_round64(v * 32);
+            m1[2 * j] = static_cast<int16_t>(iu >> 5);
+            m1[2 * j + 1] = static_cast<int16_t>(iv >> 5);
+            m2[j] = static_cast<uint16_t>((iv & 31) * 32 + (iu & 31));
+        }
+    }
+    return true;
+}
+
 }  // namespace mst

@@ -75,6 +75,14 @@ struct BandGeometry {
     Rect tl_br;                 // x,y = tl_new ; width,height = br_new - tl_new (bordered size)
     int top = 0, left = 0, bottom = 0, right = 0;
 };
+// Lens undistortion: cv::initUndistortRectifyMap(K, dist, R, newK, size, CV_16SC2, map1, map2)
+// as the reference's RunTestEyeFishMap calls it (DRV:201-238).  K, newK, R (or nullptr = identity): 3x3 row-major
+// doubles; dist: 0, 4, 5 or 8 coefficients k1 k2 p1 p2 [k3 [k4 k5 k6]].  map1: h x w x 2 shorts (integer source
+// coordinate), map2: h x w ushorts ((fy << 5) | fx, the row of cv::remap's bilinear weight table).  False if
+// the coefficient count is not one OpenCV accepts.
+bool init_undistort_rectify_map(const double K[9], const double* dist, int ndist, const double* R, const double newK[9],
+                                int width, int height, int16_t* map1, uint16_t* map2);
+
 int  multiband_num_bands(int actual_num_bands, const Rect& dst_roi);     // blenders.cpp:207-209
 Rect multiband_padded_roi(const Rect& dst_roi, int num_bands);           // blenders.cpp:211-213
 BandGeometry multiband_feed_geometry(const Rect& padded_roi, int num_bands, const Rect& image);

@@ -76,6 +76,38 @@ __global__ __launch_bounds__(256) void k_warp_u8(const CamDesc* __restrict__ cam
     }
 }
 
+// cv::remap(src, dst, map1 CV_16SC2, map2 CV_16UC1, INTER_LINEAR) with the default constant border (DRV:741):
+// the integer tap comes from map1, the 5-bit fractions from map2, the weights and rounding are those of the
+// float-map path.  One launch covers every camera of every frame set of a batch: blockIdx.z = set * n_cams + cam.
+__global__ __launch_bounds__(256) void k_remap_fixed(const UndistortCam* __restrict__ ucams, int n_cams, FrameBatch src,
+                                                     FrameBatch dst)
+{
+    const int set = blockIdx.z / n_cams, cam = blockIdx.z - set * n_cams;
+    const UndistortCam u = ucams[cam];
+    if (!u.map1 || !src.f[set].ptr[cam]) return;      // no maps, or a camera that is not part of this call
+    const int x = blockIdx.x * kTileW + threadIdx.x, y = blockIdx.y * kTileH + threadIdx.y;
+    if (x >= u.w || y >= u.h) return;
+    const uint8_t* __restrict__ s = src.f[set].ptr[cam];
+    const uint32_t sstride = src.f[set].stride[cam];
+    uint8_t* __restrict__ d = const_cast<uint8_t*>(dst.f[set].ptr[cam]) + static_cast<size_t>(y) * dst.f[set].stride[cam] + x * 3;
+    const uint32_t idx = static_cast<uint32_t>(y) * u.w + x;
+    const uint32_t xy = *reinterpret_cast<const uint32_t MST_GLOBAL*>(gp(u.map1) + 2 * idx);
+    const int sx = static_cast<int>(static_cast<short>(xy & 0xFFFFu)), sy = static_cast<int>(xy) >> 16;
+    const int a = gp(u.map2)[idx] & 1023;
+    const int fx = a & 31, fy = a >> 5;
+    Taps t;
+    t.w00 = (32 - fx) * (32 - fy) * 32; t.w01 = fx * (32 - fy) * 32;
+    t.w10 = (32 - fx) * fy * 32;        t.w11 = fx * fy * 32;
+    t.x0 = static_cast<unsigned>(sx) < static_cast<unsigned>(u.w) ? sx : -1;
+    t.x1 = static_cast<unsigned>(sx + 1) < static_cast<unsigned>(u.w) ? sx + 1 : -1;
+    t.y0 = static_cast<unsigned>(sy) < static_cast<unsigned>(u.h) ? sy : -1;
+    t.y1 = static_cast<unsigned>(sy + 1) < static_cast<unsigned>(u.h) ? sy + 1 : -1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        d[k] = static_cast<uint8_t>(blend_taps(t, tap_u8(s, sstride, 3, t.x0, t.y0, k), tap_u8(s, sstride, 3, t.x1, t.y0, k),
+                                               tap_u8(s, sstride, 3, t.x0, t.y1, k), tap_u8(s, sstride, 3, t.x1, t.y1, k)));
+}
+
 __global__ __launch_bounds__(256) void k_exposure_apply(const CamDesc* __restrict__ cam, uint8_t* __restrict__ img,
                                                         size_t stride, int w, int h)
 {
@@ -280,6 +312,15 @@ void launch_warp_u8(const CamDesc* d_cam, const uint8_t* d_src, size_t src_strid
         else MST_LAUNCH_WARP(1, false, false);
     }
 #undef MST_LAUNCH_WARP
+}
+
+void launch_remap_fixed(const UndistortCam* d_ucams, int n_cams, int max_w, int max_h, const FrameBatch& src,
+                        const FrameBatch& dst, int batch, hipStream_t s)
+{
+    if (n_cams <= 0 || batch <= 0 || max_w <= 0 || max_h <= 0) return;
+    dim3 grid = grid2d(max_w, max_h);
+    grid.z = static_cast<unsigned>(n_cams * batch);
+    hipLaunchKernelGGL(k_remap_fixed, grid, block2d(), 0, s, d_ucams, n_cams, src, dst);
 }
 
 void launch_exposure_apply(const CamDesc* d_cam, uint8_t* d_img, size_t stride, int w, int h, hipStream_t s)

@@ -12,6 +12,9 @@ void launch_build_maps(const CamDesc* d_cam, float* d_xmap, float* d_ymap, int w
 void launch_warp_u8(const CamDesc* d_cam, const uint8_t* d_src, size_t src_stride, int channels,
                     int interp, int border, uint8_t* d_dst, size_t dst_stride, int w, int h, hipStream_t s);
 void launch_exposure_apply(const CamDesc* d_cam, uint8_t* d_img, size_t stride, int w, int h, hipStream_t s);
+// lens-undistort pre-pass: dst.f[set].ptr[cam] <- remap(src.f[set].ptr[cam]) for every camera that has maps
+void launch_remap_fixed(const UndistortCam* d_ucams, int n_cams, int max_w, int max_h, const FrameBatch& src,
+                        const FrameBatch& dst, int batch, hipStream_t s);
 
 // ---- calibration-time static products ----
 void launch_weight_level0(const CamDesc* d_cams, int cam, float* d_w0, int bw, int bh, hipStream_t s);

@@ -135,6 +135,36 @@ def multiband_geometry(canvas, num_bands, image):
     return pad.tuple(), nb.value, list(out)
 
 
+def init_undistort_rectify_map(K, dist, size, R=None, newK=None):
+    """cv::initUndistortRectifyMap(K, dist, R, newK, size, CV_16SC2) (DRV:232) ->
+    (map1 int16 (h, w, 2), map2 uint16 (h, w)); host only."""
+    w, h = size
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    newK = K if newK is None else np.ascontiguousarray(newK, np.float64).reshape(9)
+    dist = np.ascontiguousarray(dist, np.float64).reshape(-1)
+    Rp = None if R is None else np.ascontiguousarray(R, np.float64).reshape(9)
+    m1 = np.empty((h, w, 2), np.int16)
+    m2 = np.empty((h, w), np.uint16)
+    capi.check(capi.load().mst_init_undistort_rectify_map(
+        K.ctypes.data, dist.ctypes.data if dist.size else None, dist.size, None if Rp is None else Rp.ctypes.data,
+        newK.ctypes.data, w, h, m1.ctypes.data, m2.ctypes.data))
+    return m1, m2
+
+
+def remap_fixed(image, map1, map2, device=0):
+    """cv::remap(image, dst, map1, map2, INTER_LINEAR) with CV_16SC2 / CV_16UC1 maps on a CV_8UC3 image (DRV:741)."""
+    image = np.ascontiguousarray(image, np.uint8)
+    h, w = image.shape[:2]
+    m1 = np.ascontiguousarray(map1, np.int16)
+    m2 = np.ascontiguousarray(map2, np.uint16)
+    if m1.shape != (h, w, 2) or m2.shape != (h, w):
+        raise ValueError("maps must have the image's size")
+    out = np.empty_like(image)
+    capi.check(capi.load().mst_remap_fixed(device, image.ctypes.data, w, h, image.strides[0], m1.ctypes.data,
+                                           m2.ctypes.data, out.ctypes.data, out.strides[0]))
+    return out
+
+
 def synth_frame(camera, frame_index, width, height):
     """Synthetic BGR frame of SURVEY.md section 8d (texture + PCG32 noise)."""
     out = np.empty((height, width, 3), np.uint8)
@@ -207,6 +237,14 @@ class PanoramaEngine:
             keep.append(m)
             arr[i].mask, arr[i].mask_width, arr[i].mask_height = m.ctypes.data, m.shape[1], m.shape[0]
             arr[i].mask_stride = m.strides[0]
+            und = c.get("undistort")               # (map1 int16 (h, w, 2), map2 uint16 (h, w)) or None
+            if und is not None:
+                m1 = np.ascontiguousarray(und[0], np.int16)
+                m2 = np.ascontiguousarray(und[1], np.uint16)
+                if m1.shape != (arr[i].src_height, arr[i].src_width, 2) or m2.shape != m1.shape[:2]:
+                    raise ValueError("undistort maps must be frame-sized (h, w, 2) int16 and (h, w) uint16")
+                keep += [m1, m2]
+                arr[i].undistort_map1, arr[i].undistort_map2 = m1.ctypes.data, m2.ctypes.data
         cal = capi.Calibration(C.sizeof(capi.Calibration), n, float(scale), arr)
         self._check(self._L.mst_update(self._h, C.byref(cal)))
 

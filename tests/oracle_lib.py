@@ -79,6 +79,10 @@ def lib():
     L.mo_warp_8u.restype = Rect
     L.mo_warp_8u.argtypes = [C.c_int, C.c_float, fp, fp, fp, vp, C.c_int, C.c_int, C.c_size_t,
                              C.c_int, C.c_int, C.c_int, vp]
+    L.mo_init_undistort_rectify_map.restype = C.c_int
+    L.mo_init_undistort_rectify_map.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.mo_remap_8u_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, C.c_int, C.c_int,
+                                    C.c_size_t, vp, vp]
     L.mo_bilinear_tab_i.restype = C.POINTER(C.c_int16)
     L.mo_resize_linear_32f.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
     L.mo_blocks_gain_apply.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_int, C.c_int]
@@ -160,6 +164,35 @@ def remap(src, xmap, ymap, interp, border):
     dst = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), np.uint8)
     lib().mo_remap_8u(_ptr(src), sw, sh, sw * cn, cn, _ptr(dst), dw, dh, dw * cn,
                       _ptr(xmap), _ptr(ymap), dw, interp, border)
+    return dst
+
+
+def init_undistort_rectify_map(K, dist, size, R=None, newK=None):
+    """initUndistortRectifyMap(K, dist, R, newK, size, CV_16SC2) -> (map1 int16 (h, w, 2), map2 uint16 (h, w))."""
+    w, h = size
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    newK = K if newK is None else np.ascontiguousarray(newK, np.float64).reshape(9)
+    dist = np.ascontiguousarray(dist, np.float64).reshape(-1)
+    Rp = None if R is None else np.ascontiguousarray(R, np.float64).reshape(9)
+    m1 = np.empty((h, w, 2), np.int16)
+    m2 = np.empty((h, w), np.uint16)
+    rc = lib().mo_init_undistort_rectify_map(_ptr(K), _ptr(dist), dist.size, None if Rp is None else _ptr(Rp),
+                                             _ptr(newK), w, h, _ptr(m1), _ptr(m2))
+    if rc != 0:
+        raise ValueError("bad distortion coefficient count")
+    return m1, m2
+
+
+def remap_fixed(src, map1, map2):
+    """remap(src, dst, map1 CV_16SC2, map2 CV_16UC1, INTER_LINEAR) (BORDER_CONSTANT 0)."""
+    src = np.ascontiguousarray(src)
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    map1 = np.ascontiguousarray(map1, np.int16)
+    map2 = np.ascontiguousarray(map2, np.uint16)
+    dh, dw = map2.shape
+    dst = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), np.uint8)
+    lib().mo_remap_8u_fixed(_ptr(src), sw, sh, sw * cn, cn, _ptr(dst), dw, dh, dw * cn, _ptr(map1), _ptr(map2))
     return dst
 
 
