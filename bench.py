@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap consecutive frames (latency mode)")
     ap.add_argument("--batch", type=int, default=8,
                     help="frame sets per step (mst_compose_device_batch); 1 = one frame set per launch sequence")
+    ap.add_argument("--undistort", action="store_true",
+                    help="add the driver's lens-undistort pre-pass (DRV:741) to every camera (not part of the headline)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = sized to ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = min(host cores, 32))")
     return ap.parse_args()
@@ -95,6 +97,15 @@ def main():
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
                            overlap_frames=not args.no_overlap and blend == "multiband" and batch == 1,
                            max_batch=batch)
+    if args.undistort:
+        # the reference's fisheye intrinsics (DRV:209-216, quoted for 1280x720) scaled to the frame size
+        fw, fh = rig["size"]
+        import numpy as np
+        Ku = np.array([[655.6 * fw / 1280.0, 0, 625.06 * fw / 1280.0], [0, 656.4 * fh / 720.0, 361.96 * fh / 720.0],
+                       [0, 0, 1]])
+        und = S.init_undistort_rectify_map(Ku, [-0.382, 0.195, -0.00363, 0.00237], (fw, fh))
+        for c in rig["cameras"]:
+            c["undistort"] = und
     eng.update(rig["scale"], rig["cameras"])
     cx, cy, cw, ch = eng.canvas()
 
@@ -192,7 +203,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d BGR8 streams, %s warp, gain_blocks, %s blend (5 bands), canvas %dx%d"
                                    % (args.config, n_cam, rig["size"][0], rig["size"][1], rig["warp"], blend, cw, ch),
-                       "frames_resident_in_hbm": True, "frame_sets_per_step": batch,
+                       "frames_resident_in_hbm": True, "frame_sets_per_step": batch, "lens_undistort": bool(args.undistort),
                        "parallelism": "frames sharded over %d rank(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic * batch if traffic else None,

@@ -79,33 +79,92 @@ __global__ __launch_bounds__(256) void k_warp_u8(const CamDesc* __restrict__ cam
 // cv::remap(src, dst, map1 CV_16SC2, map2 CV_16UC1, INTER_LINEAR) with the default constant border (DRV:741):
 // the integer tap comes from map1, the 5-bit fractions from map2, the weights and rounding are those of the
 // float-map path.  One launch covers every camera of every frame set of a batch: blockIdx.z = set * n_cams + cam.
+// A thread produces four consecutive pixels (one 16-byte and one 8-byte map load, 12 output bytes stored as three
+// dwords when the row allows it); a pixel whose 2x2 window lies inside the frame reads it as two aligned 12-byte
+// loads, the others resolve the constant border tap by tap.
+constexpr int kRemapPx = 4;
 __global__ __launch_bounds__(256) void k_remap_fixed(const UndistortCam* __restrict__ ucams, int n_cams, FrameBatch src,
                                                      FrameBatch dst)
 {
     const int set = blockIdx.z / n_cams, cam = blockIdx.z - set * n_cams;
     const UndistortCam u = ucams[cam];
-    if (!u.map1 || !src.f[set].ptr[cam]) return;      // no maps, or a camera that is not part of this call
-    const int x = blockIdx.x * kTileW + threadIdx.x, y = blockIdx.y * kTileH + threadIdx.y;
-    if (x >= u.w || y >= u.h) return;
     const uint8_t* __restrict__ s = src.f[set].ptr[cam];
-    const uint32_t sstride = src.f[set].stride[cam];
-    uint8_t* __restrict__ d = const_cast<uint8_t*>(dst.f[set].ptr[cam]) + static_cast<size_t>(y) * dst.f[set].stride[cam] + x * 3;
-    const uint32_t idx = static_cast<uint32_t>(y) * u.w + x;
-    const uint32_t xy = *reinterpret_cast<const uint32_t MST_GLOBAL*>(gp(u.map1) + 2 * idx);
-    const int sx = static_cast<int>(static_cast<short>(xy & 0xFFFFu)), sy = static_cast<int>(xy) >> 16;
-    const int a = gp(u.map2)[idx] & 1023;
-    const int fx = a & 31, fy = a >> 5;
-    Taps t;
-    t.w00 = (32 - fx) * (32 - fy) * 32; t.w01 = fx * (32 - fy) * 32;
-    t.w10 = (32 - fx) * fy * 32;        t.w11 = fx * fy * 32;
-    t.x0 = static_cast<unsigned>(sx) < static_cast<unsigned>(u.w) ? sx : -1;
-    t.x1 = static_cast<unsigned>(sx + 1) < static_cast<unsigned>(u.w) ? sx + 1 : -1;
-    t.y0 = static_cast<unsigned>(sy) < static_cast<unsigned>(u.h) ? sy : -1;
-    t.y1 = static_cast<unsigned>(sy + 1) < static_cast<unsigned>(u.h) ? sy + 1 : -1;
+    if (!u.map1 || !s) return;                      // no maps, or a camera that is not part of this call
+    const int x0 = (blockIdx.x * kTileW + threadIdx.x) * kRemapPx, y = blockIdx.y * kTileH + threadIdx.y;
+    if (x0 >= u.w || y >= u.h) return;
+    const uint32_t sstride = src.f[set].stride[cam], dstride = dst.f[set].stride[cam];
+    uint8_t* __restrict__ drow = const_cast<uint8_t*>(dst.f[set].ptr[cam]) + static_cast<size_t>(y) * dstride;
+    const uint32_t lo2 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s)) & 3u;
+    const uint8_t* __restrict__ s_al = s - lo2;
+    const uint32_t idx = static_cast<uint32_t>(y) * u.w + x0;
+    const int npx = min(kRemapPx, u.w - x0);
+    uint32_t xy[kRemapPx];
+    uint32_t fr[kRemapPx];
+    const int16_t MST_GLOBAL* m1 = gp(u.map1) + 2 * static_cast<size_t>(idx);
+    const uint16_t MST_GLOBAL* m2 = gp(u.map2) + idx;
+    if (npx == kRemapPx && (idx & 3u) == 0) {         // 16-byte / 8-byte aligned: the maps are tight and w * y + x0 is 0 mod 4
+        const uint4 v = load_global(reinterpret_cast<const uint4*>(u.map1 + 2 * static_cast<size_t>(idx)));
+        const uint2 f = load_global(reinterpret_cast<const uint2*>(u.map2 + idx));
+        xy[0] = v.x; xy[1] = v.y; xy[2] = v.z; xy[3] = v.w;
+        fr[0] = f.x & 0xFFFFu; fr[1] = f.x >> 16; fr[2] = f.y & 0xFFFFu; fr[3] = f.y >> 16;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        d[k] = static_cast<uint8_t>(blend_taps(t, tap_u8(s, sstride, 3, t.x0, t.y0, k), tap_u8(s, sstride, 3, t.x1, t.y0, k),
-                                               tap_u8(s, sstride, 3, t.x0, t.y1, k), tap_u8(s, sstride, 3, t.x1, t.y1, k)));
+        for (int k = 0; k < kRemapPx; ++k) {
+            const int kk = min(k, npx - 1);
+            xy[k] = static_cast<uint32_t>(static_cast<uint16_t>(m1[2 * kk])) | static_cast<uint32_t>(static_cast<uint16_t>(m1[2 * kk + 1])) << 16;
+            fr[k] = m2[kk];
+        }
+    }
+    // issue the window loads of all four pixels before the first use
+    uint32_t a[kRemapPx][3], c[kRemapPx][3], sh0[kRemapPx], sh1[kRemapPx];
+    bool fast[kRemapPx];
+#pragma unroll
+    for (int k = 0; k < kRemapPx; ++k) {
+        const int sx = static_cast<int>(static_cast<short>(xy[k] & 0xFFFFu)), sy = static_cast<int>(xy[k]) >> 16;
+        fast[k] = sx >= 0 && sx < u.w - 1 && sy >= 0 && sy < u.h - 1 && (sx < u.w - 3 || sy < u.h - 2);
+        const uint32_t ox = fast[k] ? static_cast<uint32_t>(sx) : 0u, oy = fast[k] ? static_cast<uint32_t>(sy) : 0u;
+        const uint32_t o0 = __umul24(oy, sstride) + ox * 3u + lo2, o1 = o0 + sstride;
+        sh0[k] = o0 & 3u; sh1[k] = o1 & 3u;
+        const uint32_t* q0 = reinterpret_cast<const uint32_t*>(s_al + (o0 & ~3u));
+        const uint32_t* q1 = reinterpret_cast<const uint32_t*>(s_al + (o1 & ~3u));
+        a[k][0] = q0[0]; a[k][1] = q0[1]; a[k][2] = q0[2];
+        c[k][0] = q1[0]; c[k][1] = q1[1]; c[k][2] = q1[2];
+    }
+    uint32_t px[kRemapPx];
+#pragma unroll
+    for (int k = 0; k < kRemapPx; ++k) {
+        const int fx = fr[k] & 31, fy = (fr[k] >> 5) & 31;
+        int o[3];
+        if (fast[k]) {
+            bilinear_window_c3(a[k][0], a[k][1], a[k][2], c[k][0], c[k][1], c[k][2], sh0[k], sh1[k], fx, fy, o);
+        } else {
+            const int sx = static_cast<int>(static_cast<short>(xy[k] & 0xFFFFu)), sy = static_cast<int>(xy[k]) >> 16;
+            Taps t;
+            t.w00 = (32 - fx) * (32 - fy) * 32; t.w01 = fx * (32 - fy) * 32;
+            t.w10 = (32 - fx) * fy * 32;        t.w11 = fx * fy * 32;
+            t.x0 = static_cast<unsigned>(sx) < static_cast<unsigned>(u.w) ? sx : -1;
+            t.x1 = static_cast<unsigned>(sx + 1) < static_cast<unsigned>(u.w) ? sx + 1 : -1;
+            t.y0 = static_cast<unsigned>(sy) < static_cast<unsigned>(u.h) ? sy : -1;
+            t.y1 = static_cast<unsigned>(sy + 1) < static_cast<unsigned>(u.h) ? sy + 1 : -1;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                o[ch] = blend_taps(t, tap_u8(s, sstride, 3, t.x0, t.y0, ch), tap_u8(s, sstride, 3, t.x1, t.y0, ch),
+                                   tap_u8(s, sstride, 3, t.x0, t.y1, ch), tap_u8(s, sstride, 3, t.x1, t.y1, ch));
+        }
+        px[k] = static_cast<uint32_t>(o[0]) | static_cast<uint32_t>(o[1]) << 8 | static_cast<uint32_t>(o[2]) << 16;
+    }
+    uint8_t* d = drow + x0 * 3;
+    if (npx == kRemapPx && ((reinterpret_cast<uintptr_t>(d)) & 3u) == 0) {
+        uint32_t MST_GLOBAL* d32 = (uint32_t MST_GLOBAL*)d;               // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        d32[0] = px[0] | px[1] << 24;
+        d32[1] = px[1] >> 8 | px[2] << 16;
+        d32[2] = px[2] >> 16 | px[3] << 8;
+    } else {
+        for (int k = 0; k < npx; ++k) {
+            d[3 * k] = static_cast<uint8_t>(px[k]); d[3 * k + 1] = static_cast<uint8_t>(px[k] >> 8);
+            d[3 * k + 2] = static_cast<uint8_t>(px[k] >> 16);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_exposure_apply(const CamDesc* __restrict__ cam, uint8_t* __restrict__ img,
@@ -318,7 +377,7 @@ void launch_remap_fixed(const UndistortCam* d_ucams, int n_cams, int max_w, int 
                         const FrameBatch& dst, int batch, hipStream_t s)
 {
     if (n_cams <= 0 || batch <= 0 || max_w <= 0 || max_h <= 0) return;
-    dim3 grid = grid2d(max_w, max_h);
+    dim3 grid = grid2d((max_w + kRemapPx - 1) / kRemapPx, max_h);
     grid.z = static_cast<unsigned>(n_cams * batch);
     hipLaunchKernelGGL(k_remap_fixed, grid, block2d(), 0, s, d_ucams, n_cams, src, dst);
 }

@@ -152,6 +152,29 @@ __device__ __forceinline__ int blend_taps(const Taps& t, int v00, int v01, int v
     return sat_u8((v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11 + (1 << 14)) >> 15);
 }
 
+// cv::remap's fixed-point bilinear sum for one BGR pixel whose 2x2 window lies inside the image, from the aligned
+// dwords covering the two 6-byte pixel pairs (a0..a2 top row, c0..c2 bottom row; sh0/sh1 = byte offset of the
+// pair inside its dwords).  With wx in {32-fx, fx} and wy in {32-fy, fy},
+//   (sum v * wx * wy * 32 + 2^14) >> 15  ==  (sum_y wy * (sum_x wx * v) + 512) >> 10   in exact integers;
+// after the funnel shift the pair sits at fixed bytes (B0 G0 R0 B1 | G1 R1 . .), so one more constant shift per
+// channel lines every channel up with the same byte-0 / byte-3 weight register for v_dot4_u32_u8.
+__device__ __forceinline__ void bilinear_window_c3(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t c0, uint32_t c1,
+                                                   uint32_t c2, uint32_t sh0, uint32_t sh1, int fx, int fy, int out[3])
+{
+    const uint32_t wx = static_cast<uint32_t>(32 - fx) | static_cast<uint32_t>(fx) << 24;
+    const uint32_t wy0 = static_cast<uint32_t>(32 - fy), wy1 = static_cast<uint32_t>(fy);
+    const uint32_t lo0 = __builtin_amdgcn_alignbyte(a1, a0, sh0), hi0 = __builtin_amdgcn_alignbyte(a2, a1, sh0);
+    const uint32_t lo1 = __builtin_amdgcn_alignbyte(c1, c0, sh1), hi1 = __builtin_amdgcn_alignbyte(c2, c1, sh1);
+    const uint32_t g0 = __builtin_amdgcn_alignbyte(hi0, lo0, 1), r0 = __builtin_amdgcn_alignbyte(hi0, lo0, 2);
+    const uint32_t g1 = __builtin_amdgcn_alignbyte(hi1, lo1, 1), r1 = __builtin_amdgcn_alignbyte(hi1, lo1, 2);
+    const uint32_t hb0 = __builtin_amdgcn_udot4(lo0, wx, 0u, false), hb1 = __builtin_amdgcn_udot4(lo1, wx, 0u, false);
+    const uint32_t hg0 = __builtin_amdgcn_udot4(g0, wx, 0u, false), hg1 = __builtin_amdgcn_udot4(g1, wx, 0u, false);
+    const uint32_t hr0 = __builtin_amdgcn_udot4(r0, wx, 0u, false), hr1 = __builtin_amdgcn_udot4(r1, wx, 0u, false);
+    out[0] = static_cast<int>((__umul24(hb0, wy0) + __umul24(hb1, wy1) + 512u) >> 10);
+    out[1] = static_cast<int>((__umul24(hg0, wy0) + __umul24(hg1, wy1) + 512u) >> 10);
+    out[2] = static_cast<int>((__umul24(hr0, wy0) + __umul24(hr1, wy1) + 512u) >> 10);
+}
+
 // INTER_LINEAR + BORDER_REFLECT on CV_8UC3: the image path of RotationWarper::warp
 __device__ __forceinline__ void sample_linear_reflect_c3(const uint8_t* __restrict__ src, size_t stride,
                                                          int sw, int sh, float mx, float my, int out[3])
