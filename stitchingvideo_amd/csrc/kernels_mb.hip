@@ -954,6 +954,21 @@ struct QuadIter {
 #pragma unroll
         for (int k = 0; k < 4; ++k) valid[k] = (x + (k & 1)) < r.x1 && (y + (k >> 1)) < r.y1;
     }
+    // The same quads in blocks of 8 x 8 (one block = 16 x 16 pixels = one wave): a seam that crosses the tile then
+    // runs through few waves, and a wave whose pixels all belong to one camera skips the other cameras' work as a
+    // whole (the per-camera `continue`s of band_quad are taken by every lane).  Needs qw and the quad rows to be
+    // multiples of 8; row-major otherwise.
+    __device__ __forceinline__ bool blockable() const { return (qw & 7) == 0 && ((nq / qw) & 7) == 0; }
+    __device__ __forceinline__ void at_blocked(int q, int& x, int& y, bool valid[4]) const
+    {
+        const int blk = q >> 6, in = q & 63;
+        const int bpr = qw >> 3;                          // blocks per block row
+        const int by = blk / bpr, bx = blk - __mul24(by, bpr);
+        x = r.x0 + 2 * (8 * bx + (in & 7));
+        y = r.y0 + 2 * (8 * by + (in >> 3));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) valid[k] = (x + (k & 1)) < r.x1 && (y + (k >> 1)) < r.y1;
+    }
 };
 
 // phase 1: normalised band of one coarse level into its LDS region
@@ -1190,10 +1205,12 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
     }
     // two bytes per store when the panorama rows allow it (even base and stride)
     const bool pair_stores = ((reinterpret_cast<uintptr_t>(pano) | a.pano_stride) & 1u) == 0;
+    const bool blocked = !PURE && !(MST_ABLATE_C & 256) && it.blockable();
     for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
         int x, y;
         bool valid[4];
-        it.at(q, x, y, valid);
+        if (blocked) it.at_blocked(q, x, y, valid);
+        else it.at(q, x, y, valid);
         int n[4][3];
         float ws[4];
         if (MST_ABLATE_C & 8) {
