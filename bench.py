@@ -95,7 +95,7 @@ def main():
     # HBM before each call, as MST_FLAG_OVERLAP_FRAMES requires); --no-overlap keeps one stream
     batch = max(1, min(args.batch, 8))
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
-                           overlap_frames=not args.no_overlap and blend == "multiband" and batch == 1,
+                           overlap_frames=not args.no_overlap and blend == "multiband",
                            max_batch=batch)
     if args.undistort:
         # the reference's fisheye intrinsics (DRV:209-216, quoted for 1280x720) scaled to the frame size

@@ -77,9 +77,9 @@ extern "C" {
                                       (feedSizeRemap, DRV:150-177); requires MST_BLEND_NO */
 
 #define MST_FLAG_DEBUG        2u   /* keep a copy of the collapsed canvas levels for mst_debug_read */
-#define MST_FLAG_OVERLAP_FRAMES 4u /* throughput mode for mst_compose_device: the per-camera kernels of frame t+1
-                                      run on an engine-owned stream while the canvas kernel of frame t is still
-                                      running on the caller's stream (two pyramid sets alternate).  Results and
+#define MST_FLAG_OVERLAP_FRAMES 4u /* throughput mode for mst_compose_device(_batch): the per-camera kernels of call t+1
+                                      run on an engine-owned stream while the canvas kernel of call t is still
+                                      running on the caller's stream (two runs of pyramid sets alternate).  Results and
                                       their order on `stream` are unchanged.  Contract: the frames passed to a call
                                       must be complete in device memory when the call is made (they are read without
                                       waiting for work still queued on `stream`), and must stay untouched until

@@ -303,8 +303,10 @@ void Engine::update(const mst_calibration& calib)
     }
 
     // frame sets in flight: one per frame set of a batch, two for frame pipelining
-    st->num_sets = std::max(1, std::min<int>(cfg_.max_batch, kMaxBatch));
-    if ((cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && cfg_.blend_kind == MST_BLEND_MULTI_BAND) st->num_sets = std::max(st->num_sets, 2);
+    // (pipelining alternates between two halves of the sets, each as large as a batch)
+    st->sets_per_slot = std::max(1, std::min<int>(cfg_.max_batch, kMaxBatch));
+    st->num_sets = st->sets_per_slot;
+    if ((cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && cfg_.blend_kind == MST_BLEND_MULTI_BAND) st->num_sets = 2 * st->sets_per_slot;
 
     // optional lens-undistort maps (DRV:232): uploaded once, applied to every frame before the warp
     st->ucams.assign(n, UndistortCam{nullptr, nullptr, 0, 0});
@@ -496,7 +498,7 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
     if (!d_frames || !strides || !d_panos) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama table"};
     if (count < 1 || count > kMaxBatch) throw Error{MST_ERR_INVALID_ARG, "batch size out of range"};
-    if ((st->blend_kind == MST_BLEND_MULTI_BAND || st->any_undistort) && count > 1 && count > st->num_sets)
+    if ((st->blend_kind == MST_BLEND_MULTI_BAND || st->any_undistort) && count > 1 && count > st->sets_per_slot)
         throw Error{MST_ERR_INVALID_ARG, "batch larger than mst_config.max_batch"};
     hipStream_t s = stream ? stream : stream_;
     FrameBatch fb{};
@@ -535,13 +537,14 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
         fb = ub;
     };
     if (st->blend_kind == MST_BLEND_MULTI_BAND) {
-        // Frame pipelining (single frame sets only): the per-camera kernels (A, B) of this frame go to front_stream_
+        // Frame pipelining: the per-camera kernels (A, B) of this call (one frame set or a batch) go to front_stream_
         // and only wait for the canvas kernel that last read this pyramid set (two frames ago); the canvas kernel
         // (C) stays on the caller's stream behind them.  Frame t+1's A/B therefore overlap frame t's C.
-        const bool overlap = count == 1 && (cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && st->num_sets >= 2 &&
+        const bool overlap = (cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && st->num_sets >= 2 * st->sets_per_slot &&
                              timer == nullptr && !in_host_compose_;
         const int slot = overlap ? static_cast<int>(frame_counter_++ & 1u) : 0;
-        const CamDesc* desc = st->d_desc + static_cast<size_t>(slot) * st->n;
+        const int first_set = slot * st->sets_per_slot;           // the slot's run of descriptor / buffer sets
+        const CamDesc* desc = st->d_desc + static_cast<size_t>(first_set) * st->n;
         hipStream_t sf = overlap ? front_stream_ : s;
         if (overlap && canvas_pending_[slot])
             check_hip(hipStreamWaitEvent(sf, ev_canvas_done_[slot], 0), "hipStreamWaitEvent");
@@ -551,7 +554,7 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
                     check_hip(hipStreamWaitEvent(s, ev_canvas_done_[k], 0), "hipStreamWaitEvent");
                     canvas_pending_[k] = false;
                 }
-        undistort(slot, sf);
+        undistort(first_set, sf);
         launch_warp_pyr(desc, st->n, cfg_.warp_kind, st->warp_list, fb, count, st->warp_table, st->warp_table_base, sf);
         mark("k_warp_pyr");
         // where the frame crosses from the front stream to the caller's stream: after the warp kernel (the small

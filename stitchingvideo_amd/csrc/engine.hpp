@@ -57,7 +57,8 @@ struct CalibState {
     std::vector<CameraSetup> cams;
     std::vector<CamDesc> desc;      // host copy of the device array
     CamDesc* d_desc = nullptr;      // num_sets copies back to back: same cameras, own Gaussian pyramids per set
-    int num_sets = 1;               // (frame pipelining uses sets 0/1, a batched launch set f for frame set f)
+    int num_sets = 1;               // a batched launch uses set f for frame set f; frame pipelining alternates
+    int sets_per_slot = 1;          // between two runs of sets_per_slot sets
     std::vector<uint32_t*> pyr_base;   // per camera: the contiguous Gaussian pyramid block (first set)
     std::vector<size_t> pyr_bytes;
     Rect canvas;                    // resultRoi(corners, sizes)
