@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap consecutive frames (latency mode)")
     ap.add_argument("--batch", type=int, default=8,
                     help="frame sets per step (mst_compose_device_batch); 1 = one frame set per launch sequence")
+    ap.add_argument("--shard", default="frames", choices=["frames", "cameras"],
+                    help="N > 1: frames = every rank stitches its own frame sets (default, no collective); "
+                         "cameras = camera i on rank i %% N, pyramids sent to rank 0 over RCCL, rank 0 blends (SURVEY 8e)")
     ap.add_argument("--undistort", action="store_true",
                     help="add the driver's lens-undistort pre-pass (DRV:741) to every camera (not part of the headline)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = sized to ~15 s)")
@@ -93,9 +96,10 @@ def main():
     n_cam = len(rig["cameras"])
     # throughput mode: frame t+1's per-camera kernels overlap frame t's canvas kernel (frames are resident in
     # HBM before each call, as MST_FLAG_OVERLAP_FRAMES requires); --no-overlap keeps one stream
-    batch = max(1, min(args.batch, 8))
+    by_camera = args.shard == "cameras" and blend == "multiband"
+    batch = 1 if by_camera else max(1, min(args.batch, 8))
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
-                           overlap_frames=not args.no_overlap and blend == "multiband",
+                           overlap_frames=not args.no_overlap and blend == "multiband" and not by_camera,
                            max_batch=batch)
     if args.undistort:
         # the reference's fisheye intrinsics (DRV:209-216, quoted for 1280x720) scaled to the frame size
@@ -129,7 +133,17 @@ def main():
         sets = [dev_sets[(first + k) % n_sets] for k in range(batch)]
         return [[t.data_ptr() for t in ds] for ds in sets], [[t.stride(0) for t in ds] for ds in sets]
 
-    if batch == 1:
+    if by_camera:
+        # camera streams sharded over ranks: a step = every rank's per-camera kernels, one exchange of the
+        # Gaussian pyramids to rank 0 (point-to-point over RCCL), the canvas kernel on rank 0
+        stitcher = sharding_mod.ShardedStitcher(eng, rank, world, root=0, device=dev)
+
+        def camera_call(ds):
+            ptrs = {c: ds[c].data_ptr() for c in stitcher.mine}
+            strides = {c: ds[c].stride(0) for c in stitcher.mine}
+            return lambda: stitcher.compose(ptrs, strides, pano.data_ptr(), pano.stride(0), stream=stream)
+        calls = [camera_call(ds) for ds in dev_sets]
+    elif batch == 1:
         calls = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),
                                       pano.stride(0), stream=stream) for ds in dev_sets]
     else:
@@ -160,7 +174,19 @@ def main():
     from stitchingvideo_amd import sharding
     wall, dev_ms = sharding.max_over_ranks([wall, dev_ms], device=dev)     # slowest rank sets the job time
 
-    if rank == 0:
+    if rank == 0 and by_camera:
+        frames_done = args.steps                      # one panorama per step for the whole job
+        print(json.dumps({
+            "metric": "stitched panorama frames/sec, 6x1080p->360deg canvas", "value": round(frames_done / wall, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall * 1000.0 / args.steps, 5), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8/s16 fixed-point (f32 weights)", "data": "synthetic",
+            "config": {"workload": "%s: %dx%dx%d BGR8 streams, %s warp, gain_blocks, %s blend (5 bands), canvas %dx%d"
+                                   % (args.config, n_cam, rig["size"][0], rig["size"][1], rig["warp"], blend, cw, ch),
+                       "frames_resident_in_hbm": True,
+                       "parallelism": "cameras sharded over %d rank(s), pyramids sent to rank 0 (RCCL point-to-point)" % world},
+        }), flush=True)
+    elif rank == 0:
         # per-kernel durations: HIP events between launches on the compose stream, averaged over a few frames
         reps = 10
         acc = {}
