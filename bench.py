@@ -7,7 +7,7 @@ A step is one pass of the per-frame hot path (warp -> exposure gain -> Laplacian
 -> 8-bit panorama) over one batch of --batch (default 8) sets of N_cam synthetic frames that are already
 resident in HBM: every kernel of the path is launched once per step over all frame sets of the batch
 (mst_compose_device_batch) and `value` counts panoramas, i.e. steps x batch.  --batch 1 is one frame set
-per launch sequence (with frame pipelining unless --no-overlap).  The workload at every N is BASELINE
+per launch sequence; --overlap additionally pipelines consecutive calls over two streams.  The workload at every N is BASELINE
 config C3: 6x1920x1080 streams, spherical warp, block gains, 5-band multi-band blend, canvas 7852x1020.
 
 N > 1 shards *frames*: every rank owns the full calibration and stitches its own stream of frame
@@ -40,7 +40,10 @@ def parse_args():
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--frame-sets", type=int, default=3, help="distinct synthetic frame sets cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="do not overlap consecutive frames (latency mode)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="pipeline consecutive calls (MST_FLAG_OVERLAP_FRAMES): +2-3 %% throughput, but kernels of two "
+                         "calls then run concurrently and per-kernel durations (here and in rocprofv3) stop being comparable")
+    ap.add_argument("--no-overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--batch", type=int, default=8,
                     help="frame sets per step (mst_compose_device_batch); 1 = one frame set per launch sequence")
     ap.add_argument("--shard", default="frames", choices=["frames", "cameras"],
@@ -94,12 +97,12 @@ def main():
     rig = rigmod.build_rig(cfg)
     blend = cfg["blend"]
     n_cam = len(rig["cameras"])
-    # throughput mode: frame t+1's per-camera kernels overlap frame t's canvas kernel (frames are resident in
-    # HBM before each call, as MST_FLAG_OVERLAP_FRAMES requires); --no-overlap keeps one stream
+    # --overlap: call t+1's per-camera kernels overlap call t's canvas kernel (frames are resident in HBM before
+    # each call, as MST_FLAG_OVERLAP_FRAMES requires); the default keeps everything on one stream
     by_camera = args.shard == "cameras" and blend == "multiband"
     batch = 1 if by_camera else max(1, min(args.batch, 8))
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
-                           overlap_frames=not args.no_overlap and blend == "multiband" and not by_camera,
+                           overlap_frames=args.overlap and not args.no_overlap and blend == "multiband" and not by_camera,
                            max_batch=batch)
     if args.undistort:
         # the reference's fisheye intrinsics (DRV:209-216, quoted for 1280x720) scaled to the frame size
