@@ -179,6 +179,23 @@ __device__ __forceinline__ void bilinear_window_c3(uint32_t a0, uint32_t a1, uin
 __device__ __forceinline__ void sample_linear_reflect_c3(const uint8_t* __restrict__ src, size_t stride,
                                                          int sw, int sh, float mx, float my, int out[3])
 {
+    // common case: the 2x2 window lies inside the source and its two 12-byte reads stay inside the frame (they
+    // run at most 8 bytes past the pixel pair: the next row, except on the last one) -> two aligned dwordx3 loads
+    // and the separable v_dot4 form (bilinear_window_c3); frames up to 4 GiB with rows below 16 MiB only
+    {
+        const int fsx = cv_round(mx * 32.f), fsy = cv_round(my * 32.f);
+        const int sx = sat_s16(fsx >> 5), sy = sat_s16(fsy >> 5);
+        if (sx >= 0 && sx < sw - 1 && sy >= 0 && sy < sh - 1 && (sx < sw - 3 || sy < sh - 2) && stride < (size_t{1} << 24)) {
+            const uint32_t lo2 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src)) & 3u;
+            const uint8_t* s_al = src - lo2;
+            const uint32_t o0 = __umul24(sy, static_cast<uint32_t>(stride)) + static_cast<uint32_t>(sx) * 3u + lo2;
+            const uint32_t o1 = o0 + static_cast<uint32_t>(stride);
+            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(s_al + (o0 & ~3u));
+            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(s_al + (o1 & ~3u));
+            bilinear_window_c3(q0[0], q0[1], q0[2], q1[0], q1[1], q1[2], o0 & 3u, o1 & 3u, fsx & 31, fsy & 31, out);
+            return;
+        }
+    }
     const Taps t = linear_taps<true>(mx, my, sw, sh);
     const uint8_t* r0 = src + static_cast<size_t>(t.y0) * stride;
     const uint8_t* r1 = src + static_cast<size_t>(t.y1) * stride;
