@@ -509,6 +509,8 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
             if (!p) throw Error{MST_ERR_INVALID_ARG, "null frame pointer"};
             if (stride < static_cast<size_t>(st->cams[i].src_w) * 3) throw Error{MST_ERR_INVALID_ARG, "frame stride too small"};
             if (stride >= (size_t{1} << 24)) throw Error{MST_ERR_INVALID_ARG, "frame stride must be below 16 MiB"};
+            if (stride * static_cast<size_t>(st->cams[i].src_h) > 0xFFFFFFFFull)
+                throw Error{MST_ERR_INVALID_ARG, "frames of 4 GiB and more are not supported (32-bit byte offsets)"};
             fb.f[f].ptr[i] = static_cast<const uint8_t*>(p);
             fb.f[f].stride[i] = static_cast<uint32_t>(stride);
         }
@@ -516,6 +518,8 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
     if (pano_stride >= (size_t{1} << 24) || mask_stride >= (size_t{1} << 24))
         throw Error{MST_ERR_INVALID_ARG, "panorama and mask strides must be below 16 MiB"};
     if (d_masks && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
+    if (pano_stride * static_cast<size_t>(st->out_h) > 0xFFFFFFFFull)
+        throw Error{MST_ERR_INVALID_ARG, "panoramas of 4 GiB and more are not supported (32-bit byte offsets)"};
     for (int f = 0; f < count; ++f)
         if (!d_panos[f]) throw Error{MST_ERR_INVALID_ARG, "null panorama pointer"};
 
