@@ -3,7 +3,8 @@
 // Everything here runs once per mst_update on the host CPU (the north star keeps
 // registration-time work on the host); nothing here touches pixels.  It produces the small
 // tables the HIP kernels consume so that the backward map and the gain field are evaluated
-// in registers, bit-exactly, with no per-pixel map traffic.
+// on the device, bit-exactly, from per-column / per-row constants (the multi-band kernel additionally
+// caches the resulting fixed-point coordinates per calibration, see kernels_mb.hip).
 //
 // Reference behaviour followed (R64 = /root/reference/stitching/OpenCV2.4.11-Stitching-64bit/
 // OpenCV2.4.11-Stitching):

@@ -76,9 +76,6 @@ __device__ __forceinline__ int xcd_run_index(int b, int n)
 #ifndef MST_A_TH0
 #define MST_A_TH0 32
 #endif
-#ifndef MST_A_PATCH
-#define MST_A_PATCH 0      // 1: border pixels in a separate patch pass; 0: inline (measured faster on MI355X)
-#endif
 #ifndef MST_ABLATE_A
 #define MST_ABLATE_A 0     // timing experiments only: 1 no gather, 2 no gain, 4 no pyrDown, 8 no map, 16 no blend math
 #endif
@@ -86,7 +83,7 @@ constexpr int A_TW0 = 124, A_TH0 = MST_A_TH0;  // level-0 interior of a tile
 constexpr int A_LW = A_TW0 + 4, A_LH = A_TH0 + 4;   // with the 2-pixel pyrDown halo: 128 x 36
 constexpr int A_TW1 = A_TW0 / 2, A_TH1 = A_TH0 / 2; // level-1 outputs: 62 x 16
 constexpr int A_ROWS_PER_THREAD = A_LH / 2;    // 256 threads = 128 columns x 2 row halves
-constexpr int A_GAIN_ROWS = 4;                 // gain-map rows a tile may span and still stay in registers
+constexpr int A_GAIN_ROWS = 4;                 // gain-map rows a tile may span and still be served from LDS
 
 // saturate_cast<uchar>(uchar * float): cvRound + clamp.  For gain < 8e6 the product is far inside
 // int range and clamping in float first is the same function (NaN -> 0 both ways).
@@ -370,7 +367,7 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     k.src = frames.ptr[cam]; k.stride = frames.stride[cam];
     k.src_lo2 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(k.src)) & 3u;
     k.src_al = k.src - k.src_lo2;
-    // this tile's slice of the per-calibration map table: [row][col], one coalesced 8-byte load per pixel
+    // this tile's slice of the per-calibration map table: [row][col], one coalesced 4-byte load per pixel
     const uint32_t* __restrict__ tab = table + static_cast<size_t>(list.first + li) * (A_LH * A_LW);
     int tbx = 0, tby = 0;
     if (USE_TABLE) {
@@ -392,7 +389,7 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     __syncthreads();
 
     // BlocksGainCompensator's resize(gain_map): this column's horizontal interpolation of the few gain-map
-    // rows the tile touches, kept in registers (same float products and sums as the per-pixel form)
+    // rows the tile touches, kept in LDS (same float products and sums as the per-pixel form)
     int gmin = INT_MAX, gmax = INT_MIN;
     {
         const int lane = tid & 63;
