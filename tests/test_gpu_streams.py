@@ -178,3 +178,51 @@ def test_batched_launch_matches_oracle(blend, count):
         with pytest.raises(Exception):
             eng.compose_device_batch([ptrs[0]] * 5, [strides[0]] * 5, [panos[0].data_ptr()] * 5, panos[0].stride(0))
     eng.close()
+
+
+def test_recalibration_from_a_second_thread_while_composing():
+    """The reference recalibrates every 30 s on a worker thread while the frame loop keeps running (DRV:842-847):
+    mst_update from another thread must not disturb composes in flight, and takes effect at a later compose."""
+    import threading
+    import torch
+    rig = rigmod.build_rig(rigmod.scaled_config("C3", 8))
+    cams_b = [dict(c) for c in rig["cameras"]]
+    for c in cams_b:
+        c["gain_map"] = (c["gain_map"] * np.float32(0.8)).astype(np.float32)
+    rig_b = dict(rig, cameras=cams_b)
+    eng = H.make_engine(rig, max_batch=2, overlap_frames=True)
+    _, _, cw, ch = eng.canvas()
+    dev = torch.device("cuda", 0)
+    host = rigmod.frames_for(rig, 7)
+    dfr = [torch.from_numpy(f).to(dev) for f in host]
+    ptrs, strides = [t.data_ptr() for t in dfr], [t.stride(0) for t in dfr]
+    pano = torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev)
+    _, pano_a, _ = H.oracle_compose(rig, host)
+    _, pano_b, _ = H.oracle_compose(rig_b, host)
+    torch.cuda.synchronize()
+    errors = []
+
+    def recalibrate():
+        try:
+            for i in range(6):
+                eng.update(rig["scale"], cams_b if i % 2 == 0 else rig["cameras"])
+            eng.update(rig["scale"], cams_b)
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+
+    t = threading.Thread(target=recalibrate)
+    t.start()
+    seen = set()
+    for i in range(300):
+        eng.compose_device(ptrs, strides, pano.data_ptr(), pano.stride(0))
+        if i % 25 == 0:
+            eng.synchronize()
+            got = pano.cpu().numpy()
+            assert np.array_equal(got, pano_a) or np.array_equal(got, pano_b), "compose %d saw a torn calibration" % i
+            seen.add(bool(np.array_equal(got, pano_b)))
+    t.join()
+    assert not errors, errors
+    eng.compose_device(ptrs, strides, pano.data_ptr(), pano.stride(0))
+    eng.synchronize()
+    assert np.array_equal(pano.cpu().numpy(), pano_b)          # the last update won
+    eng.close()
