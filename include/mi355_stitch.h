@@ -85,6 +85,11 @@ extern "C" {
                                       waiting for work still queued on `stream`), and must stay untouched until
                                       the panorama of that call is complete.  Multi-band only; not with MST_FLAG_DEBUG. */
 
+/* MultiBandBlender weight pyramid type (blenders.cpp:189-194): CV_32F (default) or CV_16S (weights 0, 2..256,
+ * integer pyrDown, `dst += short((src * w) >> 8)`, normalise `(v << 8) / (w + 1)`; blenders.cpp:289-292,331-355,406-423) */
+#define MST_WEIGHT_32F 0
+#define MST_WEIGHT_16S 1
+
 #define MST_MAX_CAMERAS 16
 #define MST_MAX_BATCH 8
 #define MST_MAX_BANDS   10
@@ -104,6 +109,7 @@ typedef struct mst_config {
     float    upblack, downblack, leftblack, rightblack;   /* DRV:47 crop margins (LUT path) */
     int32_t  max_batch;          /* frame sets per mst_compose_device_batch call, 0/1 = none, <= MST_MAX_BATCH;
                                   * multi-band keeps one set of Gaussian pyramids per frame set of a batch */
+    int32_t  weight_type;        /* MST_WEIGHT_*: MultiBandBlender's weight_type (blenders.hpp:101), default CV_32F */
 } mst_config;
 
 typedef struct mst_camera {

@@ -41,7 +41,7 @@ class Config(C.Structure):
                 ("blend_kind", C.c_int32), ("num_bands", C.c_int32), ("feather_sharpness", C.c_float),
                 ("expos_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("upblack", C.c_float), ("downblack", C.c_float), ("leftblack", C.c_float),
-                ("rightblack", C.c_float), ("max_batch", C.c_int32)]
+                ("rightblack", C.c_float), ("max_batch", C.c_int32), ("weight_type", C.c_int32)]
 
 
 class Camera(C.Structure):

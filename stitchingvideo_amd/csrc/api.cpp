@@ -86,6 +86,7 @@ int mst_create(const mst_config* cfg, mst_engine** out)
         require(!(cfg->flags & MST_FLAG_OVERLAP_FRAMES) || !(cfg->flags & MST_FLAG_DEBUG),
                 "MST_FLAG_OVERLAP_FRAMES cannot be combined with MST_FLAG_DEBUG");
         require(cfg->max_batch >= 0 && cfg->max_batch <= MST_MAX_BATCH, "max_batch out of range");
+        require(cfg->weight_type == MST_WEIGHT_32F || cfg->weight_type == MST_WEIGHT_16S, "weight_type must be CV_32F or CV_16S");
         static_assert(MST_MAX_BATCH == mst::kMaxBatch, "public and device batch limits differ");
         created = new mst_engine(*cfg);
         created->impl.init();

@@ -110,6 +110,7 @@ struct BlendArgs {
     int32_t lds_off[kMaxLevels];              // LDS offset (in pixels) of each level's region buffer
     int16_t* dbg_C[kMaxLevels];               // optional dump of the collapsed levels (MST_FLAG_DEBUG)
     float alpha;                              // (float)(1./255.)
+    int32_t weights_16s;                      // MultiBandBlender weight_type CV_16S: integer weights, >> 8 accumulate
 };
 
 // Work lists (static per calibration): only tiles whose output can reach the panorama are launched.

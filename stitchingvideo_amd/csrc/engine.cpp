@@ -409,8 +409,9 @@ void Engine::update(const mst_calibration& calib)
         for (int i = 0; i < n; ++i) {
             const CamDesc& d = st->desc[i];
             launch_border_mask(st->d_desc, i, mask_b[i], d.lw[0], d.lh[0], s);
-            launch_weight_level0(st->d_desc, i, wpyr[i][0], d.lw[0], d.lh[0], s);
-            for (int l = 0; l < nb; ++l) launch_pyrdown_f32(wpyr[i][l], d.lw[l], d.lh[l], wpyr[i][l + 1], s);
+            const bool w16 = cfg_.weight_type == MST_WEIGHT_16S;
+            launch_weight_level0(st->d_desc, i, wpyr[i][0], d.lw[0], d.lh[0], w16, s);
+            for (int l = 0; l < nb; ++l) launch_pyrdown_f32(wpyr[i][l], d.lw[l], d.lh[l], wpyr[i][l + 1], w16, s);
         }
         for (int l = 0; l <= nb; ++l) launch_band_weight_sum(st->d_desc, n, l, ws[l], cv.cw[l], cv.ch[l], s);
         check_hip(hipGetLastError(), "weight pyramid kernels");
@@ -431,6 +432,7 @@ void Engine::update(const mst_calibration& calib)
         for (int l = 0; l <= nb; ++l) { ba.cw[l] = cv.cw[l]; ba.ch[l] = cv.ch[l]; ba.dbg_C[l] = cv.C[l]; }
         ba.final_w = cv.final_w; ba.final_h = cv.final_h;
         ba.alpha = static_cast<float>(1. / 255.);
+        ba.weights_16s = cfg_.weight_type == MST_WEIGHT_16S ? 1 : 0;
         build_mb_plan(st->desc, wh, ba, st->plan);
         const MbPlanHost& plan = st->plan;
         ba.tiles_x = plan.blend_tiles_x;

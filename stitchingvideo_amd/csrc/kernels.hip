@@ -183,6 +183,8 @@ __global__ __launch_bounds__(256) void k_exposure_apply(const CamDesc* __restric
 // ------------------------------------------------------------------------------------------
 
 // mask.convertTo(CV_32F, 1./255.) + copyMakeBorder(BORDER_CONSTANT)   blenders.cpp:287,295
+// weight_type CV_16S (alpha == 0): mask.convertTo(CV_16S); add(weight, 1, weight, mask != 0)   blenders.cpp:289-292;
+// those weights (0, 2..256) and every level pyrDown'ed from them are small integers, kept exactly in the float arrays
 __global__ __launch_bounds__(256) void k_weight_level0(const CamDesc* __restrict__ cams, int cam,
                                                        float* __restrict__ w0, int bw, int bh, float alpha)
 {
@@ -193,7 +195,10 @@ __global__ __launch_bounds__(256) void k_weight_level0(const CamDesc* __restrict
     float w = 0.f;
     if (static_cast<unsigned>(rx) < static_cast<unsigned>(c.roi_w) &&
         static_cast<unsigned>(ry) < static_cast<unsigned>(c.roi_h))
-        w = static_cast<float>(gp(c.mask)[static_cast<size_t>(ry) * c.roi_w + rx]) * alpha + 0.f;
+    {
+        const int m = gp(c.mask)[static_cast<size_t>(ry) * c.roi_w + rx];
+        w = alpha != 0.f ? static_cast<float>(m) * alpha + 0.f : static_cast<float>(m + (m != 0));
+    }
     w0[static_cast<size_t>(y) * bw + x] = w;
 }
 
@@ -238,6 +243,27 @@ __global__ __launch_bounds__(256) void k_pyrdown_f32(const float* __restrict__ s
         out = (row[2] * 6 + (row[1] + row[3]) * 4 + row[0] + row[4]) * (1.f / 256);
     }
     dst[static_cast<size_t>(y) * dw + x] = out;
+}
+
+// cv::pyrDown on a CV_16SC1 weight level (weight_type CV_16S, blenders.cpp:298): integer [1 4 6 4 1]^2,
+// (v + 128) >> 8, BORDER_REFLECT_101; values travel as exact small integers in float arrays
+__global__ __launch_bounds__(256) void k_pyrdown_s16(const float* __restrict__ src, int w, int h,
+                                                     float* __restrict__ dst, int dw, int dh)
+{
+    const int x = blockIdx.x * kTileW + threadIdx.x, y = blockIdx.y * kTileH + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    int xi[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) xi[k] = reflect<1>(2 * x + k - 2, w);
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float* s = src + static_cast<size_t>(reflect<1>(2 * y + k - 2, h)) * w;
+        const int r = static_cast<int>(s[xi[2]]) * 6 + (static_cast<int>(s[xi[1]]) + static_cast<int>(s[xi[3]])) * 4 +
+                      static_cast<int>(s[xi[0]]) + static_cast<int>(s[xi[4]]);
+        acc += r * ((k == 2) ? 6 : ((k == 1 || k == 3) ? 4 : 1));
+    }
+    dst[static_cast<size_t>(y) * dw + x] = static_cast<float>((acc + 128) >> 8);
 }
 
 // dst_band_weights_[level]: `dst_weight_row[x] += weight_row[x_]` in feed order   blenders.cpp:324
@@ -387,9 +413,9 @@ void launch_exposure_apply(const CamDesc* d_cam, uint8_t* d_img, size_t stride, 
     hipLaunchKernelGGL(k_exposure_apply, grid2d(w, h), block2d(), 0, s, d_cam, d_img, stride, w, h);
 }
 
-void launch_weight_level0(const CamDesc* d_cams, int cam, float* d_w0, int bw, int bh, hipStream_t s)
+void launch_weight_level0(const CamDesc* d_cams, int cam, float* d_w0, int bw, int bh, bool weights_16s, hipStream_t s)
 {
-    const float alpha = static_cast<float>(1. / 255.);
+    const float alpha = weights_16s ? 0.f : static_cast<float>(1. / 255.);
     hipLaunchKernelGGL(k_weight_level0, grid2d(bw, bh), block2d(), 0, s, d_cams, cam, d_w0, bw, bh, alpha);
 }
 
@@ -398,10 +424,11 @@ void launch_border_mask(const CamDesc* d_cams, int cam, uint8_t* d_out, int bw, 
     hipLaunchKernelGGL(k_border_mask, grid2d(bw, bh), block2d(), 0, s, d_cams, cam, d_out, bw, bh);
 }
 
-void launch_pyrdown_f32(const float* d_src, int w, int h, float* d_dst, hipStream_t s)
+void launch_pyrdown_f32(const float* d_src, int w, int h, float* d_dst, bool weights_16s, hipStream_t s)
 {
     const int dw = (w + 1) / 2, dh = (h + 1) / 2;
-    hipLaunchKernelGGL(k_pyrdown_f32, grid2d(dw, dh), block2d(), 0, s, d_src, w, h, d_dst, dw, dh);
+    if (weights_16s) hipLaunchKernelGGL(k_pyrdown_s16, grid2d(dw, dh), block2d(), 0, s, d_src, w, h, d_dst, dw, dh);
+    else hipLaunchKernelGGL(k_pyrdown_f32, grid2d(dw, dh), block2d(), 0, s, d_src, w, h, d_dst, dw, dh);
 }
 
 void launch_band_weight_sum(const CamDesc* d_cams, int n_cams, int level, float* d_ws, int cw, int ch, hipStream_t s)

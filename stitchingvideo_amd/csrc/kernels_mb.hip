@@ -775,7 +775,11 @@ __device__ __forceinline__ void pyrup_quad_lds(const uint2* __restrict__ s, int 
 // there (checked once per calibration, mb_plan.cpp).  Then  short(lap * 1.0f) == lap,  the weight sum is
 // 1.0f, and  short(lap / (1.0f + 1e-5f)) == lap - sign(lap)  for every |lap| <= 255 (lap/1.00001f lies
 // strictly between |lap|-1 and |lap|): the band needs no weight loads, no float conversion and no divide.
-template <bool TOP, bool FINAL, bool PURE>
+// W16: MultiBandBlender weight_type CV_16S (blenders.cpp:289-292,331-355,406-423): weights are the integers
+// mask + (mask != 0) and their integer pyrDown (carried exactly in the float arrays), a camera adds
+// short((lap * w) >> 8), and a band is normalised as short((v << 8) / (w + 1)) with C integer division.  The pure
+// path is the same for both types: w == 256 gives (lap * 256) >> 8 == lap and (lap << 8) / 257 == lap - sign(lap).
+template <bool TOP, bool FINAL, bool PURE, bool W16 = false>
 __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, const BlendArgs& a, int l, int x, int y,
                                           const bool valid[4], uint32_t cam_bits, int out[4][3], float ws[4])
 {
@@ -845,7 +849,12 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
                 w[q] = 0.f;
                 g[q] = 0u;
                 if (in) {
-                    w[q] = FINAL ? static_cast<float>(gp(c.mask_b)[off]) * a.alpha + 0.f : gp(c.W[l])[off];
+                    if (FINAL) {
+                        const int m = gp(c.mask_b)[off];
+                        w[q] = W16 ? static_cast<float>(m + (m != 0)) : static_cast<float>(m) * a.alpha + 0.f;
+                    } else {
+                        w[q] = gp(c.W[l])[off];
+                    }
                     g[q] = gp(c.G[l])[off];
                     any = true;
                 }
@@ -864,10 +873,11 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
                 // level-0 weight = mask.convertTo(32F, 1/255) with BORDER_CONSTANT 0 around the roi (mask_b)
                 const uint32_t m01 = static_cast<uint32_t>(*(const uint16_t MST_GLOBAL*)(gp(c.mask_b) + off)) |
                                      static_cast<uint32_t>(*(const uint16_t MST_GLOBAL*)(gp(c.mask_b) + off + lw)) << 16;
-                w[0] = static_cast<float>(m01 & 0xFF) * a.alpha + 0.f;
-                w[1] = static_cast<float>((m01 >> 8) & 0xFF) * a.alpha + 0.f;
-                w[2] = static_cast<float>((m01 >> 16) & 0xFF) * a.alpha + 0.f;
-                w[3] = static_cast<float>(m01 >> 24) * a.alpha + 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = static_cast<int>((m01 >> (8 * q)) & 0xFFu);
+                    w[q] = W16 ? static_cast<float>(m + (m != 0)) : static_cast<float>(m) * a.alpha + 0.f;
+                }
             } else {
                 const float2 w0 = load_global(reinterpret_cast<const float2*>(c.W[l] + off));
                 const float2 w1 = load_global(reinterpret_cast<const float2*>(c.W[l] + off + lw));
@@ -906,9 +916,16 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
             const int lb = static_cast<int>(g[q] & 0xFF) - static_cast<int>(ubr[q] & 0xFFFF);
             const int lg = static_cast<int>((g[q] >> 8) & 0xFF) - static_cast<int>(ug[q]);
             const int lr = static_cast<int>((g[q] >> 16) & 0xFF) - static_cast<int>(ubr[q] >> 16);
-            acc[q][0] = wrap_s16(acc[q][0] + static_cast<int>(static_cast<float>(lb) * w[q]));
-            acc[q][1] = wrap_s16(acc[q][1] + static_cast<int>(static_cast<float>(lg) * w[q]));
-            acc[q][2] = wrap_s16(acc[q][2] + static_cast<int>(static_cast<float>(lr) * w[q]));
+            if (W16) {       // dst += short((src * w) >> 8): int product, arithmetic shift, wrap to short, wrapping add
+                const int wi = static_cast<int>(w[q]);
+                acc[q][0] = wrap_s16(acc[q][0] + wrap_s16((lb * wi) >> 8));
+                acc[q][1] = wrap_s16(acc[q][1] + wrap_s16((lg * wi) >> 8));
+                acc[q][2] = wrap_s16(acc[q][2] + wrap_s16((lr * wi) >> 8));
+            } else {
+                acc[q][0] = wrap_s16(acc[q][0] + static_cast<int>(static_cast<float>(lb) * w[q]));
+                acc[q][1] = wrap_s16(acc[q][1] + static_cast<int>(static_cast<float>(lg) * w[q]));
+                acc[q][2] = wrap_s16(acc[q][2] + static_cast<int>(static_cast<float>(lr) * w[q]));
+            }
         }
     }
 
@@ -919,17 +936,25 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
     // where they sum to 0 the accumulator is 0 and so is the quotient.  Only the remaining pixels divide.
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const bool unit = ws[q] == 1.0f || ws[q] == 0.f;
+        // (CV_16S weights: the floor of (lap * w) >> 8 can push a sum of several cameras past the +-257 where
+        // (v << 8) / 257 == v - sign(v) stops holding, so only the all-zero case is short-cut there)
+        const bool unit = (!W16 && ws[q] == 1.0f) || ws[q] == 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             const int v = acc[q][ch];
             out[q][ch] = v - (v > 0) + (v < 0);
         }
         if (!unit) {
-            const float d = ws[q] + kWeightEps;
+            if (W16) {       // (row[x] << 8) / (weight + 1): ints, division truncates toward zero; the sum of weights is a short
+                const int d = wrap_s16(static_cast<int>(ws[q])) + 1;
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch)
-                out[q][ch] = wrap_s16(static_cast<int>(static_cast<float>(acc[q][ch]) / d));
+                for (int ch = 0; ch < 3; ++ch) out[q][ch] = d != 0 ? wrap_s16((acc[q][ch] * 256) / d) : 0;
+            } else {
+                const float d = ws[q] + kWeightEps;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    out[q][ch] = wrap_s16(static_cast<int>(static_cast<float>(acc[q][ch]) / d));
+            }
         }
     }
 }
@@ -972,7 +997,7 @@ struct QuadIter {
 };
 
 // phase 1: normalised band of one coarse level into its LDS region
-template <bool TOP, bool PURE>
+template <bool TOP, bool PURE, bool W16 = false>
 __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int l, int tx, int ty,
                                            uint32_t cam_bits, uint2* __restrict__ lds)
 {
@@ -987,7 +1012,7 @@ __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, con
         if (MST_ABLATE_C & 1) {
             for (int k = 0; k < 4; ++k) n[k][0] = n[k][1] = n[k][2] = x + y + k;
         } else {
-            band_quad<TOP, false, PURE>(cams, a, l, x, y, valid, cam_bits, n, ws);
+            band_quad<TOP, false, PURE, W16>(cams, a, l, x, y, valid, cam_bits, n, ws);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1001,7 +1026,7 @@ __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, con
 // course, five times in a row.  Here the quads of every level form one index space cut into 64-quad chunks
 // (coarsest level first); the waves of the block take chunks round-robin, so the levels are in flight together.
 // The level of a chunk is wave-uniform, which keeps every descriptor access scalar.
-template <bool PURE>
+template <bool PURE, bool W16 = false>
 __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, const BlendArgs& a, int top, int tx, int ty,
                                             uint32_t cam_bits, uint2* __restrict__ lds)
 {
@@ -1034,9 +1059,9 @@ __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, co
         if (MST_ABLATE_C & 1) {
             for (int k = 0; k < 4; ++k) n[k][0] = n[k][1] = n[k][2] = x + y + k;
         } else if (l == top) {
-            band_quad<true, false, PURE>(cams, a, l, x, y, valid, cam_bits, n, ws);
+            band_quad<true, false, PURE, W16>(cams, a, l, x, y, valid, cam_bits, n, ws);
         } else {
-            band_quad<false, false, PURE>(cams, a, l, x, y, valid, cam_bits, n, ws);
+            band_quad<false, false, PURE, W16>(cams, a, l, x, y, valid, cam_bits, n, ws);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1191,7 +1216,7 @@ __device__ __forceinline__ void final_level_pure_full(const CamDesc* __restrict_
 }
 
 // phase 3: level 0 band + pyrUp of collapsed level 1 -> crop, mask, convertTo(8U), panorama
-template <bool TOP, bool PURE>
+template <bool TOP, bool PURE, bool W16 = false>
 __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int tx, int ty,
                                             uint32_t cam_bits, const uint2* __restrict__ lds, uint8_t* __restrict__ pano,
                                             uint8_t* __restrict__ pano_mask)
@@ -1216,7 +1241,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
         if (MST_ABLATE_C & 8) {
             for (int k = 0; k < 4; ++k) { n[k][0] = n[k][1] = n[k][2] = x + y + k; ws[k] = 1.f; }
         } else {
-            band_quad<TOP, true, PURE>(cams, a, 0, x, y, valid, cam_bits, n, ws);
+            band_quad<TOP, true, PURE, W16>(cams, a, 0, x, y, valid, cam_bits, n, ws);
         }
         int up[4][3];
         if (MST_ABLATE_C & 4) {
@@ -1237,6 +1262,9 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
     }
 }
 
+// W16 (weight_type CV_16S) is a separate instantiation: its integer divides would otherwise set the register
+// allocation (and spill) for the default kernel as well.
+template <bool W16>
 __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__ cams_all, BlendArgs a)
 {
     const CamDesc* __restrict__ cams = cams_all + blockIdx.y * a.n_cams;
@@ -1252,7 +1280,7 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
     const int top = a.nlev - 1;
     if (top == 0) {
         if (pure) final_level<true, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
-        else final_level<true, false>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
+        else final_level<true, false, W16>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
         return;
     }
     // phase 1: every coarse band, independent of each other -> no barrier until all are in LDS
@@ -1267,7 +1295,7 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
     } else if (pure) {
         band_levels<true>(cams, a, top, tx, ty, cam_bits, lds);
     } else {
-        band_levels<false>(cams, a, top, tx, ty, cam_bits, lds);
+        band_levels<false, W16>(cams, a, top, tx, ty, cam_bits, lds);
     }
     __syncthreads();
     // phase 2: collapse coarse to fine (LDS only)
@@ -1290,7 +1318,7 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
     const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
     if (pure && full && !(MST_ABLATE_C & 64)) final_level_pure_full(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
     else if (pure) final_level<false, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
-    else final_level<false, false>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
+    else final_level<false, false, W16>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
 }
 
 }  // namespace
@@ -1355,7 +1383,8 @@ void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, i
 void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int batch, size_t lds_bytes, hipStream_t s)
 {
     static const size_t pad = tuning_env("MST_C_PAD_LDS");
-    hipLaunchKernelGGL(k_blend, dim3(num_blocks, batch), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
+    if (a.weights_16s) hipLaunchKernelGGL(k_blend<true>, dim3(num_blocks, batch), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
+    else hipLaunchKernelGGL(k_blend<false>, dim3(num_blocks, batch), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
 }
 
 }  // namespace mst

@@ -74,6 +74,7 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                    const BlendArgs& blend, MbPlanHost& plan)
 {
     const int n = static_cast<int>(desc.size());
+    const float unit = blend.weights_16s ? 256.f : 1.f;       // the weight of a fully owned pixel (mask 255)
     const int nlev = blend.nlev, nb = nlev - 1;
     int a_tw0, a_th0, b_t, c_tw, c_th;
     mb_tile_dims(&a_tw0, &a_th0, &b_t, &c_tw, &c_th);
@@ -193,7 +194,7 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                     const std::vector<float>& w = weights[c][l];
                     for (int y = y0; y < y1 && pure; ++y)
                         for (int x = x0; x < x1; ++x)
-                            if (w[static_cast<size_t>(y) * d.lw[l] + x] != 1.0f) { pure = false; break; }
+                            if (w[static_cast<size_t>(y) * d.lw[l] + x] != unit) { pure = false; break; }
                 }
                 if (pure) bits |= 0x80000000u;
             }

@@ -182,7 +182,7 @@ class PanoramaEngine:
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
                  feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False,
-                 overlap_frames=False, max_batch=0):
+                 overlap_frames=False, max_batch=0, weight_type="32f"):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -198,6 +198,7 @@ class PanoramaEngine:
             (capi.FLAG_OVERLAP_FRAMES if overlap_frames else 0)
         cfg.upblack, cfg.downblack, cfg.leftblack, cfg.rightblack = crop
         cfg.max_batch = max_batch
+        cfg.weight_type = {"32f": 0, "16s": 1}[weight_type] if isinstance(weight_type, str) else int(weight_type)
         self.num_cameras = num_cameras
         self.device = device
         capi.check(self._L.mst_create(C.byref(cfg), C.byref(self._h)))

@@ -255,3 +255,24 @@ def test_full_size_c3_against_oracle():
     rect, opano, omask = H.oracle_compose(rig, frames, threads=8)
     assert np.array_equal(mask, omask)
     assert np.array_equal(pano, opano), H.diff_report(pano, opano)
+
+
+@pytest.mark.parametrize("name,div,bands,soft", [("C3", 8, 5, False), ("C3", 6, 3, True), ("C2", 4, 4, True), ("C4", 8, 6, False)])
+def test_compose_multiband_16s_weights_bit_exact(name, div, bands, soft):
+    """MultiBandBlender(weight_type = CV_16S): integer weights, `>> 8` accumulate, `(v << 8) / (w + 1)` normalise."""
+    rig = _rig(name, div)
+    if soft:                                # fractional weights everywhere: exercises the integer divide
+        rng = np.random.default_rng(11)
+        for c in rig["cameras"]:
+            m = c["mask"]
+            vals = rng.integers(0, 256, size=((m.shape[0] + 7) // 8, (m.shape[1] + 7) // 8)).astype(np.uint8)
+            c["mask"] = np.where(m != 0, np.kron(vals, np.ones((8, 8), np.uint8))[:m.shape[0], :m.shape[1]], 0).astype(np.uint8)
+    frames = rigmod.frames_for(rig, 4)
+    eng = H.make_engine(rig, blend="multiband", num_bands=bands, weight_type="16s")
+    pano, mask = eng.compose(frames)
+    rect, opano, omask = H.oracle_compose(rig, frames, blend="multiband", num_bands=bands, weight_type="16s")
+    assert eng.canvas() == rect
+    assert np.array_equal(mask, omask), H.diff_report(mask, omask)
+    assert np.array_equal(pano, opano), H.diff_report(pano, opano)
+    p32, _ = H.make_engine(rig, blend="multiband", num_bands=bands).compose(frames)
+    assert not np.array_equal(p32, pano)        # the two weight types really are different arithmetic

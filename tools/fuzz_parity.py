@@ -55,7 +55,9 @@ def one_case(rng, idx):
                                                            float(rng.uniform(-0.01, 0.01)), float(rng.uniform(-0.01, 0.01))], (w, h))
                 rig["cameras"][i]["undistort"] = maps[i]
     count = int(rng.integers(1, 4))
-    eng = H.make_engine(rig, blend=blend, num_bands=bands, max_batch=count, overlap_frames=bool(rng.integers(0, 2)) and blend == "multiband")
+    wt = "16s" if (blend == "multiband" and rng.integers(0, 3) == 0) else "32f"
+    eng = H.make_engine(rig, blend=blend, num_bands=bands, max_batch=count, weight_type=wt,
+                        overlap_frames=bool(rng.integers(0, 2)) and blend == "multiband")
     _, _, cw, ch = eng.canvas()
     dev = torch.device("cuda", 0)
     host = [rigmod.frames_for(rig, int(rng.integers(0, 1000))) for _ in range(count)]
@@ -71,11 +73,11 @@ def one_case(rng, idx):
     ok = True
     for f in range(count):
         und = [fr if m is None else O.remap_fixed(fr, m[0], m[1]) for fr, m in zip(host[f], maps)]
-        rect, opano, omask = H.oracle_compose(rig, und, blend=blend, num_bands=bands)
+        rect, opano, omask = H.oracle_compose(rig, und, blend=blend, num_bands=bands, weight_type=wt)
         ok &= eng.canvas() == rect and np.array_equal(panos[f].cpu().numpy(), opano) and np.array_equal(masks[f].cpu().numpy(), omask)
     eng.close()
-    desc = "%s n=%d %dx%d f=%.0f s=%.0f %s %s b=%d seams=%d batch=%d lens=%d canvas=%dx%d" % (
-        warp, n, w, h, focal, scale, expos, blend, bands, seams, count, sum(m is not None for m in maps), cw, ch)
+    desc = "%s n=%d %dx%d f=%.0f s=%.0f %s %s/%s b=%d seams=%d batch=%d lens=%d canvas=%dx%d" % (
+        warp, n, w, h, focal, scale, expos, blend, wt, bands, seams, count, sum(m is not None for m in maps), cw, ch)
     return ("ok   " if ok else "FAIL ") + desc
 
 
