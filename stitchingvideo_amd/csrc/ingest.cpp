@@ -1,0 +1,225 @@
+// ingest.cpp -- include/mi355_ingest.h: the reference's shared-memory frame hand-off (Stitching_sharemem,
+// R64/stitching_sharemem.{h,cpp}) over POSIX shared memory and process-shared semaphores.
+#include "../../include/mi355_ingest.h"
+
+#include <fcntl.h>
+#include <semaphore.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/mi355_stitch.h"
+
+namespace {
+
+constexpr uint32_t kMagic = 0x4D535446u;        // "MSTF"
+
+// Control block at the start of the segment; the reference's layout (packet, then pixels at buferPointer + 1)
+// starts at data_offset.
+struct Control {
+    uint32_t magic;
+    uint32_t data_offset;
+    uint64_t segment_bytes;
+    uint64_t max_frame_bytes;
+    sem_t client_ready;           // hClientReadOver: "the client wants a frame"
+    sem_t server_wrote;           // hServerWriteOver: "header and pixels are in place"
+};
+
+constexpr size_t kDataOffset = (sizeof(Control) + 63) & ~size_t{63};
+
+int wait_sem(sem_t* s, int timeout_ms)
+{
+    if (timeout_ms < 0) {
+        while (sem_wait(s) != 0)
+            if (errno != EINTR) return MST_ERR_INVALID_ARG;
+        return MST_OK;
+    }
+    timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    ts.tv_sec += timeout_ms / 1000;
+    ts.tv_nsec += static_cast<long>(timeout_ms % 1000) * 1000000L;
+    if (ts.tv_nsec >= 1000000000L) { ts.tv_sec += 1; ts.tv_nsec -= 1000000000L; }
+    while (sem_timedwait(s, &ts) != 0) {
+        if (errno == EINTR) continue;
+        return errno == ETIMEDOUT ? MST_ERR_TIMEOUT : MST_ERR_INVALID_ARG;
+    }
+    return MST_OK;
+}
+
+}  // namespace
+
+struct mst_shm {
+    std::string name;
+    bool server = false;
+    int fd = -1;
+    void* base = nullptr;
+    size_t bytes = 0;
+    bool registered = false;      // page-locked for the device copies
+    Control* ctl() const { return static_cast<Control*>(base); }
+    uint8_t* data() const { return static_cast<uint8_t*>(base) + ctl()->data_offset; }
+};
+
+extern "C" {
+
+int mst_shm_serve(const char* name, size_t max_frame_bytes, mst_shm** out)
+{
+    if (out) *out = nullptr;
+    if (!name || !out || name[0] != '/' || max_frame_bytes == 0) return MST_ERR_INVALID_ARG;
+    mst_shm* s = new (std::nothrow) mst_shm;
+    if (!s) return MST_ERR_OUT_OF_MEMORY;
+    s->name = name;
+    s->server = true;
+    s->bytes = kDataOffset + sizeof(mst_frame_packet) + 1 + max_frame_bytes;
+    shm_unlink(name);
+    s->fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (s->fd < 0 || ftruncate(s->fd, static_cast<off_t>(s->bytes)) != 0) { mst_shm_close(s); return MST_ERR_INVALID_ARG; }
+    s->base = mmap(nullptr, s->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, s->fd, 0);
+    if (s->base == MAP_FAILED) { s->base = nullptr; mst_shm_close(s); return MST_ERR_OUT_OF_MEMORY; }
+    Control* c = s->ctl();
+    std::memset(c, 0, kDataOffset);
+    c->data_offset = static_cast<uint32_t>(kDataOffset);
+    c->segment_bytes = s->bytes;
+    c->max_frame_bytes = max_frame_bytes;
+    if (sem_init(&c->client_ready, 1, 0) != 0 || sem_init(&c->server_wrote, 1, 0) != 0) { mst_shm_close(s); return MST_ERR_INVALID_ARG; }
+    __atomic_store_n(&c->magic, kMagic, __ATOMIC_RELEASE);          // attachers look for this last
+    *out = s;
+    return MST_OK;
+}
+
+int mst_shm_publish(mst_shm* s, const char* file_path, int width, int height, const uint8_t* bgr, size_t stride,
+                    int timeout_ms)
+{
+    if (!s || !s->server || !bgr || width <= 0 || height <= 0 || stride < static_cast<size_t>(width) * 3)
+        return MST_ERR_INVALID_ARG;
+    const size_t row = static_cast<size_t>(width) * 3, nbytes = row * height;
+    if (nbytes > s->ctl()->max_frame_bytes || nbytes > 0x7FFFFFFFu) return MST_ERR_INVALID_ARG;
+    const int rc = wait_sem(&s->ctl()->client_ready, timeout_ms);
+    if (rc != MST_OK) return rc;
+    mst_frame_packet p;
+    std::memset(&p, 0, sizeof(p));
+    if (file_path) std::strncpy(p.filePath, file_path, sizeof(p.filePath) - 1);
+    p.width = width;
+    p.height = height;
+    p.flag = static_cast<int32_t>(nbytes);
+    p.buferPointer = static_cast<int32_t>(sizeof(mst_frame_packet));     // pixels at packet + buferPointer + 1
+    uint8_t* q = s->data();
+    std::memcpy(q, &p, sizeof(p));
+    uint8_t* px = q + p.buferPointer + 1;
+    for (int y = 0; y < height; ++y) std::memcpy(px + static_cast<size_t>(y) * row, bgr + static_cast<size_t>(y) * stride, row);
+    sem_post(&s->ctl()->server_wrote);
+    return MST_OK;
+}
+
+int mst_shm_attach(const char* name, mst_shm** out)
+{
+    if (out) *out = nullptr;
+    if (!name || !out || name[0] != '/') return MST_ERR_INVALID_ARG;
+    mst_shm* s = new (std::nothrow) mst_shm;
+    if (!s) return MST_ERR_OUT_OF_MEMORY;
+    s->name = name;
+    s->fd = shm_open(name, O_RDWR, 0600);
+    struct stat st;
+    if (s->fd < 0 || fstat(s->fd, &st) != 0 || static_cast<size_t>(st.st_size) < kDataOffset + sizeof(mst_frame_packet) + 2) {
+        mst_shm_close(s);
+        return MST_ERR_INVALID_ARG;          // "OpenFileMapping fail" (cpp:50-58)
+    }
+    s->bytes = static_cast<size_t>(st.st_size);
+    s->base = mmap(nullptr, s->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, s->fd, 0);
+    if (s->base == MAP_FAILED) { s->base = nullptr; mst_shm_close(s); return MST_ERR_OUT_OF_MEMORY; }
+    const Control* c = s->ctl();
+    if (__atomic_load_n(&c->magic, __ATOMIC_ACQUIRE) != kMagic || c->segment_bytes != s->bytes ||
+        c->data_offset != kDataOffset) {
+        mst_shm_close(s);
+        return MST_ERR_INVALID_ARG;
+    }
+    *out = s;
+    return MST_OK;
+}
+
+namespace {
+// the common part of GetMemData: request, wait, validate the header the server wrote
+int request_frame(mst_shm* s, mst_frame_packet* hdr, const uint8_t** pixels, int timeout_ms)
+{
+    if (!s || s->server || !hdr) return MST_ERR_INVALID_ARG;
+    sem_post(&s->ctl()->client_ready);                                   // SetEvent(hClientReadOver)
+    const int rc = wait_sem(&s->ctl()->server_wrote, timeout_ms);        // WaitForSingleObject(hServerWriteOver)
+    if (rc != MST_OK) {
+        // withdraw the request if the server has not taken it; if it has, the frame is on its way and has to be
+        // consumed (a stale "server wrote" would let the next request overlap with the server's next write)
+        if (sem_trywait(&s->ctl()->client_ready) == 0) return rc;
+        const int rc2 = wait_sem(&s->ctl()->server_wrote, -1);
+        if (rc2 != MST_OK) return rc2;
+    }
+    const uint8_t* q = s->data();
+    std::memcpy(hdr, q, sizeof(*hdr));
+    hdr->filePath[sizeof(hdr->filePath) - 1] = 0;
+    const size_t avail = s->bytes - s->ctl()->data_offset;
+    if (hdr->width <= 0 || hdr->height <= 0 || hdr->flag < 0 || hdr->buferPointer < 0 ||
+        static_cast<size_t>(hdr->buferPointer) + 1 + static_cast<size_t>(hdr->flag) > avail ||
+        static_cast<size_t>(hdr->flag) != static_cast<size_t>(hdr->width) * hdr->height * 3)
+        return MST_ERR_INVALID_ARG;
+    *pixels = q + hdr->buferPointer + 1;
+    return MST_OK;
+}
+}  // namespace
+
+int mst_shm_get(mst_shm* s, mst_frame_packet* hdr, uint8_t* dst, size_t dst_stride, size_t dst_capacity, int timeout_ms)
+{
+    const uint8_t* px = nullptr;
+    const int rc = request_frame(s, hdr, &px, timeout_ms);
+    if (rc != MST_OK || !dst) return rc;
+    const size_t row = static_cast<size_t>(hdr->width) * 3;
+    if (dst_stride < row || dst_capacity < dst_stride * (hdr->height - 1) + row) return MST_ERR_INVALID_ARG;
+    for (int y = 0; y < hdr->height; ++y) std::memcpy(dst + static_cast<size_t>(y) * dst_stride, px + static_cast<size_t>(y) * row, row);
+    return MST_OK;
+}
+
+int mst_shm_get_device(mst_shm* s, mst_frame_packet* hdr, void* d_dst, size_t dst_stride, size_t dst_capacity,
+                       void* stream, int timeout_ms)
+{
+    if (!d_dst) return MST_ERR_INVALID_ARG;
+    const uint8_t* px = nullptr;
+    const int rc = request_frame(s, hdr, &px, timeout_ms);
+    if (rc != MST_OK) return rc;
+    const size_t row = static_cast<size_t>(hdr->width) * 3;
+    if (dst_stride < row || dst_capacity < dst_stride * (hdr->height - 1) + row) return MST_ERR_INVALID_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MST_ERR_NO_DEVICE;
+    if (!s->registered) {
+        // page-lock the segment once: the copies below then run as DMA straight out of the shared mapping
+        s->registered = hipHostRegister(s->base, s->bytes, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = (dst_stride == row)
+                       ? hipMemcpyAsync(d_dst, px, row * hdr->height, hipMemcpyHostToDevice, st)
+                       : hipMemcpy2DAsync(d_dst, dst_stride, px, row, row, hdr->height, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);       // the server may overwrite the segment after the next request
+    return e == hipSuccess ? MST_OK : MST_ERR_HIP;
+}
+
+void mst_shm_close(mst_shm* s)
+{
+    if (!s) return;
+    if (s->base) {
+        if (s->registered) (void)hipHostUnregister(s->base);
+        if (s->server) {
+            sem_destroy(&s->ctl()->client_ready);
+            sem_destroy(&s->ctl()->server_wrote);
+        }
+        munmap(s->base, s->bytes);
+    }
+    if (s->fd >= 0) close(s->fd);
+    if (s->server) shm_unlink(s->name.c_str());
+    delete s;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+"""Frame ingest over shared memory (include/mi355_ingest.h): the reference's DatePacket wire format and two-event
+handshake (R64/stitching_sharemem.{h,cpp}) between a capture process and the stitcher."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from stitchingvideo_amd import ingest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SERVER = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from stitchingvideo_amd import ingest
+name, shapes = sys.argv[1], eval(sys.argv[2])
+with ingest.FrameServer(name, max(h * w * 3 for h, w in shapes)) as srv:
+    print("ready", flush=True)
+    for i, (h, w) in enumerate(shapes):
+        frame = np.random.default_rng(100 + i).integers(0, 256, (h, w, 3)).astype(np.uint8)
+        srv.publish(frame, path="rtsp://camera/%%d" %% i, timeout_ms=20000)
+    sys.stdin.read()          # keep the segment alive until the client is done
+""" % ROOT
+
+
+def test_packet_layout_is_the_reference_struct():
+    assert C.sizeof(ingest.FramePacket) == 120 + 4 * 4
+    assert ingest.FramePacket.width.offset == 120 and ingest.FramePacket.buferPointer.offset == 132
+
+
+def test_frames_cross_processes_bit_exact():
+    name = "/mst_ingest_test_%d" % os.getpid()
+    shapes = [(48, 64), (33, 47), (48, 64), (1, 1)]
+    srv = subprocess.Popen([sys.executable, "-c", SERVER, name, repr(shapes)], stdin=subprocess.PIPE,
+                           stdout=subprocess.PIPE, text=True)
+    try:
+        assert srv.stdout.readline().strip() == "ready"
+        with ingest.FrameClient(name) as cli:
+            buf = np.zeros((48, 64, 3), np.uint8)            # one Mat re-used for every frame, as DRV:739-741 does
+            for i, (h, w) in enumerate(shapes):
+                if (h, w) != buf.shape[:2]:
+                    view, path = cli.get(np.zeros((h, w, 3), np.uint8), timeout_ms=20000)
+                else:
+                    view, path = cli.get(buf, timeout_ms=20000)
+                want = np.random.default_rng(100 + i).integers(0, 256, (h, w, 3)).astype(np.uint8)
+                assert view.shape == (h, w, 3) and np.array_equal(view, want)
+                assert path == "rtsp://camera/%d" % i
+            with pytest.raises(ingest.IngestError) as ei:    # nothing more is coming: the request is withdrawn
+                cli.get(buf, timeout_ms=200)
+            assert ei.value.code == ingest.ERR_TIMEOUT
+            with pytest.raises(ingest.IngestError):          # a destination that cannot hold the frame
+                ingest.FrameClient(name + "_missing")
+    finally:
+        srv.stdin.close()
+        srv.wait(timeout=20)
+    assert srv.returncode == 0
+    with pytest.raises(ingest.IngestError):                  # the server unlinked its segment on close
+        ingest.FrameClient(name)
+
+
+def test_handshake_between_threads_and_small_destination():
+    name = "/mst_ingest_thr_%d" % os.getpid()
+    frames = [np.full((20, 30, 3), 7 * (i + 1), np.uint8) for i in range(5)]
+    with ingest.FrameServer(name, 20 * 30 * 3) as srv:
+        with pytest.raises(ingest.IngestError):              # larger than the segment was made for
+            srv.publish(np.zeros((40, 30, 3), np.uint8), timeout_ms=0)
+        with pytest.raises(ingest.IngestError) as ei:        # no client asked for a frame
+            srv.publish(frames[0], timeout_ms=100)
+        assert ei.value.code == ingest.ERR_TIMEOUT
+        t = threading.Thread(target=lambda: [srv.publish(f, path="f%d" % i, timeout_ms=20000) for i, f in enumerate(frames)])
+        t.start()
+        with ingest.FrameClient(name) as cli:
+            out = np.zeros((20, 30, 3), np.uint8)
+            for i, f in enumerate(frames[:4]):
+                view, path = cli.get(out, timeout_ms=20000)
+                assert np.array_equal(view, f) and path == "f%d" % i
+            with pytest.raises(ingest.IngestError):          # too small for the 20 x 30 frame (it is consumed anyway)
+                cli.get(np.zeros((10, 30, 3), np.uint8), timeout_ms=20000)
+        t.join()
+
+
+@pytest.mark.gpu
+def test_frame_lands_in_device_memory():
+    import torch
+    name = "/mst_ingest_gpu_%d" % os.getpid()
+    frame = np.random.default_rng(5).integers(0, 256, (270, 480, 3)).astype(np.uint8)
+    with ingest.FrameServer(name, frame.nbytes) as srv, ingest.FrameClient(name) as cli:
+        t = threading.Thread(target=lambda: [srv.publish(frame, path="cam", timeout_ms=20000) for _ in range(2)])
+        t.start()
+        dev = torch.zeros((270, 480, 3), dtype=torch.uint8, device="cuda")
+        assert cli.get_device(dev.data_ptr(), dev.stride(0), dev.numel())[:2] == (480, 270)
+        assert np.array_equal(dev.cpu().numpy(), frame)
+        padded = torch.zeros((270, 1500), dtype=torch.uint8, device="cuda")        # strided destination
+        cli.get_device(padded.data_ptr(), padded.stride(0), padded.numel())
+        assert np.array_equal(padded[:, :1440].cpu().numpy().reshape(270, 480, 3), frame)
+        t.join()
