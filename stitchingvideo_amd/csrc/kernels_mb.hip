@@ -530,16 +530,22 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
 // ======================================================================================================
 // B: pyrDown chain level b -> b+1 .. b+k (k <= B_KMAX) inside LDS
 // ======================================================================================================
-// Measured on MI355X (C3): a 4-deep chain per block needs 62 KB of LDS and serialises four
-// barrier-separated phases in too few resident blocks (36-67 us); 2-deep launches with many threads per
-// tile keep the per-thread instruction stream short, which is what bounds these small kernels.
-constexpr int B_T = 64;                         // base-level interior of a tile
+// Measured on MI355X (C3): a 4-deep chain per block needs 62 KB of LDS and serialises four barrier-separated
+// phases in too few resident blocks (36-67 us); 2-deep launches it is.  These launches are latency-bound (load ->
+// barrier -> reduce -> barrier -> reduce), so what helps is many small blocks in different phases on a CU: 32 x 32
+// tiles with 256 threads (8 blocks per CU) run 8.6 us per batched frame set against 9.4 for 64 x 64 / 1024
+// threads and 14.9 for 128 x 128, although the smaller tile re-reads more halo (41^2 loads for 32^2 pixels).
+#ifndef MST_B_T
+#define MST_B_T 32
+#endif
+constexpr int B_T = MST_B_T;                    // base-level interior of a tile (a power of two >= 16)
 #ifndef MST_B_THREADS
-#define MST_B_THREADS 1024
+#define MST_B_THREADS 256
 #endif
 constexpr int B_THREADS = MST_B_THREADS;
 constexpr int B_KMAX = 2;
-constexpr int B_E0 = 73, B_E1 = 35;             // region extents for a full k = 2 chain (e2 = 16)
+// region extents of a full k = 2 chain: e2 = B_T / 4 outputs, each level below needs 2 e + 3 inputs
+constexpr int B_E1 = 2 * (B_T / 4) + 3, B_E0 = 2 * B_E1 + 3;
 
 template <int K>
 __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restrict__ cams_all, TileList list, int base,
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
     const int tid = threadIdx.x;
 
     // extents e[j] (compile-time) and origins lo[j] (in level base+j coordinates) of the regions each level covers
-    constexpr int e[B_KMAX + 1] = {K == 2 ? 73 : 67, K == 2 ? 35 : 32, 16};
+    constexpr int e[B_KMAX + 1] = {K == 2 ? B_E0 : 2 * (B_T / 2) + 3, K == 2 ? B_E1 : B_T / 2, B_T / 4};
     int lox[B_KMAX + 1], loy[B_KMAX + 1];
     lox[k] = (tx * B_T) >> k;
     loy[k] = (ty * B_T) >> k;

@@ -132,7 +132,9 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
             const int tiles_x = (d.lw[base] + b_t - 1) / b_t, tiles_y = (d.lh[base] + b_t - 1) / b_t;
             std::vector<uint8_t> used(static_cast<size_t>(tiles_x) * tiles_y, 0);
             for (int j = 1; j <= k; ++j) {
-                const int l = base + j, shift = 6 - j;      // b_t == 64
+                int log2_bt = 0;
+                while ((1 << log2_bt) < b_t) ++log2_bt;
+                const int l = base + j, shift = log2_bt - j;
                 const std::vector<uint8_t>& need = plan.cams[c].need[l];
                 for (int y = 0; y < d.lh[l]; ++y) {
                     const uint8_t* row = need.data() + static_cast<size_t>(y) * d.lw[l];
