@@ -226,3 +226,33 @@ def test_recalibration_from_a_second_thread_while_composing():
     eng.synchronize()
     assert np.array_equal(pano.cpu().numpy(), pano_b)          # the last update won
     eng.close()
+
+
+def test_profile_entry_points_report_every_launch():
+    """mst_compose_profile(_batch): one HIP event between consecutive launches, names and durations per stage."""
+    import torch
+    rig = rigmod.build_rig(rigmod.scaled_config("C3", 8))
+    eng = H.make_engine(rig, max_batch=2)
+    _, _, cw, ch = eng.canvas()
+    dev = torch.device("cuda", 0)
+    host = [rigmod.frames_for(rig, i) for i in range(2)]
+    dfr = [[torch.from_numpy(f).to(dev) for f in fr] for fr in host]
+    panos = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    ptrs = [[t.data_ptr() for t in fr] for fr in dfr]
+    strides = [[t.stride(0) for t in fr] for fr in dfr]
+    torch.cuda.synchronize()
+    single = eng.profile_stages(ptrs[0], strides[0], panos[0].data_ptr(), panos[0].stride(0))
+    batch = eng.profile_stages_batch(ptrs, strides, [p.data_ptr() for p in panos], panos[0].stride(0))
+    for stages in (single, batch):
+        assert [n for n, _ in stages] == ["k_warp_pyr", "k_pyr_chain", "k_pyr_chain", "k_blend"]
+        assert all(0.0 < ms < 50.0 for _, ms in stages)
+    eng.synchronize()
+    for i in range(2):
+        assert np.array_equal(panos[i].cpu().numpy(), H.oracle_compose(rig, host[i])[1])
+    call = eng.make_device_batch_call(ptrs, strides, [p.data_ptr() for p in panos], panos[0].stride(0))
+    for p in panos:
+        p.zero_()
+    call(); call()
+    eng.synchronize()
+    assert np.array_equal(panos[1].cpu().numpy(), H.oracle_compose(rig, host[1])[1])
+    eng.close()
