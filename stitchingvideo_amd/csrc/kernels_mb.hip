@@ -505,8 +505,33 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     if (nlev < 2 || (MST_ABLATE_A & 4)) return;
     __syncthreads();
 
-    // pyrDown straight from the LDS tile: output (j, i) reads rows 2i..2i+4, columns 2j..2j+4
+    // pyrDown straight from the LDS tile: output (j, i) reads rows 2i..2i+4, columns 2j..2j+4.  A thread owns one
+    // output column and a run of A_TH1 / 4 consecutive output rows, so the horizontal [1 4 6 4 1] of a tile row is
+    // formed once for every output row that uses it (2 R + 3 row sums for R outputs instead of 5 R).
     const int x1 = tx * A_TW1, y1 = ty * A_TH1;
+    if (A_TH1 % 4 == 0 && !(MST_ABLATE_A & 64)) {
+        constexpr int R = A_TH1 / 4;
+        if (tid < 4 * A_TW1) {
+            const int g = tid / A_TW1, j = tid - g * A_TW1;
+            uint32_t hbr[2 * R + 3], hg[2 * R + 3];
+#pragma unroll
+            for (int r = 0; r < 2 * R + 3; ++r) {
+                const uint32_t* p = &s_l0[2 * R * g + r][2 * j];
+                const uint2 p01 = *reinterpret_cast<const uint2*>(p);      // 8-byte aligned: 2j is even
+                const uint2 p23 = *reinterpret_cast<const uint2*>(p + 2);
+                tap5(p01.x, p01.y, p23.x, p23.y, p[4], hbr[r], hg[r]);
+            }
+#pragma unroll
+            for (int o = 0; o < R; ++o) {
+                const int i = R * g + o;
+                if (x1 + j >= lw1 || y1 + i >= lh1) continue;
+                const uint32_t vbr = hbr[2 * o] + hbr[2 * o + 4] + 4u * (hbr[2 * o + 1] + hbr[2 * o + 3]) + 6u * hbr[2 * o + 2];
+                const uint32_t vg = hg[2 * o] + hg[2 * o + 4] + 4u * (hg[2 * o + 1] + hg[2 * o + 3]) + 6u * hg[2 * o + 2];
+                g1out[__umul24(y1 + i, lw1) + x1 + j] = pyrdown_finish(vbr, vg);
+            }
+        }
+        return;
+    }
     for (int idx = tid; idx < A_TH1 * A_TW1; idx += 256) {
         const int i = idx / A_TW1, j = idx - i * A_TW1;
         if (x1 + j >= lw1 || y1 + i >= lh1) continue;
