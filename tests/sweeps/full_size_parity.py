@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """One frame of each BASELINE config at full size, engine vs oracle, bit for bit (the test-suite does C3 only:
-the 4K oracle run takes a while).  Usage: python tools/full_size_parity.py [C2 C4 C5 ...]"""
+the 4K oracle run takes a while).  Usage: python tests/sweeps/full_size_parity.py [C2 C4 C5 ...]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402,F401

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: random rigs (warp kind, poses, sizes, focal/scale ratio), exposure modes,
 mask styles, band counts, blenders, batch sizes and lens maps -- engine output against the CPU oracle, bit for bit.
-Usage: python tools/fuzz_parity.py [cases] [seed]      (prints one line per case, exits non-zero on a mismatch)"""
+Usage: python tests/sweeps/fuzz_parity.py [cases] [seed]      (prints one line per case, exits non-zero on a mismatch)"""
 import math
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
