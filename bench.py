@@ -1,59 +1,110 @@
 #!/usr/bin/env python3
 """bench.py -- stitched panorama frames/sec on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the per-frame hot path (warp -> exposure gain -> Laplacian multi-band blend
--> 8-bit panorama) over one batch of --batch (default 8) sets of N_cam synthetic frames that are already
-resident in HBM: every kernel of the path is launched once per step over all frame sets of the batch
-(mst_compose_device_batch) and `value` counts panoramas, i.e. steps x batch.  --batch 1 is one frame set
-per launch sequence; --overlap additionally pipelines consecutive calls over two streams.  The workload at every N is BASELINE
-config C3: 6x1920x1080 streams, spherical warp, block gains, 5-band multi-band blend, canvas 7852x1020.
+N > 1 without a torch.distributed environment: this process spawns the N ranks itself (torch.distributed.run,
+127.0.0.1 rendezvous) BEFORE anything touches a GPU and forwards rank 0's JSON line; when the driver launches
+the ranks (RANK / WORLD_SIZE set) it runs as one of them.
 
-N > 1 shards *frames*: every rank owns the full calibration and stitches its own stream of frame
-sets (independent panoramas, no data-path collective) -> "scaling": "weak".
+Workload (every N): BASELINE config C3 -- 6x1920x1080 streams, spherical warp, block gains, 5-band multi-band
+blend, canvas 7852x1020 -- with the frames already resident in HBM.
+
+A step is one pass of the per-frame hot path (warp -> exposure gain -> Laplacian multi-band blend -> 8-bit
+panorama) over one batch of synthetic input.  The batch of a step is `reps` consecutive launch sequences of
+--batch (default 8) independent frame sets each (mst_compose_device_batch: every kernel of the path launched once
+over the 8 sets); `reps` is sized once, from the warm-up, so that the K timed steps last at least --min-time
+(1 s): exactly K steps are timed, and a 15 ms timed region (20 steps of one launch sequence) is a thing of the
+past.  `value` counts panoramas: K x reps x batch x N / wall.
+
+N > 1, default: *frames* are sharded -- every rank owns the full calibration and stitches its own stream of frame
+sets (independent panoramas, no data-path collective) -> "scaling": "weak".  The north-star split (camera i on GPU
+i % N, one exchange of the per-camera pyramid payload to rank 0 over RCCL, rank 0 blends: SURVEY 8e, BASELINE C4)
+is measured in the same run on the C4 rig and reported in the `camera_sharded` object of the same line (or as the
+headline with --shard cameras).
 
 Extra objects on the JSON line:
-  roofline      HBM roofline of a step: algorithmic bytes 3*(N_cam*W*H + Wc*Hc) per frame set
-                x batch over the measured device time of the step; per-kernel times come from HIP events
-                recorded between launches on the compose stream (mst_compose_profile_batch).
-  cpu_baseline  the CPU oracle (oracle/, a port of the reference arithmetic) timed on this box's
-                host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+  roofline      HBM roofline of the dominant kernel and of the whole step: algorithmic bytes
+                3*(N_cam*W*H + Wc*Hc) per frame set x frame sets per launch over the launch duration,
+                measured live with HIP events recorded between the launches on the compose stream
+                (mst_compose_profile_batch); `traffic` = HBM bytes per launch from the rocprofv3 PMC passes in
+                profiles/traffic.json, reported only while that file was produced from the current kernel sources.
+  latency_mode  one frame set per launch sequence (the reference's one StitchingAll() per frame), same engine.
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference arithmetic) timed on this box's host cores on a
+                bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+METRIC = "stitched panorama frames/sec, 6x1080p->360deg canvas"
+KERNEL_SOURCES = ["stitchingvideo_amd/csrc/kernels_mb.hip", "stitchingvideo_amd/csrc/kernels.hip",
+                  "stitchingvideo_amd/csrc/kernels_common.hpp", "stitchingvideo_amd/csrc/device_types.hpp"]
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--min-time", type=float, default=1.0, help="the K timed steps last at least this long (seconds)")
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--frame-sets", type=int, default=3, help="distinct synthetic frame sets cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
-                    help="pipeline consecutive calls (MST_FLAG_OVERLAP_FRAMES): +2-3 %% throughput, but kernels of two "
-                         "calls then run concurrently and per-kernel durations (here and in rocprofv3) stop being comparable")
+                    help="pipeline consecutive calls (MST_FLAG_OVERLAP_FRAMES): kernels of two calls then run "
+                         "concurrently and per-kernel durations (here and in rocprofv3) stop being comparable")
     ap.add_argument("--no-overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--batch", type=int, default=8,
-                    help="frame sets per step (mst_compose_device_batch); 1 = one frame set per launch sequence")
+                    help="frame sets per launch sequence (mst_compose_device_batch); 1 = one frame set per sequence")
     ap.add_argument("--shard", default="frames", choices=["frames", "cameras"],
-                    help="N > 1: frames = every rank stitches its own frame sets (default, no collective); "
-                         "cameras = camera i on rank i %% N, pyramids sent to rank 0 over RCCL, rank 0 blends (SURVEY 8e)")
+                    help="N > 1 headline: frames = every rank stitches its own frame sets (default, no collective); "
+                         "cameras = camera i on rank i %% N, payload sent to rank 0 over RCCL, rank 0 blends (SURVEY 8e)")
+    ap.add_argument("--no-camera-leg", action="store_true", help="N > 1: skip the camera-sharded secondary measurement")
+    ap.add_argument("--camera-leg-steps", type=int, default=100)
     ap.add_argument("--undistort", action="store_true",
                     help="add the driver's lens-undistort pre-pass (DRV:741) to every camera (not part of the headline)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = sized to ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = min(host cores, 32))")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """--gpus N from a plain shell: start the N ranks as child processes and hand back their exit code.  Nothing in
+    this process has touched a GPU (torch.cuda.device_count() does not initialise one on this image), and nothing
+    is exec'ed: the children are ordinary subprocesses."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(rig, frames, blend, budget_s=15.0, max_frames=0, threads=0):
@@ -76,6 +127,8 @@ def cpu_baseline(rig, frames, blend, budget_s=15.0, max_frames=0, threads=0):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,14 +144,12 @@ def main():
 
     import stitchingvideo_amd as S
     from stitchingvideo_amd import rig as rigmod
-    from stitchingvideo_amd import sharding as sharding_mod
+    from stitchingvideo_amd import sharding
 
     cfg = rigmod.CONFIGS[args.config]
     rig = rigmod.build_rig(cfg)
     blend = cfg["blend"]
     n_cam = len(rig["cameras"])
-    # --overlap: call t+1's per-camera kernels overlap call t's canvas kernel (frames are resident in HBM before
-    # each call, as MST_FLAG_OVERLAP_FRAMES requires); the default keeps everything on one stream
     by_camera = args.shard == "cameras" and blend == "multiband"
     batch = 1 if by_camera else max(1, min(args.batch, 8))
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
@@ -114,32 +165,31 @@ def main():
         for c in rig["cameras"]:
             c["undistort"] = und
     eng.update(rig["scale"], rig["cameras"])
-    cx, cy, cw, ch = eng.canvas()
+    (cx, cy, cw, ch), _ = eng.acquire()
 
     # frames resident in HBM: a few distinct sets, each rank its own (frame index offset by rank)
     dev = torch.device("cuda", local_rank)
     host_sets, dev_sets = [], []
     n_sets = max(args.frame_sets, batch)
     for s in range(n_sets):
-        fr = rigmod.frames_for(rig, frame_index=sharding_mod.global_frame_index(rank, world, s))
+        fr = rigmod.frames_for(rig, frame_index=sharding.global_frame_index(rank, world, s))
         host_sets.append(fr)
         dev_sets.append([torch.from_numpy(f).to(dev) for f in fr])
     panos = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(batch)]
     pano = panos[0]
-    # a real (non-null) stream, made torch's current one, so torch.cuda.Event brackets the launches
+    # a real (non-null) stream, made torch's current one: torch.cuda.Event brackets the launches and RCCL's
+    # point-to-point operations (camera-sharded mode) order against the same stream as the kernels
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
-    # a step = one batch of `batch` frame sets through one launch sequence (consecutive sets, rotating start)
+
     def tables(first):
         sets = [dev_sets[(first + k) % n_sets] for k in range(batch)]
         return [[t.data_ptr() for t in ds] for ds in sets], [[t.stride(0) for t in ds] for ds in sets]
 
     if by_camera:
-        # camera streams sharded over ranks: a step = every rank's per-camera kernels, one exchange of the
-        # Gaussian pyramids to rank 0 (point-to-point over RCCL), the canvas kernel on rank 0
-        stitcher = sharding_mod.ShardedStitcher(eng, rank, world, root=0, device=dev)
+        stitcher = sharding.ShardedStitcher(eng, rank, world, root=0, device=dev)
 
         def camera_call(ds):
             ptrs = {c: ds[c].data_ptr() for c in stitcher.mine}
@@ -157,8 +207,23 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def run(n_calls, first=0):
+        for i in range(n_calls):
+            calls[(first + i) % len(calls)]()
+
+    # size `reps` (launch sequences per step) from a short probe so that K steps last >= --min-time on every rank
+    run(3)
+    torch.cuda.synchronize()
+    probe = 10
+    t0 = time.perf_counter()
+    run(probe)
+    torch.cuda.synchronize()
+    t_seq = (time.perf_counter() - t0) / probe
+    t_seq = sharding.max_over_ranks([t_seq], device=dev)[0]
+    reps = max(1, int(math.ceil(args.min_time / max(args.steps, 1) / max(t_seq, 1e-6))))
+
     for i in range(args.warmup):
-        calls[i % len(calls)]()
+        run(reps, i * reps)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -166,35 +231,36 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
-        calls[i % len(calls)]()
+        run(reps, i * reps)
     ev1.record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-
-    from stitchingvideo_amd import sharding
     wall, dev_ms = sharding.max_over_ranks([wall, dev_ms], device=dev)     # slowest rank sets the job time
 
+    workload = "%s: %dx%dx%d BGR8 streams, %s warp, gain_blocks, %s blend (5 bands), canvas %dx%d" % (
+        args.config, n_cam, rig["size"][0], rig["size"][1], rig["warp"], blend, cw, ch)
+    alg_bytes = rigmod.algorithmic_bytes(rig, (cw, ch))
+    out = None
     if rank == 0 and by_camera:
-        frames_done = args.steps                      # one panorama per step for the whole job
-        print(json.dumps({
-            "metric": "stitched panorama frames/sec, 6x1080p->360deg canvas", "value": round(frames_done / wall, 3),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall * 1000.0 / args.steps, 5), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u8/s16 fixed-point (f32 weights)", "data": "synthetic",
-            "config": {"workload": "%s: %dx%dx%d BGR8 streams, %s warp, gain_blocks, %s blend (5 bands), canvas %dx%d"
-                                   % (args.config, n_cam, rig["size"][0], rig["size"][1], rig["warp"], blend, cw, ch),
-                       "frames_resident_in_hbm": True,
-                       "parallelism": "cameras sharded over %d rank(s), pyramids sent to rank 0 (RCCL point-to-point)" % world},
-        }), flush=True)
+        seqs = args.steps * reps                      # one panorama per launch sequence for the whole job
+        out = {
+            "metric": METRIC, "value": round(seqs / wall, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(wall * 1000.0 / args.steps, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8/s16 fixed-point (f32 weights)", "data": "synthetic",
+            "config": {"workload": workload, "frames_resident_in_hbm": True, "frame_sets_per_step": reps,
+                       "parallelism": "cameras sharded over %d rank(s), pyramid payload sent to rank 0 (RCCL point-to-point)" % world},
+            "roofline": {"bound": "hbm", "achieved": round(alg_bytes * seqs / wall / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg_bytes * seqs / wall / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "scope": "whole job (all ranks' kernels + exchange per panorama)"},
+        }
     elif rank == 0:
-        # per-kernel durations: HIP events between launches on the compose stream, averaged over a few frames
-        reps = 10
-        acc = {}
-        order = []
-        for i in range(reps):
+        # per-kernel durations: HIP events between launches on the compose stream, averaged over a few sequences
+        reps_prof = 10
+        acc, order = {}, []
+        for i in range(reps_prof):
             st = eng.profile_stages_batch(*tables(i % n_sets), [p.data_ptr() for p in panos], pano.stride(0),
                                           stream=stream)
             for name, ms in st:
@@ -203,23 +269,28 @@ def main():
                     order.append(name)
                 acc[name][0] += ms
                 acc[name][1] += 1
-        kernels = [{"name": k, "launches_per_step": acc[k][1] // reps, "avg_ms": round(acc[k][0] / acc[k][1], 5),
-                    "ms_per_frame": round(acc[k][0] / reps / batch, 5)} for k in order]
+        kernels = [{"name": k, "launches_per_sequence": acc[k][1] // reps_prof, "avg_ms": round(acc[k][0] / acc[k][1], 5),
+                    "ms_per_frame": round(acc[k][0] / reps_prof / batch, 5)} for k in order]
         dominant = max(kernels, key=lambda k: k["ms_per_frame"]) if kernels else None
-
+        seqs = args.steps * reps
         ms_per_step = wall * 1000.0 / args.steps
-        dev_ms_per_step = dev_ms / args.steps
-        alg_bytes = rigmod.algorithmic_bytes(rig, (cw, ch))
-        traffic = None      # HBM bytes per frame from the committed rocprofv3 PMC passes of this same workload
+        dev_ms_per_seq = dev_ms / seqs
+        traffic, traffic_note = None, "profiles/traffic.json absent"
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.config]["bytes_per_frame"]
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get("kernel_source_sha16") == kernel_source_hash():
+                traffic = tj[args.config]["bytes_per_frame"] * batch
+                traffic_note = tj.get("source", "")
+            else:
+                traffic_note = "profiles/traffic.json predates the current kernel sources (re-run tools/profile_gpu.sh)"
         except (OSError, KeyError, ValueError):
             pass
-        # one step = one launch of every kernel over `batch` frame sets: algorithmic bytes per launch = batch x frame
-        achieved = alg_bytes * batch / (dev_ms_per_step * 1e-3) / 1e9
+        # one launch of a kernel processes `batch` frame sets: algorithmic bytes per launch = batch x frame.
+        # Whole-step figure: all launches of a sequence together move those bytes once.
+        achieved = alg_bytes * batch / (dev_ms_per_seq * 1e-3) / 1e9
         out = {
-            "metric": "stitched panorama frames/sec, 6x1080p->360deg canvas",
-            "value": round(sharding.aggregate_throughput(world, args.steps * batch, wall), 3),
+            "metric": METRIC,
+            "value": round(sharding.aggregate_throughput(world, seqs * batch, wall), 3),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -230,20 +301,59 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/s16 fixed-point (f32 weights)",
             "data": "synthetic",
-            "config": {"workload": "%s: %dx%dx%d BGR8 streams, %s warp, gain_blocks, %s blend (5 bands), canvas %dx%d"
-                                   % (args.config, n_cam, rig["size"][0], rig["size"][1], rig["warp"], blend, cw, ch),
-                       "frames_resident_in_hbm": True, "frame_sets_per_step": batch, "lens_undistort": bool(args.undistort),
+            "config": {"workload": workload, "frames_resident_in_hbm": True, "frame_sets_per_step": batch * reps,
+                       "launch_sequences_per_step": reps, "frame_sets_per_launch": batch,
+                       "lens_undistort": bool(args.undistort), "timed_region_s": round(wall, 4),
                        "parallelism": "frames sharded over %d rank(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic * batch if traffic else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_frame": alg_bytes,
                          "algorithmic_bytes_per_launch": alg_bytes * batch,
-                         "device_ms_per_frame": round(dev_ms_per_step / batch, 5),
-                         "scope": "whole step (%d launches over %d frame sets)"
-                                  % (sum(k["launches_per_step"] for k in kernels), batch),
+                         "device_ms_per_frame": round(dev_ms_per_seq / batch, 5),
+                         "scope": "whole launch sequence (%d launches over %d frame sets); the dominant kernel alone "
+                                  "moves the same algorithmic bytes in its own duration"
+                                  % (sum(k["launches_per_sequence"] for k in kernels), batch),
                          "dominant_kernel": dominant, "kernels": kernels},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if batch > 1:
+            # latency mode on the same engine: one frame set per launch sequence, as the reference's StitchingAll()
+            one = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),
+                                        pano.stride(0), stream=stream) for ds in dev_sets]
+            for i in range(20):
+                one[i % len(one)]()
+            torch.cuda.synchronize()
+            n1 = max(50, int(0.4 / max(t_seq / batch, 1e-6)))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(n1):
+                one[i % len(one)]()
+            e1.record()
+            torch.cuda.synchronize()
+            ms1 = e0.elapsed_time(e1) / n1
+            out["latency_mode"] = {"frame_sets_per_launch": 1, "frames": n1, "ms_per_frame": round(ms1, 5),
+                                   "frames_per_s": round(1000.0 / ms1, 2),
+                                   "roofline_frac": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    # ---- N > 1: the north-star split measured beside the headline (C4: 8 cameras, camera i on rank i % N) ----
+    if world > 1 and not by_camera and not args.no_camera_leg:
+        def give_up():          # every rank: a hung exchange must not take the headline (or the launcher) with it
+            if rank == 0:
+                out["camera_sharded"] = {"error": "timed out after 240 s (exchange did not complete)"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(240.0 if rank == 0 else 250.0, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            leg = camera_sharded_leg(args, rank, world, local_rank, dev, stream)
+        except Exception as e:          # noqa: BLE001  -- the headline must survive a failure of the secondary leg
+            leg = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
+        if rank == 0:
+            out["camera_sharded"] = leg
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and not by_camera:
             out["cpu_baseline"] = cpu_baseline(rig, host_sets[0], blend, max_frames=args.cpu_frames, threads=args.cpu_threads)
         print(json.dumps(out), flush=True)
 
@@ -251,6 +361,57 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def camera_sharded_leg(args, rank, world, local_rank, dev, stream):
+    """BASELINE C4 as specified: 8x1080p, camera i on GPU i % N, one exchange of the per-camera payload to rank 0
+    per frame over RCCL (grouped point-to-point, every peer on its own xGMI link), rank 0 blends.  Strong scaling:
+    the job is one panorama stream.  Runs on every rank; rank 0 returns the result object."""
+    import torch
+    import torch.distributed as dist
+    import stitchingvideo_amd as S
+    from stitchingvideo_amd import rig as rigmod
+    from stitchingvideo_amd import sharding
+    cfg = rigmod.CONFIGS["C4"]
+    rig = rigmod.build_rig(cfg)
+    n_cam = len(rig["cameras"])
+    eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend="multiband", expos=rig["expos"], num_bands=5, device=local_rank)
+    eng.update(rig["scale"], rig["cameras"])
+    (_, _, cw, ch), _ = eng.acquire()
+    st = sharding.ShardedStitcher(eng, rank, world, root=0, device=dev)
+    sets = []
+    for s in range(2):
+        fr = rigmod.frames_for(rig, frame_index=s)
+        sets.append({c: torch.from_numpy(fr[c]).to(dev) for c in st.mine})
+    pano = torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev)
+
+    def call(i):
+        ds = sets[i % len(sets)]
+        st.compose({c: t.data_ptr() for c, t in ds.items()}, {c: t.stride(0) for c, t in ds.items()},
+                   pano.data_ptr(), pano.stride(0), stream=stream)
+
+    for i in range(10):
+        call(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    n = max(10, args.camera_leg_steps)
+    t0 = time.perf_counter()
+    for i in range(n):
+        call(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = sharding.max_over_ranks([time.perf_counter() - t0], device=dev)[0]
+    payload = st.payload_bytes()
+    eng.close()
+    alg = rigmod.algorithmic_bytes(rig, (cw, ch))
+    return {"workload": "C4: %dx%dx%d BGR8 streams, spherical warp, gain_blocks, multiband blend (5 bands), canvas %dx%d"
+                        % (n_cam, rig["size"][0], rig["size"][1], cw, ch),
+            "parallelism": "camera i on rank i %% %d, payload to rank 0 over RCCL point-to-point, rank 0 blends" % world,
+            "scaling": "strong", "frames": n, "frames_per_s": round(n / wall, 2), "ms_per_frame": round(wall * 1e3 / n, 4),
+            "payload_bytes_per_frame_to_root": payload,
+            "roofline_frac": round(alg * n / wall / 1e9 / HBM_PEAK_GBS, 5)}
 
 
 if __name__ == "__main__":

@@ -145,8 +145,9 @@ typedef struct mst_rect { int32_t x, y, width, height; } mst_rect;
 /* ---- engine lifetime ------------------------------------------------------------------- */
 int  mst_create(const mst_config *cfg, mst_engine **out);
 void mst_destroy(mst_engine *e);
-/* message of the last failure on this engine (or of the last failed call without an engine
- * when e == NULL); valid until the next call on the same thread */
+/* message of the last failed call made by the CALLING THREAD (on any engine or without one; `e` is accepted for
+ * symmetry and ignored); valid until that thread's next failing call.  Per thread because mst_update and
+ * mst_compose* may run -- and fail -- concurrently on one engine. */
 const char *mst_last_error(const mst_engine *e);
 
 /* Publish a calibration: builds every frame-invariant product on the device (ROI geometry,
@@ -154,7 +155,17 @@ const char *mst_last_error(const mst_engine *e);
  * state and swaps it in atomically; the next mst_compose uses it (UpdateMat, DRV:696-722). */
 int  mst_update(mst_engine *e, const mst_calibration *calib);
 
-/* resultRoi of the current calibration; with MST_FLAG_DRIVER_LUT the cropped output rect */
+/* Latch the newest published calibration for the frame thread and return its canvas and generation (1, 2, ... in
+ * mst_update order).  This is the reference's `if (Upflag) UpdateMat();` at the top of the frame loop
+ * (DRV:835-836): the thread that composes decides when a new calibration takes effect, so the panorama size
+ * cannot change between sizing the output buffer and composing into it.  From the first call on, every
+ * mst_compose* / mst_stage* / mst_canvas of this engine uses the latched calibration until the next
+ * mst_acquire_calibration; an engine that never calls it keeps the old behaviour (each call picks up the newest
+ * calibration on entry -- then size panorama buffers for the largest canvas a recalibration can produce, or do
+ * not recalibrate concurrently).  Call it from the compose thread only. */
+int  mst_acquire_calibration(mst_engine *e, mst_rect *canvas, uint64_t *generation);
+/* resultRoi of the calibration the next compose will use (see mst_acquire_calibration); with
+ * MST_FLAG_DRIVER_LUT the cropped output rect */
 int  mst_canvas(const mst_engine *e, mst_rect *canvas);
 /* corners[i] / sizes[i] */
 int  mst_camera_roi(const mst_engine *e, int camera, mst_rect *roi);
@@ -204,6 +215,8 @@ int  mst_stage_cameras(mst_engine *e, uint32_t camera_mask, const void *const *d
                        const size_t *frame_strides, void *stream);   /* entries outside the mask are ignored */
 int  mst_stage_canvas(mst_engine *e, void *d_pano, size_t pano_stride, void *d_pano_mask,
                       size_t pano_mask_stride, void *stream);
+/* The buffer belongs to the calibration the call resolves to (see mst_acquire_calibration) and is freed when that
+ * calibration is retired: query it again after every mst_update / mst_acquire_calibration, never cache it across. */
 int  mst_pyramid_buffer(mst_engine *e, int camera, void **d_ptr, size_t *bytes);
 
 /* ---- stage-level entry points (the reference's plugin interfaces) ------------------------ */

@@ -26,7 +26,7 @@ DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, 
     1, 2, 3, 4, 5, 6
 
 EXPORTS = [
-    "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_canvas", "mst_camera_roi",
+    "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_acquire_calibration", "mst_canvas", "mst_camera_roi",
     "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_device_batch", "mst_compose_profile",
     "mst_compose_profile_batch", "mst_synchronize", "mst_warp_roi",
     "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
@@ -101,6 +101,8 @@ def load():
     L.mst_last_error.argtypes = [vp]
     L.mst_update.restype = C.c_int
     L.mst_update.argtypes = [vp, C.POINTER(Calibration)]
+    L.mst_acquire_calibration.restype = C.c_int
+    L.mst_acquire_calibration.argtypes = [vp, C.POINTER(Rect), C.POINTER(C.c_uint64)]
     L.mst_canvas.restype = C.c_int
     L.mst_canvas.argtypes = [vp, C.POINTER(Rect)]
     L.mst_camera_roi.restype = C.c_int

@@ -17,8 +17,10 @@ thread_local std::string g_last_error;
 
 int fail(mst_engine* e, const mst::Error& err)
 {
+    // per thread, not per engine: the calibration thread (mst_update) and the frame thread (mst_compose*) may fail
+    // concurrently on one engine, and a shared string would race and dangle
+    (void)e;
     g_last_error = err.msg;
-    if (e) e->impl.last_error = err.msg;
     return err.code;
 }
 
@@ -106,7 +108,7 @@ void mst_destroy(mst_engine* e)
 
 const char* mst_last_error(const mst_engine* e)
 {
-    if (e) return e->impl.last_error.c_str();
+    (void)e;
     return g_last_error.c_str();
 }
 
@@ -118,6 +120,21 @@ int mst_update(mst_engine* e, const mst_calibration* calib)
         require(calib->struct_size == static_cast<int32_t>(sizeof(mst_calibration)), "mst_calibration.struct_size mismatch");
         e->impl.update(*calib);
     });
+}
+
+int mst_acquire_calibration(mst_engine* e, mst_rect* canvas, uint64_t* generation)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    auto st = e->impl.acquire();
+    if (!st) return MST_ERR_NOT_CALIBRATED;
+    if (canvas) {
+        canvas->x = st->canvas.x + st->crop_x;
+        canvas->y = st->canvas.y + st->crop_y;
+        canvas->width = st->out_w;
+        canvas->height = st->out_h;
+    }
+    if (generation) *generation = st->generation;
+    return MST_OK;
 }
 
 int mst_canvas(const mst_engine* e, mst_rect* canvas)

@@ -37,11 +37,23 @@ DevicePool::~DevicePool()
 
 void* DevicePool::alloc_bytes(size_t bytes)
 {
-    void* p = nullptr;
-    check_hip(hipMalloc(&p, std::max<size_t>(bytes, 16)), "hipMalloc");
-    ptrs_.push_back(p);
+    constexpr size_t kAlign = 256, kSlab = size_t{64} << 20;
+    const size_t need = (std::max<size_t>(bytes, 16) + kAlign - 1) & ~(kAlign - 1);
+    if (need > left_) {
+        // a request of slab size or more gets a slab of its own and leaves the current one open
+        const size_t slab = need >= kSlab ? need : kSlab;
+        void* p = nullptr;
+        check_hip(hipMalloc(&p, slab + kAlign), "hipMalloc");     // + guard: kernels may read a few bytes past a buffer
+        ptrs_.push_back(p);
+        if (need >= kSlab) { total_ += bytes; return p; }
+        cur_ = static_cast<char*>(p);
+        left_ = slab;
+    }
+    void* out = cur_;
+    cur_ += need;
+    left_ -= need;
     total_ += bytes;
-    return p;
+    return out;
 }
 
 template <typename T> T* DevicePool::upload(const T* host, size_t n, hipStream_t s)
@@ -229,7 +241,9 @@ Engine::~Engine()
     (void)hipSetDevice(cfg_.device);
     (void)hipDeviceSynchronize();
     current_.reset();
+    latched_.reset();
     in_flight_.reset();
+    retired_.clear();
     for (uint8_t* p : d_frames_) (void)hipFree(p);
     if (d_pano_) (void)hipFree(d_pano_);
     if (d_mask_) (void)hipFree(d_mask_);
@@ -245,7 +259,33 @@ Engine::~Engine()
 std::shared_ptr<CalibState> Engine::state() const
 {
     std::lock_guard<std::mutex> lk(mu_);
-    return current_;
+    return latching_ ? latched_ : current_;
+}
+
+std::shared_ptr<CalibState> Engine::acquire()
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    latched_ = current_;
+    latching_ = true;
+    return latched_;
+}
+
+void Engine::set_in_flight(std::shared_ptr<CalibState> st)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (in_flight_ == st) return;
+    if (in_flight_) retired_.push_back(std::move(in_flight_));     // pointer move only: no teardown on this thread
+    in_flight_ = std::move(st);
+}
+
+void Engine::drop_retired()
+{
+    std::vector<std::shared_ptr<CalibState>> old;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        old.swap(retired_);
+    }
+    old.clear();          // ~CalibState (device sync + frees) outside the lock
 }
 
 void Engine::synchronize()
@@ -257,6 +297,7 @@ void Engine::synchronize()
 void Engine::update(const mst_calibration& calib)
 {
     select_device(cfg_.device);
+    drop_retired();
     if (calib.num_cameras != cfg_.num_cameras || !calib.cameras)
         throw Error{MST_ERR_INVALID_ARG, "calibration camera count does not match the engine"};
     if (!(calib.warped_image_scale > 0.f)) throw Error{MST_ERR_INVALID_ARG, "warped_image_scale must be > 0"};
@@ -479,8 +520,14 @@ void Engine::update(const mst_calibration& calib)
     check_hip(hipGetLastError(), "calibration kernels");
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(calibration)");
 
-    std::lock_guard<std::mutex> lk(mu_);
-    current_ = std::move(st);     // takes effect at the next compose (Upflag / UpdateMat)
+    std::shared_ptr<CalibState> old;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        st->generation = ++next_generation_;
+        old = std::move(current_);
+        current_ = std::move(st);     // takes effect at the next compose / acquire (Upflag / UpdateMat)
+    }
+    old.reset();                      // if nobody else holds it: torn down here, on the calibration thread
 }
 
 void Engine::compose_device(const void* const* d_frames, const size_t* strides, void* d_pano, size_t pano_stride,
@@ -495,8 +542,16 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
                            size_t pano_stride, void* const* d_masks, size_t mask_stride, hipStream_t stream,
                            StageTimer* timer)
 {
+    compose_batch_on(state(), count, d_frames, strides, d_panos, pano_stride, d_masks, mask_stride, stream, timer);
+}
+
+// One calibration state for the whole call: callers that size buffers first (compose_host) pass the snapshot they
+// sized them from, so a concurrent mst_update cannot slip a different canvas in between.
+void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
+                              void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
+                              hipStream_t stream, StageTimer* timer)
+{
     select_device(cfg_.device);
-    std::shared_ptr<CalibState> st = state();
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
     if (!d_frames || !strides || !d_panos) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama table"};
     if (count < 1 || count > kMaxBatch) throw Error{MST_ERR_INVALID_ARG, "batch size out of range"};
@@ -608,8 +663,7 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
         }
     }
     check_hip(hipGetLastError(), "compose kernels");
-    std::lock_guard<std::mutex> lk(mu_);
-    in_flight_ = std::move(st);
+    set_in_flight(std::move(st));
 }
 
 namespace {
@@ -639,8 +693,9 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
     FrameArgs& fa = fb.f[0];
     for (int i = 0; i < st->n; ++i) {
         if (!(camera_mask >> i & 1u)) continue;
-        if (!d_frames[i] || strides[i] < static_cast<size_t>(st->cams[i].src_w) * 3 || strides[i] >= (size_t{1} << 24))
-            throw Error{MST_ERR_INVALID_ARG, "bad frame for a camera in the mask"};
+        if (!d_frames[i] || strides[i] < static_cast<size_t>(st->cams[i].src_w) * 3 || strides[i] >= (size_t{1} << 24) ||
+            strides[i] * static_cast<size_t>(st->cams[i].src_h) > 0xFFFFFFFFull)
+            throw Error{MST_ERR_INVALID_ARG, "bad frame for a camera in the mask (stride below 16 MiB, frame below 4 GiB)"};
         fa.ptr[i] = static_cast<const uint8_t*>(d_frames[i]);
         fa.stride[i] = static_cast<uint32_t>(strides[i]);
     }
@@ -673,8 +728,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
             launch_pyr_chain(st->d_desc, st->n, tl, plan.chain[k].base, plan.chain[k].k, 1, s);
         }
     check_hip(hipGetLastError(), "camera stage kernels");
-    std::lock_guard<std::mutex> lk(mu_);
-    in_flight_ = std::move(st);
+    set_in_flight(std::move(st));
 }
 
 void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t mask_stride, hipStream_t stream)
@@ -687,14 +741,15 @@ void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t
     if (pano_stride >= (size_t{1} << 24) || mask_stride >= (size_t{1} << 24))
         throw Error{MST_ERR_INVALID_ARG, "panorama and mask strides must be below 16 MiB"};
     if (d_mask && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
+    if (pano_stride * static_cast<size_t>(st->out_h) > 0xFFFFFFFFull)
+        throw Error{MST_ERR_INVALID_ARG, "panoramas of 4 GiB and more are not supported (32-bit byte offsets)"};
     hipStream_t s = stream ? stream : stream_;
     BlendArgs ba = st->blend;
     ba.pano[0] = static_cast<uint8_t*>(d_pano); ba.pano_stride = static_cast<uint32_t>(pano_stride);
     ba.pano_mask[0] = static_cast<uint8_t*>(d_mask); ba.mask_stride = static_cast<uint32_t>(mask_stride);
     launch_blend(st->d_desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, 1, st->plan.lds_bytes, s);
     check_hip(hipGetLastError(), "canvas stage kernel");
-    std::lock_guard<std::mutex> lk(mu_);
-    in_flight_ = std::move(st);
+    set_in_flight(std::move(st));
 }
 
 void Engine::pyramid_buffer(int camera, void** d_ptr, size_t* bytes)
@@ -748,7 +803,9 @@ void Engine::compose_host(const uint8_t* const* frames, const size_t* strides, u
     }
     in_host_compose_ = true;     // the H2D copies above are queued on stream_: keep everything in stream order
     try {
-        compose_device(dptr.data(), dstride.data(), d_pano_, prow, pano_mask ? d_mask_ : nullptr, mrow, stream_);
+        void* panos[1] = {d_pano_};
+        void* masks[1] = {d_mask_};
+        compose_batch_on(st, 1, dptr.data(), dstride.data(), panos, prow, pano_mask ? masks : nullptr, mrow, stream_, nullptr);
     } catch (...) {
         in_host_compose_ = false;
         throw;

@@ -27,6 +27,9 @@ struct Error {
 };
 
 // Owns every device allocation of one calibration state (or one stage-level call).
+// Allocations are carved out of a few large slabs (bump pointer, 256-byte aligned): a calibration state holds
+// several hundred buffers, and one hipMalloc / hipFree each is what used to dominate mst_update and the
+// teardown of a retired state.
 class DevicePool {
 public:
     DevicePool() = default;
@@ -39,7 +42,9 @@ public:
     template <typename T> T* upload(const std::vector<T>& v, hipStream_t s) { return upload(v.data(), v.size(), s); }
     size_t bytes() const { return total_; }
 private:
-    std::vector<void*> ptrs_;
+    std::vector<void*> ptrs_;       // slabs
+    char* cur_ = nullptr;           // bump pointer inside the newest slab
+    size_t left_ = 0;
     size_t total_ = 0;
 };
 
@@ -82,6 +87,7 @@ struct CalibState {
     float* d_feather_ws = nullptr;
     // output rectangle (== canvas unless the driver LUT crop is active)
     int crop_x = 0, crop_y = 0, out_w = 0, out_h = 0;
+    uint64_t generation = 0;            // 1, 2, ... in mst_update order (mst_acquire_calibration)
     ~CalibState();
 };
 
@@ -116,13 +122,20 @@ public:
     void stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t mask_stride, hipStream_t stream);
     void pyramid_buffer(int camera, void** d_ptr, size_t* bytes);
     void synchronize();
+    // The calibration the next compose call will use: the newest published one, or -- once the frame thread has
+    // called acquire() -- the one it latched there (the reference's `if (Upflag) UpdateMat()`, DRV:835-836).
     std::shared_ptr<CalibState> state() const;
+    std::shared_ptr<CalibState> acquire();             // latch the newest calibration for the following composes
     void debug_read(int what, int camera, int level, void* buf, size_t buf_bytes, int* w, int* h);
 
     const mst_config& config() const { return cfg_; }
-    std::string last_error;
 
 private:
+    void compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
+                          void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
+                          hipStream_t stream, StageTimer* timer);
+    void set_in_flight(std::shared_ptr<CalibState> st);   // keeps `st` alive; the previous one goes to retired_
+    void drop_retired();                                   // calibration thread / destructor: tear old states down
     mst_config cfg_;
     hipStream_t stream_ = nullptr;        // compose stream
     hipStream_t calib_stream_ = nullptr;  // mst_update builds the next state here
@@ -136,7 +149,13 @@ private:
     uint64_t frame_counter_ = 0;
     mutable std::mutex mu_;
     std::shared_ptr<CalibState> current_;
+    std::shared_ptr<CalibState> latched_;     // acquire(): what compose uses while latching_ (else current_)
+    bool latching_ = false;
+    uint64_t next_generation_ = 0;
     std::shared_ptr<CalibState> in_flight_;   // state used by the most recent compose
+    // States no compose will start on any more.  Their teardown (device sync + frees) must not run on the frame
+    // thread: they are parked here by pointer move and destroyed by the next mst_update or by the destructor.
+    std::vector<std::shared_ptr<CalibState>> retired_;
     // staging for compose_host
     std::vector<uint8_t*> d_frames_;
     std::vector<size_t> d_frame_bytes_;

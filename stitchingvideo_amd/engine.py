@@ -249,6 +249,13 @@ class PanoramaEngine:
         cal = capi.Calibration(C.sizeof(capi.Calibration), n, float(scale), arr)
         self._check(self._L.mst_update(self._h, C.byref(cal)))
 
+    def acquire(self):
+        """Latch the newest calibration for the following compose calls (the frame thread's
+        `if (Upflag) UpdateMat();`, DRV:835-836) -> (canvas rect, generation)."""
+        r, g = capi.Rect(), C.c_uint64()
+        self._check(self._L.mst_acquire_calibration(self._h, C.byref(r), C.byref(g)))
+        return r.tuple(), g.value
+
     def canvas(self):
         r = capi.Rect()
         self._check(self._L.mst_canvas(self._h, C.byref(r)))
@@ -271,7 +278,9 @@ class PanoramaEngine:
               for f in frames]
         ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in fr])
         strides = (C.c_size_t * n)(*[f.strides[0] for f in fr])
-        _, _, w, h = self.canvas()
+        # latch first, size the buffers from the latched canvas, compose against the same calibration: a concurrent
+        # update() cannot change the panorama size in between
+        (_, _, w, h), _ = self.acquire()
         pano = np.empty((h, w, 3), np.uint8)
         mask = np.empty((h, w), np.uint8) if want_mask else None
         self._check(self._L.mst_compose(self._h, ptrs, strides, pano.ctypes.data, pano.strides[0],

@@ -105,6 +105,10 @@ class ShardedStitcher:
          (grouped point-to-point over RCCL: every peer has its own xGMI link to the root; no all-reduce --
          the payload is ragged and must arrive bit-exact);
       3. the root runs the canvas kernel (mst_stage_canvas).
+
+    The pyramid buffers belong to a calibration state and are freed when it is retired, so the zero-copy views
+    are tied to the calibration generation: compose() latches the calibration (engine.acquire()) and rebuilds
+    the views whenever the generation moved.  Every rank must publish the same calibrations in the same order.
     """
 
     def __init__(self, engine, rank, world, root=0, device=None):
@@ -113,21 +117,56 @@ class ShardedStitcher:
         n = engine.num_cameras
         self.owners = [owner_of_stream(c, world) for c in range(n)]
         self.mine = streams_of_rank(rank, world, n)
-        self.views = {c: pyramid_tensor(engine, c, device) for c in range(n)}
+        self.generation = None
+        self.views = {}
+
+    def refresh(self):
+        """Latch the newest calibration; (re)build the views of its pyramid buffers if it changed."""
+        _, gen = self.engine.acquire()
+        if gen != self.generation:
+            cams = range(self.engine.num_cameras) if self.rank == self.root else self.mine
+            self.views = {c: pyramid_tensor(self.engine, c, self.device) for c in cams}
+            self.generation = gen
+        return gen
+
+    def payload_bytes(self):
+        """Bytes the root receives per frame (0 on one rank); valid after the first refresh()/compose()."""
+        if self.generation is None:
+            self.refresh()
+        if self.rank != self.root:
+            return sum(int(self.views[c].numel()) for c in self.mine)
+        return sum(int(self.views[c].numel()) for c, o in enumerate(self.owners) if o != self.root)
 
     def compose(self, frame_ptrs, frame_strides, pano_ptr=None, pano_stride=0, stream=None):
-        """frame_ptrs / frame_strides: {camera: value} for the cameras this rank owns."""
+        """frame_ptrs / frame_strides: {camera: value} for the cameras this rank owns.
+
+        The kernels and the point-to-point transfers must share one stream order: RCCL orders its operations
+        against torch's CURRENT stream only, so `stream` defaults to exactly that (never the engine's private
+        stream) and a caller that passes one must have made it torch's current stream."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.refresh()
         self.engine.stage_cameras(self.mine, frame_ptrs, frame_strides, stream=stream)
         if self.world > 1:
-            reqs = []
+            ops = []
             if self.rank == self.root:
                 for c, owner in enumerate(self.owners):
                     if owner != self.root:
-                        reqs.append(dist.irecv(self.views[c], src=owner, tag=c))
+                        ops.append(dist.P2POp(dist.irecv, self.views[c], owner, tag=c))
             else:
                 for c in self.mine:
-                    reqs.append(dist.isend(self.views[c], dst=self.root, tag=c))
-            for r in reqs:
-                r.wait()
+                    ops.append(dist.P2POp(dist.isend, self.views[c], self.root, tag=c))
+            if ops:
+                for r in dist.batch_isend_irecv(ops):      # one ncclGroupStart/End around all transfers of the frame
+                    r.wait()
         if self.rank == self.root:
             self.engine.stage_canvas(pano_ptr, pano_stride, stream=stream)
+
+
+def copy_payload(src_engine, dst_engine, cameras, device, stream=None):
+    """One-GPU stand-in for the exchange step: copy the hand-off payload of `cameras` from one engine into
+    another (tests emulate two ranks with two engines on one device)."""
+    for c in cameras:
+        src, dst = pyramid_tensor(src_engine, c, device), pyramid_tensor(dst_engine, c, device)
+        assert src.numel() == dst.numel() and src.numel() > 0
+        dst.copy_(src)

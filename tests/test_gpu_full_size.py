@@ -1,0 +1,75 @@
+"""Every BASELINE config at full size in the driver-run suite (SURVEY.md 8d geometry), one frame each, engine vs
+oracle, bit for bit: C2 (2x1080p plane + feather), C3 (test_gpu_parity.py), C4 (8x1080p spherical, through the
+camera-sharded stage calls of two engines -- the one-GPU emulation of the per-GPU split) and C5 (6x4K cylindrical,
+5 bands: the config closest to the 32-bit offset / 24-bit row-product / map-table window limits)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from stitchingvideo_amd import rig as rigmod
+
+pytestmark = pytest.mark.gpu
+
+THREADS = min(32, os.cpu_count() or 1)
+
+
+def test_full_size_c2_feather():
+    rig = rigmod.build_rig(rigmod.CONFIGS["C2"])
+    frames = rigmod.frames_for(rig, 1)
+    eng = H.make_engine(rig)
+    assert eng.canvas()[2:] == (3259, 1406)
+    pano, mask = eng.compose(frames)
+    rect, opano, omask = H.oracle_compose(rig, frames, threads=THREADS)
+    assert eng.canvas() == rect
+    assert np.array_equal(mask, omask), H.diff_report(mask, omask)
+    assert np.array_equal(pano, opano), H.diff_report(pano, opano)
+    eng.close()
+
+
+def test_full_size_c5_4k_cylindrical_multiband():
+    rig = rigmod.build_rig(rigmod.CONFIGS["C5"])
+    frames = rigmod.frames_for(rig, 1)
+    eng = H.make_engine(rig)
+    assert eng.canvas()[2:] == (15706, 2159)
+    assert eng.num_bands() == 5
+    pano, mask = eng.compose(frames)
+    rect, opano, omask = H.oracle_compose(rig, frames, threads=THREADS)
+    assert eng.canvas() == rect
+    assert np.array_equal(mask, omask), H.diff_report(mask, omask)
+    assert np.array_equal(pano, opano), H.diff_report(pano, opano)
+    eng.close()
+
+
+def test_full_size_c4_camera_sharded_two_engines():
+    """C4 as specified is 8 cameras on 8 GPUs with one gather; on one GPU two engines stand in for two ranks:
+    each stages its own cameras, the hand-off payload of rank 1's cameras is copied into rank 0 (what the RCCL
+    point-to-point exchange does), rank 0 runs the canvas stage.  Also checked: the plain one-engine compose."""
+    import torch
+    from stitchingvideo_amd import sharding as sh
+    rig = rigmod.build_rig(rigmod.CONFIGS["C4"])
+    frames = rigmod.frames_for(rig, 2)
+    dev = torch.device("cuda", 0)
+    e0, e1 = H.make_engine(rig), H.make_engine(rig)
+    assert e0.canvas()[2:] == (11308, 1050)
+    n = len(frames)
+    dfr = [torch.from_numpy(f).to(dev) for f in frames]
+    ptrs = {i: dfr[i].data_ptr() for i in range(n)}
+    strides = {i: dfr[i].stride(0) for i in range(n)}
+    mine0, mine1 = sh.streams_of_rank(0, 2, n), sh.streams_of_rank(1, 2, n)
+    _, _, cw, ch = e0.canvas()
+    pano = torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        e0.stage_cameras(mine0, {i: ptrs[i] for i in mine0}, {i: strides[i] for i in mine0}, stream=stream.cuda_stream)
+        e1.stage_cameras(mine1, {i: ptrs[i] for i in mine1}, {i: strides[i] for i in mine1}, stream=stream.cuda_stream)
+        sh.copy_payload(e1, e0, mine1, dev, stream=stream.cuda_stream)
+        e0.stage_canvas(pano.data_ptr(), pano.stride(0), stream=stream.cuda_stream)
+    stream.synchronize()
+    rect, opano, omask = H.oracle_compose(rig, frames, threads=THREADS)
+    assert e0.canvas() == rect
+    assert np.array_equal(pano.cpu().numpy(), opano), H.diff_report(pano.cpu().numpy(), opano)
+    p1, m1 = e1.compose(frames)
+    assert np.array_equal(p1, opano) and np.array_equal(m1, omask)
+    e0.close(); e1.close()

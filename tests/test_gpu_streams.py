@@ -228,6 +228,63 @@ def test_recalibration_from_a_second_thread_while_composing():
     eng.close()
 
 
+def test_recalibration_that_changes_the_canvas_size_while_composing():
+    """A recalibration that moves R / scale changes the canvas rectangle.  The frame thread latches the calibration
+    (mst_acquire_calibration = `if (Upflag) UpdateMat();`, DRV:835-836), sizes its buffers from the latched canvas and
+    composes against exactly that state, while a second thread keeps publishing calibrations of two different canvas
+    sizes: every panorama must be one of the two oracle panoramas at its own size (host-buffer and device paths)."""
+    import threading
+    import torch
+    cfg_a = rigmod.scaled_config("C3", 8)
+    cfg_b = dict(cfg_a, focal=cfg_a["focal"] * 1.13, yaws=[y + 7.0 for y in cfg_a["yaws"]])
+    rig_a, rig_b = rigmod.build_rig(cfg_a), rigmod.build_rig(cfg_b)
+    host = rigmod.frames_for(rig_a, 3)
+    rect_a, pano_a, _ = H.oracle_compose(rig_a, host)
+    rect_b, pano_b, _ = H.oracle_compose(rig_b, host)
+    assert rect_a[2:] != rect_b[2:] and rect_b[3] > rect_a[3]          # B is wider AND taller than A
+    eng = H.make_engine(rig_a)
+    dev = torch.device("cuda", 0)
+    dfr = [torch.from_numpy(f).to(dev) for f in host]
+    ptrs, strides = [t.data_ptr() for t in dfr], [t.stride(0) for t in dfr]
+    errors, stop = [], threading.Event()
+
+    def recalibrate():
+        try:
+            i = 0
+            while not stop.is_set() and i < 40:
+                r = rig_b if i % 2 == 0 else rig_a
+                eng.update(r["scale"], r["cameras"])
+                i += 1
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+
+    t = threading.Thread(target=recalibrate)
+    t.start()
+    seen = set()
+    try:
+        for i in range(60):
+            if i % 2 == 0:                       # host-buffer path: sizes from the latch inside compose()
+                pano, mask = eng.compose(host)
+            else:                                # device path: explicit latch, then buffers, then compose
+                (_, _, cw, ch), gen = eng.acquire()
+                d_pano = torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev)
+                eng.compose_device(ptrs, strides, d_pano.data_ptr(), d_pano.stride(0))
+                eng.synchronize()
+                assert eng.canvas()[2:] == (cw, ch)          # still the latched one, whatever was published meanwhile
+                pano = d_pano.cpu().numpy()
+            want = pano_a if pano.shape == pano_a.shape else pano_b
+            assert pano.shape == want.shape and np.array_equal(pano, want), "compose %d: wrong geometry or pixels" % i
+            seen.add(pano.shape == pano_b.shape)
+    finally:
+        stop.set()
+        t.join()
+    assert not errors, errors
+    eng.update(rig_b["scale"], rig_b["cameras"])
+    pano, _ = eng.compose(host)
+    assert np.array_equal(pano, pano_b) and eng.canvas() == rect_b
+    eng.close()
+
+
 def test_profile_entry_points_report_every_launch():
     """mst_compose_profile(_batch): one HIP event between consecutive launches, names and durations per stage."""
     import torch
