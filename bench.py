@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--shard", default="frames", choices=["frames", "cameras"],
                     help="N > 1 headline: frames = every rank stitches its own frame sets (default, no collective); "
                          "cameras = camera i on rank i %% N, payload sent to rank 0 over RCCL, rank 0 blends (SURVEY 8e)")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the one-frame-set-per-sequence measurement (profiling runs)")
     ap.add_argument("--no-camera-leg", action="store_true", help="N > 1: skip the camera-sharded secondary measurement")
     ap.add_argument("--camera-leg-steps", type=int, default=100)
     ap.add_argument("--undistort", action="store_true",
@@ -315,7 +316,7 @@ def main():
                                   % (sum(k["launches_per_sequence"] for k in kernels), batch),
                          "dominant_kernel": dominant, "kernels": kernels},
         }
-        if batch > 1:
+        if batch > 1 and not args.no_latency_leg:
             # latency mode on the same engine: one frame set per launch sequence, as the reference's StitchingAll()
             one = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),
                                         pano.stride(0), stream=stream) for ds in dev_sets]

@@ -436,6 +436,13 @@ int mst_multiband_geometry(mst_rect canvas, int num_bands, mst_rect image, mst_r
     });
 }
 
+// Diagnostic builds only (make CXXFLAGS+=-DMST_STAMPS): in-kernel phase stamps of the last launches of kernels A (0)
+// and C (1), 16 slots per block.  Not declared in the public header; tools/stamps.py binds it by name.
+int mst_debug_stamps(int which, unsigned long long* out, size_t n)
+{
+    return mst::mb_read_stamps(which, out, n);
+}
+
 // ---- synthetic frames ------------------------------------------------------------------------------
 
 int mst_synth_frame(int camera, int frame_index, int width, int height, uint8_t* dst, size_t stride)

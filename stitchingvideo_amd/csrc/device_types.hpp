@@ -105,8 +105,11 @@ struct BlendArgs {
     uint8_t* pano[kMaxBatch]; uint32_t pano_stride;          // one panorama (and optional mask) per frame set
     uint8_t* pano_mask[kMaxBatch]; uint32_t mask_stride;
     const uint32_t* block_cams;               // per block: bit i set = camera i has non-zero weight under the tile
+    const uint32_t* block_pure;               // per block: bit l set = level l of the tile is owned by ONE camera with
+                                              // weight exactly 1 (integer band path); that camera's index << 16
     const uint32_t* block_order;              // tile index (ty * tiles_x + tx) handled by block i
     int32_t tiles_x;
+    int32_t n_tiles, n_sets;                  // canvas tiles and frame sets of this launch (filled in by launch_blend)
     int32_t lds_off[kMaxLevels];              // LDS offset (in pixels) of each level's region buffer
     int16_t* dbg_C[kMaxLevels];               // optional dump of the collapsed levels (MST_FLAG_DEBUG)
     float alpha;                              // (float)(1./255.)

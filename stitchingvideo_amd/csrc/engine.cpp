@@ -480,6 +480,7 @@ void Engine::update(const mst_calibration& calib)
         for (int l = 0; l <= nb; ++l) ba.lds_off[l] = plan.lds_off[l];
         if (plan.lds_bytes > 64 * 1024) throw Error{MST_ERR_INVALID_ARG, "canvas kernel LDS budget exceeded"};
         ba.block_cams = st->pool.upload(plan.block_cams, s);
+        ba.block_pure = st->pool.upload(plan.block_pure, s);
         ba.block_order = st->pool.upload(plan.block_order, s);
         st->warp_list.tiles = st->pool.upload(plan.warp_tiles, s);
         st->warp_list.count = static_cast<int32_t>(plan.warp_tiles.size());

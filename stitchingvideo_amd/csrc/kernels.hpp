@@ -27,8 +27,11 @@ void launch_feather_weight_sum(const CamDesc* d_cams, int n_cams, float* d_ws, i
 
 // ---- per-frame hot path: multi-band (kernels_mb.hip) ----
 void mb_tile_dims(int* a_tw0, int* a_th0, int* b_t, int* c_tw, int* c_th);
+int  mb_read_stamps(int which, unsigned long long* out, size_t n);                // diagnostic builds (-DMST_STAMPS) only
+int  mb_read_stamps(int which, unsigned long long* out, size_t n);                // diagnostic builds (-DMST_STAMPS) only
 int  mb_chain_depth();                                                           // levels per k_pyr_chain launch
 void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4]);   // x0, y0, x1, y1
+int  mb_blend_region_lds_pixels(const BlendArgs& a, int tx, int ty, int level);      // LDS footprint of that region
 size_t mb_warp_table_entries(int num_tiles);                                         // 32-bit entries for `num_tiles` tiles
 void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, int2* d_tile_base,
                        hipStream_t s);

@@ -26,6 +26,7 @@
 // packed pixels + SWAR pyramids, the per-calibration map table with BORDER_REFLECT folded into it, integer
 // paths wherever the weights are exactly 0/1, keeping the software pipelines intact through the compiler
 // (global address space, no branches around in-flight loads, full unrolling), and batching frame sets.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -37,6 +38,25 @@
 namespace mst {
 
 using namespace dev;
+
+#if defined(MST_STAMPS)
+// Diagnostic build only (-DMST_STAMPS, tools/stamps.sh): per block, shader-clock stamps at the phase boundaries of
+// kernels A and C, written to a buffer nothing else reads and copied out by mst_debug_stamps().  Never timed.
+__device__ unsigned long long g_stamps[2][1 << 17];
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MST_STAMP(which, slot) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 13)) g_stamps[which][blockIdx.x * 16 + (slot)] = stamp_now(); } while (0)
+#define MST_STAMP_VAL(which, slot, v) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 13)) g_stamps[which][blockIdx.x * 16 + (slot)] = (v); } while (0)
+#else
+#define MST_STAMP(which, slot) do {} while (0)
+#define MST_STAMP_VAL(which, slot, v) do {} while (0)
+#endif
 
 namespace {
 
@@ -338,19 +358,31 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
 // USE_TABLE: read the backward map from the per-calibration table instead of evaluating it (fewer VALU
 // instructions, one more dependent load per pixel).  Measured on MI355X (C3): 81.5 us with the table vs
 // 76 us without while the gather comes from global memory, so the default evaluates the map in place.
+#ifndef MST_A_WAVES
+#define MST_A_WAVES 1
+#endif
 template <int KIND, bool USE_TABLE>
-__global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ cams_all, TileList list, FrameBatch batch,
+__global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __restrict__ cams_all, TileList list, FrameBatch batch,
                                                   const uint32_t* __restrict__ table, const int2* __restrict__ tile_base,
-                                                  int n_cams)
+                                                  int n_cams, int n_sets)
 {
-    // blockIdx.y = frame set of a batched launch: its own frames and its own copy of the descriptors (pyramids)
-    const CamDesc* __restrict__ cams = cams_all + blockIdx.y * n_cams;
-    const FrameArgs& frames = batch.f[blockIdx.y];
+    // One block per (tile, frame set) of a batched launch, on a 1-D grid ordered so that the frame sets of a tile are
+    // consecutive entries of one XCD's run (xcd_run_index): they are dispatched together onto that XCD, and the
+    // tile's slice of the backward-map table -- frame-invariant, 18 KB, and at 46.6 MB per frame set the largest
+    // stream of this kernel when every frame set fetched it from HBM for itself -- is fetched once into that XCD's
+    // L2 and served from there to the other frame sets.  (With the frame set on grid.y the same tile's blocks were a
+    // whole grid row apart: different XCDs, and long evicted.)  A frame set has its own frames and its own copy of
+    // the descriptors (pyramids).
+    MST_STAMP(0, 0);
+    const int pair = xcd_run_index(blockIdx.x, list.count * n_sets);
+    const int set = pair % n_sets;
+    const CamDesc* __restrict__ cams = cams_all + set * n_cams;
+    const FrameArgs& frames = batch.f[set];
     __shared__ __attribute__((aligned(16))) uint32_t s_l0[A_LH][A_LW];   // level-0 tile with halo, packed (18 KB)
     __shared__ RowEntry s_rows[A_LH];
     __shared__ float s_gain_rows[A_GAIN_ROWS][A_LW];   // BlocksGainCompensator: HResizeLinear of the rows the tile spans
 
-    const int li = xcd_run_index(blockIdx.x, list.count);       // position in the tile list
+    const int li = pair / n_sets;                               // position in the tile list
     const uint32_t t = list.tiles[li];
     const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
@@ -434,6 +466,7 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
         }
     }
     const float* H = &s_gain_rows[0][col];
+    MST_STAMP(0, 1);
 
     const int gx = lx0 + col;
     const bool col_interior = col >= 2 && col < A_LW - 2 && gx < bw;
@@ -502,8 +535,10 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
     } else {
         if (big) run(std::integral_constant<int, 0>{}, Yes{}); else run(std::integral_constant<int, 0>{}, No{});
     }
+    MST_STAMP(0, 2);
     if (nlev < 2 || (MST_ABLATE_A & 4)) return;
     __syncthreads();
+    MST_STAMP(0, 3);
 
     // pyrDown straight from the LDS tile: output (j, i) reads rows 2i..2i+4, columns 2j..2j+4.  A thread owns one
     // output column and a run of A_TH1 / 4 consecutive output rows, so the horizontal [1 4 6 4 1] of a tile row is
@@ -530,6 +565,7 @@ __global__ __launch_bounds__(256) void k_warp_pyr(const CamDesc* __restrict__ ca
                 g1out[__umul24(y1 + i, lw1) + x1 + j] = pyrdown_finish(vbr, vg);
             }
         }
+        MST_STAMP(0, 4);
         return;
     }
     for (int idx = tid; idx < A_TH1 * A_TW1; idx += 256) {
@@ -572,15 +608,31 @@ constexpr int B_KMAX = 2;
 // region extents of a full k = 2 chain: e2 = B_T / 4 outputs, each level below needs 2 e + 3 inputs
 constexpr int B_E1 = 2 * (B_T / 4) + 3, B_E0 = 2 * B_E1 + 3;
 
+// LDS row pitch of a region whose rows are read by consecutive lanes at a stride of two pixels (8-byte reads),
+// `en` lanes per output row (en even): with pitch == en (mod 32) the lanes that continue on the next output row
+// start exactly where the previous row's lanes stopped (mod the 64 banks), so a wave's reads tile the banks without
+// a conflict; any other pitch puts two lanes on a bank for part of every row pair.  The pitch stays even, which keeps
+// every row's pixel pairs 8-byte aligned.
+constexpr int chain_pitch(int es, int en)
+{
+    int p = (es / 32) * 32 + (en % 32);
+    return p >= es ? p : p + 32;
+}
+constexpr int even_up(int v) { return (v + 1) & ~1; }
+
 template <int K>
 __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restrict__ cams_all, TileList list, int base,
                                                          int n_cams)
 {
     const CamDesc* __restrict__ cams = cams_all + blockIdx.y * n_cams;
     constexpr int k = K;
-    // regions of levels base and base+1, back to back (21.3 + 4.9 KB)
-    constexpr int kOff1 = B_E0 * B_E0;
-    __shared__ uint32_t s_all[kOff1 + B_E1 * B_E1];
+    // extents e[j] (compile-time) of the regions each level covers, and their LDS pitches
+    constexpr int e[B_KMAX + 1] = {K == 2 ? B_E0 : 2 * (B_T / 2) + 3, K == 2 ? B_E1 : B_T / 2, B_T / 4};
+    constexpr int pitch[B_KMAX] = {chain_pitch(e[0], even_up(e[1])), chain_pitch(e[1], even_up(e[2]))};
+    static_assert(pitch[0] % 2 == 0 && pitch[1] % 2 == 0, "8-byte aligned pixel pairs need an even pitch");
+    // regions of levels base and base+1, back to back
+    constexpr int kOff1 = (pitch[0] * e[0] + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) uint32_t s_all[kOff1 + pitch[1] * e[1]];
     uint32_t* const s_e0 = s_all;
 
     const uint32_t t = list.tiles[xcd_run_index(blockIdx.x, list.count)];
@@ -588,8 +640,7 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
     const CamDesc& c = cams[cam];
     const int tid = threadIdx.x;
 
-    // extents e[j] (compile-time) and origins lo[j] (in level base+j coordinates) of the regions each level covers
-    constexpr int e[B_KMAX + 1] = {K == 2 ? B_E0 : 2 * (B_T / 2) + 3, K == 2 ? B_E1 : B_T / 2, B_T / 4};
+    // origins lo[j] (in level base+j coordinates) of the regions
     int lox[B_KMAX + 1], loy[B_KMAX + 1];
     lox[k] = (tx * B_T) >> k;
     loy[k] = (ty * B_T) >> k;
@@ -620,7 +671,8 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
             const int idx = tid + u * B_THREADS;
-            if (idx < n0) s_e0[idx] = v[u];
+            const int yy = idx / e[0], xx = idx - yy * e[0];
+            if (idx < n0) s_e0[yy * pitch[0] + xx] = v[u];
         }
     }
     __syncthreads();
@@ -632,25 +684,27 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
         const uint32_t* __restrict__ s = s_all + offs[j];
         uint32_t* __restrict__ d = (j + 1 < B_KMAX) ? s_all + offs[j + 1] : nullptr;
         uint32_t MST_GLOBAL* __restrict__ gout = gp(c.G[base + j + 1]);
-        constexpr int dummy = 0; (void)dummy;
-        const int en = e[j + 1], es = e[j];
+        const int en = e[j + 1], es = pitch[j];
+        const int enp = even_up(en);                                 // lanes per output row (see chain_pitch)
         // interior of this tile at the destination level
         const int ix0 = (tx * B_T) >> (j + 1), iy0 = (ty * B_T) >> (j + 1), isz = B_T >> (j + 1);
-        for (int idx = tid; idx < en * en; idx += B_THREADS) {
-            const int yy = idx / en, xx = idx - yy * en;
+        for (int idx = tid; idx < enp * en; idx += B_THREADS) {
+            const int yy = idx / enp, xx = idx - yy * enp;
             const int ox = lox[j + 1] + xx, oy = loy[j + 1] + yy;    // destination coordinates
-            if (static_cast<unsigned>(ox) >= static_cast<unsigned>(dw) ||
+            if (xx >= en || static_cast<unsigned>(ox) >= static_cast<unsigned>(dw) ||
                 static_cast<unsigned>(oy) >= static_cast<unsigned>(dh))
                 continue;
             uint32_t vbr = 0, vg = 0;
             // lox[j] == 2*lox[j+1] - 2, so away from the image border tap q of output xx is column 2*xx + q
             const bool interior = 2 * ox - 2 >= 0 && 2 * ox + 2 < sw && 2 * oy - 2 >= 0 && 2 * oy + 2 < sh;
             if (interior) {
-                const uint32_t* r = s + (2 * yy) * es + 2 * xx;
+                const uint32_t* r = s + (2 * yy) * es + 2 * xx;          // even dword offset: 8-byte aligned pairs
 #pragma unroll
                 for (int ky = 0; ky < 5; ++ky, r += es) {
                     uint32_t hbr, hg;
-                    tap5(r[0], r[1], r[2], r[3], r[4], hbr, hg);
+                    const uint2 p01 = *reinterpret_cast<const uint2*>(r);
+                    const uint2 p23 = *reinterpret_cast<const uint2*>(r + 2);
+                    tap5(p01.x, p01.y, p23.x, p23.y, r[4], hbr, hg);
                     const uint32_t wy = (ky == 2) ? 6u : ((ky == 1 || ky == 3) ? 4u : 1u);
                     vbr += wy * hbr;
                     vg += wy * hg;
@@ -673,7 +727,7 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
                 }
             }
             const uint32_t v = pyrdown_finish(vbr, vg);
-            if (d && j + 1 < k) d[idx] = v;
+            if (d && j + 1 < k) d[yy * pitch[(j + 1 < B_KMAX) ? j + 1 : 0] + xx] = v;
             if (ox >= ix0 && ox < ix0 + isz && oy >= iy0 && oy < iy0 + isz)
                 gout[__umul24(oy, dw) + ox] = v;
         }
@@ -749,6 +803,16 @@ __device__ __forceinline__ uint2 pack3(int c0, int c1, int c2)
 {
     return make_uint2((static_cast<uint32_t>(c0) & 0xFFFFu) | (static_cast<uint32_t>(c1) << 16),
                       static_cast<uint32_t>(c2) & 0xFFFFu);
+}
+
+// Two horizontally adjacent pixels of an LDS level region as one 16-byte access.  Region origins, widths and quad
+// coordinates are all even and the dynamic LDS base is 16-byte aligned, so (row * width + x) * 8 is a multiple of
+// 16 for every quad: one ds_write_b128 / ds_read_b128 per quad row instead of two 8-byte accesses at a 16-byte
+// lane stride (which land two lanes on every bank).
+__device__ __forceinline__ void lds_store_pair(uint2* s, int idx, const int a[3], const int b[3])
+{
+    const uint2 pa = pack3(a[0], a[1], a[2]), pb = pack3(b[0], b[1], b[2]);
+    *reinterpret_cast<uint4*>(s + idx) = make_uint4(pa.x, pa.y, pb.x, pb.y);
 }
 
 // pyrUp of the collapsed coarser level held in LDS (signed shorts) around coarse pixel (j, i) given in
@@ -993,12 +1057,17 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
 #ifndef MST_ABLATE_C
 #define MST_ABLATE_C 0     // timing experiments only: 1 no coarse bands, 2 no collapse, 4 no final pyrUp, 8 no final band,
 #endif                     // 16 no panorama stores, 32 every tile on the single-camera integer path
+// LDS row pitch (in pixels) of a level region: its width rounded up to even, so that a quad row is one aligned
+// 16-byte access even where the top level's width is odd (the pad column takes the pair's second pixel there)
+__host__ __device__ inline int region_pitch(const Region& r) { return (r.x1 - r.x0 + 1) & ~1; }
+
 struct QuadIter {
     Region r;
-    int rw, qw, nq;
+    int rw, qw, nq, pitch;
     __device__ __forceinline__ QuadIter(const Region& reg) : r(reg)
     {
         rw = r.x1 - r.x0;
+        pitch = region_pitch(r);
         qw = (rw + 1) >> 1;
         nq = qw * ((r.y1 - r.y0 + 1) >> 1);
     }
@@ -1045,10 +1114,11 @@ __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, con
         } else {
             band_quad<TOP, false, PURE, W16>(cams, a, l, x, y, valid, cam_bits, n, ws);
         }
+        // (x, region origin and region width are even: both pixels of a quad row are valid or invalid together)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (valid[k])
-                s_out[__mul24(y + (k >> 1) - it.r.y0, it.rw) + (x + (k & 1) - it.r.x0)] = pack3(n[k][0], n[k][1], n[k][2]);
+        for (int ry = 0; ry < 2; ++ry)
+            if (valid[2 * ry])
+                lds_store_pair(s_out, __mul24(y + ry - it.r.y0, it.pitch) + (x - it.r.x0), n[2 * ry], n[2 * ry + 1]);
     }
 }
 
@@ -1057,9 +1127,12 @@ __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, con
 // course, five times in a row.  Here the quads of every level form one index space cut into 64-quad chunks
 // (coarsest level first); the waves of the block take chunks round-robin, so the levels are in flight together.
 // The level of a chunk is wave-uniform, which keeps every descriptor access scalar.
+// Tiles that are not pure still own most of their levels outright (a tile a few hundred pixels from a seam mixes
+// cameras on its coarsest levels only): `owned_levels` (bit l) / `owner_bits` send those levels down the integer path.
 template <bool PURE, bool W16 = false>
 __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, const BlendArgs& a, int top, int tx, int ty,
-                                            uint32_t cam_bits, uint2* __restrict__ lds)
+                                            uint32_t cam_bits, uint2* __restrict__ lds, uint32_t owned_levels = 0,
+                                            uint32_t owner_bits = 0)
 {
     constexpr int kWaves = C_THREADS / 64;
     const int lane = static_cast<int>(threadIdx.x & 63u);
@@ -1094,10 +1167,11 @@ __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, co
         } else {
             band_quad<false, false, PURE, W16>(cams, a, l, x, y, valid, cam_bits, n, ws);
         }
+        // (x, region origin and region width are even: both pixels of a quad row are valid or invalid together)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (valid[k])
-                s_out[__mul24(y + (k >> 1) - it.r.y0, it.rw) + (x + (k & 1) - it.r.x0)] = pack3(n[k][0], n[k][1], n[k][2]);
+        for (int ry = 0; ry < 2; ++ry)
+            if (valid[2 * ry])
+                lds_store_pair(s_out, __mul24(y + ry - it.r.y0, it.pitch) + (x - it.r.x0), n[2 * ry], n[2 * ry + 1]);
     }
 }
 
@@ -1122,17 +1196,19 @@ __device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx
         bool valid[4];
         it.at(q, x, y, valid);
         int up[4][3];
-        pyrup_quad_lds(s_up, ur.x0, ur.y0, ur.x1 - ur.x0, a.cw[l + 1], a.ch[l + 1], x >> 1, y >> 1, up);
+        pyrup_quad_lds(s_up, ur.x0, ur.y0, region_pitch(ur), a.cw[l + 1], a.ch[l + 1], x >> 1, y >> 1, up);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!valid[k]) continue;
-            const int px = x + (k & 1), py = y + (k >> 1);
-            uint2* p = s_io + __mul24(py - it.r.y0, it.rw) + (px - it.r.x0);
-            const uint2 n = *p;
-            const int v[3] = {sat_s16(up[k][0] + s16_lo(n.x)), sat_s16(up[k][1] + s16_hi(n.x)),
-                              sat_s16(up[k][2] + s16_lo(n.y))};           // cv::add saturates
-            *p = pack3(v[0], v[1], v[2]);
-            if (a.dbg_C[l]) dump_level(a, l, px, py, v);
+        for (int ry = 0; ry < 2; ++ry) {
+            if (!valid[2 * ry]) continue;
+            const int py = y + ry;
+            uint2* p = s_io + __mul24(py - it.r.y0, it.pitch) + (x - it.r.x0);
+            const uint4 n = *reinterpret_cast<const uint4*>(p);          // the quad row: two pixels, 16 bytes, aligned
+            const int v0[3] = {sat_s16(up[2 * ry][0] + s16_lo(n.x)), sat_s16(up[2 * ry][1] + s16_hi(n.x)),
+                               sat_s16(up[2 * ry][2] + s16_lo(n.y))};     // cv::add saturates
+            const int v1[3] = {sat_s16(up[2 * ry + 1][0] + s16_lo(n.z)), sat_s16(up[2 * ry + 1][1] + s16_hi(n.z)),
+                               sat_s16(up[2 * ry + 1][2] + s16_lo(n.w))};
+            lds_store_pair(s_io, __mul24(py - it.r.y0, it.pitch) + (x - it.r.x0), v0, v1);
+            if (a.dbg_C[l]) { dump_level(a, l, x, py, v0); dump_level(a, l, x + 1, py, v1); }
         }
     }
 }
@@ -1185,7 +1261,7 @@ __device__ __forceinline__ void final_level_pure_full(const CamDesc* __restrict_
     const Region r = blend_region(a, tx, ty, 0);
     const Region ur = blend_region(a, tx, ty, 1);
     const uint2* s_up = lds + a.lds_off[1];
-    const int upitch = ur.x1 - ur.x0;
+    const int upitch = region_pitch(ur);
     const CamDesc& c = cams[__builtin_ctz(cam_bits)];
     const int lw = c.lw[0], sw = c.lw[1], sh = c.lh[1];
     const int x = r.x0 + 2 * static_cast<int>(threadIdx.x & (C_TW / 2 - 1));
@@ -1277,7 +1353,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
         int up[4][3];
         if (MST_ABLATE_C & 4) {
             for (int k = 0; k < 4; ++k) up[k][0] = up[k][1] = up[k][2] = x - y + k;
-        } else if (!TOP) pyrup_quad_lds(s_up, ur.x0, ur.y0, ur.x1 - ur.x0, a.cw[1], a.ch[1], x >> 1, y >> 1, up);
+        } else if (!TOP) pyrup_quad_lds(s_up, ur.x0, ur.y0, region_pitch(ur), a.cw[1], a.ch[1], x >> 1, y >> 1, up);
         uint32_t o8[4][3];
         bool m[4];
 #pragma unroll
@@ -1295,20 +1371,35 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
 
 // W16 (weight_type CV_16S) is a separate instantiation: its integer divides would otherwise set the register
 // allocation (and spill) for the default kernel as well.
+#ifndef MST_C_WAVES
+#define MST_C_WAVES 1      // minimum waves per SIMD the register allocation must allow (occupancy experiments)
+#endif
 template <bool W16>
-__global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__ cams_all, BlendArgs a)
+__global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend(const CamDesc* __restrict__ cams_all, BlendArgs a)
 {
-    const CamDesc* __restrict__ cams = cams_all + blockIdx.y * a.n_cams;
-    uint8_t* __restrict__ pano = a.pano[blockIdx.y];
-    uint8_t* __restrict__ pano_mask = a.pano_mask[blockIdx.y];
+    // 1-D grid over (tile, frame set).  Blocks are dealt to the XCDs round-robin, so XCD k = blockIdx.x % 8 sees the
+    // blocks j = blockIdx.x / 8 in order: consecutive j are the frame sets of one tile (the weight pyramids and
+    // masks a seam tile reads are frame-invariant: fetched into that XCD's L2 once, shared by the other sets), and
+    // tiles go to the XCDs round-robin in launch order, which keeps "most expensive first" true on every XCD.
+    const int xj = blockIdx.x >> 3, xk = blockIdx.x & 7;
+    const int q = (xj / a.n_sets) * 8 + xk, set = xj % a.n_sets;
+    if (q >= a.n_tiles) return;
+    const CamDesc* __restrict__ cams = cams_all + set * a.n_cams;
+    uint8_t* __restrict__ pano = a.pano[set];
+    uint8_t* __restrict__ pano_mask = a.pano_mask[set];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* lds = reinterpret_cast<uint2*>(smem);
-    const uint32_t tile = a.block_order[blockIdx.x];
+    const uint32_t tile = a.block_order[q];
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const uint32_t entry = a.block_cams[tile];
     const bool pure = (MST_ABLATE_C & 32) ? true : (entry >> 31) != 0;   // see band_quad: one camera, weight exactly 1 everywhere
     const uint32_t cam_bits = entry & 0x7FFFFFFFu;
+    // levels of this tile owned by one camera with weight exactly 1 (bit l), and that camera
+    const uint32_t own = (MST_ABLATE_C & 512) ? 0u : a.block_pure[tile];
+    const uint32_t owned_levels = own & 0xFFFFu, owner_bits = 1u << (own >> 16);
     const int top = a.nlev - 1;
+    MST_STAMP(1, 0);
+    MST_STAMP_VAL(1, 8, static_cast<unsigned long long>(entry));
     if (top == 0) {
         if (pure) final_level<true, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
         else final_level<true, false, W16>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
@@ -1326,16 +1417,18 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
     } else if (pure) {
         band_levels<true>(cams, a, top, tx, ty, cam_bits, lds);
     } else {
-        band_levels<false, W16>(cams, a, top, tx, ty, cam_bits, lds);
+        band_levels<false, W16>(cams, a, top, tx, ty, cam_bits, lds, owned_levels, owner_bits);
     }
+    MST_STAMP(1, 1);
     __syncthreads();
+    MST_STAMP(1, 2);
     // phase 2: collapse coarse to fine (LDS only)
     if (a.dbg_C[top]) {
         const QuadIter it(blend_region(a, tx, ty, top));
         const uint2* s = lds + a.lds_off[top];
         for (int i = threadIdx.x; i < it.rw * (it.r.y1 - it.r.y0); i += C_THREADS) {
             const int py = it.r.y0 + i / it.rw, px = it.r.x0 + i % it.rw;
-            const uint2 n = s[i];
+            const uint2 n = s[(py - it.r.y0) * it.pitch + (px - it.r.x0)];
             const int v[3] = {s16_lo(n.x), s16_hi(n.x), s16_lo(n.y)};
             dump_level(a, top, px, py, v);
         }
@@ -1345,11 +1438,16 @@ __global__ __launch_bounds__(C_THREADS) void k_blend(const CamDesc* __restrict__
         __syncthreads();
     }
     // phase 3
+    MST_STAMP(1, 3);
     const Region r0 = blend_region(a, tx, ty, 0);
     const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
-    if (pure && full && !(MST_ABLATE_C & 64)) final_level_pure_full(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
-    else if (pure) final_level<false, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
+    // level 0 owned outright (true of every pure tile, and of most tiles near -- but not on -- a seam)
+    const bool own0 = pure || (owned_levels & 1u);
+    const uint32_t bits0 = pure ? cam_bits : owner_bits;
+    if (own0 && full && !(MST_ABLATE_C & 64)) final_level_pure_full(cams, a, tx, ty, bits0, lds, pano, pano_mask);
+    else if (own0) final_level<false, true>(cams, a, tx, ty, bits0, lds, pano, pano_mask);
     else final_level<false, false, W16>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
+    MST_STAMP(1, 4);
 }
 
 }  // namespace
@@ -1372,10 +1470,29 @@ void mb_tile_dims(int* a_tw0, int* a_th0, int* b_t, int* c_tw, int* c_th)
 
 int mb_chain_depth() { return B_KMAX; }
 
+int mb_read_stamps(int which, unsigned long long* out, size_t n)
+{
+#if defined(MST_STAMPS)
+    if (which < 0 || which > 1 || n > (size_t{1} << 17)) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long),
+                               static_cast<size_t>(which) * sizeof(unsigned long long) * (size_t{1} << 17),
+                               hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+#else
+    (void)which; (void)out; (void)n;
+    return -3;       // not a diagnostic build
+#endif
+}
+
 void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4])
 {
     const Region r = blend_region(a, tx, ty, level);
     out[0] = r.x0; out[1] = r.y0; out[2] = r.x1; out[3] = r.y1;
+}
+
+int mb_blend_region_lds_pixels(const BlendArgs& a, int tx, int ty, int level)
+{
+    const Region r = blend_region(a, tx, ty, level);
+    return region_pitch(r) * (r.y1 - r.y0);
 }
 
 size_t mb_warp_table_entries(int num_tiles) { return static_cast<size_t>(num_tiles) * A_LH * A_LW; }
@@ -1395,7 +1512,7 @@ void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList
     if (list.count <= 0 || batch <= 0) return;
     static const size_t pad = tuning_env("MST_A_PAD_LDS");
 #define MST_LAUNCH_A(K, T) \
-    hipLaunchKernelGGL((k_warp_pyr<K, T>), dim3(list.count, batch), dim3(256), pad, s, d_cams, list, frames, d_table, d_tile_base, n_cams)
+    hipLaunchKernelGGL((k_warp_pyr<K, T>), dim3(list.count * batch), dim3(256), pad, s, d_cams, list, frames, d_table, d_tile_base, n_cams, batch)
     if (d_table) {
         if (kind == 0) MST_LAUNCH_A(0, true); else if (kind == 1) MST_LAUNCH_A(1, true); else MST_LAUNCH_A(2, true);
     } else {
@@ -1411,11 +1528,16 @@ void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, i
     else hipLaunchKernelGGL(k_pyr_chain<2>, dim3(list.count, batch), dim3(B_THREADS), 0, s, d_cams, list, base, n_cams);
 }
 
-void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int batch, size_t lds_bytes, hipStream_t s)
+void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, int batch, size_t lds_bytes, hipStream_t s)
 {
     static const size_t pad = tuning_env("MST_C_PAD_LDS");
-    if (a.weights_16s) hipLaunchKernelGGL(k_blend<true>, dim3(num_blocks, batch), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
-    else hipLaunchKernelGGL(k_blend<false>, dim3(num_blocks, batch), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
+    if (num_blocks <= 0 || batch <= 0) return;
+    BlendArgs a = a_in;
+    a.n_tiles = num_blocks;
+    a.n_sets = batch;
+    const int grid = ((num_blocks + 7) / 8) * 8 * batch;
+    if (a.weights_16s) hipLaunchKernelGGL(k_blend<true>, dim3(grid), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
+    else hipLaunchKernelGGL(k_blend<false>, dim3(grid), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
 }
 
 }  // namespace mst

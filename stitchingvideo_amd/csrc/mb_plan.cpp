@@ -157,50 +157,76 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
     plan.blend_tiles_x = (blend.cw[0] + c_tw - 1) / c_tw;
     plan.blend_tiles_y = (blend.ch[0] + c_th - 1) / c_th;
     plan.block_cams.assign(static_cast<size_t>(plan.blend_tiles_x) * plan.blend_tiles_y, 0u);
+    plan.block_pure.assign(plan.block_cams.size(), 0u);
     std::vector<int> max_area(nlev, 0);
+    // any non-zero weight of camera c at level l inside [x0,x1) x [y0,y1) of the canvas level?  all exactly `unit`
+    // (and the camera's window covering the rectangle)?
+    auto any_nonzero = [&](int c, int l, int rx0, int ry0, int rx1, int ry1) {
+        const CamDesc& d = desc[c];
+        const int x0 = std::max(rx0 - d.ox[l], 0), y0 = std::max(ry0 - d.oy[l], 0);
+        const int x1 = std::min(rx1 - d.ox[l], d.lw[l]), y1 = std::min(ry1 - d.oy[l], d.lh[l]);
+        if (x0 >= x1 || y0 >= y1) return false;
+        const std::vector<uint8_t>& nz = plan.cams[c].nz[l];
+        for (int y = y0; y < y1; ++y) {
+            const uint8_t* row = nz.data() + static_cast<size_t>(y) * d.lw[l];
+            for (int x = x0; x < x1; ++x)
+                if (row[x]) return true;
+        }
+        return false;
+    };
+    auto all_unit = [&](int c, int l, int rx0, int ry0, int rx1, int ry1) {
+        const CamDesc& d = desc[c];
+        const int x0 = rx0 - d.ox[l], y0 = ry0 - d.oy[l], x1 = rx1 - d.ox[l], y1 = ry1 - d.oy[l];
+        if (x0 < 0 || y0 < 0 || x1 > d.lw[l] || y1 > d.lh[l]) return false;
+        const std::vector<float>& w = weights[c][l];
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x)
+                if (w[static_cast<size_t>(y) * d.lw[l] + x] != unit) return false;
+        return true;
+    };
     for (int ty = 0; ty < plan.blend_tiles_y; ++ty)
         for (int tx = 0; tx < plan.blend_tiles_x; ++tx) {
             uint32_t bits = 0;
+            // Levels on which the tile's region is owned by ONE camera with a weight of exactly 1.0f everywhere (and no
+            // other camera has a non-zero weight there): kernel C forms those bands on its integer-only path.  Level 0
+            // only counts the part of the region inside the final crop (pixels outside are never stored).  A tile whose
+            // levels are all owned by the same camera is "pure" (bit 31 of block_cams): no float arithmetic at all.
+            uint32_t level_mask = 0;
+            int owner = -1;
             for (int l = 0; l < nlev; ++l) {
                 int r[4];
                 mb_blend_region(blend, tx, ty, l, r);
-                max_area[l] = std::max(max_area[l], (r[2] - r[0]) * (r[3] - r[1]));
-                for (int c = 0; c < n; ++c) {
-                    if (bits >> c & 1u) continue;
-                    const CamDesc& d = desc[c];
-                    const int x0 = std::max(r[0] - d.ox[l], 0), y0 = std::max(r[1] - d.oy[l], 0);
-                    const int x1 = std::min(r[2] - d.ox[l], d.lw[l]), y1 = std::min(r[3] - d.oy[l], d.lh[l]);
-                    if (x0 >= x1 || y0 >= y1) continue;
-                    const std::vector<uint8_t>& nz = plan.cams[c].nz[l];
-                    bool any = false;
-                    for (int y = y0; y < y1 && !any; ++y) {
-                        const uint8_t* row = nz.data() + static_cast<size_t>(y) * d.lw[l];
-                        for (int x = x0; x < x1; ++x)
-                            if (row[x]) { any = true; break; }
+                max_area[l] = std::max(max_area[l], mb_blend_region_lds_pixels(blend, tx, ty, l));
+                uint32_t lbits = 0;
+                for (int c = 0; c < n; ++c)
+                    if (any_nonzero(c, l, r[0], r[1], r[2], r[3])) lbits |= 1u << c;
+                bits |= lbits;
+                if (l == 0) {           // ownership of level 0 is judged inside the crop
+                    r[2] = std::min(r[2], blend.final_w);
+                    r[3] = std::min(r[3], blend.final_h);
+                    if (r[0] >= r[2] || r[1] >= r[3]) continue;
+                    lbits = 0;
+                    for (int c = 0; c < n; ++c)
+                        if (any_nonzero(c, l, r[0], r[1], r[2], r[3])) lbits |= 1u << c;
+                }
+                if (lbits != 0 && (lbits & (lbits - 1)) == 0) {
+                    const int c = __builtin_ctz(lbits);
+                    if ((owner < 0 || owner == c) && all_unit(c, l, r[0], r[1], r[2], r[3])) {
+                        owner = c;
+                        level_mask |= 1u << l;
                     }
-                    if (any) bits |= 1u << c;
                 }
             }
-            // "pure" tile (bit 31): exactly one camera, and over every level's region that camera's window covers
-            // the region and its weight is exactly 1.0f -> kernel C takes the integer-only band path
-            if (bits != 0 && (bits & (bits - 1)) == 0) {
-                int c = 0;
-                while (!(bits >> c & 1u)) ++c;
-                const CamDesc& d = desc[c];
-                bool pure = true;
-                for (int l = 0; l < nlev && pure; ++l) {
-                    int r[4];
-                    mb_blend_region(blend, tx, ty, l, r);
-                    const int x0 = r[0] - d.ox[l], y0 = r[1] - d.oy[l], x1 = r[2] - d.ox[l], y1 = r[3] - d.oy[l];
-                    if (x0 < 0 || y0 < 0 || x1 > d.lw[l] || y1 > d.lh[l]) { pure = false; break; }
-                    const std::vector<float>& w = weights[c][l];
-                    for (int y = y0; y < y1 && pure; ++y)
-                        for (int x = x0; x < x1; ++x)
-                            if (w[static_cast<size_t>(y) * d.lw[l] + x] != unit) { pure = false; break; }
-                }
-                if (pure) bits |= 0x80000000u;
+            const size_t ti = static_cast<size_t>(ty) * plan.blend_tiles_x + tx;
+            // all levels owned, and by the one camera that has weights under the tile at all -> the pure tile of old
+            // (level 0 judged over the whole region there as well, as the pure path's band covers all of it)
+            if (owner >= 0 && level_mask == (1u << nlev) - 1u && bits == (1u << owner)) {
+                int r[4];
+                mb_blend_region(blend, tx, ty, 0, r);
+                if (all_unit(owner, 0, r[0], r[1], r[2], r[3])) bits |= 0x80000000u;
             }
-            plan.block_cams[static_cast<size_t>(ty) * plan.blend_tiles_x + tx] = bits;
+            plan.block_cams[ti] = bits;
+            plan.block_pure[ti] = owner >= 0 ? (level_mask | static_cast<uint32_t>(owner) << 16) : 0u;
         }
     // launch order: every canvas tile is resident at once on a 256-CU part, so the dispatcher's round-robin
     // placement is the only load balancing there is -- hand out the expensive tiles (several cameras under the
@@ -210,7 +236,9 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
     auto cost = [&](uint32_t tile) {
         const uint32_t e = plan.block_cams[tile];
         const int cams_under = __builtin_popcount(e & 0x7FFFFFFFu);
-        return (e >> 31) ? 2 : 5 * cams_under;          // relative: integer path ~ 2, float path ~ 5 per camera
+        if (e >> 31) return 4;                          // relative: integer path everywhere
+        const bool l0_owned = plan.block_pure[tile] & 1u;       // float bands on some coarse levels only
+        return (l0_owned ? 6 : 10) + 2 * cams_under;
     };
     std::stable_sort(plan.block_order.begin(), plan.block_order.end(),
                      [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });

@@ -33,6 +33,7 @@ struct MbPlanHost {
     struct ChainStep { int base, k; std::vector<uint32_t> tiles; std::vector<int> cam_start; };
     std::vector<ChainStep> chain;                             // kernel B launches
     std::vector<uint32_t> block_cams;                         // kernel C, one entry per canvas tile
+    std::vector<uint32_t> block_pure;                         // kernel C: levels owned by one camera | owner << 16
     std::vector<uint32_t> block_order;                        // kernel C, tile index launched as block i
     int blend_tiles_x = 0, blend_tiles_y = 0;
     int lds_off[kMaxLevels] = {};
