@@ -486,13 +486,10 @@ void Engine::update(const mst_calibration& calib)
         st->warp_list.count = static_cast<int32_t>(plan.warp_tiles.size());
         st->warp_list.first = 0;
         // frame-invariant backward map of every launched tile, in the order kernel A consumes it
-        const char* table_env = std::getenv("MST_WARP_TABLE");   // "0": evaluate the map per frame instead
-        if (!(table_env && table_env[0] == '0')) {
-            st->warp_table = st->pool.alloc<uint32_t>(mb_warp_table_entries(st->warp_list.count));
-            st->warp_table_base = st->pool.alloc<int2>(st->warp_list.count);
-            launch_warp_table(st->d_desc, cfg_.warp_kind, st->warp_list, st->warp_table, st->warp_table_base, s);
-            check_hip(hipGetLastError(), "k_warp_table");
-        }
+        st->warp_table = st->pool.alloc<uint32_t>(mb_warp_table_entries(st->warp_list.count));
+        st->warp_blobs = st->pool.alloc<uint32_t>(mb_warp_blob_entries(st->warp_list.count));
+        launch_warp_table(st->d_desc, cfg_.warp_kind, st->warp_list, st->warp_table, st->warp_blobs, s);
+        check_hip(hipGetLastError(), "k_warp_table");
         st->chain_lists.clear();
         for (const MbPlanHost::ChainStep& step : plan.chain) {
             TileList tl;
@@ -617,7 +614,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
                     canvas_pending_[k] = false;
                 }
         undistort(first_set, sf);
-        launch_warp_pyr(desc, st->n, cfg_.warp_kind, st->warp_list, fb, count, st->warp_table, st->warp_table_base, sf);
+        launch_warp_pyr(desc, st->n, cfg_.warp_kind, st->warp_list, fb, count, st->warp_table, st->warp_blobs, sf);
         mark("k_warp_pyr");
         // where the frame crosses from the front stream to the caller's stream: after the warp kernel (the small
         // pyramid-chain launches then fill in beside the next frame's warp) or after the chain
@@ -717,7 +714,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
         tl.tiles = st->warp_list.tiles + plan.warp_cam_start[i];
         tl.count = plan.warp_cam_start[i + 1] - plan.warp_cam_start[i];
         tl.first = plan.warp_cam_start[i];
-        launch_warp_pyr(st->d_desc, st->n, cfg_.warp_kind, tl, fb, 1, st->warp_table, st->warp_table_base, s);
+        launch_warp_pyr(st->d_desc, st->n, cfg_.warp_kind, tl, fb, 1, st->warp_table, st->warp_blobs, s);
     }
     for (size_t k = 0; k < st->chain_lists.size(); ++k)
         for (int i = 0; i < st->n; ++i) {

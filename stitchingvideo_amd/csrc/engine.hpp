@@ -80,7 +80,7 @@ struct CalibState {
     int undist_max_w = 0, undist_max_h = 0;
     std::vector<uint8_t*> undist_frames;   // num_sets x n engine-owned undistorted frames (nullptr: camera has no maps)
     uint32_t* warp_table = nullptr;     // per-tile backward-map table (frame-invariant), see kernels_mb.hip
-    int2* warp_table_base = nullptr;    // per tile: the source coordinate its table entries are relative to
+    uint32_t* warp_blobs = nullptr;     // per tile: calibration constants of kernel A (gain rows, row weights, table origin)
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step
     BlendArgs blend{};                  // kernel C (pano pointers filled per frame)
     // feather

@@ -33,12 +33,13 @@ int  mb_chain_depth();                                                          
 void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4]);   // x0, y0, x1, y1
 int  mb_blend_region_lds_pixels(const BlendArgs& a, int tx, int ty, int level);      // LDS footprint of that region
 size_t mb_warp_table_entries(int num_tiles);                                         // 32-bit entries for `num_tiles` tiles
-void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, int2* d_tile_base,
+size_t mb_warp_blob_entries(int num_tiles);                                          // 32-bit words of per-tile constants
+// per calibration: the backward-map table and the per-tile constants of every launched tile of kernel A
+void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, uint32_t* d_blobs,
                        hipStream_t s);
-// d_table == nullptr: evaluate the backward map in the kernel (default); else read it from the table
-// `batch` frame sets per launch (grid.y): set f uses frames.f[f] and the descriptors d_cams[f * n_cams ...]
+// `batch` frame sets per launch: set f uses frames.f[f] and the descriptors d_cams[f * n_cams ...]
 void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
-                     int batch, const uint32_t* d_table, const int2* d_tile_base, hipStream_t s);
+                     int batch, const uint32_t* d_table, const uint32_t* d_blobs, hipStream_t s);
 void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s);
 void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int batch, size_t lds_bytes, hipStream_t s);
 

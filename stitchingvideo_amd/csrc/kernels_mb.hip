@@ -105,6 +105,17 @@ constexpr int A_TW1 = A_TW0 / 2, A_TH1 = A_TH0 / 2; // level-1 outputs: 62 x 16
 constexpr int A_ROWS_PER_THREAD = A_LH / 2;    // 256 threads = 128 columns x 2 row halves
 constexpr int A_GAIN_ROWS = 4;                 // gain-map rows a tile may span and still be served from LDS
 
+// Everything about a tile that depends on the calibration only, as one block of A_BLOB dwords per launched tile,
+// built by k_warp_table next to the map table: a thread block copies it into LDS with one coalesced load per
+// thread, where it used to chase list -> descriptor -> row table -> gain map through four dependent round trips
+// and three barriers (a quarter of the block's lifetime, by in-kernel stamps).
+//   [0, 512)     BlocksGainCompensator: HResizeLinear of the A_GAIN_ROWS gain-map rows the tile spans, per column
+//   [512, 548)   per tile row: offsets (in floats) of its two map rows in that table, low | high << 16
+//   [548, 620)   per tile row: the two VResizeLinear weights
+//   [620, 624)   gain mode (see fetch_pixel), "some gain >= 8e6" flag, tile_base.x, tile_base.y
+constexpr int A_BLOB = 640, A_BLOB_GY = A_GAIN_ROWS * A_LW, A_BLOB_W = A_BLOB_GY + A_LH, A_BLOB_META = A_BLOB_W + 2 * A_LH;
+static_assert(A_BLOB_META + 4 <= A_BLOB && A_BLOB <= 3 * 256, "tile block layout");
+
 // saturate_cast<uchar>(uchar * float): cvRound + clamp.  For gain < 8e6 the product is far inside
 // int range and clamping in float first is the same function (NaN -> 0 both ways).
 __device__ __forceinline__ int apply_gain_bounded(int v, float g)
@@ -211,11 +222,18 @@ __device__ __forceinline__ MapPx map_px(const float kr[9], int src_w, int src_h,
 
 // GAIN: how the exposure gain of the pixel is formed -- 0: the camera's scalar gain (1 for "no compensation":
 // uchar * 1.0f rounds to itself), 1: block gain map, horizontally interpolated rows of this tile in LDS,
-// 2: block gain map read from global memory (tile spans more map rows than the LDS table holds).
-// The caller picks the mode once per tile, so the loop body carries no uniform branch.
+// 2: block gain map read from global memory (tile spans more map rows than the LDS table holds; rare, slow).
+// The mode is a per-tile constant, so the loop body carries no uniform branch.
+struct GainSrc {
+    const float* col;          // LDS: this column of the tile's gain rows
+    const uint32_t* gy;        // LDS: per tile row, offsets of its two map rows
+    const float* w;            // LDS: per tile row, the two weights (w[row], w[A_LH + row])
+    const CamDesc* cam;        // mode 2
+    int rx, ly0;               // mode 2: roi column of this thread, level-0 row of tile row 0
+};
+
 template <int GAIN>
-__device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const MapPx& e, const ColEntry& ce, const RowEntry& re,
-                                            const float* s_gain, PixelFetch& f)
+__device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const MapPx& e, const GainSrc& gs, int row, PixelFetch& f)
 {
     const int fx = e.fx, fy = e.fy;
     f.sx = e.sx;
@@ -244,20 +262,17 @@ __device__ __forceinline__ void fetch_pixel(const WarpConsts& k, const MapPx& e,
         }
     }
     // exposure gain: k.gain is the camera's scalar gain (1 for "no compensation": uchar * 1.0f rounds to itself);
-    // with a block gain map the two horizontally interpolated map rows of this tile row come from LDS.  Kept
-    // branch-free: the reads are always issued (row index wrapped into the LDS table) and selected afterwards.
+    // with a block gain map the two horizontally interpolated map rows of this tile row come from LDS.
     f.gain = k.gain;
     if (!(MST_ABLATE_A & 2)) {
         if (GAIN == 1) {
-            // gy0/gy1 of the tile's row entries were rewritten to offsets into the LDS table
-            const float r0 = s_gain[re.gy0], r1 = s_gain[re.gy1];
-            f.gain = r0 * re.gyw0 + r1 * re.gyw1;                            // VResizeLinear
+            const uint32_t o = gs.gy[row];
+            const float r0 = gs.col[o & 0xFFFFu], r1 = gs.col[o >> 16];
+            f.gain = r0 * gs.w[row] + r1 * gs.w[A_LH + row];                 // VResizeLinear
         } else if (GAIN == 2) {
-            const float MST_GLOBAL* g0 = gp(k.gain_map) + re.gy0 * k.gw;
-            const float MST_GLOBAL* g1 = gp(k.gain_map) + re.gy1 * k.gw;
-            const float q0 = g0[ce.gx0] * ce.gxw0 + g0[ce.gx1] * ce.gxw1;   // HResizeLinear
-            const float q1 = g1[ce.gx0] * ce.gxw0 + g1[ce.gx1] * ce.gxw1;
-            f.gain = q0 * re.gyw0 + q1 * re.gyw1;
+            const CamDesc& c = *gs.cam;
+            const int by = reflect<1>(gs.ly0 + row, c.lh[0]);
+            f.gain = gain_at(c, gs.rx, reflect<0>(by - c.top, c.roi_h));
         }
     }
 }
@@ -304,17 +319,25 @@ __device__ __forceinline__ uint32_t blend_pixel(const WarpConsts& k, const Pixel
         if (BIG) {
             b = apply_gain(b, f.gain); g = apply_gain(g, f.gain); r = apply_gain(r, f.gain);
         } else {
-            b = apply_gain_bounded(b, f.gain); g = apply_gain_bounded(g, f.gain); r = apply_gain_bounded(r, f.gain);
+            // saturate_cast<uchar>(uchar * gain) for gains below 8e6 is clamp(rint(product), 0, 255) with NaN -> 0 (see
+            // apply_gain_bounded), which is what v_cvt_pk_u8_f32 computes in the default rounding mode -- checked on
+            // gfx950 over 2^28 sampled bit patterns and every tie (tools/ubench/cvt_pk_u8.hip) -- and it drops the byte
+            // into the packed pixel as well: three instructions per channel instead of seven.
+            uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>(b) * f.gain, 0u, 0u);
+            px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>(g) * f.gain, 1u, px);
+            px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>(r) * f.gain, 2u, px);
+            return px;
         }
     }
     return static_cast<uint32_t>(b) | (static_cast<uint32_t>(g) << 8) | (static_cast<uint32_t>(r) << 16);
 }
 
 // Per-calibration: the backward map of every pixel of every launched tile, in the tile/row/column order in
-// which k_warp_pyr's threads consume it, relative to the tile's smallest window coordinate (tile_base).
+// which k_warp_pyr's threads consume it, relative to the tile's smallest window coordinate, and the tile's block of
+// constants (layout above).
 template <int KIND>
 __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ cams, TileList list,
-                                                    uint32_t* __restrict__ table, int2* __restrict__ tile_base)
+                                                    uint32_t* __restrict__ table, uint32_t* __restrict__ blobs)
 {
     __shared__ RowEntry s_rows[A_LH];
     __shared__ int s_min[2];
@@ -327,6 +350,7 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
     float kr[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) kr[i] = c.kr[i];
+    // per tile row: pyrDown's REFLECT_101 into the bordered image, then copyMakeBorder's REFLECT into the roi
     if (tid < A_LH) {
         const int by = reflect<1>(ly0 + tid, bh);
         const int ry = reflect<0>(by - c.top, c.roi_h);
@@ -347,23 +371,69 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
     if (x_lo != INT_MAX) { atomicMin(&s_min[0], x_lo); atomicMin(&s_min[1], y_lo); }
     __syncthreads();
     const int tbx = s_min[0] == INT_MAX ? 0 : s_min[0], tby = s_min[1] == INT_MAX ? 0 : s_min[1];
-    if (tid == 0) tile_base[list.first + blockIdx.x] = make_int2(tbx, tby);
     uint32_t* __restrict__ out = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW) + col;
     for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
         const int row = half * A_ROWS_PER_THREAD + it;
         out[row * A_LW] = pack_map(map_px<KIND>(kr, c.src_w, c.src_h, ce, s_rows[row]), tbx, tby);
     }
+
+    // ---- the tile's block of constants
+    uint32_t* __restrict__ blob = blobs + static_cast<size_t>(list.first + blockIdx.x) * A_BLOB;
+    // BlocksGainCompensator's resize(gain_map): which map rows the tile touches
+    int gmin = INT_MAX, gmax = INT_MIN;
+    for (int r = 0; r < A_LH; ++r) {
+        gmin = min(gmin, s_rows[r].gy0);
+        gmax = max(gmax, s_rows[r].gy1);
+    }
+    // how this tile forms its gains (see fetch_pixel) and whether any of them can overflow the bounded rounding
+    const float scalar_gain = c.expos == 0 ? 1.f : c.gain;
+    int gain_mode = 0;
+    int big = scalar_gain >= 8.0e6f;
+    if (c.expos == 2) {
+        if (gmax - gmin < A_GAIN_ROWS) {
+            gain_mode = 1;
+            bool col_big = false;
+            if (half == 0) {
+#pragma unroll
+                for (int i = 0; i < A_GAIN_ROWS; ++i) {
+                    // this column's horizontal interpolation of map row gmin + i (same float products and sums as the
+                    // per-pixel form)
+                    const float MST_GLOBAL* g = gp(c.gain_map) + min(gmin + i, c.gh - 1) * c.gw;
+                    const float v = g[ce.gx0] * ce.gxw0 + g[ce.gx1] * ce.gxw1;
+                    blob[i * A_LW + col] = __float_as_uint(v);
+                    col_big |= v >= 4.0e6f;     // conservative: the vertical interpolation stays below 2x the rows
+                }
+            }
+            big = __syncthreads_or(col_big) != 0;
+        } else {
+            gain_mode = 2;
+            big = 1;
+        }
+    }
+    if (gain_mode != 1 && half == 0)
+        for (int i = 0; i < A_GAIN_ROWS; ++i) blob[i * A_LW + col] = 0u;
+    if (tid < A_LH) {
+        const RowEntry re = s_rows[tid];
+        const bool lds_rows = gain_mode == 1;
+        blob[A_BLOB_GY + tid] = lds_rows ? static_cast<uint32_t>((re.gy0 - gmin) * A_LW) | static_cast<uint32_t>((re.gy1 - gmin) * A_LW) << 16 : 0u;
+        blob[A_BLOB_W + tid] = __float_as_uint(re.gyw0);
+        blob[A_BLOB_W + A_LH + tid] = __float_as_uint(re.gyw1);
+    }
+    if (tid == 0) {
+        blob[A_BLOB_META + 0] = static_cast<uint32_t>(gain_mode);
+        blob[A_BLOB_META + 1] = static_cast<uint32_t>(big);
+        blob[A_BLOB_META + 2] = static_cast<uint32_t>(tbx);
+        blob[A_BLOB_META + 3] = static_cast<uint32_t>(tby);
+    }
+    if (tid >= A_BLOB_META + 4 - 512 + 0 && tid < A_BLOB - 512) blob[512 + tid] = 0u;       // padding: deterministic
 }
 
-// USE_TABLE: read the backward map from the per-calibration table instead of evaluating it (fewer VALU
-// instructions, one more dependent load per pixel).  Measured on MI355X (C3): 81.5 us with the table vs
-// 76 us without while the gather comes from global memory, so the default evaluates the map in place.
 #ifndef MST_A_WAVES
-#define MST_A_WAVES 1
+#define MST_A_WAVES 7      // 7 blocks of 256 threads per CU is what the LDS tile allows: keep the registers within that
 #endif
-template <int KIND, bool USE_TABLE>
+template <int KIND>
 __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __restrict__ cams_all, TileList list, FrameBatch batch,
-                                                  const uint32_t* __restrict__ table, const int2* __restrict__ tile_base,
+                                                  const uint32_t* __restrict__ table, const uint32_t* __restrict__ blobs,
                                                   int n_cams, int n_sets)
 {
     // One block per (tile, frame set) of a batched launch, on a 1-D grid ordered so that the frame sets of a tile are
@@ -374,21 +444,28 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     // whole grid row apart: different XCDs, and long evicted.)  A frame set has its own frames and its own copy of
     // the descriptors (pyramids).
     MST_STAMP(0, 0);
+    __shared__ __attribute__((aligned(16))) uint32_t s_l0[A_LH][A_LW];   // level-0 tile with halo, packed (18 KB)
+    __shared__ __attribute__((aligned(16))) uint32_t s_blob[A_BLOB];     // the tile's calibration constants
+    const int tid = threadIdx.x;
     const int pair = xcd_run_index(blockIdx.x, list.count * n_sets);
     const int set = pair % n_sets;
+    const int li = pair / n_sets;                               // position in the tile list
+    // the tile's block of constants: its address needs nothing but the block index, so the loads go out first
+    {
+        const uint32_t MST_GLOBAL* __restrict__ gb = gp(blobs) + static_cast<size_t>(list.first + li) * A_BLOB;
+        const uint32_t v0 = gb[tid], v1 = gb[tid + 256];
+        const uint32_t v2 = tid < A_BLOB - 512 ? gb[tid + 512] : 0u;
+        s_blob[tid] = v0;
+        s_blob[tid + 256] = v1;
+        if (tid < A_BLOB - 512) s_blob[tid + 512] = v2;
+    }
     const CamDesc* __restrict__ cams = cams_all + set * n_cams;
     const FrameArgs& frames = batch.f[set];
-    __shared__ __attribute__((aligned(16))) uint32_t s_l0[A_LH][A_LW];   // level-0 tile with halo, packed (18 KB)
-    __shared__ RowEntry s_rows[A_LH];
-    __shared__ float s_gain_rows[A_GAIN_ROWS][A_LW];   // BlocksGainCompensator: HResizeLinear of the rows the tile spans
-
-    const int li = pair / n_sets;                               // position in the tile list
     const uint32_t t = list.tiles[li];
     const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
     const int bw = c.lw[0], bh = c.lh[0], nlev = c.nlev;
     const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;    // level-0 origin of the halo'd tile
-    const int tid = threadIdx.x;
     uint32_t MST_GLOBAL* __restrict__ g0out = gp(c.G[0]);
     uint32_t MST_GLOBAL* __restrict__ g1out = gp(c.G[1]);
     const int lw1 = c.lw[1], lh1 = c.lh[1];
@@ -401,71 +478,23 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     k.src_al = k.src - k.src_lo2;
     // this tile's slice of the per-calibration map table: [row][col], one coalesced 4-byte load per pixel
     const uint32_t* __restrict__ tab = table + static_cast<size_t>(list.first + li) * (A_LH * A_LW);
-    int tbx = 0, tby = 0;
-    if (USE_TABLE) {
-        const int2 tb = tile_base[list.first + li];
-        tbx = tb.x; tby = tb.y;
-    }
-
-    // per tile row: pyrDown's REFLECT_101 into the bordered image, then copyMakeBorder's REFLECT into the roi
-    if (tid < A_LH) {
-        const int by = reflect<1>(ly0 + tid, bh);
-        const int ry = reflect<0>(by - c.top, c.roi_h);
-        s_rows[tid] = load_global(c.rows + ry);
-    }
     const int col = tid & (A_LW - 1);
     const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int bx = reflect<1>(lx0 + col, bw);
-    const int rx = reflect<0>(bx - c.left, c.roi_w);
-    const ColEntry ce = load_global(c.cols + rx);
-    __syncthreads();
-
-    // BlocksGainCompensator's resize(gain_map): this column's horizontal interpolation of the few gain-map
-    // rows the tile touches, kept in LDS (same float products and sums as the per-pixel form)
-    int gmin = INT_MAX, gmax = INT_MIN;
-    {
-        const int lane = tid & 63;
-#pragma unroll
-        for (int r = lane; r < A_LH; r += 64) {
-            gmin = min(gmin, s_rows[r].gy0);
-            gmax = max(gmax, s_rows[r].gy1);
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            gmin = min(gmin, __shfl_xor(gmin, o));
-            gmax = max(gmax, __shfl_xor(gmax, o));
-        }
-    }
-    gmin = __builtin_amdgcn_readfirstlane(gmin);
-    gmax = __builtin_amdgcn_readfirstlane(gmax);
-    // how this tile forms its gains (see fetch_pixel) and whether any of them can overflow the bounded rounding
-    int gain_mode = 0;
-    bool big = k.gain >= 8.0e6f;
-    if (k.expos == 2) {
-        if (gmax - gmin < A_GAIN_ROWS) {
-            gain_mode = 1;
-            __syncthreads();                // every wave has derived gmin/gmax from the row entries
-            if (tid < A_LH) {               // row entries now carry offsets into s_gain_rows instead of map rows
-                s_rows[tid].gy0 = (s_rows[tid].gy0 - gmin) * A_LW;
-                s_rows[tid].gy1 = (s_rows[tid].gy1 - gmin) * A_LW;
-            }
-            bool col_big = false;
-            if (half == 0) {
-#pragma unroll
-                for (int i = 0; i < A_GAIN_ROWS; ++i) {
-                    const float MST_GLOBAL* g = gp(k.gain_map) + min(gmin + i, k.gh - 1) * k.gw;
-                    const float v = g[ce.gx0] * ce.gxw0 + g[ce.gx1] * ce.gxw1;
-                    s_gain_rows[i][col] = v;
-                    col_big |= v >= 4.0e6f;     // conservative: the vertical interpolation stays below 2x the rows
-                }
-            }
-            big = __syncthreads_or(col_big) != 0;
-        } else {
-            gain_mode = 2;
-            big = true;
-        }
-    }
-    const float* H = &s_gain_rows[0][col];
+    __syncthreads();                                             // the tile's constants are in LDS
+    const int gain_mode = __builtin_amdgcn_readfirstlane(static_cast<int>(s_blob[A_BLOB_META + 0]));
+    const bool big = __builtin_amdgcn_readfirstlane(static_cast<int>(s_blob[A_BLOB_META + 1])) != 0;
+    const int tbx = __builtin_amdgcn_readfirstlane(static_cast<int>(s_blob[A_BLOB_META + 2]));
+    const int tby = __builtin_amdgcn_readfirstlane(static_cast<int>(s_blob[A_BLOB_META + 3]));
+    GainSrc gs;
+    gs.col = reinterpret_cast<const float*>(s_blob) + col;
+    gs.gy = s_blob + A_BLOB_GY;
+    gs.w = reinterpret_cast<const float*>(s_blob) + A_BLOB_W;
+    gs.cam = &c;
+    gs.ly0 = ly0;
+    // roi column of this thread: pyrDown's REFLECT_101 into the bordered image, then copyMakeBorder's REFLECT into
+    // the roi (only the rare paths below evaluate anything per column: the map table and the tile's constants
+    // already carry the rest)
+    gs.rx = reflect<0>(reflect<1>(lx0 + col, bw) - c.left, c.roi_w);
     MST_STAMP(0, 1);
 
     const int gx = lx0 + col;
@@ -474,24 +503,26 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     // software pipeline over two explicit register sets: the gather of the next pixel is in flight while
     // the current one is blended (A_ROWS_PER_THREAD is even; the last prefetch re-reads the last row)
     static_assert(A_ROWS_PER_THREAD % 2 == 0, "two-stage pipeline needs an even row count");
+    // Level 0 goes to LDS only inside the loop and to global memory in one pass after it.  A store issued between
+    // the gathers is not free even though nothing waits for it explicitly: the memory counter retires in issue
+    // order, so every gather issued after a store could only be consumed once that store had been acknowledged by
+    // L2 -- which tied the loop to the write latency (11.6 of this kernel's 37.5 us per frame set, by ablation).
+    const bool store_in_loop = (bw & 3) != 0;                 // rows not 16-byte aligned (one band): keep the simple form
     auto emit = [&](int row, uint32_t px) {
         s_l0[row][col] = px;
         const int gy = ly0 + row;
-        if (col_interior && row >= 2 && row < A_LH - 2 && gy < bh)
+        if (store_in_loop && col_interior && row >= 2 && row < A_LH - 2 && gy < bh)
             g0out[__umul24(gy, bw) + gx] = px;
     };
     const int row_last = row0 + A_ROWS_PER_THREAD - 1;
     const uint32_t* __restrict__ tcol = tab + col;
-    float kr[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) kr[i] = c.kr[i];
     auto entry = [&](int row) -> MapPx {
         if (MST_ABLATE_A & 8) {
             MapPx m;
             m.sx = col + 200; m.sy = row + 200; m.fx = (col * 7) & 31; m.fy = (row * 3) & 31; m.fast = true;
             return m;
         }
-        return USE_TABLE ? unpack_map(tcol[row * A_LW], tbx, tby) : map_px<KIND>(kr, k.src_w, k.src_h, ce, s_rows[row]);
+        return unpack_map(tcol[row * A_LW], tbx, tby);
     };
     // Table entries run two rows ahead of the gather, the gather one row ahead of the blend.  The loop body is
     // one basic block (no uniform branch on the gain mode, no divergent branch for border pixels: those are
@@ -503,26 +534,33 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
         PixelFetch fa, fb;
         uint32_t slow_rows = 0;           // rows of this column that need the per-tap border path
         MapPx e0 = entry(row0), e1 = entry(row0 + 1);
-        fetch_pixel<GM>(k, e0, ce, s_rows[row0], H, fa);
+        fetch_pixel<GM>(k, e0, gs, row0, fa);
         // fully unrolled: a back edge would carry the in-flight gather registers through copies, and a copy of
         // a register that is still being loaded is a wait for the load
 #pragma unroll
         for (int it = 0; it < A_ROWS_PER_THREAD; it += 2) {
             const int row = row0 + it;
             e0 = entry(min(row + 2, row_last));
-            fetch_pixel<GM>(k, e1, ce, s_rows[row + 1], H, fb);
+            fetch_pixel<GM>(k, e1, gs, row + 1, fb);
             e1 = entry(min(row + 3, row_last));
             slow_rows |= static_cast<uint32_t>(!fa.fast) << it;
             emit(row, blend_pixel<false, BG>(k, fa));
-            fetch_pixel<GM>(k, e0, ce, s_rows[min(row + 2, row_last)], H, fa);
+            fetch_pixel<GM>(k, e0, gs, min(row + 2, row_last), fa);
             slow_rows |= static_cast<uint32_t>(!fb.fast) << (it + 1);
             emit(row + 1, blend_pixel<false, BG>(k, fb));
         }
         while (slow_rows) {               // rare: windows at the very end of the frame, one-pixel sources
             const int it = __builtin_ctz(slow_rows);
             slow_rows &= slow_rows - 1;
-            // (the table does not keep coordinates of windows it cannot address: evaluate the map)
-            fetch_pixel<GM>(k, map_px<KIND>(kr, k.src_w, k.src_h, ce, s_rows[row0 + it]), ce, s_rows[row0 + it], H, fa);
+            // (the table does not keep coordinates of windows it cannot address: evaluate the map from the camera's
+            // per-column / per-row constants)
+            float kr[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) kr[i] = c.kr[i];
+            const int by = reflect<1>(ly0 + row0 + it, bh);
+            const ColEntry ce = load_global(c.cols + gs.rx);
+            const RowEntry re = load_global(c.rows + reflect<0>(by - c.top, c.roi_h));
+            fetch_pixel<GM>(k, map_px<KIND>(kr, k.src_w, k.src_h, ce, re), gs, row0 + it, fa);
             emit(row0 + it, blend_pixel<true, BG>(k, fa));
         }
     };
@@ -536,8 +574,23 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
         if (big) run(std::integral_constant<int, 0>{}, Yes{}); else run(std::integral_constant<int, 0>{}, No{});
     }
     MST_STAMP(0, 2);
-    if (nlev < 2 || (MST_ABLATE_A & 4)) return;
     __syncthreads();
+    if (!store_in_loop && !(MST_ABLATE_A & 128)) {
+        // interior of the tile, four pixels (16 bytes) per lane: a tile row is 31 such groups, and because the level
+        // width is a multiple of four and the tile origin a multiple of 124, a group lies inside the level as a whole
+        // or not at all, and is 16-byte aligned in global memory (8-byte aligned in LDS: the interior starts at column 2)
+        constexpr int kGroups = A_TW0 / 4;
+        for (int i = tid; i < A_TH0 * kGroups; i += 256) {
+            const int r = i / kGroups, g = i - r * kGroups;
+            const int gy = ly0 + 2 + r, gx4 = lx0 + 2 + 4 * g;
+            if (gy >= bh || gx4 >= bw) continue;
+            const uint2 lo = *reinterpret_cast<const uint2*>(&s_l0[2 + r][2 + 4 * g]);
+            const uint2 hi = *reinterpret_cast<const uint2*>(&s_l0[2 + r][4 + 4 * g]);
+            typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+            *reinterpret_cast<u32x4 MST_GLOBAL*>(g0out + __umul24(gy, bw) + gx4) = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+    }
+    if (nlev < 2 || (MST_ABLATE_A & 4)) return;
     MST_STAMP(0, 3);
 
     // pyrDown straight from the LDS tile: output (j, i) reads rows 2i..2i+4, columns 2j..2j+4.  A thread owns one
@@ -1214,10 +1267,50 @@ __device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx
 }
 
 // crop to dst_roi_final_, mask, convertTo(8U) results of one quad -> panorama (+ optional mask plane)
+//
+// store_mode 2 (wide): the panorama's base and stride are multiples of four and lane pairs (2i, 2i+1) hold
+// horizontally adjacent quads starting at a multiple of four pixels.  The two lanes then swap half of their quads
+// over DPP -- the even lane ends up with the upper row of both quads (4 pixels = 12 bytes), the odd lane with the
+// lower row -- and each issues ONE aligned 12-byte store; a wave writes two runs of 384 contiguous bytes per
+// instruction.  The narrow form it replaces (three 2-byte stores per quad row at a 6-byte lane stride) kept the
+// write path busy for about half of this kernel's run time: every instruction touched every cache line of the run
+// with a sparse byte mask.  store_mode 1: 2-byte stores (even base and stride); 0: byte stores.
+__device__ __forceinline__ uint32_t lane_swap1(uint32_t v)       // value of lane ^ 1 (quad_perm [1,0,3,2])
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xB1, 0xF, 0xF, false));
+}
+
 __device__ __forceinline__ void store_quad(const BlendArgs& a, uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask,
                                            int x, int y, const bool valid[4], const uint32_t o8[4][3], const bool m[4],
-                                           bool pair_stores)
+                                           int store_mode)
 {
+    bool narrow = true;
+    if (store_mode == 2) {
+        // every lane of an active pair takes part in the swap; the pair falls back to the narrow stores when its four
+        // pixels are not all inside the crop and the region (right edge of the panorama)
+        const bool odd = (threadIdx.x & 1u) != 0;
+        const int xe = odd ? x - 2 : x;                                       // first pixel of the pair's run of four
+        const bool mine = valid[0] && valid[1] && valid[2] && valid[3];
+        const bool pair_ok = mine && lane_swap1(mine ? 1u : 0u) != 0u && xe + 3 < a.final_w && (xe & 3) == 0;
+        // 6 bytes per quad row: B0 G0 R0 B1 | G1 R1
+        const uint32_t lo0 = o8[0][0] | o8[0][1] << 8 | o8[0][2] << 16 | o8[1][0] << 24, hi0 = o8[1][1] | o8[1][2] << 8;
+        const uint32_t lo1 = o8[2][0] | o8[2][1] << 8 | o8[2][2] << 16 | o8[3][0] << 24, hi1 = o8[3][1] | o8[3][2] << 8;
+        const uint32_t rlo = lane_swap1(odd ? lo0 : lo1), rhi = lane_swap1(odd ? hi0 : hi1);   // what the partner needs
+        const uint32_t flo = odd ? rlo : lo0, fhi = odd ? rhi : hi0;          // first six bytes of my row of four pixels
+        const uint32_t slo = odd ? lo1 : rlo, shi = odd ? hi1 : rhi;          // last six
+        const int py = odd ? y + 1 : y;
+        if (pair_ok) {
+            narrow = false;
+            if (py < a.final_h && !((MST_ABLATE_C & 16) && flo != 77777u)) {
+                uint32_t* o = reinterpret_cast<uint32_t*>(pano + __umul24(py, a.pano_stride) + xe * 3);
+                uint3 v;
+                v.x = flo;
+                v.y = (fhi & 0xFFFFu) | slo << 16;
+                v.z = slo >> 16 | shi << 16;
+                *reinterpret_cast<uint3*>(o) = v;
+            }
+        }
+    }
 #pragma unroll
     for (int ry = 0; ry < 2; ++ry) {
         const int py = y + ry;
@@ -1228,14 +1321,16 @@ __device__ __forceinline__ void store_quad(const BlendArgs& a, uint8_t* __restri
         const uint32_t* p1 = o8[2 * ry + 1];
         const bool both = valid[2 * ry + 1] && x + 1 < a.final_w;
         if (x < a.final_w) {
-            if (both && pair_stores) {
-                uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
-                o16[0] = static_cast<uint16_t>(p0[0] | p0[1] << 8);
-                o16[1] = static_cast<uint16_t>(p0[2] | p1[0] << 8);
-                o16[2] = static_cast<uint16_t>(p1[1] | p1[2] << 8);
-            } else {
-                o[0] = static_cast<uint8_t>(p0[0]); o[1] = static_cast<uint8_t>(p0[1]); o[2] = static_cast<uint8_t>(p0[2]);
-                if (both) { o[3] = static_cast<uint8_t>(p1[0]); o[4] = static_cast<uint8_t>(p1[1]); o[5] = static_cast<uint8_t>(p1[2]); }
+            if (narrow) {
+                if (both && store_mode >= 1) {
+                    uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
+                    o16[0] = static_cast<uint16_t>(p0[0] | p0[1] << 8);
+                    o16[1] = static_cast<uint16_t>(p0[2] | p1[0] << 8);
+                    o16[2] = static_cast<uint16_t>(p1[1] | p1[2] << 8);
+                } else {
+                    o[0] = static_cast<uint8_t>(p0[0]); o[1] = static_cast<uint8_t>(p0[1]); o[2] = static_cast<uint8_t>(p0[2]);
+                    if (both) { o[3] = static_cast<uint8_t>(p1[0]); o[4] = static_cast<uint8_t>(p1[1]); o[5] = static_cast<uint8_t>(p1[2]); }
+                }
             }
             if (pano_mask) {
                 uint8_t* om = pano_mask + __umul24(py, a.mask_stride) + x;
@@ -1244,6 +1339,15 @@ __device__ __forceinline__ void store_quad(const BlendArgs& a, uint8_t* __restri
             }
         }
     }
+}
+
+// how a tile's level-0 quads may be stored (see store_quad): `pairs` = consecutive lanes hold horizontally adjacent
+// quads and even lanes start on a multiple of four pixels
+__device__ __forceinline__ int pano_store_mode(const BlendArgs& a, const uint8_t* pano, bool pairs)
+{
+    const uint32_t al = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(pano)) | a.pano_stride;
+    if (pairs && (al & 3u) == 0 && !(MST_ABLATE_C & 1024)) return 2;
+    return (al & 1u) == 0 ? 1 : 0;
 }
 
 // phase 3 for a tile that is pure (see band_quad), not the top level, covers a whole C_TW x C_TH region and lies
@@ -1274,7 +1378,7 @@ __device__ __forceinline__ void final_level_pure_full(const CamDesc* __restrict_
     const int uc[3] = {cjm - ur.x0, cj - ur.x0, cjp - ur.x0};
     const uint32_t MST_GLOBAL* __restrict__ g0p = gp(c.G[0]);
     const uint32_t MST_GLOBAL* __restrict__ g1p = gp(c.G[1]);
-    const bool pair_stores = ((reinterpret_cast<uintptr_t>(pano) | a.pano_stride) & 1u) == 0;
+    const int store_mode = pano_store_mode(a, pano, true);      // x0 is a multiple of C_TW, a lane's x = x0 + 2 * (lane)
 
     struct Stage { uint32_t g[4]; uint32_t nb[3][3]; uint2 u[3][3]; };
     auto load = [&](Stage& st, int y) {
@@ -1309,7 +1413,7 @@ __device__ __forceinline__ void final_level_pure_full(const CamDesc* __restrict_
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) o8[q][ch] = static_cast<uint32_t>(sat_u8(sat_s16(up[q][ch] + n[ch])));
         }
-        store_quad(a, pano, pano_mask, x, y, all, o8, all, pair_stores);
+        store_quad(a, pano, pano_mask, x, y, all, o8, all, store_mode);
     };
     Stage sa, sb;
     load(sa, y0);
@@ -1335,9 +1439,10 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
         ur = blend_region(a, tx, ty, 1);
         s_up = lds + a.lds_off[1];
     }
-    // two bytes per store when the panorama rows allow it (even base and stride)
-    const bool pair_stores = ((reinterpret_cast<uintptr_t>(pano) | a.pano_stride) & 1u) == 0;
     const bool blocked = !PURE && !(MST_ABLATE_C & 256) && it.blockable();
+    // lane pairs hold horizontally adjacent quads when a quad row has an even number of quads (row-major order) or in
+    // the 8 x 8 blocked order; the region starts on a multiple of C_TW
+    const int store_mode = pano_store_mode(a, pano, blocked || (it.qw & 1) == 0);
     for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
         int x, y;
         bool valid[4];
@@ -1365,7 +1470,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
                 o8[k][ch] = m[k] ? static_cast<uint32_t>(sat_u8(v)) : 0u;
             }
         }
-        store_quad(a, pano, pano_mask, x, y, valid, o8, m, pair_stores);
+        store_quad(a, pano, pano_mask, x, y, valid, o8, m, store_mode);
     }
 }
 
@@ -1497,27 +1602,25 @@ int mb_blend_region_lds_pixels(const BlendArgs& a, int tx, int ty, int level)
 
 size_t mb_warp_table_entries(int num_tiles) { return static_cast<size_t>(num_tiles) * A_LH * A_LW; }
 
-void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, int2* d_tile_base,
+size_t mb_warp_blob_entries(int num_tiles) { return static_cast<size_t>(num_tiles) * A_BLOB; }
+
+void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, uint32_t* d_blobs,
                        hipStream_t s)
 {
     if (list.count <= 0) return;
-#define MST_LAUNCH_T(K) hipLaunchKernelGGL(k_warp_table<K>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table, d_tile_base)
+#define MST_LAUNCH_T(K) hipLaunchKernelGGL(k_warp_table<K>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table, d_blobs)
     if (kind == 0) MST_LAUNCH_T(0); else if (kind == 1) MST_LAUNCH_T(1); else MST_LAUNCH_T(2);
 #undef MST_LAUNCH_T
 }
 
 void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
-                     int batch, const uint32_t* d_table, const int2* d_tile_base, hipStream_t s)
+                     int batch, const uint32_t* d_table, const uint32_t* d_blobs, hipStream_t s)
 {
     if (list.count <= 0 || batch <= 0) return;
     static const size_t pad = tuning_env("MST_A_PAD_LDS");
-#define MST_LAUNCH_A(K, T) \
-    hipLaunchKernelGGL((k_warp_pyr<K, T>), dim3(list.count * batch), dim3(256), pad, s, d_cams, list, frames, d_table, d_tile_base, n_cams, batch)
-    if (d_table) {
-        if (kind == 0) MST_LAUNCH_A(0, true); else if (kind == 1) MST_LAUNCH_A(1, true); else MST_LAUNCH_A(2, true);
-    } else {
-        if (kind == 0) MST_LAUNCH_A(0, false); else if (kind == 1) MST_LAUNCH_A(1, false); else MST_LAUNCH_A(2, false);
-    }
+#define MST_LAUNCH_A(K) \
+    hipLaunchKernelGGL((k_warp_pyr<K>), dim3(list.count * batch), dim3(256), pad, s, d_cams, list, frames, d_table, d_blobs, n_cams, batch)
+    if (kind == 0) MST_LAUNCH_A(0); else if (kind == 1) MST_LAUNCH_A(1); else MST_LAUNCH_A(2);
 #undef MST_LAUNCH_A
 }
 

@@ -19,6 +19,10 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int iters, unsigned seed
             if (KIND == 4) { fa = __builtin_amdgcn_rcpf(fa) + fd; fb = rintf(fb * fc); }               // rcp / rndne
             if (KIND == 5) { a = __builtin_amdgcn_alignbyte(a, c, b & 3u); b = __builtin_amdgcn_ubfe(b, 3, 9) + d; }  // alignbyte / bfe
             if (KIND == 6) { fa = (float)(int)a * fc; a = (unsigned)(int)fa + c; }                      // cvt i32<->f32 + mul
+            if (KIND == 7) { a = __builtin_amdgcn_udot4(a, c, b, false); b = __builtin_amdgcn_udot4(b, d, a, false); }   // v_dot4_u32_u8
+            if (KIND == 8) { a = __builtin_amdgcn_cvt_pk_u8_f32(fa, 1u, a); fa = fa + fd; b = __builtin_amdgcn_cvt_pk_u8_f32(fb, 2u, b); fb = fb + fd; }   // cvt_pk_u8 + add
+            if (KIND == 9) { a = __umul24(a, c) + 512u; b = (__umul24(b, d) + a) >> 10; }               // mul24 / mad24 / shift
+            if (KIND == 10) { a = min(max((int)a, -32768), 32767) + c; b = ((int)b >> 16) + d; }        // med3 / ashr / add
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d + (unsigned)fa + (unsigned)fb;
@@ -52,5 +56,9 @@ int main()
     run<4>("rcp+add / mul+rndne", 4);
     run<5>("alignbyte / bfe+add", 4);
     run<6>("cvt+mul / cvt+add", 4);
+    run<7>("v_dot4_u32_u8", 2);
+    run<8>("cvt_pk_u8_f32 + add", 4);
+    run<9>("mul24+add / mad24+shift", 4);
+    run<10>("med3+add / ashr+add", 4);
     return 0;
 }
