@@ -54,10 +54,32 @@ extern "C" {
 #define MST_ERR_NEED_MORE_IMGS -5  /* Stitcher::ERR_NEED_MORE_IMGS (stitcher.hpp:62) */
 #define MST_ERR_OUT_OF_MEMORY -6
 
-/* --warp (CLI:102); projector kinds of detail/warpers.hpp */
+/* --warp (CLI:102); projector kinds of detail/warpers.hpp:88-503.  Plane, spherical and cylindrical maps are
+ * evaluated on the device from per-column / per-row tables; the others call libm per pixel in the reference
+ * (detail/warpers_inl.hpp:302-759), so the engine evaluates their backward maps on the host once per calibration --
+ * RotationWarperBase::buildMaps -- and the kernels read them.  The per-frame path is the same for all. */
 #define MST_WARP_PLANE        0
 #define MST_WARP_SPHERICAL    1
 #define MST_WARP_CYLINDRICAL  2
+#define MST_WARP_FISHEYE                   3
+#define MST_WARP_STEREOGRAPHIC             4
+#define MST_WARP_COMPRESSED_PLANE          5    /* CompressedRectilinearWarper(scale, A, B) */
+#define MST_WARP_COMPRESSED_PLANE_PORTRAIT 6
+#define MST_WARP_PANINI                    7    /* PaniniWarper(scale, A, B) */
+#define MST_WARP_PANINI_PORTRAIT           8
+#define MST_WARP_MERCATOR                  9
+#define MST_WARP_TRANSVERSE_MERCATOR       10
+#define MST_WARP_SPHERICAL_PORTRAIT        11   /* detail::SphericalPortraitWarper (no --warp name) */
+#define MST_WARP_CYLINDRICAL_PORTRAIT      12
+#define MST_WARP_PLANE_PORTRAIT            13
+/* A, B of the compressed-rectilinear and Panini projectors ride in bits 8-9 of the kind: 0 = the constructors'
+ * defaults (1, 1); MST_WARP_A2B1 / MST_WARP_A1_5B1 = the pairs behind the command line's "...A2B1" / "...A1.5B1"
+ * names (CLI:561-568); MST_WARP_AB_CUSTOM = mst_config.warp_a / warp_b (engine only). */
+#define MST_WARP_A2B1         (1 << 8)
+#define MST_WARP_A1_5B1       (2 << 8)
+#define MST_WARP_AB_CUSTOM    (3 << 8)
+/* the reference's --warp names (CLI:102,556-570) -> kind; -1 for an unknown name */
+int mst_warp_kind_from_name(const char *name);
 /* --blend (CLI:112); Blender::NO/FEATHER/MULTI_BAND, detail/blenders.hpp:58 */
 #define MST_BLEND_NO          0
 #define MST_BLEND_FEATHER     1
@@ -110,6 +132,8 @@ typedef struct mst_config {
     int32_t  max_batch;          /* frame sets per mst_compose_device_batch call, 0/1 = none, <= MST_MAX_BATCH;
                                   * multi-band keeps one set of Gaussian pyramids per frame set of a batch */
     int32_t  weight_type;        /* MST_WEIGHT_*: MultiBandBlender's weight_type (blenders.hpp:101), default CV_32F */
+    float    warp_a, warp_b;     /* A, B of CompressedRectilinear* / Panini* warpers when warp_kind carries
+                                  * MST_WARP_AB_CUSTOM (detail/warpers.hpp:232-305) */
 } mst_config;
 
 typedef struct mst_camera {

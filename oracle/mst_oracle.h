@@ -30,7 +30,17 @@ extern "C" {
 #endif
 
 /* ---- enums (values follow OpenCV 2.4.11 / the reference headers) ---------- */
-enum { MO_WARP_PLANE = 0, MO_WARP_SPHERICAL = 1, MO_WARP_CYLINDRICAL = 2 };
+enum { MO_WARP_PLANE = 0, MO_WARP_SPHERICAL = 1, MO_WARP_CYLINDRICAL = 2,
+       /* the other projectors of detail/warpers.hpp:190-493 (warpers_inl.hpp:302-759) */
+       MO_WARP_FISHEYE = 3, MO_WARP_STEREOGRAPHIC = 4, MO_WARP_COMPRESSED_PLANE = 5,
+       MO_WARP_COMPRESSED_PLANE_PORTRAIT = 6, MO_WARP_PANINI = 7, MO_WARP_PANINI_PORTRAIT = 8,
+       MO_WARP_MERCATOR = 9, MO_WARP_TRANSVERSE_MERCATOR = 10, MO_WARP_SPHERICAL_PORTRAIT = 11,
+       MO_WARP_CYLINDRICAL_PORTRAIT = 12, MO_WARP_PLANE_PORTRAIT = 13, MO_WARP_KINDS = 14 };
+/* The A, B parameters of the compressed-rectilinear and Panini projectors travel in bits 8-9 of the kind:
+ * 0 = the constructors' defaults (1, 1); 1 = (2, 1) and 2 = (1.5, 1), the two the command line offers
+ * (CLI:561-568); 3 = the pair last given to mo_set_custom_ab. */
+#define MO_WARP_AB(kind, preset) ((kind) | ((preset) << 8))
+void mo_set_custom_ab(float a, float b);
 enum { MO_INTER_NEAREST = 0, MO_INTER_LINEAR = 1 };
 enum { MO_BORDER_CONSTANT = 0, MO_BORDER_REPLICATE = 1, MO_BORDER_REFLECT = 2,
        MO_BORDER_WRAP = 3, MO_BORDER_REFLECT_101 = 4 };
@@ -50,6 +60,7 @@ typedef struct {
     float r_kinv[9];
     float k_rinv[9];
     float t[3];
+    float a, b;               /* CompressedRectilinear* / Panini* projectors */
 } mo_projector;
 
 /* worker threads for the row-parallel loops (OpenMP); results do not depend on it */

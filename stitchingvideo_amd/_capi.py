@@ -14,6 +14,20 @@ MST_OK = 0
 ERR_INVALID_ARG, ERR_NOT_CALIBRATED, ERR_HIP, ERR_NO_DEVICE, ERR_NEED_MORE_IMGS, ERR_OUT_OF_MEMORY = \
     -1, -2, -3, -4, -5, -6
 WARP_PLANE, WARP_SPHERICAL, WARP_CYLINDRICAL = 0, 1, 2
+(WARP_FISHEYE, WARP_STEREOGRAPHIC, WARP_COMPRESSED_PLANE, WARP_COMPRESSED_PLANE_PORTRAIT, WARP_PANINI,
+ WARP_PANINI_PORTRAIT, WARP_MERCATOR, WARP_TRANSVERSE_MERCATOR, WARP_SPHERICAL_PORTRAIT,
+ WARP_CYLINDRICAL_PORTRAIT, WARP_PLANE_PORTRAIT) = range(3, 14)
+WARP_A2B1, WARP_A1_5B1, WARP_AB_CUSTOM = 1 << 8, 2 << 8, 3 << 8
+# the reference's --warp names (CLI:102) plus the three detail:: portrait warpers that have none
+WARP_NAMES = {
+    "plane": 0, "spherical": 1, "cylindrical": 2, "fisheye": 3, "stereographic": 4,
+    "compressedPlaneA2B1": 5 | WARP_A2B1, "compressedPlaneA1.5B1": 5 | WARP_A1_5B1,
+    "compressedPlanePortraitA2B1": 6 | WARP_A2B1, "compressedPlanePortraitA1.5B1": 6 | WARP_A1_5B1,
+    "paniniA2B1": 7 | WARP_A2B1, "paniniA1.5B1": 7 | WARP_A1_5B1,
+    "paniniPortraitA2B1": 8 | WARP_A2B1, "paniniPortraitA1.5B1": 8 | WARP_A1_5B1,
+    "mercator": 9, "transverseMercator": 10,
+    "sphericalPortrait": 11, "cylindricalPortrait": 12, "planePortrait": 13,
+}
 BLEND_NO, BLEND_FEATHER, BLEND_MULTI_BAND = 0, 1, 2
 EXPOS_NO, EXPOS_GAIN, EXPOS_GAIN_BLOCKS = 0, 1, 2
 INTER_NEAREST, INTER_LINEAR = 0, 1
@@ -26,7 +40,7 @@ DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, 
     1, 2, 3, 4, 5, 6
 
 EXPORTS = [
-    "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_acquire_calibration", "mst_canvas", "mst_camera_roi",
+    "mst_warp_kind_from_name", "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_acquire_calibration", "mst_canvas", "mst_camera_roi",
     "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_device_batch", "mst_compose_profile",
     "mst_compose_profile_batch", "mst_synchronize", "mst_warp_roi",
     "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
@@ -41,7 +55,8 @@ class Config(C.Structure):
                 ("blend_kind", C.c_int32), ("num_bands", C.c_int32), ("feather_sharpness", C.c_float),
                 ("expos_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("upblack", C.c_float), ("downblack", C.c_float), ("leftblack", C.c_float),
-                ("rightblack", C.c_float), ("max_batch", C.c_int32), ("weight_type", C.c_int32)]
+                ("rightblack", C.c_float), ("max_batch", C.c_int32), ("weight_type", C.c_int32),
+                ("warp_a", C.c_float), ("warp_b", C.c_float)]
 
 
 class Camera(C.Structure):
@@ -93,6 +108,8 @@ def load():
             pass
     L = C.CDLL(LIB_PATH)
     fp, vp, ip = C.POINTER(C.c_float), C.c_void_p, C.POINTER(C.c_int)
+    L.mst_warp_kind_from_name.restype = C.c_int
+    L.mst_warp_kind_from_name.argtypes = [C.c_char_p]
     L.mst_create.restype = C.c_int
     L.mst_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.mst_destroy.restype = None

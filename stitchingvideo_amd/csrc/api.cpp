@@ -43,15 +43,20 @@ void require(bool cond, const char* msg)
     if (!cond) throw mst::Error{MST_ERR_INVALID_ARG, msg};
 }
 
-bool valid_warp(int k) { return k == MST_WARP_PLANE || k == MST_WARP_SPHERICAL || k == MST_WARP_CYLINDRICAL; }
+bool valid_warp(int k)
+{
+    const int base = k & 0xFF;
+    return k >= 0 && (k >> 10) == 0 && base < mst::kWarpKinds;
+}
 
 mst::Projector make_projector(int kind, float scale, const float K[9], const float R[9], const float T[3])
 {
     require(valid_warp(kind), "unknown warp kind");
+    require((kind & MST_WARP_AB_CUSTOM) != MST_WARP_AB_CUSTOM, "MST_WARP_AB_CUSTOM needs an engine (mst_config.warp_a / warp_b)");
     require(K && R, "K and R must not be null");
     require(scale > 0.f, "scale must be > 0");
     mst::Projector p;
-    p.kind = kind;
+    mst::set_projector_kind(p, kind, 1.f, 1.f);
     p.scale = scale;
     p.set(K, R, T);
     return p;
@@ -70,6 +75,26 @@ struct StageCtx {
 
 extern "C" {
 
+int mst_warp_kind_from_name(const char* name)
+{
+    if (!name) return -1;
+    static const struct { const char* name; int kind; } kNames[] = {      // CLI:556-570
+        {"plane", MST_WARP_PLANE}, {"cylindrical", MST_WARP_CYLINDRICAL}, {"spherical", MST_WARP_SPHERICAL},
+        {"fisheye", MST_WARP_FISHEYE}, {"stereographic", MST_WARP_STEREOGRAPHIC},
+        {"compressedPlaneA2B1", MST_WARP_COMPRESSED_PLANE | MST_WARP_A2B1},
+        {"compressedPlaneA1.5B1", MST_WARP_COMPRESSED_PLANE | MST_WARP_A1_5B1},
+        {"compressedPlanePortraitA2B1", MST_WARP_COMPRESSED_PLANE_PORTRAIT | MST_WARP_A2B1},
+        {"compressedPlanePortraitA1.5B1", MST_WARP_COMPRESSED_PLANE_PORTRAIT | MST_WARP_A1_5B1},
+        {"paniniA2B1", MST_WARP_PANINI | MST_WARP_A2B1}, {"paniniA1.5B1", MST_WARP_PANINI | MST_WARP_A1_5B1},
+        {"paniniPortraitA2B1", MST_WARP_PANINI_PORTRAIT | MST_WARP_A2B1},
+        {"paniniPortraitA1.5B1", MST_WARP_PANINI_PORTRAIT | MST_WARP_A1_5B1},
+        {"mercator", MST_WARP_MERCATOR}, {"transverseMercator", MST_WARP_TRANSVERSE_MERCATOR},
+    };
+    for (const auto& e : kNames)
+        if (std::strcmp(name, e.name) == 0) return e.kind;
+    return -1;
+}
+
 int mst_create(const mst_config* cfg, mst_engine** out)
 {
     if (out) *out = nullptr;
@@ -79,6 +104,8 @@ int mst_create(const mst_config* cfg, mst_engine** out)
         require(cfg->struct_size == static_cast<int32_t>(sizeof(mst_config)), "mst_config.struct_size mismatch");
         require(cfg->num_cameras >= 1 && cfg->num_cameras <= MST_MAX_CAMERAS, "num_cameras out of range");
         require(valid_warp(cfg->warp_kind), "unknown warp kind");
+        require((cfg->warp_kind & MST_WARP_AB_CUSTOM) != MST_WARP_AB_CUSTOM || (cfg->warp_a > 0.f && cfg->warp_b > 0.f),
+                "MST_WARP_AB_CUSTOM needs positive mst_config.warp_a / warp_b");
         require(cfg->blend_kind >= MST_BLEND_NO && cfg->blend_kind <= MST_BLEND_MULTI_BAND, "unsupported blending method");
         require(cfg->expos_kind >= MST_EXPOS_NO && cfg->expos_kind <= MST_EXPOS_GAIN_BLOCKS,
                 "unsupported exposure compensation method");

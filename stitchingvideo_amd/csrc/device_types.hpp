@@ -42,6 +42,9 @@ struct CamDesc {
     float   one_minus_t2;          // (1 - t[2]) of the plane projector
     const float* col_a; const float* col_b;
     const float* row_a; const float* row_b;
+    // non-separable projectors (kind >= 3): the backward map itself, roi_h x roi_w floats each, evaluated on the
+    // host per calibration (RotationWarperBase::buildMaps); nullptr for plane / spherical / cylindrical
+    const float* xmap; const float* ymap;
     const ColEntry* cols;          // same data, packed per column (fused kernels)
     const RowEntry* rows;
     // ---- exposure (a7)

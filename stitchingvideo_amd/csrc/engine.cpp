@@ -93,6 +93,15 @@ void fill_camera_desc(DevicePool& pool, hipStream_t s, const Projector& proj, co
     MapTables t = build_map_tables(proj, roi);
     d.col_a = pool.upload(t.col_a, s); d.col_b = pool.upload(t.col_b, s);
     d.row_a = pool.upload(t.row_a, s); d.row_b = pool.upload(t.row_b, s);
+    d.xmap = d.ymap = nullptr;
+    std::vector<float> xmap, ymap;
+    if (!separable_map(proj.kind)) {
+        const size_t px = static_cast<size_t>(roi.width) * roi.height;
+        xmap.resize(px); ymap.resize(px);
+        build_maps_host(proj, roi, xmap.data(), ymap.data());
+        d.xmap = pool.upload(xmap, s);
+        d.ymap = pool.upload(ymap, s);
+    }
     d.expos = expos_kind;
     d.gain = gain;
     d.gain_map = nullptr; d.gw = d.gh = 0;
@@ -314,7 +323,7 @@ void Engine::update(const mst_calibration& calib)
         const mst_camera& c = calib.cameras[i];
         if (c.src_width <= 0 || c.src_height <= 0) throw Error{MST_ERR_INVALID_ARG, "bad source size"};
         CameraSetup& cs = st->cams[i];
-        cs.proj.kind = cfg_.warp_kind;
+        set_projector_kind(cs.proj, cfg_.warp_kind, cfg_.warp_a, cfg_.warp_b);
         cs.proj.scale = calib.warped_image_scale;
         cs.proj.set(c.K, c.R, c.T);
         cs.src_w = c.src_width; cs.src_h = c.src_height;
@@ -488,7 +497,7 @@ void Engine::update(const mst_calibration& calib)
         // frame-invariant backward map of every launched tile, in the order kernel A consumes it
         st->warp_table = st->pool.alloc<uint32_t>(mb_warp_table_entries(st->warp_list.count));
         st->warp_blobs = st->pool.alloc<uint32_t>(mb_warp_blob_entries(st->warp_list.count));
-        launch_warp_table(st->d_desc, cfg_.warp_kind, st->warp_list, st->warp_table, st->warp_blobs, s);
+        launch_warp_table(st->d_desc, cfg_.warp_kind & 0xFF, st->warp_list, st->warp_table, st->warp_blobs, s);
         check_hip(hipGetLastError(), "k_warp_table");
         st->chain_lists.clear();
         for (const MbPlanHost::ChainStep& step : plan.chain) {
@@ -614,7 +623,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
                     canvas_pending_[k] = false;
                 }
         undistort(first_set, sf);
-        launch_warp_pyr(desc, st->n, cfg_.warp_kind, st->warp_list, fb, count, st->warp_table, st->warp_blobs, sf);
+        launch_warp_pyr(desc, st->n, cfg_.warp_kind & 0xFF, st->warp_list, fb, count, st->warp_table, st->warp_blobs, sf);
         mark("k_warp_pyr");
         // where the frame crosses from the front stream to the caller's stream: after the warp kernel (the small
         // pyramid-chain launches then fill in beside the next frame's warp) or after the chain
@@ -714,7 +723,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
         tl.tiles = st->warp_list.tiles + plan.warp_cam_start[i];
         tl.count = plan.warp_cam_start[i + 1] - plan.warp_cam_start[i];
         tl.first = plan.warp_cam_start[i];
-        launch_warp_pyr(st->d_desc, st->n, cfg_.warp_kind, tl, fb, 1, st->warp_table, st->warp_blobs, s);
+        launch_warp_pyr(st->d_desc, st->n, cfg_.warp_kind & 0xFF, tl, fb, 1, st->warp_table, st->warp_blobs, s);
     }
     for (size_t k = 0; k < st->chain_lists.size(); ++k)
         for (int i = 0; i < st->n; ++i) {

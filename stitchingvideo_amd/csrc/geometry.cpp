@@ -6,6 +6,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 namespace mst {
 
@@ -96,8 +97,238 @@ void Projector::set(const float K[9], const float R[9], const float T[3])
     for (int i = 0; i < 3; ++i) t[i] = T ? T[i] : 0.f;
 }
 
+namespace {
+
+// The ray through source pixel (x, y), R * K^-1 * (x, y, 1); the portrait projectors read it with the first two
+// components exchanged.
+struct Ray { float x, y, z; };
+inline Ray ray_through(const float m[9], float x, float y)
+{
+    Ray r;
+    r.x = m[0] * x + m[1] * y + m[2];
+    r.y = m[3] * x + m[4] * y + m[5];
+    r.z = m[6] * x + m[7] * y + m[8];
+    return r;
+}
+inline float norm3(const Ray& r) { return sqrtf(r.x * r.x + r.y * r.y + r.z * r.z); }
+
+}  // namespace
+
+// detail/warpers_inl.hpp:302-752 (forward maps of the eleven non-separable projectors); float libm calls exactly
+// where the reference has them, the double ones (cos, sin, fabs without suffix) likewise
+static void forward_other(const Projector& p, float x, float y, float& u, float& v)
+{
+    const float scale = p.scale, a = p.a, b = p.b;
+    Ray r = ray_through(p.r_kinv, x, y);
+    const bool swapped_in = p.kind == kCompressedPlanePortrait || p.kind == kPaniniPortrait;
+    if (swapped_in) std::swap(r.x, r.y);
+    switch (p.kind) {
+    case kFisheye: {
+        const float lon = atan2f(r.x, r.z);
+        const float lat = static_cast<float>(kPi) - acosf(r.y / norm3(r));
+        u = scale * lat * cosf(lon);
+        v = scale * lat * sinf(lon);
+        return;
+    }
+    case kStereographic: {
+        const float lon = atan2f(r.x, r.z);
+        const float lat = static_cast<float>(kPi) - acosf(r.y / norm3(r));
+        const float rad = sinf(lat) / (1 - cosf(lat));
+        u = static_cast<float>(scale * rad * std::cos(static_cast<double>(lon)));
+        v = static_cast<float>(scale * rad * std::sin(static_cast<double>(lon)));
+        return;
+    }
+    case kCompressedPlane:
+    case kCompressedPlanePortrait: {
+        const float lon = atan2f(r.x, r.z);
+        const float lat = asinf(r.y / norm3(r));
+        u = p.kind == kCompressedPlane ? scale * a * tanf(lon / a) : -scale * a * tanf(lon / a);
+        v = scale * b * tanf(lat) / cosf(lon);
+        return;
+    }
+    case kPanini:
+    case kPaniniPortrait: {
+        const float lon = atan2f(r.x, r.z);
+        const float lat = asinf(r.y / norm3(r));
+        const float tg = a * tanf(lon / a);
+        u = p.kind == kPanini ? scale * tg : -scale * tg;
+        const float sinu = sinf(lon);
+        if (std::fabs(static_cast<double>(sinu)) < 1E-7) v = scale * b * tanf(lat);
+        else v = scale * b * tg * tanf(lat) / sinu;
+        return;
+    }
+    case kMercator: {
+        const float lon = atan2f(r.x, r.z);
+        const float lat = asinf(r.y / norm3(r));
+        u = scale * lon;
+        v = scale * logf(tanf(static_cast<float>(kPi / 4) + lat / 2));
+        return;
+    }
+    case kTransverseMercator: {
+        const float lon = atan2f(r.x, r.z);
+        const float lat = asinf(r.y / norm3(r));
+        const float B = cosf(lat) * sinf(lon);
+        u = scale / 2 * logf((1 + B) / (1 - B));
+        v = scale * atan2f(tanf(lat), cosf(lon));
+        return;
+    }
+    default:
+        break;
+    }
+    // the three portrait variants of the separable projectors: components exchanged, u negated
+    std::swap(r.x, r.y);
+    float pu, pv;
+    if (p.kind == kSphericalPortrait) {
+        pu = scale * atan2f(r.x, r.z);
+        pv = scale * (static_cast<float>(kPi) - acosf(r.y / norm3(r)));
+    } else if (p.kind == kCylindricalPortrait) {
+        pu = scale * atan2f(r.x, r.z);
+        pv = scale * r.y / sqrtf(r.x * r.x + r.z * r.z);
+    } else {
+        const float px = p.t[0] + r.x / r.z * (1 - p.t[2]);
+        const float py = p.t[1] + r.y / r.z * (1 - p.t[2]);
+        pu = scale * px;
+        pv = scale * py;
+    }
+    u = -pu;
+    v = pv;
+}
+
+// detail/warpers_inl.hpp:318-773 (backward maps)
+void Projector::backward(float u, float v, float& x, float& y) const
+{
+    const float* kr = k_rinv;
+    if (kind == kPlanePortrait) {
+        const float pu = -u / scale - t[0];
+        const float pv = v / scale - t[1];
+        x = kr[0] * pv + kr[1] * pu + kr[2] * (1 - t[2]);
+        y = kr[3] * pv + kr[4] * pu + kr[5] * (1 - t[2]);
+        const float z = kr[6] * pv + kr[7] * pu + kr[8] * (1 - t[2]);
+        x /= z;
+        y /= z;
+        return;
+    }
+    Ray r{0.f, 0.f, 0.f};
+    auto from_lon_lat = [&](float lon, float lat, bool portrait) {      // unit ray of (longitude, latitude)
+        const float cl = cosf(lat);
+        const float along = cl * sinf(lon), up = sinf(lat);
+        r.x = portrait ? up : along;
+        r.y = portrait ? along : up;
+        r.z = cl * cosf(lon);
+    };
+    auto from_polar = [&](float lon, float colat) {                      // fisheye family: angle from the -y pole
+        const float s = sinf(static_cast<float>(kPi) - colat);
+        r.x = s * sinf(lon);
+        r.y = cosf(static_cast<float>(kPi) - colat);
+        r.z = s * cosf(lon);
+    };
+    switch (kind) {
+    case kFisheye: {
+        u /= scale; v /= scale;
+        const float lon = atan2f(v, u);
+        from_polar(lon, sqrtf(u * u + v * v));
+        break;
+    }
+    case kStereographic: {
+        u /= scale; v /= scale;
+        const float lon = atan2f(v, u);
+        const float rad = sqrtf(u * u + v * v);
+        from_polar(lon, 2 * atanf(1.f / rad));
+        break;
+    }
+    case kCompressedPlane:
+    case kCompressedPlanePortrait: {
+        const bool portrait = kind == kCompressedPlanePortrait;
+        u /= portrait ? -scale : scale;
+        v /= scale;
+        const float lon = a * atanf(u / a);
+        from_lon_lat(lon, atanf(v * cosf(lon) / b), portrait);
+        break;
+    }
+    case kPanini:
+    case kPaniniPortrait: {
+        const bool portrait = kind == kPaniniPortrait;
+        u /= portrait ? -scale : scale;
+        v /= scale;
+        const float lon = a * atanf(u / a);
+        float lat;
+        if (std::fabs(static_cast<double>(lon)) > 1E-7) lat = atanf(v * sinf(lon) / (b * a * tanf(lon / a)));
+        else lat = atanf(v / b);
+        from_lon_lat(lon, lat, portrait);
+        break;
+    }
+    case kMercator: {
+        u /= scale; v /= scale;
+        from_lon_lat(u, atanf(sinhf(v)), false);
+        break;
+    }
+    case kTransverseMercator: {
+        u /= scale; v /= scale;
+        const float lat = asinf(sinf(v) / coshf(u));
+        const float lon = atan2f(sinhf(u), static_cast<float>(std::cos(static_cast<double>(v))));
+        from_lon_lat(lon, lat, false);
+        break;
+    }
+    case kSphericalPortrait: {
+        const float pu = -u / scale, pv = v / scale;
+        const float s = sinf(static_cast<float>(kPi) - pv);
+        r.y = s * sinf(pu);                                   // x0_ -> y_
+        r.x = cosf(static_cast<float>(kPi) - pv);             // y0_ -> x_
+        r.z = s * cosf(pu);
+        break;
+    }
+    default: {  // kCylindricalPortrait
+        const float pu = -u / scale, pv = v / scale;
+        r.y = sinf(pu);
+        r.x = pv;
+        r.z = cosf(pu);
+        break;
+    }
+    }
+    x = kr[0] * r.x + kr[1] * r.y + kr[2] * r.z;
+    y = kr[3] * r.x + kr[4] * r.y + kr[5] * r.z;
+    const float z = kr[6] * r.x + kr[7] * r.y + kr[8] * r.z;
+    if (z > 0) { x /= z; y /= z; }
+    else x = y = -1;
+}
+
+void set_projector_kind(Projector& p, int kind, float custom_a, float custom_b)
+{
+    p.kind = kind & 0xFF;
+    switch ((kind >> 8) & 3) {
+    case 1:  p.a = 2.f;  p.b = 1.f; break;          // "...A2B1"   (CLI:561,563,565,567)
+    case 2:  p.a = 1.5f; p.b = 1.f; break;          // "...A1.5B1" (CLI:562,564,566,568)
+    case 3:  p.a = custom_a; p.b = custom_b; break;
+    default: p.a = 1.f;  p.b = 1.f; break;          // float A = 1, float B = 1
+    }
+}
+
+void build_maps_host(const Projector& p, const Rect& roi, float* xmap, float* ymap)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int workers = static_cast<int>(std::min<unsigned>(hw, 64u));
+    auto rows = [&](int j0, int j1) {
+        for (int j = j0; j < j1; ++j)
+            for (int i = 0; i < roi.width; ++i) {
+                float x, y;
+                p.backward(static_cast<float>(roi.x + i), static_cast<float>(roi.y + j), x, y);
+                xmap[static_cast<size_t>(j) * roi.width + i] = x;
+                ymap[static_cast<size_t>(j) * roi.width + i] = y;
+            }
+    };
+    if (workers == 1 || roi.height < 64) { rows(0, roi.height); return; }
+    std::vector<std::thread> pool;
+    const int per = (roi.height + workers - 1) / workers;
+    for (int w = 0; w < workers; ++w) {
+        const int j0 = w * per, j1 = std::min(roi.height, j0 + per);
+        if (j0 < j1) pool.emplace_back(rows, j0, j1);
+    }
+    for (std::thread& t : pool) t.join();
+}
+
 void Projector::forward(float x, float y, float& u, float& v) const
 {
+    if (kind >= kFisheye) { forward_other(*this, x, y, u, v); return; }
     float x_ = r_kinv[0] * x + r_kinv[1] * y + r_kinv[2];
     float y_ = r_kinv[3] * x + r_kinv[4] * y + r_kinv[5];
     float z_ = r_kinv[6] * x + r_kinv[7] * y + r_kinv[8];
@@ -124,7 +355,35 @@ void Projector::forward(float x, float y, float& u, float& v) const
 void detect_result_roi(const Projector& p, int src_w, int src_h, int& tl_x, int& tl_y, int& br_x, int& br_y)
 {
     Bounds b;
-    if (p.kind == kPlane) {
+    if (p.kind == kSphericalPortrait || p.kind == kCylindricalPortrait || p.kind == kPlanePortrait) {
+        // detectResultRoiByBorder (detail/warpers.hpp:479-502); the spherical one then adds the poles it contains,
+        // which lie on the x axis for this projector (warpers.cpp:389-430)
+        b = border_walk(p, src_w, src_h);
+        if (p.kind == kSphericalPortrait) {
+            float tl_uf = static_cast<float>(static_cast<int>(b.tl_u)), tl_vf = static_cast<float>(static_cast<int>(b.tl_v));
+            float br_uf = static_cast<float>(static_cast<int>(b.br_u)), br_vf = static_cast<float>(static_cast<int>(b.br_v));
+            for (int pole = 0; pole < 2; ++pole) {
+                const float x = p.rinv[0], y = pole == 0 ? p.rinv[3] : -p.rinv[3], z = p.rinv[6];
+                if (!(y > 0.f)) continue;
+                const float x_ = (p.k[0] * x + p.k[1] * y) / z + p.k[2];
+                const float y_ = p.k[4] * y / z + p.k[5];
+                if (x_ > 0.f && x_ < src_w && y_ > 0.f && y_ < src_h) {
+                    const float pv = pole == 0 ? static_cast<float>(kPi * p.scale) : 0.f;
+                    tl_uf = std::min(tl_uf, 0.f); tl_vf = std::min(tl_vf, pv);
+                    br_uf = std::max(br_uf, 0.f); br_vf = std::max(br_vf, pv);
+                }
+            }
+            b.tl_u = tl_uf; b.tl_v = tl_vf; b.br_u = br_uf; b.br_v = br_vf;
+        }
+    } else if (p.kind >= kFisheye) {
+        // RotationWarperBase::detectResultRoi (detail/warpers_inl.hpp:143-166): every source pixel is projected
+        float u, v;
+        for (int y = 0; y < src_h; ++y)
+            for (int x = 0; x < src_w; ++x) {
+                p.forward(static_cast<float>(x), static_cast<float>(y), u, v);
+                b.add(u, v);
+            }
+    } else if (p.kind == kPlane) {
         float u, v;
         p.forward(0, 0, u, v);                                                        b.add(u, v);
         p.forward(0, static_cast<float>(src_h - 1), u, v);                            b.add(u, v);
@@ -183,8 +442,9 @@ Rect result_roi(const std::vector<Rect>& rois)
 MapTables build_map_tables(const Projector& p, const Rect& roi)
 {
     MapTables t;
-    t.col_a.resize(roi.width); t.col_b.resize(roi.width);
-    t.row_a.resize(roi.height); t.row_b.resize(roi.height);
+    t.col_a.assign(roi.width, 0.f); t.col_b.assign(roi.width, 0.f);
+    t.row_a.assign(roi.height, 0.f); t.row_b.assign(roi.height, 0.f);
+    if (!separable_map(p.kind)) return t;          // those kernels read the full map instead (build_maps_host)
     for (int i = 0; i < roi.width; ++i) {
         float u = static_cast<float>(roi.x + i);
         if (p.kind == kPlane) {
@@ -215,6 +475,7 @@ MapTables build_map_tables(const Projector& p, const Rect& roi)
 
 void backward_map_host(const Projector& p, const Rect& roi, const MapTables& t, float* xmap, float* ymap)
 {
+    if (!separable_map(p.kind)) { build_maps_host(p, roi, xmap, ymap); return; }
     const float* kr = p.k_rinv;
     for (int j = 0; j < roi.height; ++j)
         for (int i = 0; i < roi.width; ++i) {

@@ -30,16 +30,35 @@ struct Rect {
     int br_y() const { return y + height; }
 };
 
-enum WarpKind { kPlane = 0, kSpherical = 1, kCylindrical = 2 };
+// MST_WARP_* of the public header.  Plane, spherical and cylindrical maps separate into per-column and per-row
+// terms (MapTables below) and are evaluated on the device; the other eleven projectors of
+// detail/warpers_inl.hpp:302-759 need libm per pixel, so their backward maps are evaluated on the host once per
+// calibration -- RotationWarperBase::buildMaps, detail/warpers_inl.hpp:62-85 -- and the kernels read them.
+enum WarpKind {
+    kPlane = 0, kSpherical = 1, kCylindrical = 2,
+    kFisheye = 3, kStereographic = 4, kCompressedPlane = 5, kCompressedPlanePortrait = 6, kPanini = 7,
+    kPaniniPortrait = 8, kMercator = 9, kTransverseMercator = 10, kSphericalPortrait = 11,
+    kCylindricalPortrait = 12, kPlanePortrait = 13, kWarpKinds = 14
+};
+inline bool separable_map(int kind) { return kind <= kCylindrical; }
 
 struct Projector {
     int kind = kSpherical;
     float scale = 1.f;
+    float a = 1.f, b = 1.f;           // CompressedRectilinear* / Panini* (detail/warpers.hpp:226-305)
     float k[9], rinv[9], r_kinv[9], k_rinv[9], t[3];
 
     void set(const float K[9], const float R[9], const float T[3]);
     void forward(float x, float y, float& u, float& v) const;
+    void backward(float u, float v, float& x, float& y) const;     // kinds >= kFisheye only
 };
+
+// kind = MST_WARP_* with the A/B preset in bits 8-9 (include/mi355_stitch.h); custom_a/b serve preset 3
+void set_projector_kind(Projector& p, int kind, float custom_a, float custom_b);
+
+// RotationWarperBase::buildMaps for the non-separable projectors: roi.width x roi.height floats each, rows in
+// parallel on the host's cores.
+void build_maps_host(const Projector& p, const Rect& roi, float* xmap, float* ymap);
 
 // inclusive top-left / bottom-right, as the reference's detectResultRoi returns them
 void detect_result_roi(const Projector& p, int src_w, int src_h, int& tl_x, int& tl_y, int& br_x, int& br_y);

@@ -79,6 +79,12 @@ __device__ __forceinline__ int reflect(int p, int len)
 // ---- backward map (generic form, table per axis) -------------------------------------------------
 __device__ __forceinline__ void backward_map(const CamDesc& c, int x, int y, float& mx, float& my)
 {
+    if (c.kind >= 3) {          // non-separable projector: the host-built map (device_types.hpp)
+        const uint32_t i = static_cast<uint32_t>(y) * static_cast<uint32_t>(c.roi_w) + static_cast<uint32_t>(x);
+        mx = gp(c.xmap)[i];
+        my = gp(c.ymap)[i];
+        return;
+    }
     const float ca = gp(c.col_a)[x];
     const float ra = gp(c.row_a)[y];
     float X, Y, Z;

@@ -174,22 +174,28 @@ __device__ __forceinline__ MapPx unpack_map(uint32_t e, int bx, int by)
     return m;
 }
 
+// KIND 3 stands for every non-separable projector: its map comes from the host-built xmap / ymap (rx, ry index it)
 template <int KIND>
-__device__ __forceinline__ MapPx map_px(const float kr[9], int src_w, int src_h, const ColEntry& ce, const RowEntry& re)
+__device__ __forceinline__ MapPx map_px(const CamDesc& c, const float kr[9], int src_w, int src_h, const ColEntry& ce,
+                                        const RowEntry& re, int rx, int ry)
 {
     float X, Y, Z, mx, my;
-    if (KIND == 1) {
-        const float x_ = re.ra * ce.ca, z_ = re.ra * ce.cb;
-        X = (kr[0] * x_ + re.b[0]) + kr[2] * z_;
-        Y = (kr[3] * x_ + re.b[1]) + kr[5] * z_;
-        Z = (kr[6] * x_ + re.b[2]) + kr[8] * z_;
+    if (KIND == 3) {
+        backward_map(c, rx, ry, mx, my);
     } else {
-        X = (ce.a[0] + re.b[0]) + ce.c[0];
-        Y = (ce.a[1] + re.b[1]) + ce.c[1];
-        Z = (ce.a[2] + re.b[2]) + ce.c[2];
+        if (KIND == 1) {
+            const float x_ = re.ra * ce.ca, z_ = re.ra * ce.cb;
+            X = (kr[0] * x_ + re.b[0]) + kr[2] * z_;
+            Y = (kr[3] * x_ + re.b[1]) + kr[5] * z_;
+            Z = (kr[6] * x_ + re.b[2]) + kr[8] * z_;
+        } else {
+            X = (ce.a[0] + re.b[0]) + ce.c[0];
+            Y = (ce.a[1] + re.b[1]) + ce.c[1];
+            Z = (ce.a[2] + re.b[2]) + ce.c[2];
+        }
+        if (KIND == 0 || Z > 0) { mx = X / Z; my = Y / Z; }
+        else { mx = -1.f; my = -1.f; }
     }
-    if (KIND == 0 || Z > 0) { mx = X / Z; my = Y / Z; }
-    else { mx = -1.f; my = -1.f; }
     const int fsx = cv_round(mx * 32.f), fsy = cv_round(my * 32.f);
     int sx = sat_s16(fsx >> 5), sy = sat_s16(fsy >> 5);
     int fx = fsx & 31, fy = fsy & 31;
@@ -340,6 +346,7 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
                                                     uint32_t* __restrict__ table, uint32_t* __restrict__ blobs)
 {
     __shared__ RowEntry s_rows[A_LH];
+    __shared__ int s_ry[A_LH];
     __shared__ int s_min[2];
     const uint32_t t = list.tiles[blockIdx.x];
     const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
@@ -355,6 +362,7 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
         const int by = reflect<1>(ly0 + tid, bh);
         const int ry = reflect<0>(by - c.top, c.roi_h);
         s_rows[tid] = load_global(c.rows + ry);
+        s_ry[tid] = ry;
     }
     if (tid == 0) { s_min[0] = INT_MAX; s_min[1] = INT_MAX; }
     const int col = tid & (A_LW - 1);
@@ -365,7 +373,8 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
     __syncthreads();
     int x_lo = INT_MAX, y_lo = INT_MAX;
     for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
-        const MapPx m = map_px<KIND>(kr, c.src_w, c.src_h, ce, s_rows[half * A_ROWS_PER_THREAD + it]);
+        const int row = half * A_ROWS_PER_THREAD + it;
+        const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, ce, s_rows[row], rx, s_ry[row]);
         if (m.fast) { x_lo = min(x_lo, m.sx); y_lo = min(y_lo, m.sy); }
     }
     if (x_lo != INT_MAX) { atomicMin(&s_min[0], x_lo); atomicMin(&s_min[1], y_lo); }
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
     uint32_t* __restrict__ out = table + static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW) + col;
     for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
         const int row = half * A_ROWS_PER_THREAD + it;
-        out[row * A_LW] = pack_map(map_px<KIND>(kr, c.src_w, c.src_h, ce, s_rows[row]), tbx, tby);
+        out[row * A_LW] = pack_map(map_px<KIND>(c, kr, c.src_w, c.src_h, ce, s_rows[row], rx, s_ry[row]), tbx, tby);
     }
 
     // ---- the tile's block of constants
@@ -558,9 +567,10 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
 #pragma unroll
             for (int i = 0; i < 9; ++i) kr[i] = c.kr[i];
             const int by = reflect<1>(ly0 + row0 + it, bh);
+            const int ry = reflect<0>(by - c.top, c.roi_h);
             const ColEntry ce = load_global(c.cols + gs.rx);
-            const RowEntry re = load_global(c.rows + reflect<0>(by - c.top, c.roi_h));
-            fetch_pixel<GM>(k, map_px<KIND>(kr, k.src_w, k.src_h, ce, re), gs, row0 + it, fa);
+            const RowEntry re = load_global(c.rows + ry);
+            fetch_pixel<GM>(k, map_px<KIND>(c, kr, k.src_w, k.src_h, ce, re, gs.rx, ry), gs, row0 + it, fa);
             emit(row0 + it, blend_pixel<true, BG>(k, fa));
         }
     };
@@ -1609,7 +1619,7 @@ void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, ui
 {
     if (list.count <= 0) return;
 #define MST_LAUNCH_T(K) hipLaunchKernelGGL(k_warp_table<K>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table, d_blobs)
-    if (kind == 0) MST_LAUNCH_T(0); else if (kind == 1) MST_LAUNCH_T(1); else MST_LAUNCH_T(2);
+    if (kind == 0) MST_LAUNCH_T(0); else if (kind == 1) MST_LAUNCH_T(1); else if (kind == 2) MST_LAUNCH_T(2); else MST_LAUNCH_T(3);
 #undef MST_LAUNCH_T
 }
 
@@ -1620,7 +1630,7 @@ void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList
     static const size_t pad = tuning_env("MST_A_PAD_LDS");
 #define MST_LAUNCH_A(K) \
     hipLaunchKernelGGL((k_warp_pyr<K>), dim3(list.count * batch), dim3(256), pad, s, d_cams, list, frames, d_table, d_blobs, n_cams, batch)
-    if (kind == 0) MST_LAUNCH_A(0); else if (kind == 1) MST_LAUNCH_A(1); else MST_LAUNCH_A(2);
+    if (kind == 0) MST_LAUNCH_A(0); else if (kind == 1) MST_LAUNCH_A(1); else if (kind == 2) MST_LAUNCH_A(2); else MST_LAUNCH_A(3);
 #undef MST_LAUNCH_A
 }
 

@@ -29,13 +29,16 @@ def _f3(a):
 
 
 class RotationWarper:
-    """cv::detail::RotationWarper for the three projections on the hot path."""
+    """cv::detail::RotationWarper: every projector of detail/warpers.hpp (plane / spherical / cylindrical maps are
+    evaluated on the device, the others are built on the host per calibration and read by the kernels)."""
 
     kind = None
 
-    def __init__(self, scale, device=0):
+    def __init__(self, scale, device=0, kind=None):
         self.scale = float(scale)
         self.device = device
+        if kind is not None:
+            self.kind = capi.WARP_NAMES[kind] if isinstance(kind, str) else int(kind)
 
     def warpRoi(self, src_size, K, R, T=None):
         """src_size = (width, height) -> (x, y, width, height).  Host only."""
@@ -88,8 +91,16 @@ class CylindricalWarper(RotationWarper):
     kind = capi.WARP_CYLINDRICAL
 
 
+def _named_warper(name):
+    """A RotationWarper subclass for one of the reference's --warp names (CLI:556-570), e.g. PaniniWarper(scale, 2, 1)
+    == WARPERS["paniniA2B1"](scale)."""
+    return type(name[0].upper() + name[1:].replace(".", "_") + "Warper", (RotationWarper,), {"kind": capi.WARP_NAMES[name]})
+
+
 WARPERS = {"plane": PlaneWarper, "spherical": SphericalWarper, "cylindrical": CylindricalWarper}
-WARP_KINDS = {"plane": capi.WARP_PLANE, "spherical": capi.WARP_SPHERICAL, "cylindrical": capi.WARP_CYLINDRICAL}
+for _n in capi.WARP_NAMES:
+    WARPERS.setdefault(_n, _named_warper(_n))
+WARP_KINDS = dict(capi.WARP_NAMES)
 BLEND_KINDS = {"no": capi.BLEND_NO, "feather": capi.BLEND_FEATHER, "multiband": capi.BLEND_MULTI_BAND}
 EXPOS_KINDS = {"no": capi.EXPOS_NO, "gain": capi.EXPOS_GAIN, "gain_blocks": capi.EXPOS_GAIN_BLOCKS}
 
@@ -182,7 +193,7 @@ class PanoramaEngine:
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
                  feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False,
-                 overlap_frames=False, max_batch=0, weight_type="32f"):
+                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -199,6 +210,9 @@ class PanoramaEngine:
         cfg.upblack, cfg.downblack, cfg.leftblack, cfg.rightblack = crop
         cfg.max_batch = max_batch
         cfg.weight_type = {"32f": 0, "16s": 1}[weight_type] if isinstance(weight_type, str) else int(weight_type)
+        if warp_ab is not None:          # CompressedRectilinear* / Panini* with arbitrary (A, B)
+            cfg.warp_kind = (cfg.warp_kind & 0xFF) | capi.WARP_AB_CUSTOM
+            cfg.warp_a, cfg.warp_b = float(warp_ab[0]), float(warp_ab[1])
         self.num_cameras = num_cameras
         self.device = device
         capi.check(self._L.mst_create(C.byref(cfg), C.byref(self._h)))

@@ -5,7 +5,7 @@ import oracle_lib as O
 import stitchingvideo_amd as S
 from stitchingvideo_amd import rig as rigmod
 
-WARP_O = {"plane": O.WARP_PLANE, "spherical": O.WARP_SPHERICAL, "cylindrical": O.WARP_CYLINDRICAL}
+WARP_O = dict(S.capi.WARP_NAMES)      # the oracle numbers its projectors (and A/B presets) like the product does
 BLEND_O = {"no": O.BLEND_NO, "feather": O.BLEND_FEATHER, "multiband": O.BLEND_MULTI_BAND}
 EXPOS_O = {"no": O.EXPOS_NO, "gain": O.EXPOS_GAIN, "gain_blocks": O.EXPOS_GAIN_BLOCKS}
 

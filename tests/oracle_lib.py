@@ -14,6 +14,7 @@ ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "build", "libmst_oracle.so")
 
 WARP_PLANE, WARP_SPHERICAL, WARP_CYLINDRICAL = 0, 1, 2
+# MO_WARP_* of mst_oracle.h: the same numbering, and the same A/B presets in bits 8-9, as the product's MST_WARP_*
 INTER_NEAREST, INTER_LINEAR = 0, 1
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = 0, 1, 2, 3, 4
 BLEND_NO, BLEND_FEATHER, BLEND_MULTI_BAND = 0, 1, 2

@@ -27,5 +27,5 @@ pass tcc TCC_HIT_sum TCC_MISS_sum
 pass grbm GRBM_GUI_ACTIVE
 fi
 cd "$REPO"
-python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt"
+python3 tools/summarize_prof.py "$OUT" "$OUT/traffic.json" > "$OUT/summary.txt"
 grep -E "^k_(blend|warp_pyr|pyr_chain)|FETCH_SIZE|WRITE_SIZE|LDS_BANK|LDS_IDX|avg_us|^k_" "$OUT/summary.txt" | head -60

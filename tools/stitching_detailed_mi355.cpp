@@ -69,7 +69,9 @@ void usage()
         "Flags:\n"
         "  --yaw a0,a1,...          camera yaw angles in degrees (default: evenly spaced ring)\n"
         "  --focal <float>          focal length in pixels = warp scale (default 1250)\n"
-        "  --warp (plane|cylindrical|spherical)              default spherical\n"
+        "  --warp (plane|cylindrical|spherical|fisheye|stereographic|compressedPlaneA2B1|compressedPlaneA1.5B1|\n"
+        "          compressedPlanePortraitA2B1|compressedPlanePortraitA1.5B1|paniniA2B1|paniniA1.5B1|paniniPortraitA2B1|\n"
+        "          paniniPortraitA1.5B1|mercator|transverseMercator)                 default spherical (CLI:102)\n"
         "  --expos_comp (no|gain_blocks)                     default gain_blocks (synthetic block gains)\n"
         "  --blend (no|feather|multiband)                    default multiband\n"
         "  --blend_strength <float>   [0,100], default 5 (same rule as the sample: width = sqrt(area)*s/100)\n"
@@ -135,7 +137,8 @@ int main(int argc, char** argv)
     if (yaws.empty()) for (int i = 0; i < num_images; ++i) yaws.push_back(360.0 * i / num_images);
     if (static_cast<int>(yaws.size()) != num_images) { std::printf("--yaw needs one angle per image\n"); return -1; }
 
-    const int warp_kind = warp_type == "plane" ? MST_WARP_PLANE : warp_type == "cylindrical" ? MST_WARP_CYLINDRICAL : MST_WARP_SPHERICAL;
+    const int warp_kind = mst_warp_kind_from_name(warp_type.c_str());
+    if (warp_kind < 0) { std::fprintf(stderr, "Bad warping method\n"); return 1; }       // CLI:573-577
     int blend_kind = blend == "no" ? MST_BLEND_NO : blend == "feather" ? MST_BLEND_FEATHER : MST_BLEND_MULTI_BAND;
     const int expos_kind = expos == "no" ? MST_EXPOS_NO : MST_EXPOS_GAIN_BLOCKS;
     const float scale = static_cast<float>(focal);
