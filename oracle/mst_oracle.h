@@ -135,6 +135,11 @@ void mo_add_16s(const int16_t *a, const int16_t *b, int16_t *dst, size_t n);
 void mo_subtract_16s(const int16_t *a, const int16_t *b, int16_t *dst, size_t n);
 void mo_distance_transform_l1(const uint8_t *mask, int w, int h, float *dist);
 
+/* ---- seam-mask fix-up (a9: stitcher.cpp:291-294) ------------------------------ */
+void mo_dilate3x3_8u(const uint8_t *src, int w, int h, uint8_t *dst);
+void mo_resize_linear_8u(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh);
+void mo_mask_fixup(const uint8_t *seam_mask, int sw, int sh, const uint8_t *mask_warped, int w, int h, uint8_t *out);
+
 /* ---- util (a10) -------------------------------------------------------------- */
 mo_rect mo_result_roi(const int *corners_xy, const int *sizes_wh, int n);
 int mo_overlap_roi(int tl1x, int tl1y, int tl2x, int tl2y, int w1, int h1, int w2, int h2, mo_rect *roi);

@@ -31,7 +31,8 @@ class Rect(C.Structure):
 
 class Projector(C.Structure):
     _fields_ = [("scale", C.c_float), ("k", C.c_float * 9), ("rinv", C.c_float * 9),
-                ("r_kinv", C.c_float * 9), ("k_rinv", C.c_float * 9), ("t", C.c_float * 3)]
+                ("r_kinv", C.c_float * 9), ("k_rinv", C.c_float * 9), ("t", C.c_float * 3),
+                ("a", C.c_float), ("b", C.c_float)]
 
 
 class ComposeConfig(C.Structure):
@@ -277,6 +278,30 @@ def create_weight_map(mask, sharpness):
     dst = np.empty(mask.shape, np.float32)
     lib().mo_create_weight_map(_ptr(mask), mask.shape[1], mask.shape[0], sharpness, _ptr(dst))
     return dst
+
+
+def dilate3x3(mask):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    dst = np.empty_like(mask)
+    lib().mo_dilate3x3_8u(_ptr(mask), mask.shape[1], mask.shape[0], _ptr(dst))
+    return dst
+
+
+def resize_linear_8u(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.empty((dh, dw), np.uint8)
+    lib().mo_resize_linear_8u(_ptr(src), src.shape[1], src.shape[0], _ptr(dst), dw, dh)
+    return dst
+
+
+def mask_fixup(seam_mask, mask_warped):
+    """stitcher.cpp:291-294: dilate -> resize to the warped size -> & the warped all-255 mask."""
+    seam_mask = np.ascontiguousarray(seam_mask, np.uint8)
+    mask_warped = np.ascontiguousarray(mask_warped, np.uint8)
+    out = np.empty_like(mask_warped)
+    lib().mo_mask_fixup(_ptr(seam_mask), seam_mask.shape[1], seam_mask.shape[0], _ptr(mask_warped),
+                        mask_warped.shape[1], mask_warped.shape[0], _ptr(out))
+    return out
 
 
 def multiband_feed_geometry(dst_roi, num_bands, tl, size):
