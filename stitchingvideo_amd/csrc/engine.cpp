@@ -2,7 +2,9 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -30,24 +32,55 @@ void select_device(int device)
 
 // ---- DevicePool ------------------------------------------------------------------------------
 
+namespace {
+constexpr size_t kPoolAlign = 256, kPoolSlab = size_t{64} << 20;
+}
+
+SlabCache::~SlabCache()
+{
+    for (void* p : free_) (void)hipFree(p);
+}
+
+void* SlabCache::take()
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (free_.empty()) return nullptr;
+    void* p = free_.back();
+    free_.pop_back();
+    return p;
+}
+
+void SlabCache::give(void* slab)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    free_.push_back(slab);
+}
+
 DevicePool::~DevicePool()
 {
-    for (void* p : ptrs_) (void)hipFree(p);
+    for (void* p : big_) (void)hipFree(p);
+    for (void* p : ptrs_) {
+        if (cache_) cache_->give(p);
+        else (void)hipFree(p);
+    }
 }
 
 void* DevicePool::alloc_bytes(size_t bytes)
 {
-    constexpr size_t kAlign = 256, kSlab = size_t{64} << 20;
-    const size_t need = (std::max<size_t>(bytes, 16) + kAlign - 1) & ~(kAlign - 1);
-    if (need > left_) {
-        // a request of slab size or more gets a slab of its own and leaves the current one open
-        const size_t slab = need >= kSlab ? need : kSlab;
+    const size_t need = (std::max<size_t>(bytes, 16) + kPoolAlign - 1) & ~(kPoolAlign - 1);
+    if (need >= kPoolSlab) {         // a request of slab size or more gets an allocation of its own
         void* p = nullptr;
-        check_hip(hipMalloc(&p, slab + kAlign), "hipMalloc");     // + guard: kernels may read a few bytes past a buffer
+        check_hip(hipMalloc(&p, need + kPoolAlign), "hipMalloc");     // + guard: kernels may read a few bytes past a buffer
+        big_.push_back(p);
+        total_ += bytes;
+        return p;
+    }
+    if (need > left_) {
+        void* p = cache_ ? cache_->take() : nullptr;
+        if (!p) check_hip(hipMalloc(&p, kPoolSlab + kPoolAlign), "hipMalloc");
         ptrs_.push_back(p);
-        if (need >= kSlab) { total_ += bytes; return p; }
         cur_ = static_cast<char*>(p);
-        left_ = slab;
+        left_ = kPoolSlab;
     }
     void* out = cur_;
     cur_ += need;
@@ -256,6 +289,7 @@ Engine::~Engine()
     for (uint8_t* p : d_frames_) (void)hipFree(p);
     if (d_pano_) (void)hipFree(d_pano_);
     if (d_mask_) (void)hipFree(d_mask_);
+    if (cls_host_) (void)hipHostFree(cls_host_);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (calib_stream_) (void)hipStreamDestroy(calib_stream_);
     if (front_stream_) (void)hipStreamDestroy(front_stream_);
@@ -303,15 +337,33 @@ void Engine::synchronize()
     check_hip(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
 
+namespace {
+// MST_UPDATE_TIMING=1: wall-clock marks of the stages of mst_update on stderr (tools/time_update.py)
+struct UpdateClock {
+    bool on = std::getenv("MST_UPDATE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char* what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mst_update] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+}  // namespace
+
 void Engine::update(const mst_calibration& calib)
 {
+    UpdateClock clk;
     select_device(cfg_.device);
     drop_retired();
+    clk.mark("drop retired states");
     if (calib.num_cameras != cfg_.num_cameras || !calib.cameras)
         throw Error{MST_ERR_INVALID_ARG, "calibration camera count does not match the engine"};
     if (!(calib.warped_image_scale > 0.f)) throw Error{MST_ERR_INVALID_ARG, "warped_image_scale must be > 0"};
     hipStream_t s = calib_stream_;
     auto st = std::make_shared<CalibState>();
+    st->pool.set_cache(slab_cache_);
     const int n = cfg_.num_cameras;
     st->n = n;
     st->blend_kind = cfg_.blend_kind;
@@ -352,6 +404,7 @@ void Engine::update(const mst_calibration& calib)
         check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
     }
 
+    clk.mark("camera tables + masks");
     // frame sets in flight: one per frame set of a batch, two for frame pipelining
     // (pipelining alternates between two halves of the sets, each as large as a batch)
     st->sets_per_slot = std::max(1, std::min<int>(cfg_.max_batch, kMaxBatch));
@@ -465,17 +518,43 @@ void Engine::update(const mst_calibration& calib)
         }
         for (int l = 0; l <= nb; ++l) launch_band_weight_sum(st->d_desc, n, l, ws[l], cv.cw[l], cv.ch[l], s);
         check_hip(hipGetLastError(), "weight pyramid kernels");
+        clk.mark("alloc + weight pyramid launches");
 
-        // work lists of the fused kernels: read the weight pyramids back once and walk the dependencies
-        std::vector<std::vector<std::vector<float>>> wh(n, std::vector<std::vector<float>>(nb + 1));
+        // work lists of the fused kernels: classify the weight pyramids on the device (zero / exactly one / other),
+        // bring one byte per pixel back through a page-locked buffer, and walk the dependencies on the host
+        size_t cls_total = 0;
         for (int i = 0; i < n; ++i)
-            for (int l = 0; l <= nb; ++l) {
-                const size_t px = static_cast<size_t>(st->desc[i].lw[l]) * st->desc[i].lh[l];
-                wh[i][l].resize(px);
-                check_hip(hipMemcpyAsync(wh[i][l].data(), wpyr[i][l], px * sizeof(float), hipMemcpyDeviceToHost, s),
-                          "hipMemcpyAsync(D2H weights)");
-            }
+            for (int l = 0; l <= nb; ++l) cls_total += static_cast<size_t>(st->desc[i].lw[l]) * st->desc[i].lh[l];
+        uint8_t* d_cls = st->pool.alloc<uint8_t>(cls_total);
+        if (cls_host_bytes_ < cls_total) {
+            if (cls_host_) (void)hipHostFree(cls_host_);
+            cls_host_ = nullptr;
+            check_hip(hipHostMalloc(reinterpret_cast<void**>(&cls_host_), cls_total, hipHostMallocDefault), "hipHostMalloc");
+            cls_host_bytes_ = cls_total;
+        }
+        {
+            const float unit = cfg_.weight_type == MST_WEIGHT_16S ? 256.f : 1.f;
+            size_t off = 0;
+            for (int i = 0; i < n; ++i)
+                for (int l = 0; l <= nb; ++l) {
+                    const size_t px = static_cast<size_t>(st->desc[i].lw[l]) * st->desc[i].lh[l];
+                    launch_weight_class(wpyr[i][l], d_cls + off, px, unit, s);
+                    off += px;
+                }
+        }
+        check_hip(hipMemcpyAsync(cls_host_, d_cls, cls_total, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H weight classes)");
         check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(weights)");
+        clk.mark("weight classes D2H");
+        std::vector<std::vector<std::vector<uint8_t>>> wh(n, std::vector<std::vector<uint8_t>>(nb + 1));
+        {
+            size_t off = 0;
+            for (int i = 0; i < n; ++i)
+                for (int l = 0; l <= nb; ++l) {
+                    const size_t px = static_cast<size_t>(st->desc[i].lw[l]) * st->desc[i].lh[l];
+                    wh[i][l].assign(cls_host_ + off, cls_host_ + off + px);
+                    off += px;
+                }
+        }
         BlendArgs& ba = st->blend;
         ba = BlendArgs{};
         ba.nlev = nb + 1; ba.n_cams = n;
@@ -484,6 +563,7 @@ void Engine::update(const mst_calibration& calib)
         ba.alpha = static_cast<float>(1. / 255.);
         ba.weights_16s = cfg_.weight_type == MST_WEIGHT_16S ? 1 : 0;
         build_mb_plan(st->desc, wh, ba, st->plan);
+        clk.mark("work-list plan (host)");
         const MbPlanHost& plan = st->plan;
         ba.tiles_x = plan.blend_tiles_x;
         for (int l = 0; l <= nb; ++l) ba.lds_off[l] = plan.lds_off[l];
@@ -526,6 +606,7 @@ void Engine::update(const mst_calibration& calib)
     }
     check_hip(hipGetLastError(), "calibration kernels");
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(calibration)");
+    clk.mark("tables, lists, final sync");
 
     std::shared_ptr<CalibState> old;
     {

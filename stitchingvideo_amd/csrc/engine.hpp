@@ -30,6 +30,18 @@ struct Error {
 // Allocations are carved out of a few large slabs (bump pointer, 256-byte aligned): a calibration state holds
 // several hundred buffers, and one hipMalloc / hipFree each is what used to dominate mst_update and the
 // teardown of a retired state.
+// Standard-size slabs of retired calibration states, kept for the next mst_update (a recalibration every 30 s,
+// DRV:842-847, would otherwise hipMalloc and hipFree ~1.5 GB each time).  Shared by an engine and its states.
+class SlabCache {
+public:
+    ~SlabCache();
+    void* take();                 // nullptr when empty
+    void give(void* slab);
+private:
+    std::mutex mu_;
+    std::vector<void*> free_;
+};
+
 class DevicePool {
 public:
     DevicePool() = default;
@@ -41,7 +53,10 @@ public:
     template <typename T> T* upload(const T* host, size_t n, hipStream_t s);
     template <typename T> T* upload(const std::vector<T>& v, hipStream_t s) { return upload(v.data(), v.size(), s); }
     size_t bytes() const { return total_; }
+    void set_cache(std::shared_ptr<SlabCache> cache) { cache_ = std::move(cache); }
 private:
+    std::shared_ptr<SlabCache> cache_;
+    std::vector<void*> big_;        // allocations larger than a slab: always freed
     std::vector<void*> ptrs_;       // slabs
     char* cur_ = nullptr;           // bump pointer inside the newest slab
     size_t left_ = 0;
@@ -156,11 +171,14 @@ private:
     // States no compose will start on any more.  Their teardown (device sync + frees) must not run on the frame
     // thread: they are parked here by pointer move and destroyed by the next mst_update or by the destructor.
     std::vector<std::shared_ptr<CalibState>> retired_;
+    std::shared_ptr<SlabCache> slab_cache_ = std::make_shared<SlabCache>();
     // staging for compose_host
     std::vector<uint8_t*> d_frames_;
     std::vector<size_t> d_frame_bytes_;
     uint8_t* d_pano_ = nullptr; size_t d_pano_bytes_ = 0;
     uint8_t* d_mask_ = nullptr; size_t d_mask_bytes_ = 0;
+    // mst_update: page-locked landing zone of the weight-class bytes (calibration thread only)
+    uint8_t* cls_host_ = nullptr; size_t cls_host_bytes_ = 0;
 };
 
 // Fill the warp + exposure part of a CamDesc (tables uploaded through `pool`).

@@ -283,6 +283,17 @@ __global__ __launch_bounds__(256) void k_band_weight_sum(const CamDesc* __restri
     ws[static_cast<size_t>(y) * cw + x] = acc;
 }
 
+// What the work-list planner needs to know about a weight pyramid level, one byte per pixel: bit 0 = non-zero
+// (short(laplacian * 0.f) == 0: such a pixel cannot reach the panorama), bit 1 = exactly the weight of a fully owned
+// pixel (the integer band path applies).  A quarter of the float pyramid's bytes crosses to the host.
+__global__ __launch_bounds__(256) void k_weight_class(const float* __restrict__ w, uint8_t* __restrict__ out, size_t n, float unit)
+{
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = w[i];
+    out[i] = static_cast<uint8_t>((v != 0.f ? 1 : 0) | (v == unit ? 2 : 0));
+}
+
 // FeatherBlender: dst_weight_map_ accumulation in feed order   blenders.cpp:143
 __global__ __launch_bounds__(256) void k_feather_weight_sum(const CamDesc* __restrict__ cams, int n_cams,
                                                             float* __restrict__ ws, int cw, int ch)
@@ -429,6 +440,12 @@ void launch_pyrdown_f32(const float* d_src, int w, int h, float* d_dst, bool wei
     const int dw = (w + 1) / 2, dh = (h + 1) / 2;
     if (weights_16s) hipLaunchKernelGGL(k_pyrdown_s16, grid2d(dw, dh), block2d(), 0, s, d_src, w, h, d_dst, dw, dh);
     else hipLaunchKernelGGL(k_pyrdown_f32, grid2d(dw, dh), block2d(), 0, s, d_src, w, h, d_dst, dw, dh);
+}
+
+void launch_weight_class(const float* d_w, uint8_t* d_out, size_t n, float unit, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_weight_class, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, d_w, d_out, n, unit);
 }
 
 void launch_band_weight_sum(const CamDesc* d_cams, int n_cams, int level, float* d_ws, int cw, int ch, hipStream_t s)

@@ -21,6 +21,7 @@ void launch_remap_fixed(const UndistortCam* d_ucams, int n_cams, int max_w, int 
 void launch_weight_level0(const CamDesc* d_cams, int cam, float* d_w0, int bw, int bh, bool weights_16s, hipStream_t s);
 void launch_border_mask(const CamDesc* d_cams, int cam, uint8_t* d_out, int bw, int bh, hipStream_t s);
 void launch_pyrdown_f32(const float* d_src, int w, int h, float* d_dst, bool weights_16s, hipStream_t s);
+void launch_weight_class(const float* d_w, uint8_t* d_out, size_t n, float unit, hipStream_t s);   // see k_weight_class
 void launch_band_weight_sum(const CamDesc* d_cams, int n_cams, int level, float* d_ws, int cw, int ch,
                             hipStream_t s);
 void launch_feather_weight_sum(const CamDesc* d_cams, int n_cams, float* d_ws, int cw, int ch, hipStream_t s);

@@ -2,6 +2,7 @@
 #include "mb_plan.hpp"
 
 #include <algorithm>
+#include <thread>
 
 #include "kernels.hpp"
 
@@ -70,18 +71,32 @@ void mark_footprint(const std::vector<uint8_t>& coarse, int cw, int ch, std::vec
 
 }  // namespace
 
-void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<float>>>& weights,
+namespace {
+// run f(i) for i in [0, count) on up to `max_threads` host threads (the plan is a few dozen independent passes over
+// byte maps: per camera, per canvas tile row)
+template <typename F> void parallel_for(int count, int max_threads, F&& f)
+{
+    const int hw = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+    const int workers = std::max(1, std::min(std::min(count, max_threads), hw));
+    if (workers == 1) { for (int i = 0; i < count; ++i) f(i); return; }
+    std::vector<std::thread> pool;
+    for (int w = 0; w < workers; ++w)
+        pool.emplace_back([&, w] { for (int i = w; i < count; i += workers) f(i); });
+    for (std::thread& t : pool) t.join();
+}
+}  // namespace
+
+void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<uint8_t>>>& weight_class,
                    const BlendArgs& blend, MbPlanHost& plan)
 {
     const int n = static_cast<int>(desc.size());
-    const float unit = blend.weights_16s ? 256.f : 1.f;       // the weight of a fully owned pixel (mask 255)
     const int nlev = blend.nlev, nb = nlev - 1;
     int a_tw0, a_th0, b_t, c_tw, c_th;
     mb_tile_dims(&a_tw0, &a_th0, &b_t, &c_tw, &c_th);
 
     plan = MbPlanHost{};
     plan.cams.resize(n);
-    for (int c = 0; c < n; ++c) {
+    parallel_for(n, 16, [&](int c) {
         const CamDesc& d = desc[c];
         MbCameraNeed& cn = plan.cams[c];
         cn.nz.resize(nlev);
@@ -89,15 +104,15 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
         for (int l = 0; l < nlev; ++l) {
             const size_t px = static_cast<size_t>(d.lw[l]) * d.lh[l];
             cn.nz[l].resize(px);
-            const float* w = weights[c][l].data();
-            for (size_t i = 0; i < px; ++i) cn.nz[l][i] = w[i] != 0.f;
+            const uint8_t* w = weight_class[c][l].data();
+            for (size_t i = 0; i < px; ++i) cn.nz[l][i] = w[i] & 1u;
         }
         for (int l = nb; l >= 0; --l) {
             cn.need[l] = cn.nz[l];
             if (l >= 1) mark_parents(cn.nz[l - 1], d.lw[l - 1], d.lh[l - 1], cn.need[l], d.lw[l], d.lh[l]);
             if (l < nb) mark_footprint(cn.need[l + 1], d.lw[l + 1], d.lh[l + 1], cn.need[l], d.lw[l], d.lh[l]);
         }
-    }
+    });
 
     // ---- kernel A: level-0 tiles of a_tw0 x a_th0 pixels
     for (int c = 0; c < n; ++c) {
@@ -178,13 +193,15 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
         const CamDesc& d = desc[c];
         const int x0 = rx0 - d.ox[l], y0 = ry0 - d.oy[l], x1 = rx1 - d.ox[l], y1 = ry1 - d.oy[l];
         if (x0 < 0 || y0 < 0 || x1 > d.lw[l] || y1 > d.lh[l]) return false;
-        const std::vector<float>& w = weights[c][l];
+        const std::vector<uint8_t>& w = weight_class[c][l];
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x)
-                if (w[static_cast<size_t>(y) * d.lw[l] + x] != unit) return false;
+                if (!(w[static_cast<size_t>(y) * d.lw[l] + x] & 2u)) return false;
         return true;
     };
-    for (int ty = 0; ty < plan.blend_tiles_y; ++ty)
+    std::vector<std::vector<int>> row_area(plan.blend_tiles_y, std::vector<int>(nlev, 0));
+    parallel_for(plan.blend_tiles_y, 64, [&](int ty) {
+        std::vector<int>& max_area = row_area[ty];
         for (int tx = 0; tx < plan.blend_tiles_x; ++tx) {
             uint32_t bits = 0;
             // Levels on which the tile's region is owned by ONE camera with a weight of exactly 1.0f everywhere (and no
@@ -228,6 +245,9 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
             plan.block_cams[ti] = bits;
             plan.block_pure[ti] = owner >= 0 ? (level_mask | static_cast<uint32_t>(owner) << 16) : 0u;
         }
+    });
+    for (const std::vector<int>& ra : row_area)
+        for (int l = 0; l < nlev; ++l) max_area[l] = std::max(max_area[l], ra[l]);
     // launch order: every canvas tile is resident at once on a 256-CU part, so the dispatcher's round-robin
     // placement is the only load balancing there is -- hand out the expensive tiles (several cameras under the
     // tile, float path) first so that they land on different CUs, then the single-camera integer-path tiles

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header_sizes():
     # the C side checks struct_size; these are the sizes an LP64 compiler produces for the header
-    assert C.sizeof(capi.Config) == 60
+    assert C.sizeof(capi.Config) == 68          # 15 x 4-byte fields + warp_a, warp_b
     assert C.sizeof(capi.Camera) == 8 + 36 + 36 + 12 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 16
     assert C.sizeof(capi.Calibration) == 24
 
@@ -144,7 +144,7 @@ def test_argument_validation_without_a_gpu():
     cfg.struct_size = C.sizeof(capi.Config)
     cfg.num_cameras = 99
     assert L.mst_create(C.byref(cfg), C.byref(h)) == capi.ERR_INVALID_ARG
-    cfg.num_cameras, cfg.warp_kind = 2, 7
+    cfg.num_cameras, cfg.warp_kind = 2, 14                 # kinds 0..13 exist (all of detail/warpers.hpp)
     assert L.mst_create(C.byref(cfg), C.byref(h)) == capi.ERR_INVALID_ARG
     cfg.warp_kind, cfg.blend_kind = 1, 5
     assert L.mst_create(C.byref(cfg), C.byref(h)) == capi.ERR_INVALID_ARG
