@@ -155,6 +155,13 @@ typedef struct mst_camera {
      * an engine-owned buffer and warps that. */
     const int16_t  *undistort_map1;       /* CV_16SC2: (x, y) integer source coordinate per pixel */
     const uint16_t *undistort_map2;       /* CV_16UC1: (fy << 5) | fx */
+    /* Optional: let the engine do the mask fix-up of the compose loop on the device (stitcher.cpp:291-294 =
+     * DRV:676-678):  mask_warped = resize(dilate(seam_mask), warpRoi size) & warp(all-255 mask, NEAREST, CONSTANT).
+     * seam_mask is the seam finder's output for this camera at seam scale (CV_8U, any size); when it is set,
+     * `mask` may be NULL (it is ignored).  The final mask can be read back with mst_camera_mask. */
+    const uint8_t *seam_mask;
+    int32_t  seam_mask_width, seam_mask_height;
+    size_t   seam_mask_stride;            /* bytes */
 } mst_camera;
 
 typedef struct mst_calibration {
@@ -193,6 +200,9 @@ int  mst_acquire_calibration(mst_engine *e, mst_rect *canvas, uint64_t *generati
 int  mst_canvas(const mst_engine *e, mst_rect *canvas);
 /* corners[i] / sizes[i] */
 int  mst_camera_roi(const mst_engine *e, int camera, mst_rect *roi);
+/* final mask_warped of a camera as the engine holds it (warpRoi-sized CV_8U, `stride` bytes per row): the caller's
+ * mask, or the result of the device-side fix-up when mst_camera.seam_mask was given */
+int  mst_camera_mask(mst_engine *e, int camera, uint8_t *mask, size_t stride);
 /* number of bands actually used (MultiBandBlender::prepare crop, blenders.cpp:207-209) */
 int  mst_num_bands(const mst_engine *e, int *num_bands);
 

@@ -40,7 +40,7 @@ DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, 
     1, 2, 3, 4, 5, 6
 
 EXPORTS = [
-    "mst_warp_kind_from_name", "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_acquire_calibration", "mst_canvas", "mst_camera_roi",
+    "mst_warp_kind_from_name", "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_acquire_calibration", "mst_canvas", "mst_camera_roi", "mst_camera_mask",
     "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_device_batch", "mst_compose_profile",
     "mst_compose_profile_batch", "mst_synchronize", "mst_warp_roi",
     "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
@@ -64,7 +64,9 @@ class Camera(C.Structure):
                 ("R", C.c_float * 9), ("T", C.c_float * 3), ("gain_map", C.c_void_p),
                 ("gain_w", C.c_int32), ("gain_h", C.c_int32), ("gain", C.c_float),
                 ("mask", C.c_void_p), ("mask_width", C.c_int32), ("mask_height", C.c_int32),
-                ("mask_stride", C.c_size_t), ("undistort_map1", C.c_void_p), ("undistort_map2", C.c_void_p)]
+                ("mask_stride", C.c_size_t), ("undistort_map1", C.c_void_p), ("undistort_map2", C.c_void_p),
+                ("seam_mask", C.c_void_p), ("seam_mask_width", C.c_int32), ("seam_mask_height", C.c_int32),
+                ("seam_mask_stride", C.c_size_t)]
 
 
 class Calibration(C.Structure):
@@ -124,6 +126,8 @@ def load():
     L.mst_canvas.argtypes = [vp, C.POINTER(Rect)]
     L.mst_camera_roi.restype = C.c_int
     L.mst_camera_roi.argtypes = [vp, C.c_int, C.POINTER(Rect)]
+    L.mst_camera_mask.restype = C.c_int
+    L.mst_camera_mask.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.mst_num_bands.restype = C.c_int
     L.mst_num_bands.argtypes = [vp, ip]
     L.mst_compose.restype = C.c_int

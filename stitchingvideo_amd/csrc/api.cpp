@@ -187,6 +187,12 @@ int mst_camera_roi(const mst_engine* e, int camera, mst_rect* roi)
     return MST_OK;
 }
 
+int mst_camera_mask(mst_engine* e, int camera, uint8_t* mask, size_t stride)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.camera_mask(camera, mask, stride); });
+}
+
 int mst_num_bands(const mst_engine* e, int* num_bands)
 {
     if (!e || !num_bands) return MST_ERR_INVALID_ARG;

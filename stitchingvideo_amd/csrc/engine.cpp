@@ -181,46 +181,6 @@ void fill_camera_desc(DevicePool& pool, hipStream_t s, const Projector& proj, co
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
 }
 
-namespace {
-
-// cv::distanceTransform(CV_DIST_L1, 3) + threshold(TRUNC): createWeightMap, blenders.cpp:427-432.
-// Frame-invariant, so evaluated once per calibration on the host (sequential two-pass chamfer).
-std::vector<float> feather_weight_map(const uint8_t* mask, size_t stride, int w, int h, float sharpness)
-{
-    const unsigned kInit = static_cast<unsigned>(INT_MAX >> 2), kA = 1u << 16, kB = 2u << 16;
-    const int step = w + 2;
-    std::vector<unsigned> tmp(static_cast<size_t>(step) * (h + 2), kInit);
-    for (int y = 0; y < h; ++y) {
-        unsigned* t = tmp.data() + static_cast<size_t>(y + 1) * step + 1;
-        const uint8_t* s = mask + static_cast<size_t>(y) * stride;
-        for (int x = 0; x < w; ++x) {
-            if (!s[x]) { t[x] = 0; continue; }
-            unsigned v = std::min(std::min(t[x - step - 1] + kB, t[x - step] + kA),
-                                  std::min(t[x - step + 1] + kB, t[x - 1] + kA));
-            t[x] = v;
-        }
-    }
-    std::vector<float> out(static_cast<size_t>(w) * h);
-    const float scale = 1.f / 65536.f;
-    for (int y = h - 1; y >= 0; --y) {
-        unsigned* t = tmp.data() + static_cast<size_t>(y + 1) * step + 1;
-        for (int x = w - 1; x >= 0; --x) {
-            unsigned v = t[x];
-            if (v > kA) {
-                v = std::min(v, std::min(std::min(t[x + step + 1] + kB, t[x + step] + kA),
-                                         std::min(t[x + step - 1] + kB, t[x + 1] + kA)));
-                t[x] = v;
-            }
-            float d = static_cast<float>(v) * scale;
-            d = d * sharpness + 0.f;
-            out[static_cast<size_t>(y) * w + x] = d > 1.f ? 1.f : d;
-        }
-    }
-    return out;
-}
-
-}  // namespace
-
 // ---- StageTimer --------------------------------------------------------------------------------
 
 StageTimer::~StageTimer()
@@ -383,25 +343,50 @@ void Engine::update(const mst_calibration& calib)
         if (cs.roi.width <= 0 || cs.roi.height <= 0 || cs.roi.width > 65536 || cs.roi.height > 65536)
             throw Error{MST_ERR_INVALID_ARG, "degenerate warp ROI (DRV:661-665)"};
         rois[i] = cs.roi;
-        if (!c.mask || c.mask_width != cs.roi.width || c.mask_height != cs.roi.height ||
-            c.mask_stride < static_cast<size_t>(c.mask_width))
-            throw Error{MST_ERR_INVALID_ARG, "mask must be CV_8U of exactly the camera's warpRoi size"};
         CamDesc& d = st->desc[i];
         fill_camera_desc(st->pool, s, cs.proj, cs.roi, c.src_width, c.src_height, cfg_.expos_kind, c.gain_map,
                          c.gain_w, c.gain_h, c.gain, d);
-        // tight copy of the mask
-        std::vector<uint8_t> tight(static_cast<size_t>(cs.roi.width) * cs.roi.height);
-        for (int y = 0; y < cs.roi.height; ++y)
-            std::memcpy(&tight[static_cast<size_t>(y) * cs.roi.width], c.mask + static_cast<size_t>(y) * c.mask_stride,
-                        cs.roi.width);
-        d.mask = st->pool.upload(tight, s);
-        if (cfg_.blend_kind == MST_BLEND_FEATHER) {
-            std::vector<float> fw = feather_weight_map(tight.data(), cs.roi.width, cs.roi.width, cs.roi.height,
-                                                       cfg_.feather_sharpness);
-            d.feather_w = st->pool.upload(fw, s);
-            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        const size_t mask_px = static_cast<size_t>(cs.roi.width) * cs.roi.height;
+        uint8_t* d_mask = st->pool.alloc<uint8_t>(mask_px);
+        d.mask = d_mask;
+        if (c.seam_mask) {
+            // the compose loop's mask fix-up on the device (stitcher.cpp:291-294): dilate -> resize -> & warped mask
+            if (c.seam_mask_width <= 0 || c.seam_mask_height <= 0 || c.seam_mask_stride < static_cast<size_t>(c.seam_mask_width))
+                throw Error{MST_ERR_INVALID_ARG, "bad seam mask"};
+            const int sw = c.seam_mask_width, sh = c.seam_mask_height;
+            std::vector<uint8_t> seam(static_cast<size_t>(sw) * sh);
+            for (int y = 0; y < sh; ++y)
+                std::memcpy(&seam[static_cast<size_t>(y) * sw], c.seam_mask + static_cast<size_t>(y) * c.seam_mask_stride, sw);
+            const uint8_t* d_seam = st->pool.upload(seam, s);
+            const Resize8uAxis ax = build_resize8u_axis(sw, cs.roi.width, true), ay = build_resize8u_axis(sh, cs.roi.height, false);
+            const CamDesc* d_one = st->pool.upload(&d, 1, s);
+            launch_mask_fixup(d_one, d_seam, sw, sh, st->pool.upload(ax.ofs0, s), st->pool.upload(ax.ofs1, s),
+                              st->pool.upload(ax.c0, s), st->pool.upload(ax.c1, s), st->pool.upload(ay.ofs0, s),
+                              st->pool.upload(ay.ofs1, s), st->pool.upload(ay.c0, s), st->pool.upload(ay.c1, s), d_mask,
+                              cs.roi.width, cs.roi.height, s);
+            check_hip(hipGetLastError(), "k_mask_fixup");
+            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");      // pageable host tables are local
+        } else {
+            if (!c.mask || c.mask_width != cs.roi.width || c.mask_height != cs.roi.height ||
+                c.mask_stride < static_cast<size_t>(c.mask_width))
+                throw Error{MST_ERR_INVALID_ARG, "mask must be CV_8U of exactly the camera's warpRoi size"};
+            // tight copy of the mask
+            if (c.mask_stride == static_cast<size_t>(cs.roi.width)) {
+                check_hip(hipMemcpyAsync(d_mask, c.mask, mask_px, hipMemcpyHostToDevice, s), "hipMemcpyAsync(mask)");
+            } else {
+                check_hip(hipMemcpy2DAsync(d_mask, cs.roi.width, c.mask, c.mask_stride, cs.roi.width, cs.roi.height,
+                                           hipMemcpyHostToDevice, s), "hipMemcpy2DAsync(mask)");
+            }
+            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");      // the caller's mask is only borrowed
         }
-        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        if (cfg_.blend_kind == MST_BLEND_FEATHER) {
+            // createWeightMap on the device (frame-invariant: once per calibration)
+            float* fw = st->pool.alloc<float>(mask_px);
+            int32_t* tmp = st->pool.alloc<int32_t>(mask_px);
+            launch_feather_weight_map(d_mask, cs.roi.width, cs.roi.height, cfg_.feather_sharpness, tmp, fw, s);
+            check_hip(hipGetLastError(), "feather weight map kernels");
+            d.feather_w = fw;
+        }
     }
 
     clk.mark("camera tables + masks");
@@ -838,6 +823,18 @@ void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t
     launch_blend(st->d_desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, 1, st->plan.lds_bytes, s);
     check_hip(hipGetLastError(), "canvas stage kernel");
     set_in_flight(std::move(st));
+}
+
+void Engine::camera_mask(int camera, uint8_t* mask, size_t stride)
+{
+    select_device(cfg_.device);
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "no calibration"};
+    if (camera < 0 || camera >= st->n || !mask) throw Error{MST_ERR_INVALID_ARG, "bad camera or null buffer"};
+    const Rect& r = st->cams[camera].roi;
+    if (stride < static_cast<size_t>(r.width)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
+    check_hip(hipMemcpy2D(mask, stride, st->desc[camera].mask, r.width, r.width, r.height, hipMemcpyDeviceToHost),
+              "hipMemcpy2D(mask)");
 }
 
 void Engine::pyramid_buffer(int camera, void** d_ptr, size_t* bytes)

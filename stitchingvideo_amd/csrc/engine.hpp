@@ -136,6 +136,7 @@ public:
     void stage_cameras(uint32_t camera_mask, const void* const* d_frames, const size_t* strides, hipStream_t stream);
     void stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t mask_stride, hipStream_t stream);
     void pyramid_buffer(int camera, void** d_ptr, size_t* bytes);
+    void camera_mask(int camera, uint8_t* mask, size_t stride);
     void synchronize();
     // The calibration the next compose call will use: the newest published one, or -- once the frame thread has
     // called acquire() -- the one it latched there (the reference's `if (Upflag) UpdateMat()`, DRV:835-836).

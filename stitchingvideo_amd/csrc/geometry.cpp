@@ -509,6 +509,32 @@ void backward_map_host(const Projector& p, const Rect& roi, const MapTables& t, 
         }
 }
 
+Resize8uAxis build_resize8u_axis(int src_len, int dst_len, bool is_x)
+{
+    Resize8uAxis a;
+    a.ofs0.resize(dst_len); a.ofs1.resize(dst_len); a.c0.resize(dst_len); a.c1.resize(dst_len);
+    const double inv_scale = static_cast<double>(dst_len) / src_len;
+    const double scale = 1. / inv_scale;
+    auto coef = [](float w) {      // saturate_cast<short>(w * INTER_RESIZE_COEF_SCALE)
+        const double r = std::nearbyint(static_cast<double>(w * 2048.f));
+        return static_cast<int16_t>(std::min(32767., std::max(-32768., r)));
+    };
+    for (int d = 0; d < dst_len; ++d) {
+        float f = static_cast<float>((d + 0.5) * scale - 0.5);
+        int s = floor_to_int(f);
+        f -= s;
+        if (is_x) {                    // the x axis zeroes the fraction where it clamps; the y axis only clamps rows
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= src_len - 1) { f = 0; s = src_len - 1; }
+        }
+        a.ofs0[d] = std::min(std::max(s, 0), src_len - 1);
+        a.ofs1[d] = std::min(std::max(s + 1, 0), src_len - 1);
+        a.c0[d] = coef(1.f - f);
+        a.c1[d] = coef(f);
+    }
+    return a;
+}
+
 ResizeAxis build_gain_axis_x(int src_len, int dst_len)
 {
     ResizeAxis a;

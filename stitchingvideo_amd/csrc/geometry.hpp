@@ -90,6 +90,14 @@ struct ResizeAxis {
 ResizeAxis build_gain_axis_x(int src_len, int dst_len);
 ResizeAxis build_gain_axis_y(int src_len, int dst_len);
 
+// cv::resize(..., INTER_LINEAR) tables for one axis of a CV_8U image (HResizeLinear<uchar,int,short,2048>):
+// the two source indices and their 11-bit fixed-point weights, saturate_cast<short>(w * 2048).
+struct Resize8uAxis {
+    std::vector<int32_t> ofs0, ofs1;
+    std::vector<int16_t> c0, c1;
+};
+Resize8uAxis build_resize8u_axis(int src_len, int dst_len, bool is_x);
+
 // MultiBandBlender integer geometry.
 struct BandGeometry {
     Rect tl_br;                 // x,y = tl_new ; width,height = br_new - tl_new (bordered size)

@@ -283,6 +283,94 @@ __global__ __launch_bounds__(256) void k_band_weight_sum(const CamDesc* __restri
     ws[static_cast<size_t>(y) * cw + x] = acc;
 }
 
+// The mask fix-up of the compose loop (stitcher.cpp:291-294 = DRV:676-678), one thread per pixel of the final mask:
+//   dilate(seam mask, 3x3)  ->  resize(INTER_LINEAR) to the warped size  ->  & warp(all-255, NEAREST, CONSTANT)
+// cv::resize on CV_8U works in 11-bit fixed point: rows of D = S[x0] * a0 + S[x1] * a1 (ints), then
+// (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2; the dilated values are formed on the fly.
+__global__ __launch_bounds__(256) void k_mask_fixup(const CamDesc* __restrict__ cam, const uint8_t* __restrict__ seam,
+                                                    int sw, int sh, const int32_t* __restrict__ xo0,
+                                                    const int32_t* __restrict__ xo1, const int16_t* __restrict__ xa0,
+                                                    const int16_t* __restrict__ xa1, const int32_t* __restrict__ yo0,
+                                                    const int32_t* __restrict__ yo1, const int16_t* __restrict__ yb0,
+                                                    const int16_t* __restrict__ yb1, uint8_t* __restrict__ out, int w, int h)
+{
+    const int x = blockIdx.x * kTileW + threadIdx.x, y = blockIdx.y * kTileH + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const CamDesc& c = *cam;
+    auto dil = [&](int px, int py) {              // cv::dilate, 3x3 rectangle, pixels outside the image ignored
+        int m = 0;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = py + dy;
+            if (yy < 0 || yy >= sh) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = px + dx;
+                if (xx < 0 || xx >= sw) continue;
+                m = max(m, static_cast<int>(seam[static_cast<size_t>(yy) * sw + xx]));
+            }
+        }
+        return m;
+    };
+    const int x0 = xo0[x], x1 = xo1[x], a0 = xa0[x], a1 = xa1[x];
+    const int y0 = yo0[y], y1 = yo1[y], b0 = yb0[y], b1 = yb1[y];
+    const int d0 = dil(x0, y0) * a0 + dil(x1, y0) * a1;
+    const int d1 = dil(x0, y1) * a0 + dil(x1, y1) * a1;
+    const int v = sat_u8((((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2);
+    // warp(Mat(size, CV_8U, 255), INTER_NEAREST, BORDER_CONSTANT): 255 where the rounded map lands in the source
+    float mx, my;
+    backward_map(c, x, y, mx, my);
+    const int sx = sat_s16(cv_round(mx)), sy = sat_s16(cv_round(my));
+    const bool inside = static_cast<unsigned>(sx) < static_cast<unsigned>(c.src_w) &&
+                        static_cast<unsigned>(sy) < static_cast<unsigned>(c.src_h);
+    out[static_cast<size_t>(y) * w + x] = static_cast<uint8_t>(inside ? v : 0);
+}
+
+// createWeightMap (blenders.cpp:427-432) on the device: distanceTransform(mask, CV_DIST_L1, 3) is a 3x3 chamfer with
+// costs 1 (edge) and 2 (diagonal) in 16.16 fixed point over a frame of INT_MAX >> 2 -- i.e. the exact city-block
+// distance to the nearest zero pixel, or "frame value + distance to the frame" where that is smaller -- which
+// separates into a column pass and a row pass of running minima.  Pass 1: per column, distance along the column.
+constexpr int kDtInf = INT_MAX >> 2, kDtStep = 1 << 16;
+__global__ __launch_bounds__(256) void k_dt_columns(const uint8_t* __restrict__ mask, int w, int h, int32_t* __restrict__ g)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    int run = kDtInf;                              // the frame row above the image
+    for (int y = 0; y < h; ++y) {
+        run = mask[static_cast<size_t>(y) * w + x] ? run + kDtStep : 0;
+        g[static_cast<size_t>(y) * w + x] = run;
+    }
+    run = kDtInf;                                  // the frame row below
+    for (int y = h - 1; y >= 0; --y) {
+        const size_t i = static_cast<size_t>(y) * w + x;
+        run = mask[i] ? run + kDtStep : 0;
+        g[i] = min(g[i], run);
+    }
+}
+// Pass 2: per row, min over columns of g + |dx| (and the frame columns left and right), then the float scaling of
+// distanceTransform (* 2^-16), `weight * sharpness` and threshold(..., 1, THRESH_TRUNC).  One wave per row: a
+// running minimum is a scan, done here as two sequential sweeps by lane 0's neighbours in chunks.
+__global__ __launch_bounds__(64) void k_dt_rows(const int32_t* __restrict__ g, int w, int h, float sharpness,
+                                                float* __restrict__ weight)
+{
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    if (y >= h) return;
+    const int32_t* __restrict__ row = g + static_cast<size_t>(y) * w;
+    float* __restrict__ out = weight + static_cast<size_t>(y) * w;
+    // backward sweep first, kept in the output row as bit patterns; forward sweep finishes the value
+    int run = kDtInf;                              // frame column right of the image
+    for (int x = w - 1; x >= 0; --x) {
+        run = min(row[x], run + kDtStep);
+        out[x] = __int_as_float(run);
+    }
+    run = kDtInf;                                  // frame column left
+    for (int x = 0; x < w; ++x) {
+        run = min(row[x], run + kDtStep);
+        const int v = min(run, __float_as_int(out[x]));
+        float d = static_cast<float>(v) * (1.f / 65536.f);
+        d = d * sharpness + 0.f;
+        out[x] = d > 1.f ? 1.f : d;
+    }
+}
+
 // What the work-list planner needs to know about a weight pyramid level, one byte per pixel: bit 0 = non-zero
 // (short(laplacian * 0.f) == 0: such a pixel cannot reach the panorama), bit 1 = exactly the weight of a fully owned
 // pixel (the integer band path applies).  A quarter of the float pyramid's bytes crosses to the host.
@@ -440,6 +528,21 @@ void launch_pyrdown_f32(const float* d_src, int w, int h, float* d_dst, bool wei
     const int dw = (w + 1) / 2, dh = (h + 1) / 2;
     if (weights_16s) hipLaunchKernelGGL(k_pyrdown_s16, grid2d(dw, dh), block2d(), 0, s, d_src, w, h, d_dst, dw, dh);
     else hipLaunchKernelGGL(k_pyrdown_f32, grid2d(dw, dh), block2d(), 0, s, d_src, w, h, d_dst, dw, dh);
+}
+
+void launch_mask_fixup(const CamDesc* d_cam, const uint8_t* d_seam, int sw, int sh, const int32_t* xo0, const int32_t* xo1,
+                       const int16_t* xa0, const int16_t* xa1, const int32_t* yo0, const int32_t* yo1, const int16_t* yb0,
+                       const int16_t* yb1, uint8_t* d_out, int w, int h, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mask_fixup, grid2d(w, h), block2d(), 0, s, d_cam, d_seam, sw, sh, xo0, xo1, xa0, xa1, yo0, yo1,
+                       yb0, yb1, d_out, w, h);
+}
+
+void launch_feather_weight_map(const uint8_t* d_mask, int w, int h, float sharpness, int32_t* d_tmp, float* d_weight,
+                               hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dt_columns, dim3((w + 255) / 256), dim3(256), 0, s, d_mask, w, h, d_tmp);
+    hipLaunchKernelGGL(k_dt_rows, dim3((h + 63) / 64), dim3(64), 0, s, d_tmp, w, h, sharpness, d_weight);
 }
 
 void launch_weight_class(const float* d_w, uint8_t* d_out, size_t n, float unit, hipStream_t s)

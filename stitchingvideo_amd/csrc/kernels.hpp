@@ -21,6 +21,13 @@ void launch_remap_fixed(const UndistortCam* d_ucams, int n_cams, int max_w, int 
 void launch_weight_level0(const CamDesc* d_cams, int cam, float* d_w0, int bw, int bh, bool weights_16s, hipStream_t s);
 void launch_border_mask(const CamDesc* d_cams, int cam, uint8_t* d_out, int bw, int bh, hipStream_t s);
 void launch_pyrdown_f32(const float* d_src, int w, int h, float* d_dst, bool weights_16s, hipStream_t s);
+// mask fix-up of the compose loop (stitcher.cpp:291-294) for one camera; axis tables from build_resize8u_axis
+void launch_mask_fixup(const CamDesc* d_cam, const uint8_t* d_seam, int sw, int sh, const int32_t* xo0, const int32_t* xo1,
+                       const int16_t* xa0, const int16_t* xa1, const int32_t* yo0, const int32_t* yo1, const int16_t* yb0,
+                       const int16_t* yb1, uint8_t* d_out, int w, int h, hipStream_t s);
+// FeatherBlender's createWeightMap(mask, sharpness) (blenders.cpp:427-432); d_tmp: w * h ints of scratch
+void launch_feather_weight_map(const uint8_t* d_mask, int w, int h, float sharpness, int32_t* d_tmp, float* d_weight,
+                               hipStream_t s);
 void launch_weight_class(const float* d_w, uint8_t* d_out, size_t n, float unit, hipStream_t s);   // see k_weight_class
 void launch_band_weight_sum(const CamDesc* d_cams, int n_cams, int level, float* d_ws, int cw, int ch,
                             hipStream_t s);

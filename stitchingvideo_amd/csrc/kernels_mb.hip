@@ -116,14 +116,9 @@ constexpr int A_GAIN_ROWS = 4;                 // gain-map rows a tile may span 
 constexpr int A_BLOB = 640, A_BLOB_GY = A_GAIN_ROWS * A_LW, A_BLOB_W = A_BLOB_GY + A_LH, A_BLOB_META = A_BLOB_W + 2 * A_LH;
 static_assert(A_BLOB_META + 4 <= A_BLOB && A_BLOB <= 3 * 256, "tile block layout");
 
-// saturate_cast<uchar>(uchar * float): cvRound + clamp.  For gain < 8e6 the product is far inside
-// int range and clamping in float first is the same function (NaN -> 0 both ways).
-__device__ __forceinline__ int apply_gain_bounded(int v, float g)
-{
-    const float f = rintf(static_cast<float>(v) * g);
-    return static_cast<int>(fminf(fmaxf(f, 0.f), 255.f));
-}
-
+// saturate_cast<uchar>(uchar * float) = clamp(cvRound(product), 0, 255).  For gain < 8e6 the product is far inside
+// int range and clamping in float first is the same function (NaN -> 0 both ways): that bounded form is what
+// v_cvt_pk_u8_f32 computes (blend_pixel); tiles with a larger gain use the general apply_gain.
 struct PixelFetch {           // one pixel between "addresses issued" and "blended"
     uint32_t a0, a1, a2, c0, c1, c2;   // raw dwords covering the two 6-byte pixel pairs (fast path)
     uint32_t sh0, sh1;                 // byte offsets of the pairs inside those dwords

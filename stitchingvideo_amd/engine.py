@@ -248,10 +248,17 @@ class PanoramaEngine:
                 keep.append(g)
                 arr[i].gain_map, arr[i].gain_w, arr[i].gain_h = g.ctypes.data, g.shape[1], g.shape[0]
             arr[i].gain = float(c.get("gain", 1.0))
-            m = np.ascontiguousarray(c["mask"], np.uint8)
-            keep.append(m)
-            arr[i].mask, arr[i].mask_width, arr[i].mask_height = m.ctypes.data, m.shape[1], m.shape[0]
-            arr[i].mask_stride = m.strides[0]
+            sm = c.get("seam_mask")                # seam-scale mask: the engine does the fix-up (stitcher.cpp:291-294)
+            if sm is not None:
+                sm = np.ascontiguousarray(sm, np.uint8)
+                keep.append(sm)
+                arr[i].seam_mask, arr[i].seam_mask_width, arr[i].seam_mask_height = sm.ctypes.data, sm.shape[1], sm.shape[0]
+                arr[i].seam_mask_stride = sm.strides[0]
+            if c.get("mask") is not None:
+                m = np.ascontiguousarray(c["mask"], np.uint8)
+                keep.append(m)
+                arr[i].mask, arr[i].mask_width, arr[i].mask_height = m.ctypes.data, m.shape[1], m.shape[0]
+                arr[i].mask_stride = m.strides[0]
             und = c.get("undistort")               # (map1 int16 (h, w, 2), map2 uint16 (h, w)) or None
             if und is not None:
                 m1 = np.ascontiguousarray(und[0], np.int16)
@@ -279,6 +286,13 @@ class PanoramaEngine:
         r = capi.Rect()
         self._check(self._L.mst_camera_roi(self._h, i, C.byref(r)))
         return r.tuple()
+
+    def camera_mask(self, i):
+        """Final mask_warped of camera i as the engine holds it (the caller's, or the device-side fix-up result)."""
+        _, _, w, h = self.camera_roi(i)
+        m = np.empty((h, w), np.uint8)
+        self._check(self._L.mst_camera_mask(self._h, i, m.ctypes.data, m.strides[0]))
+        return m
 
     def num_bands(self):
         v = C.c_int()
