@@ -2,6 +2,9 @@
 #include "mb_plan.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 
 #include "kernels.hpp"
@@ -21,57 +24,6 @@ int reflect101(int p, int len)
     return p;
 }
 
-// source indices cv::pyrUp reads around coarse index j (same clamping as the kernels' up_idx)
-void up_idx(int j, int n, int& jm, int& jp)
-{
-    jm = j == 0 ? std::min(1, n - 1) : j - 1;
-    jp = std::min(j + 1, n - 1);
-}
-
-// mark, at the coarser level, the 3x3 pyrUp sources of every set pixel of the finer level
-void mark_parents(const std::vector<uint8_t>& fine, int fw, int fh, std::vector<uint8_t>& coarse, int cw, int ch)
-{
-    for (int y = 0; y < fh; ++y) {
-        const uint8_t* row = fine.data() + static_cast<size_t>(y) * fw;
-        int im, ip;
-        const int i = y >> 1;
-        up_idx(i, ch, im, ip);
-        const int ys[3] = {im, i, ip};
-        for (int x = 0; x < fw; ++x) {
-            if (!row[x]) continue;
-            int jm, jp;
-            const int j = x >> 1;
-            up_idx(j, cw, jm, jp);
-            for (int yy : ys) {
-                uint8_t* d = coarse.data() + static_cast<size_t>(yy) * cw;
-                d[jm] = 1; d[j] = 1; d[jp] = 1;
-            }
-        }
-    }
-}
-
-// mark, at the finer level, the 5x5 pyrDown footprint (REFLECT_101) of every set pixel of the coarser level
-void mark_footprint(const std::vector<uint8_t>& coarse, int cw, int ch, std::vector<uint8_t>& fine, int fw, int fh)
-{
-    for (int y = 0; y < ch; ++y) {
-        const uint8_t* row = coarse.data() + static_cast<size_t>(y) * cw;
-        int ys[5];
-        for (int t = 0; t < 5; ++t) ys[t] = reflect101(2 * y + t - 2, fh);
-        for (int x = 0; x < cw; ++x) {
-            if (!row[x]) continue;
-            int xs[5];
-            for (int t = 0; t < 5; ++t) xs[t] = reflect101(2 * x + t - 2, fw);
-            for (int yy : ys) {
-                uint8_t* d = fine.data() + static_cast<size_t>(yy) * fw;
-                for (int xx : xs) d[xx] = 1;
-            }
-        }
-    }
-}
-
-}  // namespace
-
-namespace {
 // run f(i) for i in [0, count) on up to `max_threads` host threads (the plan is a few dozen independent passes over
 // byte maps: per camera, per canvas tile row)
 template <typename F> void parallel_for(int count, int max_threads, F&& f)
@@ -84,7 +36,80 @@ template <typename F> void parallel_for(int count, int max_threads, F&& f)
         pool.emplace_back([&, w] { for (int i = w; i < count; i += workers) f(i); });
     for (std::thread& t : pool) t.join();
 }
+
+// rows of a level cut into stripes for the passes below: each worker owns the OUTPUT rows of its stripe, reads the
+// input rows that can reach them, and writes nowhere else
+constexpr int kStripe = 64;
+
+// source indices cv::pyrUp reads around coarse index j (same clamping as the kernels' up_idx)
+void up_idx(int j, int n, int& jm, int& jp)
+{
+    jm = j == 0 ? std::min(1, n - 1) : j - 1;
+    jp = std::min(j + 1, n - 1);
+}
+
+// mark, at the coarser level, the 3x3 pyrUp sources of every set pixel of the finer level
+void mark_parents(const std::vector<uint8_t>& fine, int fw, int fh, std::vector<uint8_t>& coarse, int cw, int ch)
+{
+    const int stripes = (ch + kStripe - 1) / kStripe;
+    parallel_for(stripes, 32, [&](int sidx) {
+        const int c0 = sidx * kStripe, c1 = std::min(ch, c0 + kStripe);          // coarse rows this worker may write
+        // fine rows whose sources {i-1, i, i+1} (clamped) can fall into [c0, c1)
+        const int y0 = std::max(0, 2 * (c0 - 1)), y1 = std::min(fh, 2 * (c1 + 1));
+        for (int y = y0; y < y1; ++y) {
+            const uint8_t* row = fine.data() + static_cast<size_t>(y) * fw;
+            int im, ip;
+            const int i = y >> 1;
+            up_idx(i, ch, im, ip);
+            const int ys[3] = {im, i, ip};
+            for (int x = 0; x < fw; ++x) {
+                if (!row[x]) continue;
+                int jm, jp;
+                const int j = x >> 1;
+                up_idx(j, cw, jm, jp);
+                for (int yy : ys) {
+                    if (yy < c0 || yy >= c1) continue;
+                    uint8_t* d = coarse.data() + static_cast<size_t>(yy) * cw;
+                    d[jm] = 1; d[j] = 1; d[jp] = 1;
+                }
+            }
+        }
+    });
+}
+
+// mark, at the finer level, the 5x5 pyrDown footprint (REFLECT_101) of every set pixel of the coarser level
+void mark_footprint(const std::vector<uint8_t>& coarse, int cw, int ch, std::vector<uint8_t>& fine, int fw, int fh)
+{
+    const int stripes = (fh + kStripe - 1) / kStripe;
+    parallel_for(stripes, 32, [&](int sidx) {
+        const int f0 = sidx * kStripe, f1 = std::min(fh, f0 + kStripe);          // fine rows this worker may write
+        // coarse rows whose taps 2y-2 .. 2y+2 (reflected at the image border, so the border stripes look at a few
+        // more rows) can land in [f0, f1)
+        int y0 = std::max(0, (f0 - 2) / 2 - 1), y1 = std::min(ch, (f1 + 2) / 2 + 2);
+        if (f0 < 4) y0 = 0;
+        if (f1 > fh - 4) y1 = ch;
+        for (int y = y0; y < y1; ++y) {
+            const uint8_t* row = coarse.data() + static_cast<size_t>(y) * cw;
+            int ys[5];
+            bool mine = false;
+            for (int t = 0; t < 5; ++t) { ys[t] = reflect101(2 * y + t - 2, fh); mine |= ys[t] >= f0 && ys[t] < f1; }
+            if (!mine) continue;
+            for (int x = 0; x < cw; ++x) {
+                if (!row[x]) continue;
+                int xs[5];
+                for (int t = 0; t < 5; ++t) xs[t] = reflect101(2 * x + t - 2, fw);
+                for (int yy : ys) {
+                    if (yy < f0 || yy >= f1) continue;
+                    uint8_t* d = fine.data() + static_cast<size_t>(yy) * fw;
+                    for (int xx : xs) d[xx] = 1;
+                }
+            }
+        }
+    });
+}
+
 }  // namespace
+
 
 void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<uint8_t>>>& weight_class,
                    const BlendArgs& blend, MbPlanHost& plan)
@@ -94,6 +119,14 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
     int a_tw0, a_th0, b_t, c_tw, c_th;
     mb_tile_dims(&a_tw0, &a_th0, &b_t, &c_tw, &c_th);
 
+    const bool timing = std::getenv("MST_UPDATE_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!timing) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mst_update]   plan: %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     plan = MbPlanHost{};
     plan.cams.resize(n);
     parallel_for(n, 16, [&](int c) {
@@ -105,7 +138,12 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
             const size_t px = static_cast<size_t>(d.lw[l]) * d.lh[l];
             cn.nz[l].resize(px);
             const uint8_t* w = weight_class[c][l].data();
-            for (size_t i = 0; i < px; ++i) cn.nz[l][i] = w[i] & 1u;
+            uint8_t* o = cn.nz[l].data();
+            const int chunks = static_cast<int>((px + (size_t{1} << 18) - 1) >> 18);
+            parallel_for(chunks, 32, [&](int k) {
+                const size_t i0 = static_cast<size_t>(k) << 18, i1 = std::min(px, i0 + (size_t{1} << 18));
+                for (size_t i = i0; i < i1; ++i) o[i] = w[i] & 1u;
+            });
         }
         for (int l = nb; l >= 0; --l) {
             cn.need[l] = cn.nz[l];
@@ -114,23 +152,32 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
         }
     });
 
+    mark("nz / need per camera");
     // ---- kernel A: level-0 tiles of a_tw0 x a_th0 pixels
-    for (int c = 0; c < n; ++c) {
-        plan.warp_cam_start.push_back(static_cast<int>(plan.warp_tiles.size()));
-        const CamDesc& d = desc[c];
-        const int tiles_x = (d.lw[0] + a_tw0 - 1) / a_tw0, tiles_y = (d.lh[0] + a_th0 - 1) / a_th0;
-        std::vector<uint8_t> used(static_cast<size_t>(tiles_x) * tiles_y, 0);
-        const std::vector<uint8_t>& need0 = plan.cams[c].need[0];
-        for (int y = 0; y < d.lh[0]; ++y) {
-            const uint8_t* row = need0.data() + static_cast<size_t>(y) * d.lw[0];
-            uint8_t* urow = used.data() + static_cast<size_t>(y / a_th0) * tiles_x;
-            for (int x = 0; x < d.lw[0]; ++x)
-                if (row[x]) urow[x / a_tw0] = 1;
+    {
+        std::vector<std::vector<uint32_t>> per_cam(n);
+        parallel_for(n, 16, [&](int c) {
+            const CamDesc& d = desc[c];
+            const int tiles_x = (d.lw[0] + a_tw0 - 1) / a_tw0, tiles_y = (d.lh[0] + a_th0 - 1) / a_th0;
+            std::vector<uint8_t> used(static_cast<size_t>(tiles_x) * tiles_y, 0);
+            const std::vector<uint8_t>& need0 = plan.cams[c].need[0];
+            parallel_for(tiles_y, 32, [&](int ty) {                       // a tile row's flags belong to one worker
+                uint8_t* urow = used.data() + static_cast<size_t>(ty) * tiles_x;
+                for (int y = ty * a_th0; y < std::min(d.lh[0], (ty + 1) * a_th0); ++y) {
+                    const uint8_t* row = need0.data() + static_cast<size_t>(y) * d.lw[0];
+                    for (int x = 0; x < d.lw[0]; ++x)
+                        if (row[x]) urow[x / a_tw0] = 1;
+                }
+            });
+            for (int ty = 0; ty < tiles_y; ++ty)
+                for (int tx = 0; tx < tiles_x; ++tx)
+                    if (used[static_cast<size_t>(ty) * tiles_x + tx])
+                        per_cam[c].push_back(static_cast<uint32_t>(c) << 24 | static_cast<uint32_t>(ty) << 12 | tx);
+        });
+        for (int c = 0; c < n; ++c) {
+            plan.warp_cam_start.push_back(static_cast<int>(plan.warp_tiles.size()));
+            plan.warp_tiles.insert(plan.warp_tiles.end(), per_cam[c].begin(), per_cam[c].end());
         }
-        for (int ty = 0; ty < tiles_y; ++ty)
-            for (int tx = 0; tx < tiles_x; ++tx)
-                if (used[static_cast<size_t>(ty) * tiles_x + tx])
-                    plan.warp_tiles.push_back(static_cast<uint32_t>(c) << 24 | static_cast<uint32_t>(ty) << 12 | tx);
     }
 
     plan.warp_cam_start.push_back(static_cast<int>(plan.warp_tiles.size()));
@@ -168,6 +215,7 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
         base += k;
     }
 
+    mark("warp + chain tile lists");
     // ---- kernel C: canvas tiles, camera bit masks, LDS layout
     plan.blend_tiles_x = (blend.cw[0] + c_tw - 1) / c_tw;
     plan.blend_tiles_y = (blend.ch[0] + c_th - 1) / c_th;
@@ -246,6 +294,7 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
             plan.block_pure[ti] = owner >= 0 ? (level_mask | static_cast<uint32_t>(owner) << 16) : 0u;
         }
     });
+    mark("canvas tiles");
     for (const std::vector<int>& ra : row_area)
         for (int l = 0; l < nlev; ++l) max_area[l] = std::max(max_area[l], ra[l]);
     // launch order: every canvas tile is resident at once on a 256-CU part, so the dispatcher's round-robin
