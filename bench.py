@@ -73,6 +73,7 @@ def parse_args():
                          "cameras = camera i on rank i %% N, payload sent to rank 0 over RCCL, rank 0 blends (SURVEY 8e)")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the one-frame-set-per-sequence measurement (profiling runs)")
     ap.add_argument("--no-camera-leg", action="store_true", help="N > 1: skip the camera-sharded secondary measurement")
+    ap.add_argument("--camera-leg", action="store_true", help="run the camera-sharded measurement at N = 1 too (stage split only)")
     ap.add_argument("--camera-leg-steps", type=int, default=100)
     ap.add_argument("--undistort", action="store_true",
                     help="add the driver's lens-undistort pre-pass (DRV:741) to every camera (not part of the headline)")
@@ -336,7 +337,7 @@ def main():
                                    "roofline_frac": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
     # ---- N > 1: the north-star split measured beside the headline (C4: 8 cameras, camera i on rank i % N) ----
-    if world > 1 and not by_camera and not args.no_camera_leg:
+    if (world > 1 or args.camera_leg) and not by_camera and not args.no_camera_leg:
         def give_up():          # every rank: a hung exchange must not take the headline (or the launcher) with it
             if rank == 0:
                 out["camera_sharded"] = {"error": "timed out after 240 s (exchange did not complete)"}
@@ -364,7 +365,7 @@ def main():
         dist.destroy_process_group()
 
 
-def camera_sharded_leg(args, rank, world, local_rank, dev, stream):
+def camera_sharded_leg(args_ns, rank, world, local_rank, dev, stream):
     """BASELINE C4 as specified: 8x1080p, camera i on GPU i % N, one exchange of the per-camera payload to rank 0
     per frame over RCCL (grouped point-to-point, every peer on its own xGMI link), rank 0 blends.  Strong scaling:
     the job is one panorama stream.  Runs on every rank; rank 0 returns the result object."""
@@ -376,32 +377,41 @@ def camera_sharded_leg(args, rank, world, local_rank, dev, stream):
     cfg = rigmod.CONFIGS["C4"]
     rig = rigmod.build_rig(cfg)
     n_cam = len(rig["cameras"])
-    eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend="multiband", expos=rig["expos"], num_bands=5, device=local_rank)
+    eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend="multiband", expos=rig["expos"], num_bands=5, device=local_rank,
+                           max_batch=2)                       # two pyramid sets: exchange of t overlaps stage of t + 1
     eng.update(rig["scale"], rig["cameras"])
     (_, _, cw, ch), _ = eng.acquire()
     st = sharding.ShardedStitcher(eng, rank, world, root=0, device=dev)
+    st.refresh()
     sets = []
     for s in range(2):
         fr = rigmod.frames_for(rig, frame_index=s)
         sets.append({c: torch.from_numpy(fr[c]).to(dev) for c in st.mine})
-    pano = torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev)
+    panos = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
 
-    def call(i):
-        ds = sets[i % len(sets)]
-        st.compose({c: t.data_ptr() for c, t in ds.items()}, {c: t.stride(0) for c, t in ds.items()},
-                   pano.data_ptr(), pano.stride(0), stream=stream)
+    def args(t):
+        ds = sets[t % len(sets)]
+        return {c: x.data_ptr() for c, x in ds.items()}, {c: x.stride(0) for c, x in ds.items()}
 
-    for i in range(10):
-        call(i)
+    def run(n):
+        # frame t's exchange is in flight while frame t + 1's per-camera kernels run; the canvas stage of t follows
+        st.submit(0, *args(0), stream=stream)
+        for t in range(1, n):
+            st.submit(t, *args(t), stream=stream)
+            st.finish(t - 1, panos[(t - 1) % 2].data_ptr(), panos[0].stride(0), stream=stream)
+        st.finish(n - 1, panos[(n - 1) % 2].data_ptr(), panos[0].stride(0), stream=stream)
+
+    run(10)
     torch.cuda.synchronize()
-    dist.barrier()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
-    n = max(10, args.camera_leg_steps)
+    n = max(10, args_ns.camera_leg_steps)
     t0 = time.perf_counter()
-    for i in range(n):
-        call(i)
+    run(n)
     torch.cuda.synchronize()
-    dist.barrier()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     wall = sharding.max_over_ranks([time.perf_counter() - t0], device=dev)[0]
     payload = st.payload_bytes()
@@ -409,7 +419,8 @@ def camera_sharded_leg(args, rank, world, local_rank, dev, stream):
     alg = rigmod.algorithmic_bytes(rig, (cw, ch))
     return {"workload": "C4: %dx%dx%d BGR8 streams, spherical warp, gain_blocks, multiband blend (5 bands), canvas %dx%d"
                         % (n_cam, rig["size"][0], rig["size"][1], cw, ch),
-            "parallelism": "camera i on rank i %% %d, payload to rank 0 over RCCL point-to-point, rank 0 blends" % world,
+            "parallelism": "camera i on rank i %% %d, packed tile payload to rank 0 over RCCL (one grouped point-to-point "
+                           "exchange per frame, overlapped with the next frame's per-camera kernels), rank 0 blends" % world,
             "scaling": "strong", "frames": n, "frames_per_s": round(n / wall, 2), "ms_per_frame": round(wall * 1e3 / n, 4),
             "payload_bytes_per_frame_to_root": payload,
             "roofline_frac": round(alg * n / wall / 1e9 / HBM_PEAK_GBS, 5)}

@@ -249,6 +249,18 @@ int  mst_stage_cameras(mst_engine *e, uint32_t camera_mask, const void *const *d
                        const size_t *frame_strides, void *stream);   /* entries outside the mask are ignored */
 int  mst_stage_canvas(mst_engine *e, void *d_pano, size_t pano_stride, void *d_pano_mask,
                       size_t pano_mask_stride, void *stream);
+/* The hand-off payload of one camera: the interiors of its launched tiles at every pyramid level, packed back to
+ * back -- everything the canvas stage can read of that camera and nothing else (the wrap-around camera of a
+ * 360-degree rig, whose pyramid block spans the whole canvas, ships about as much as any other camera).  Sizes
+ * and layout are static per calibration and identical on every rank that published the same calibration.
+ * mst_payload_pack gathers it from the engine's pyramids into `d_payload` (device memory, mst_payload_bytes
+ * long) on the sending rank; mst_payload_unpack scatters a received one into the blending rank's pyramids.
+ * mst_stage_select_set picks which of the engine's pyramid sets (0 .. mst_config.max_batch - 1) the mst_stage_* and
+ * mst_payload_* calls work on: with two sets the exchange of frame t overlaps the per-camera stage of frame t+1. */
+int  mst_payload_bytes(mst_engine *e, int camera, size_t *bytes);
+int  mst_payload_pack(mst_engine *e, int camera, void *d_payload, void *stream);
+int  mst_payload_unpack(mst_engine *e, int camera, const void *d_payload, void *stream);
+int  mst_stage_select_set(mst_engine *e, int set);
 /* The buffer belongs to the calibration the call resolves to (see mst_acquire_calibration) and is freed when that
  * calibration is retired: query it again after every mst_update / mst_acquire_calibration, never cache it across. */
 int  mst_pyramid_buffer(mst_engine *e, int camera, void **d_ptr, size_t *bytes);

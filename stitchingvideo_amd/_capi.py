@@ -44,6 +44,7 @@ EXPORTS = [
     "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_device_batch", "mst_compose_profile",
     "mst_compose_profile_batch", "mst_synchronize", "mst_warp_roi",
     "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
+    "mst_payload_bytes", "mst_payload_pack", "mst_payload_unpack", "mst_stage_select_set",
     "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
     "mst_init_undistort_rectify_map", "mst_remap_fixed",
     "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame",
@@ -151,6 +152,14 @@ def load():
     L.mst_stage_cameras.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), vp]
     L.mst_stage_canvas.restype = C.c_int
     L.mst_stage_canvas.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
+    L.mst_payload_bytes.restype = C.c_int
+    L.mst_payload_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
+    L.mst_payload_pack.restype = C.c_int
+    L.mst_payload_pack.argtypes = [vp, C.c_int, vp, vp]
+    L.mst_payload_unpack.restype = C.c_int
+    L.mst_payload_unpack.argtypes = [vp, C.c_int, vp, vp]
+    L.mst_stage_select_set.restype = C.c_int
+    L.mst_stage_select_set.argtypes = [vp, C.c_int]
     L.mst_pyramid_buffer.restype = C.c_int
     L.mst_pyramid_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.mst_compose_profile.restype = C.c_int

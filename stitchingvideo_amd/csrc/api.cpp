@@ -284,6 +284,30 @@ int mst_pyramid_buffer(mst_engine* e, int camera, void** d_ptr, size_t* bytes)
     return guarded(e, [&] { e->impl.pyramid_buffer(camera, d_ptr, bytes); });
 }
 
+int mst_payload_bytes(mst_engine* e, int camera, size_t* bytes)
+{
+    if (!e || !bytes) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { *bytes = e->impl.payload_bytes(camera); });
+}
+
+int mst_payload_pack(mst_engine* e, int camera, void* d_payload, void* stream)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.payload_copy(camera, d_payload, true, static_cast<hipStream_t>(stream)); });
+}
+
+int mst_payload_unpack(mst_engine* e, int camera, const void* d_payload, void* stream)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.payload_copy(camera, const_cast<void*>(d_payload), false, static_cast<hipStream_t>(stream)); });
+}
+
+int mst_stage_select_set(mst_engine* e, int set)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.select_stage_set(set); });
+}
+
 int mst_synchronize(mst_engine* e)
 {
     if (!e) return MST_ERR_INVALID_ARG;

@@ -119,6 +119,13 @@ struct BlendArgs {
     int32_t weights_16s;                      // MultiBandBlender weight_type CV_16S: integer weights, >> 8 accumulate
 };
 
+// One rectangle of a camera's hand-off payload (camera-sharded multi-GPU mode): the interior of a launched tile at
+// one pyramid level, `off` pixels into the camera's packed payload.  Static per calibration.
+struct PayloadRect {
+    int32_t level, x0, y0, w, h;
+    uint32_t off;
+};
+
 // Work lists (static per calibration): only tiles whose output can reach the panorama are launched.
 struct TileList {
     const uint32_t* tiles;         // cam << 24 | ty << 12 | tx

@@ -105,6 +105,7 @@ template uint32_t* DevicePool::upload<uint32_t>(const uint32_t*, size_t, hipStre
 template int16_t* DevicePool::upload<int16_t>(const int16_t*, size_t, hipStream_t);
 template uint16_t* DevicePool::upload<uint16_t>(const uint16_t*, size_t, hipStream_t);
 template UndistortCam* DevicePool::upload<UndistortCam>(const UndistortCam*, size_t, hipStream_t);
+template PayloadRect* DevicePool::upload<PayloadRect>(const PayloadRect*, size_t, hipStream_t);
 
 CalibState::~CalibState()
 {
@@ -564,6 +565,7 @@ void Engine::update(const mst_calibration& calib)
         st->warp_blobs = st->pool.alloc<uint32_t>(mb_warp_blob_entries(st->warp_list.count));
         launch_warp_table(st->d_desc, cfg_.warp_kind & 0xFF, st->warp_list, st->warp_table, st->warp_blobs, s);
         check_hip(hipGetLastError(), "k_warp_table");
+        st->d_payload_rects = st->pool.upload(plan.payload_rects, s);
         st->chain_lists.clear();
         for (const MbPlanHost::ChainStep& step : plan.chain) {
             TileList tl;
@@ -772,10 +774,12 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
         fa.ptr[i] = static_cast<const uint8_t*>(d_frames[i]);
         fa.stride[i] = static_cast<uint32_t>(strides[i]);
     }
-    if (st->any_undistort) {            // lens-undistort pre-pass for the cameras of this call (frame set 0)
+    if (stage_set_ >= st->num_sets) throw Error{MST_ERR_INVALID_ARG, "stage set beyond mst_config.max_batch"};
+    const CamDesc* set_desc = st->d_desc + static_cast<size_t>(stage_set_) * st->n;
+    if (st->any_undistort) {            // lens-undistort pre-pass for the cameras of this call (the selected frame set)
         FrameBatch ub = fb;
         for (int i = 0; i < st->n; ++i)
-            if (uint8_t* buf = (camera_mask >> i & 1u) ? st->undist_frames[i] : nullptr) {
+            if (uint8_t* buf = (camera_mask >> i & 1u) ? st->undist_frames[static_cast<size_t>(stage_set_) * st->n + i] : nullptr) {
                 ub.f[0].ptr[i] = buf;
                 ub.f[0].stride[i] = static_cast<uint32_t>(st->cams[i].src_w) * 3u;
             }
@@ -789,7 +793,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
         tl.tiles = st->warp_list.tiles + plan.warp_cam_start[i];
         tl.count = plan.warp_cam_start[i + 1] - plan.warp_cam_start[i];
         tl.first = plan.warp_cam_start[i];
-        launch_warp_pyr(st->d_desc, st->n, cfg_.warp_kind & 0xFF, tl, fb, 1, st->warp_table, st->warp_blobs, s);
+        launch_warp_pyr(set_desc, st->n, cfg_.warp_kind & 0xFF, tl, fb, 1, st->warp_table, st->warp_blobs, s);
     }
     for (size_t k = 0; k < st->chain_lists.size(); ++k)
         for (int i = 0; i < st->n; ++i) {
@@ -798,7 +802,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
             tl.tiles = st->chain_lists[k].tiles + plan.chain[k].cam_start[i];
             tl.count = plan.chain[k].cam_start[i + 1] - plan.chain[k].cam_start[i];
             tl.first = plan.chain[k].cam_start[i];
-            launch_pyr_chain(st->d_desc, st->n, tl, plan.chain[k].base, plan.chain[k].k, 1, s);
+            launch_pyr_chain(set_desc, st->n, tl, plan.chain[k].base, plan.chain[k].k, 1, s);
         }
     check_hip(hipGetLastError(), "camera stage kernels");
     set_in_flight(std::move(st));
@@ -820,8 +824,40 @@ void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t
     BlendArgs ba = st->blend;
     ba.pano[0] = static_cast<uint8_t*>(d_pano); ba.pano_stride = static_cast<uint32_t>(pano_stride);
     ba.pano_mask[0] = static_cast<uint8_t*>(d_mask); ba.mask_stride = static_cast<uint32_t>(mask_stride);
-    launch_blend(st->d_desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, 1, st->plan.lds_bytes, s);
+    if (stage_set_ >= st->num_sets) throw Error{MST_ERR_INVALID_ARG, "stage set beyond mst_config.max_batch"};
+    launch_blend(st->d_desc + static_cast<size_t>(stage_set_) * st->n, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, 1,
+                 st->plan.lds_bytes, s);
     check_hip(hipGetLastError(), "canvas stage kernel");
+    set_in_flight(std::move(st));
+}
+
+void Engine::select_stage_set(int set)
+{
+    if (set < 0 || set >= kMaxBatch) throw Error{MST_ERR_INVALID_ARG, "bad stage set"};
+    stage_set_ = set;
+}
+
+size_t Engine::payload_bytes(int camera)
+{
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "no calibration"};
+    if (st->blend_kind != MST_BLEND_MULTI_BAND || camera < 0 || camera >= st->n)
+        throw Error{MST_ERR_INVALID_ARG, "no payload for that camera"};
+    return static_cast<size_t>(st->plan.payload_px[camera]) * sizeof(uint32_t);
+}
+
+void Engine::payload_copy(int camera, void* d_buf, bool pack, hipStream_t stream)
+{
+    select_device(cfg_.device);
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "no calibration"};
+    if (st->blend_kind != MST_BLEND_MULTI_BAND || camera < 0 || camera >= st->n || !d_buf)
+        throw Error{MST_ERR_INVALID_ARG, "no payload for that camera, or null buffer"};
+    if (stage_set_ >= st->num_sets) throw Error{MST_ERR_INVALID_ARG, "stage set beyond mst_config.max_batch"};
+    const int r0 = st->plan.payload_cam_start[camera], r1 = st->plan.payload_cam_start[camera + 1];
+    launch_payload_copy(st->d_desc + static_cast<size_t>(stage_set_) * st->n + camera, st->d_payload_rects + r0, r1 - r0,
+                        static_cast<uint32_t*>(d_buf), pack, stream ? stream : stream_);
+    check_hip(hipGetLastError(), "k_payload_copy");
     set_in_flight(std::move(st));
 }
 

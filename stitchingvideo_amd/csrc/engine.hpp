@@ -97,6 +97,7 @@ struct CalibState {
     uint32_t* warp_table = nullptr;     // per-tile backward-map table (frame-invariant), see kernels_mb.hip
     uint32_t* warp_blobs = nullptr;     // per tile: calibration constants of kernel A (gain rows, row weights, table origin)
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step
+    PayloadRect* d_payload_rects = nullptr;   // camera-sharded hand-off (plan.payload_*)
     BlendArgs blend{};                  // kernel C (pano pointers filled per frame)
     // feather
     float* d_feather_ws = nullptr;
@@ -136,6 +137,10 @@ public:
     void stage_cameras(uint32_t camera_mask, const void* const* d_frames, const size_t* strides, hipStream_t stream);
     void stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t mask_stride, hipStream_t stream);
     void pyramid_buffer(int camera, void** d_ptr, size_t* bytes);
+    // camera-sharded hand-off: the packed tile interiors of one camera (see mb_plan.hpp)
+    size_t payload_bytes(int camera);
+    void payload_copy(int camera, void* d_buf, bool pack, hipStream_t stream);
+    void select_stage_set(int set);                  // which pyramid set the mst_stage_* / mst_payload_* calls use
     void camera_mask(int camera, uint8_t* mask, size_t stride);
     void synchronize();
     // The calibration the next compose call will use: the newest published one, or -- once the frame thread has
@@ -163,6 +168,7 @@ private:
     bool canvas_pending_[2] = {false, false};
     bool in_host_compose_ = false;
     uint64_t frame_counter_ = 0;
+    int stage_set_ = 0;
     mutable std::mutex mu_;
     std::shared_ptr<CalibState> current_;
     std::shared_ptr<CalibState> latched_;     // acquire(): what compose uses while latching_ (else current_)

@@ -371,6 +371,25 @@ __global__ __launch_bounds__(64) void k_dt_rows(const int32_t* __restrict__ g, i
     }
 }
 
+// Camera-sharded hand-off: copy the rectangles of one camera's payload between its pyramid levels and a
+// packed buffer.  PACK: pyramid -> buffer (the sending rank), else buffer -> pyramid (the blending rank).
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_payload_copy(const CamDesc* __restrict__ cam, const PayloadRect* __restrict__ rects,
+                                                      uint32_t* __restrict__ buf)
+{
+    const PayloadRect r = rects[blockIdx.x];
+    const CamDesc& c = *cam;
+    uint32_t MST_GLOBAL* __restrict__ g = gp(c.G[r.level]);
+    uint32_t MST_GLOBAL* __restrict__ b = gp(buf) + r.off;
+    const int lw = c.lw[r.level], n = r.w * r.h;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int y = i / r.w, x = i - y * r.w;
+        const size_t gi = static_cast<size_t>(r.y0 + y) * lw + (r.x0 + x);
+        if (PACK) b[i] = g[gi];
+        else g[gi] = b[i];
+    }
+}
+
 // What the work-list planner needs to know about a weight pyramid level, one byte per pixel: bit 0 = non-zero
 // (short(laplacian * 0.f) == 0: such a pixel cannot reach the panorama), bit 1 = exactly the weight of a fully owned
 // pixel (the integer band path applies).  A quarter of the float pyramid's bytes crosses to the host.
@@ -543,6 +562,13 @@ void launch_feather_weight_map(const uint8_t* d_mask, int w, int h, float sharpn
 {
     hipLaunchKernelGGL(k_dt_columns, dim3((w + 255) / 256), dim3(256), 0, s, d_mask, w, h, d_tmp);
     hipLaunchKernelGGL(k_dt_rows, dim3((h + 63) / 64), dim3(64), 0, s, d_tmp, w, h, sharpness, d_weight);
+}
+
+void launch_payload_copy(const CamDesc* d_cam, const PayloadRect* d_rects, int n_rects, uint32_t* d_buf, bool pack, hipStream_t s)
+{
+    if (n_rects <= 0) return;
+    if (pack) hipLaunchKernelGGL(k_payload_copy<true>, dim3(n_rects), dim3(256), 0, s, d_cam, d_rects, d_buf);
+    else hipLaunchKernelGGL(k_payload_copy<false>, dim3(n_rects), dim3(256), 0, s, d_cam, d_rects, d_buf);
 }
 
 void launch_weight_class(const float* d_w, uint8_t* d_out, size_t n, float unit, hipStream_t s)

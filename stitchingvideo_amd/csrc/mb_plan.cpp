@@ -215,6 +215,37 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
         base += k;
     }
 
+    // ---- hand-off payload of the camera-sharded mode: tile interiors, level by level
+    {
+        const int a_tw1 = a_tw0 / 2, a_th1 = a_th0 / 2;
+        for (int c = 0; c < n; ++c) {
+            plan.payload_cam_start.push_back(static_cast<int>(plan.payload_rects.size()));
+            const CamDesc& d = desc[c];
+            uint32_t off = 0;
+            auto add = [&](int level, int x0, int y0, int w, int h) {
+                w = std::min(w, d.lw[level] - x0);
+                h = std::min(h, d.lh[level] - y0);
+                if (w <= 0 || h <= 0) return;
+                plan.payload_rects.push_back(PayloadRect{level, x0, y0, w, h, off});
+                off += static_cast<uint32_t>(w) * static_cast<uint32_t>(h);
+            };
+            for (int i = plan.warp_cam_start[c]; i < plan.warp_cam_start[c + 1]; ++i) {
+                const uint32_t t = plan.warp_tiles[i];
+                const int ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
+                add(0, tx * a_tw0, ty * a_th0, a_tw0, a_th0);
+                if (nlev >= 2) add(1, tx * a_tw1, ty * a_th1, a_tw1, a_th1);
+            }
+            for (const MbPlanHost::ChainStep& step : plan.chain)
+                for (int i = step.cam_start[c]; i < step.cam_start[c + 1]; ++i) {
+                    const uint32_t t = step.tiles[i];
+                    const int ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
+                    for (int j = 1; j <= step.k; ++j)
+                        add(step.base + j, (tx * b_t) >> j, (ty * b_t) >> j, b_t >> j, b_t >> j);
+                }
+            plan.payload_px.push_back(off);
+        }
+        plan.payload_cam_start.push_back(static_cast<int>(plan.payload_rects.size()));
+    }
     mark("warp + chain tile lists");
     // ---- kernel C: canvas tiles, camera bit masks, LDS layout
     plan.blend_tiles_x = (blend.cw[0] + c_tw - 1) / c_tw;

@@ -36,6 +36,11 @@ struct MbPlanHost {
     std::vector<uint32_t> block_pure;                         // kernel C: levels owned by one camera | owner << 16
     std::vector<uint32_t> block_order;                        // kernel C, tile index launched as block i
     int blend_tiles_x = 0, blend_tiles_y = 0;
+    // camera-sharded hand-off: per camera, the interiors of its launched tiles at every level (what the canvas kernel
+    // can read of that camera and nothing else), packed back to back
+    std::vector<PayloadRect> payload_rects;                   // grouped by camera
+    std::vector<int> payload_cam_start;                       // n+1 offsets into payload_rects
+    std::vector<uint32_t> payload_px;                         // pixels (dwords) per camera
     int lds_off[kMaxLevels] = {};
     size_t lds_bytes = 0;
     std::vector<MbCameraNeed> cams;

@@ -397,6 +397,21 @@ class PanoramaEngine:
     def stage_canvas(self, pano_ptr, pano_stride, mask_ptr=None, mask_stride=0, stream=None):
         self._check(self._L.mst_stage_canvas(self._h, pano_ptr, pano_stride, mask_ptr, mask_stride, stream))
 
+    def payload_bytes(self, camera):
+        """Bytes of the camera's hand-off payload (launched tile interiors of every level, packed)."""
+        b = C.c_size_t()
+        self._check(self._L.mst_payload_bytes(self._h, camera, C.byref(b)))
+        return b.value
+
+    def payload_pack(self, camera, buf_ptr, stream=None):
+        self._check(self._L.mst_payload_pack(self._h, camera, buf_ptr, stream))
+
+    def payload_unpack(self, camera, buf_ptr, stream=None):
+        self._check(self._L.mst_payload_unpack(self._h, camera, buf_ptr, stream))
+
+    def select_stage_set(self, s):
+        self._check(self._L.mst_stage_select_set(self._h, s))
+
     def pyramid_buffer(self, camera):
         """-> (device pointer, bytes) of the camera's contiguous Gaussian pyramid block."""
         p, b = C.c_void_p(), C.c_size_t()

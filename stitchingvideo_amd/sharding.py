@@ -96,77 +96,123 @@ def pyramid_tensor(engine, camera, device):
     return torch.as_tensor(_DevicePtr(ptr, nbytes), device=device)
 
 
+def exchange_to_root(send, recv, owners, root, rank, tag_base=0):
+    """One exchange step: every non-root owner sends its cameras' payload tensors to `root`.
+
+    send: {camera: tensor} for the cameras this rank owns (ignored on root); recv: {camera: tensor} landing
+    buffers on root for the cameras it does not own.  All transfers of the step go out as ONE
+    batch_isend_irecv (ncclGroupStart/End on RCCL: every peer streams over its own xGMI link to the root at the
+    same time).  Returns the list of work handles (empty when there is nothing to move)."""
+    ops = []
+    if rank == root:
+        for c, owner in enumerate(owners):
+            if owner != root:
+                ops.append(dist.P2POp(dist.irecv, recv[c], owner, tag=tag_base + c))
+    else:
+        for c in sorted(send):
+            ops.append(dist.P2POp(dist.isend, send[c], root, tag=tag_base + c))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
 class ShardedStitcher:
-    """Camera streams sharded one-per-rank, one gather per frame, final blend on `root`.
+    """Camera streams sharded one-per-rank, one exchange per frame, final blend on `root`.
 
-    Every rank creates the same PanoramaEngine and publishes the same calibration.  Per frame:
-      1. each rank runs the per-camera kernels for the cameras it owns (mst_stage_cameras);
-      2. the owners send those cameras' Gaussian pyramid blocks straight into the root engine's buffers
-         (grouped point-to-point over RCCL: every peer has its own xGMI link to the root; no all-reduce --
-         the payload is ragged and must arrive bit-exact);
-      3. the root runs the canvas kernel (mst_stage_canvas).
+    Every rank creates the same PanoramaEngine (max_batch >= 2 for pipelining) and publishes the same calibration.
+    Per frame t, on pyramid set t % 2:
+      1. each rank runs the per-camera kernels for the cameras it owns (mst_stage_cameras) and packs their
+         hand-off payload -- the interiors of the launched tiles of every level, a few MB per camera whatever the
+         size of its pyramid block (mst_payload_pack);
+      2. the owners send the packed payloads to the root (grouped point-to-point over RCCL: every peer has its
+         own xGMI link to the root; no all-reduce -- the payload is ragged and must arrive bit-exact);
+      3. the root unpacks them into its own pyramids (mst_payload_unpack) and runs the canvas kernel.
+    compose() does 1-3 for one frame.  submit() / finish() split it so that the exchange of frame t is in flight
+    while the per-camera stage of frame t+1 runs (two pyramid sets, two sets of payload buffers).
 
-    The pyramid buffers belong to a calibration state and are freed when it is retired, so the zero-copy views
-    are tied to the calibration generation: compose() latches the calibration (engine.acquire()) and rebuilds
-    the views whenever the generation moved.  Every rank must publish the same calibrations in the same order.
+    Payload sizes and layout depend on the calibration only: compose() latches the calibration
+    (engine.acquire()) and re-sizes its buffers whenever the generation moved.  Every rank must publish the same
+    calibrations in the same order.
     """
 
-    def __init__(self, engine, rank, world, root=0, device=None):
+    def __init__(self, engine, rank, world, root=0, device=None, sets=2):
         self.engine, self.rank, self.world, self.root = engine, rank, world, root
         self.device = device
         n = engine.num_cameras
         self.owners = [owner_of_stream(c, world) for c in range(n)]
         self.mine = streams_of_rank(rank, world, n)
+        self.sets = sets
         self.generation = None
-        self.views = {}
+        self.bufs = []               # per set: {camera: uint8 tensor}: send buffers (owners) / landing buffers (root)
+        self.pending = {}            # set -> (work handles, pano args)
 
     def refresh(self):
-        """Latch the newest calibration; (re)build the views of its pyramid buffers if it changed."""
+        """Latch the newest calibration; (re)allocate the payload buffers if it changed."""
         _, gen = self.engine.acquire()
         if gen != self.generation:
-            cams = range(self.engine.num_cameras) if self.rank == self.root else self.mine
-            self.views = {c: pyramid_tensor(self.engine, c, self.device) for c in cams}
+            n = self.engine.num_cameras
+            # the root needs a landing buffer for every camera it does not own, an owner a send buffer for its own
+            cams = [c for c in range(n) if self.owners[c] != self.root] if self.rank == self.root else self.mine
+            self.bufs = [{c: torch.empty(self.engine.payload_bytes(c), dtype=torch.uint8, device=self.device) for c in cams}
+                         for _ in range(self.sets)]
             self.generation = gen
+            self.pending = {}
         return gen
 
     def payload_bytes(self):
-        """Bytes the root receives per frame (0 on one rank); valid after the first refresh()/compose()."""
+        """Bytes the root receives per frame (what this rank sends, elsewhere); 0 on one rank."""
         if self.generation is None:
             self.refresh()
-        if self.rank != self.root:
-            return sum(int(self.views[c].numel()) for c in self.mine)
-        return sum(int(self.views[c].numel()) for c, o in enumerate(self.owners) if o != self.root)
+        return sum(int(t.numel()) for t in self.bufs[0].values()) if self.bufs else 0
 
-    def compose(self, frame_ptrs, frame_strides, pano_ptr=None, pano_stride=0, stream=None):
-        """frame_ptrs / frame_strides: {camera: value} for the cameras this rank owns.
-
-        The kernels and the point-to-point transfers must share one stream order: RCCL orders its operations
-        against torch's CURRENT stream only, so `stream` defaults to exactly that (never the engine's private
-        stream) and a caller that passes one must have made it torch's current stream."""
+    def submit(self, t, frame_ptrs, frame_strides, stream=None):
+        """Frame t, steps 1-2: per-camera stage + pack on this rank, start the exchange.  The kernels and the
+        point-to-point transfers must share one stream order: RCCL orders its operations against torch's CURRENT
+        stream, so `stream` defaults to exactly that and a caller that passes one must have made it current."""
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.refresh()
+        if self.generation is None:
+            self.refresh()
+        k = t % self.sets
+        self.engine.select_stage_set(k)
         self.engine.stage_cameras(self.mine, frame_ptrs, frame_strides, stream=stream)
+        works = []
         if self.world > 1:
-            ops = []
-            if self.rank == self.root:
+            if self.rank != self.root:
+                for c in self.mine:
+                    self.engine.payload_pack(c, self.bufs[k][c].data_ptr(), stream=stream)
+            works = exchange_to_root(self.bufs[k], self.bufs[k], self.owners, self.root, self.rank, tag_base=64 * k)
+        self.pending[k] = works
+
+    def finish(self, t, pano_ptr=None, pano_stride=0, stream=None):
+        """Frame t, step 3: wait for its exchange, unpack, blend (root only)."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        k = t % self.sets
+        for w in self.pending.pop(k, []):
+            w.wait()
+        if self.rank == self.root:
+            self.engine.select_stage_set(k)
+            if self.world > 1:
                 for c, owner in enumerate(self.owners):
                     if owner != self.root:
-                        ops.append(dist.P2POp(dist.irecv, self.views[c], owner, tag=c))
-            else:
-                for c in self.mine:
-                    ops.append(dist.P2POp(dist.isend, self.views[c], self.root, tag=c))
-            if ops:
-                for r in dist.batch_isend_irecv(ops):      # one ncclGroupStart/End around all transfers of the frame
-                    r.wait()
-        if self.rank == self.root:
+                        self.engine.payload_unpack(c, self.bufs[k][c].data_ptr(), stream=stream)
             self.engine.stage_canvas(pano_ptr, pano_stride, stream=stream)
+
+    def compose(self, frame_ptrs, frame_strides, pano_ptr=None, pano_stride=0, stream=None):
+        """One frame, unpipelined.  frame_ptrs / frame_strides: {camera: value} for the cameras this rank owns."""
+        self.refresh()
+        self.submit(0, frame_ptrs, frame_strides, stream=stream)
+        self.finish(0, pano_ptr, pano_stride, stream=stream)
 
 
 def copy_payload(src_engine, dst_engine, cameras, device, stream=None):
-    """One-GPU stand-in for the exchange step: copy the hand-off payload of `cameras` from one engine into
-    another (tests emulate two ranks with two engines on one device)."""
+    """One-GPU stand-in for the exchange step: pack the hand-off payload of `cameras` on one engine, unpack it on
+    another (tests emulate two ranks with two engines on one device).  Returns the bytes moved."""
+    moved = 0
     for c in cameras:
-        src, dst = pyramid_tensor(src_engine, c, device), pyramid_tensor(dst_engine, c, device)
-        assert src.numel() == dst.numel() and src.numel() > 0
-        dst.copy_(src)
+        nbytes = src_engine.payload_bytes(c)
+        assert nbytes == dst_engine.payload_bytes(c) and nbytes > 0
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        src_engine.payload_pack(c, buf.data_ptr(), stream=stream)
+        dst_engine.payload_unpack(c, buf.data_ptr(), stream=stream)
+        moved += nbytes
+    return moved

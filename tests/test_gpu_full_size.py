@@ -64,9 +64,15 @@ def test_full_size_c4_camera_sharded_two_engines():
     with torch.cuda.stream(stream):
         e0.stage_cameras(mine0, {i: ptrs[i] for i in mine0}, {i: strides[i] for i in mine0}, stream=stream.cuda_stream)
         e1.stage_cameras(mine1, {i: ptrs[i] for i in mine1}, {i: strides[i] for i in mine1}, stream=stream.cuda_stream)
-        sh.copy_payload(e1, e0, mine1, dev, stream=stream.cuda_stream)
+        moved = sh.copy_payload(e1, e0, mine1, dev, stream=stream.cuda_stream)
         e0.stage_canvas(pano.data_ptr(), pano.stride(0), stream=stream.cuda_stream)
     stream.synchronize()
+    # the hand-off is the launched tile interiors only: every camera -- the wrap-around one (roi 11308 x 1050, pyramid
+    # block 64 MB) included -- ships a payload of a 1080p camera's size
+    sizes = [e0.payload_bytes(c) for c in range(n)]
+    blocks = [e0.pyramid_buffer(c)[1] for c in range(n)]
+    assert max(blocks) > 60e6 and max(sizes) <= 20e6, (sizes, blocks)
+    assert moved == sum(sizes[c] for c in mine1)
     rect, opano, omask = H.oracle_compose(rig, frames, threads=THREADS)
     assert e0.canvas() == rect
     assert np.array_equal(pano.cpu().numpy(), opano), H.diff_report(pano.cpu().numpy(), opano)

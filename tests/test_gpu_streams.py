@@ -79,10 +79,9 @@ def test_camera_sharded_stages_match_oracle():
     with torch.cuda.stream(stream):
         e0.stage_cameras(mine0, {i: ptrs[i] for i in mine0}, {i: strides[i] for i in mine0}, stream=stream.cuda_stream)
         e1.stage_cameras(mine1, {i: ptrs[i] for i in mine1}, {i: strides[i] for i in mine1}, stream=stream.cuda_stream)
-        for c in mine1:                                      # the gather
-            src, dst = sh.pyramid_tensor(e1, c, dev), sh.pyramid_tensor(e0, c, dev)
-            assert src.numel() == dst.numel() and src.numel() > 0
-            dst.copy_(src)
+        moved = sh.copy_payload(e1, e0, mine1, dev, stream=stream.cuda_stream)     # the exchange: packed tile interiors
+        whole = sum(e1.pyramid_buffer(c)[1] for c in mine1)
+        assert 0 < moved <= whole
         _, _, cw, ch = e0.canvas()
         pano = torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev)
         e0.stage_canvas(pano.data_ptr(), pano.stride(0), stream=stream.cuda_stream)
@@ -97,6 +96,36 @@ def test_camera_sharded_stages_match_oracle():
     torch.cuda.synchronize()
     assert np.array_equal(pano2.cpu().numpy(), opano)
     e0.close(); e1.close()
+
+
+def test_camera_sharded_pipeline_alternates_pyramid_sets():
+    """submit(t) / finish(t) of ShardedStitcher on one rank: frame t+1's per-camera stage is issued before frame t's
+    canvas stage, on the other pyramid set -- the order the multi-rank pipeline uses to overlap the exchange."""
+    import torch
+    from stitchingvideo_amd import sharding as sh
+    rig = rigmod.build_rig(rigmod.scaled_config("C4", 8))
+    dev = torch.device("cuda", 0)
+    eng = H.make_engine(rig, max_batch=2)
+    n = len(rig["cameras"])
+    host = [rigmod.frames_for(rig, i) for i in range(4)]
+    dfr = [[torch.from_numpy(f).to(dev) for f in fr] for fr in host]
+    _, _, cw, ch = eng.canvas()
+    panos = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(4)]
+    st = sh.ShardedStitcher(eng, 0, 1, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        def args(t):
+            return ({c: dfr[t][c].data_ptr() for c in range(n)}, {c: dfr[t][c].stride(0) for c in range(n)})
+        st.submit(0, *args(0))
+        for t in range(1, 4):
+            st.submit(t, *args(t))                       # per-camera stage of t (other set) ...
+            st.finish(t - 1, panos[t - 1].data_ptr(), panos[t - 1].stride(0))     # ... then the canvas stage of t - 1
+        st.finish(3, panos[3].data_ptr(), panos[3].stride(0))
+    stream.synchronize()
+    for t in range(4):
+        _, opano, _ = H.oracle_compose(rig, host[t])
+        assert np.array_equal(panos[t].cpu().numpy(), opano), "frame %d" % t
+    eng.close()
 
 
 @pytest.mark.parametrize("blend", ["multiband", "feather", "no"])

@@ -70,3 +70,70 @@ def test_gloo_world2_reduction_and_gather():
     for rank, mx, ok in res:
         assert mx == [2.0, 10.0], mx
         assert ok, rank
+
+
+# ---- an engine-shaped exchange on CPU: ragged per-camera payloads, blended panorama checked against the oracle ----
+def _payload_worker(rank, world, port, q):
+    """Each rank warps + gain-compensates the cameras it owns (oracle arithmetic; on the GPU box this is
+    mst_stage_cameras + mst_payload_pack), the owners send their ragged payloads to rank 0 through the same
+    exchange_to_root() the GPU path uses (grouped point-to-point), and rank 0 feeds the blender and must land on the
+    panorama the single-process oracle produces."""
+    import sys
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import helpers as H
+        import oracle_lib as O
+        from stitchingvideo_amd import rig as rigmod
+        rig = rigmod.build_rig(rigmod.scaled_config("C4", 12))         # 8 cameras, one of them wrapping the canvas
+        frames = rigmod.frames_for(rig, 3)
+        n = len(frames)
+        owners = [sh.owner_of_stream(c, world) for c in range(n)]
+        mine = sh.streams_of_rank(rank, world, n)
+        kind = H.WARP_O[rig["warp"]]
+        # static per calibration, identical on every rank: payload shapes = warped roi sizes (ragged)
+        shapes = {c: (rig["sizes"][c][1], rig["sizes"][c][0], 3) for c in range(n)}
+        send = {}
+        for c in mine:
+            cam = rig["cameras"][c]
+            _, warped = O.warp(kind, rig["scale"], cam["K"], cam["R"], frames[c], O.INTER_LINEAR, O.BORDER_REFLECT)
+            send[c] = torch.from_numpy(O.blocks_gain_apply(warped, cam["gain_map"]).astype(np.int16))
+        recv = {c: torch.empty(shapes[c], dtype=torch.int16) for c in range(n) if owners[c] != 0} if rank == 0 else {}
+        for w in sh.exchange_to_root(send, recv, owners, 0, rank):
+            w.wait()
+        ok = True
+        if rank == 0:
+            tiles = {c: (send[c] if owners[c] == 0 else recv[c]).numpy() for c in range(n)}
+            b = O.Blender(O.BLEND_MULTI_BAND, 4)
+            b.prepare(rig["corners"], rig["sizes"])
+            for c in range(n):
+                b.feed(tiles[c], rig["cameras"][c]["mask"], rig["corners"][c])
+            _, pano16, pmask = b.blend()
+            pano = np.clip(pano16, 0, 255).astype(np.uint8)
+            rect, opano, omask = H.oracle_compose(rig, frames, num_bands=4)
+            ok = bool(np.array_equal(pano, opano) and np.array_equal(pmask, omask))
+            ok = ok and any(shapes[c] != shapes[0] for c in range(n))                 # the payload really is ragged
+        dist.barrier()
+        q.put((rank, ok))
+    except Exception as e:          # noqa: BLE001  -- report instead of leaving the parent to time out
+        q.put((rank, "%s: %s" % (type(e).__name__, e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_ragged_payload_blends_to_the_oracle_panorama():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_payload_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok is True for _, ok in res), res
+    assert all(p.exitcode == 0 for p in procs)
