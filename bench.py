@@ -336,6 +336,13 @@ def main():
                                    "frames_per_s": round(1000.0 / ms1, 2),
                                    "roofline_frac": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
+    # ---- host buffers: the PCIe-inclusive rate (never `value`): serial mst_compose vs the three-stage pipeline ----
+    if rank == 0 and world == 1 and not by_camera and not args.no_latency_leg and blend == "multiband":
+        try:
+            out["host_buffers"] = host_buffer_leg(eng, host_sets, cw, ch)
+        except Exception as e:          # noqa: BLE001
+            out["host_buffers"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- N > 1: the north-star split measured beside the headline (C4: 8 cameras, camera i on rank i % N) ----
     if (world > 1 or args.camera_leg) and not by_camera and not args.no_camera_leg:
         def give_up():          # every rank: a hung exchange must not take the headline (or the launcher) with it
@@ -363,6 +370,47 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_buffer_leg(eng, host_sets, cw, ch):
+    """Frames in host memory, panorama back to host memory (what the VC++ host hands over: cv::Mat data).
+    serial: mst_compose per frame, pageable numpy buffers (H2D -> kernels -> D2H in series).
+    pipeline: mst_pipeline_submit / wait, page-locked buffers, H2D(t+1) || kernels(t) || D2H(t-1)."""
+    import numpy as np
+    import stitchingvideo_amd as S
+    n_ser = 30
+    t0 = time.perf_counter()
+    for i in range(n_ser):
+        eng.compose(host_sets[i % len(host_sets)], want_mask=False)
+    serial = (time.perf_counter() - t0) / n_ser
+    pinned = []
+    for fr in host_sets:
+        row = []
+        for f in fr:
+            pa = S.PinnedArray(f.shape)
+            pa.array[...] = f
+            row.append(pa)
+        pinned.append(row)
+    panos = [S.PinnedArray((ch, cw, 3)) for _ in range(3)]
+    n_pipe = 300
+
+    def loop(n):
+        for t in range(n):
+            if t >= 3:
+                eng.pipeline_wait()
+            eng.pipeline_submit([p.array for p in pinned[t % len(pinned)]], panos[t % 3].array)
+        for _ in range(min(n, 3)):
+            eng.pipeline_wait()
+    loop(12)
+    t0 = time.perf_counter()
+    loop(n_pipe)
+    piped = (time.perf_counter() - t0) / n_pipe
+    frame_mb = sum(f.nbytes for f in host_sets[0]) / 1e6
+    return {"serial_mst_compose_fps": round(1.0 / serial, 1), "serial_ms_per_frame": round(serial * 1e3, 3),
+            "pipeline_fps": round(1.0 / piped, 1), "pipeline_ms_per_frame": round(piped * 1e3, 3),
+            "mb_in_per_frame": round(frame_mb, 1), "mb_out_per_frame": round(ch * cw * 3 / 1e6, 1),
+            "note": "PCIe-inclusive; serial = pageable buffers through mst_compose, pipeline = page-locked buffers "
+                    "through mst_pipeline_submit/wait (3 slots)"}
 
 
 def camera_sharded_leg(args_ns, rank, world, local_rank, dev, stream):

@@ -225,6 +225,24 @@ int  mst_compose_device(mst_engine *e, const void *const *d_frames, const size_t
 int  mst_compose_device_batch(mst_engine *e, int count, const void *const *d_frames, const size_t *frame_strides,
                               void *const *d_panos, size_t pano_stride, void *const *d_pano_masks,
                               size_t pano_mask_stride, void *stream);
+/* The host-buffer frame loop as a three-stage pipeline: while the kernels of frame t run, frame t+1 is copied in and
+ * the panorama of frame t-1 is copied out (three streams, a ring of MST_PIPELINE_DEPTH device frame sets).  The
+ * reference's loop is strictly serial (GetMemData -> remap ... -> imshow per frame, DRV:736-763); with host
+ * buffers mst_compose is bound by its two PCIe copies in series, the pipeline by the larger of them.
+ *   mst_pipeline_submit  queue one frame set (same arguments as mst_compose, no mask plane); returns at once.
+ *                        At most MST_PIPELINE_DEPTH frames may be in flight (MST_ERR_INVALID_ARG beyond that).
+ *   mst_pipeline_wait    block until the OLDEST submitted frame's panorama is complete in the buffer it was
+ *                        submitted with; returns that buffer and the canvas rectangle it was composed for.
+ * The frames and the panorama buffer must stay untouched from submit to the matching wait, and should be
+ * page-locked: allocate them with mst_host_alloc (or hipHostRegister your own, as mi355_ingest does for its shared
+ * memory segment) -- with pageable memory the copies serialise and nothing overlaps.  Frame thread only. */
+#define MST_PIPELINE_DEPTH 3
+void *mst_host_alloc(size_t bytes);                 /* page-locked host memory; NULL on failure */
+void  mst_host_free(void *p);
+int  mst_pipeline_submit(mst_engine *e, const uint8_t *const *frames, const size_t *frame_strides,
+                         uint8_t *pano, size_t pano_stride);
+int  mst_pipeline_wait(mst_engine *e, uint8_t **pano, mst_rect *canvas);
+int  mst_pipeline_pending(const mst_engine *e);     /* frames submitted and not yet waited for */
 int  mst_synchronize(mst_engine *e);
 /* One frame of mst_compose_device with a HIP event recorded on `stream` between consecutive
  * kernel launches: the counterpart of the reference's getTickCount() brackets

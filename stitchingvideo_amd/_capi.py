@@ -43,6 +43,7 @@ EXPORTS = [
     "mst_warp_kind_from_name", "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_acquire_calibration", "mst_canvas", "mst_camera_roi", "mst_camera_mask",
     "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_device_batch", "mst_compose_profile",
     "mst_compose_profile_batch", "mst_synchronize", "mst_warp_roi",
+    "mst_host_alloc", "mst_host_free", "mst_pipeline_submit", "mst_pipeline_wait", "mst_pipeline_pending",
     "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
     "mst_payload_bytes", "mst_payload_pack", "mst_payload_unpack", "mst_stage_select_set",
     "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
@@ -146,6 +147,16 @@ def load():
     L.mst_init_undistort_rectify_map.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
     L.mst_remap_fixed.restype = C.c_int
     L.mst_remap_fixed.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_size_t, vp, vp, vp, C.c_size_t]
+    L.mst_host_alloc.restype = vp
+    L.mst_host_alloc.argtypes = [C.c_size_t]
+    L.mst_host_free.restype = None
+    L.mst_host_free.argtypes = [vp]
+    L.mst_pipeline_submit.restype = C.c_int
+    L.mst_pipeline_submit.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), vp, C.c_size_t]
+    L.mst_pipeline_wait.restype = C.c_int
+    L.mst_pipeline_wait.argtypes = [vp, C.POINTER(vp), C.POINTER(Rect)]
+    L.mst_pipeline_pending.restype = C.c_int
+    L.mst_pipeline_pending.argtypes = [vp]
     L.mst_synchronize.restype = C.c_int
     L.mst_synchronize.argtypes = [vp]
     L.mst_stage_cameras.restype = C.c_int

@@ -308,6 +308,42 @@ int mst_stage_select_set(mst_engine* e, int set)
     return guarded(e, [&] { e->impl.select_stage_set(set); });
 }
 
+void* mst_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        g_last_error = "hipHostMalloc failed (no device, or out of page-locked memory)";
+        return nullptr;
+    }
+    return p;
+}
+
+void mst_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+int mst_pipeline_submit(mst_engine* e, const uint8_t* const* frames, const size_t* frame_strides, uint8_t* pano,
+                        size_t pano_stride)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.pipeline_submit(frames, frame_strides, pano, pano_stride); });
+}
+
+int mst_pipeline_wait(mst_engine* e, uint8_t** pano, mst_rect* canvas)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] {
+        uint8_t* p = e->impl.pipeline_wait(canvas);
+        if (pano) *pano = p;
+    });
+}
+
+int mst_pipeline_pending(const mst_engine* e)
+{
+    return e ? e->impl.pipeline_pending() : MST_ERR_INVALID_ARG;
+}
+
 int mst_synchronize(mst_engine* e)
 {
     if (!e) return MST_ERR_INVALID_ARG;

@@ -251,6 +251,15 @@ Engine::~Engine()
     if (d_pano_) (void)hipFree(d_pano_);
     if (d_mask_) (void)hipFree(d_mask_);
     if (cls_host_) (void)hipHostFree(cls_host_);
+    for (PipeSlot& ps : pipe_) {
+        for (uint8_t* p : ps.d_frames) if (p) (void)hipFree(p);
+        if (ps.d_pano) (void)hipFree(ps.d_pano);
+        if (ps.h2d_done) (void)hipEventDestroy(ps.h2d_done);
+        if (ps.compute_done) (void)hipEventDestroy(ps.compute_done);
+        if (ps.d2h_done) (void)hipEventDestroy(ps.d2h_done);
+    }
+    if (pipe_in_) (void)hipStreamDestroy(pipe_in_);
+    if (pipe_out_) (void)hipStreamDestroy(pipe_out_);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (calib_stream_) (void)hipStreamDestroy(calib_stream_);
     if (front_stream_) (void)hipStreamDestroy(front_stream_);
@@ -935,6 +944,86 @@ void Engine::compose_host(const uint8_t* const* frames, const size_t* strides, u
     copy_rows(pano, pano_stride, d_pano_, prow, prow, st->out_h, hipMemcpyDeviceToHost, stream_);
     if (pano_mask) copy_rows(pano_mask, mask_stride, d_mask_, mrow, mrow, st->out_h, hipMemcpyDeviceToHost, stream_);
     check_hip(hipStreamSynchronize(stream_), "hipStreamSynchronize(compose)");
+}
+
+void Engine::pipeline_submit(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride)
+{
+    select_device(cfg_.device);
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_pipeline_submit before a successful mst_update"};
+    if (!frames || !strides || !pano) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama pointer"};
+    if (pipeline_pending() >= kPipeDepth) throw Error{MST_ERR_INVALID_ARG, "pipeline full: call mst_pipeline_wait first"};
+    const size_t prow = static_cast<size_t>(st->out_w) * 3, pbytes = prow * st->out_h;
+    if (pano_stride < prow) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
+    if (!pipe_in_) {
+        check_hip(hipStreamCreateWithFlags(&pipe_in_, hipStreamNonBlocking), "hipStreamCreate");
+        check_hip(hipStreamCreateWithFlags(&pipe_out_, hipStreamNonBlocking), "hipStreamCreate");
+        for (PipeSlot& ps : pipe_) {
+            check_hip(hipEventCreateWithFlags(&ps.h2d_done, hipEventDisableTiming), "hipEventCreate");
+            check_hip(hipEventCreateWithFlags(&ps.compute_done, hipEventDisableTiming), "hipEventCreate");
+            check_hip(hipEventCreateWithFlags(&ps.d2h_done, hipEventDisableTiming), "hipEventCreate");
+        }
+    }
+    PipeSlot& ps = pipe_[pipe_submitted_ % kPipeDepth];       // free: its previous frame has been waited for
+    const int n = st->n;
+    if (ps.d_frames.size() != static_cast<size_t>(n)) { ps.d_frames.assign(n, nullptr); ps.d_frame_bytes.assign(n, 0); }
+    std::vector<const void*> dptr(n);
+    std::vector<size_t> dstride(n);
+    // stage 1 (copy-in stream): the slot's device frames were last read by kernels whose completion the matching
+    // wait() has already observed (d2h_done follows compute_done), so the copies may start right away
+    for (int i = 0; i < n; ++i) {
+        const int w = st->cams[i].src_w, h = st->cams[i].src_h;
+        if (!frames[i] || strides[i] < static_cast<size_t>(w) * 3) throw Error{MST_ERR_INVALID_ARG, "bad frame"};
+        const size_t row = static_cast<size_t>(w) * 3, bytes = row * h;
+        if (ps.d_frame_bytes[i] < bytes) {
+            if (ps.d_frames[i]) (void)hipFree(ps.d_frames[i]);
+            ps.d_frames[i] = nullptr;
+            check_hip(hipMalloc(reinterpret_cast<void**>(&ps.d_frames[i]), bytes + 16), "hipMalloc(frame)");
+            ps.d_frame_bytes[i] = bytes;
+        }
+        copy_rows(ps.d_frames[i], row, frames[i], strides[i], row, h, hipMemcpyHostToDevice, pipe_in_);
+        dptr[i] = ps.d_frames[i];
+        dstride[i] = row;
+    }
+    check_hip(hipEventRecord(ps.h2d_done, pipe_in_), "hipEventRecord");
+    if (ps.d_pano_bytes < pbytes) {
+        if (ps.d_pano) (void)hipFree(ps.d_pano);
+        ps.d_pano = nullptr;
+        check_hip(hipMalloc(reinterpret_cast<void**>(&ps.d_pano), pbytes), "hipMalloc(pano)");
+        ps.d_pano_bytes = pbytes;
+    }
+    // stage 2 (compute stream): kernels of this frame behind its copies
+    check_hip(hipStreamWaitEvent(stream_, ps.h2d_done, 0), "hipStreamWaitEvent");
+    in_host_compose_ = true;
+    try {
+        void* panos[1] = {ps.d_pano};
+        compose_batch_on(st, 1, dptr.data(), dstride.data(), panos, prow, nullptr, 0, stream_, nullptr);
+    } catch (...) {
+        in_host_compose_ = false;
+        throw;
+    }
+    in_host_compose_ = false;
+    check_hip(hipEventRecord(ps.compute_done, stream_), "hipEventRecord");
+    // stage 3 (copy-out stream): the panorama back to the caller's buffer
+    check_hip(hipStreamWaitEvent(pipe_out_, ps.compute_done, 0), "hipStreamWaitEvent");
+    copy_rows(pano, pano_stride, ps.d_pano, prow, prow, st->out_h, hipMemcpyDeviceToHost, pipe_out_);
+    check_hip(hipEventRecord(ps.d2h_done, pipe_out_), "hipEventRecord");
+    ps.host_pano = pano;
+    ps.canvas = mst_rect{st->canvas.x + st->crop_x, st->canvas.y + st->crop_y, st->out_w, st->out_h};
+    ps.busy = true;
+    ++pipe_submitted_;
+}
+
+uint8_t* Engine::pipeline_wait(mst_rect* canvas)
+{
+    select_device(cfg_.device);
+    if (pipeline_pending() <= 0) throw Error{MST_ERR_INVALID_ARG, "mst_pipeline_wait without a submitted frame"};
+    PipeSlot& ps = pipe_[pipe_completed_ % kPipeDepth];
+    check_hip(hipEventSynchronize(ps.d2h_done), "hipEventSynchronize(pipeline)");
+    ps.busy = false;
+    ++pipe_completed_;
+    if (canvas) *canvas = ps.canvas;
+    return ps.host_pano;
 }
 
 void Engine::debug_read(int what, int camera, int level, void* buf, size_t buf_bytes, int* w, int* h)

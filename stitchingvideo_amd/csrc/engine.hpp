@@ -142,6 +142,16 @@ public:
     void payload_copy(int camera, void* d_buf, bool pack, hipStream_t stream);
     void select_stage_set(int set);                  // which pyramid set the mst_stage_* / mst_payload_* calls use
     void camera_mask(int camera, uint8_t* mask, size_t stride);
+    // Host-buffer frame loop as a three-stage pipeline: H2D of frame t+1, kernels of frame t and D2H
+    // of frame t-1 run concurrently on three streams over a ring of kPipeDepth device frame sets / panoramas.
+    // submit() returns at once (it blocks only while the ring is full); wait() blocks until the oldest submitted
+    // frame's panorama is complete in its host buffer and returns that buffer.  The host buffers should be
+    // page-locked (host_alloc) -- pageable memory works but serialises the copies -- and must stay untouched between
+    // submit and the matching wait.
+    static constexpr int kPipeDepth = 3;
+    void pipeline_submit(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride);
+    uint8_t* pipeline_wait(mst_rect* canvas);
+    int pipeline_pending() const { return pipe_submitted_ - pipe_completed_; }
     void synchronize();
     // The calibration the next compose call will use: the newest published one, or -- once the frame thread has
     // called acquire() -- the one it latched there (the reference's `if (Upflag) UpdateMat()`, DRV:835-836).
@@ -184,6 +194,19 @@ private:
     std::vector<size_t> d_frame_bytes_;
     uint8_t* d_pano_ = nullptr; size_t d_pano_bytes_ = 0;
     uint8_t* d_mask_ = nullptr; size_t d_mask_bytes_ = 0;
+    // pipeline_submit / pipeline_wait state (frame thread only)
+    struct PipeSlot {
+        std::vector<uint8_t*> d_frames;
+        std::vector<size_t> d_frame_bytes;
+        uint8_t* d_pano = nullptr; size_t d_pano_bytes = 0;
+        hipEvent_t h2d_done = nullptr, compute_done = nullptr, d2h_done = nullptr;
+        uint8_t* host_pano = nullptr;
+        mst_rect canvas{};
+        bool busy = false;
+    };
+    PipeSlot pipe_[kPipeDepth];
+    hipStream_t pipe_in_ = nullptr, pipe_out_ = nullptr;
+    long pipe_submitted_ = 0, pipe_completed_ = 0;
     // mst_update: page-locked landing zone of the weight-class bytes (calibration thread only)
     uint8_t* cls_host_ = nullptr; size_t cls_host_bytes_ = 0;
 };

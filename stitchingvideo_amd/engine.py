@@ -176,6 +176,23 @@ def remap_fixed(image, map1, map2, device=0):
     return out
 
 
+class PinnedArray:
+    """A numpy view of page-locked host memory from mst_host_alloc (freed with the object)."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._L = capi.load()
+        self._p = self._L.mst_host_alloc(self.nbytes)
+        if not self._p:
+            raise capi.StitchError(capi.ERR_OUT_OF_MEMORY, "mst_host_alloc failed")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self._p)).view(dtype).reshape(shape)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self._L.mst_host_free(self._p)
+            self._p = None
+
+
 def synth_frame(camera, frame_index, width, height):
     """Synthetic BGR frame of SURVEY.md section 8d (texture + PCG32 noise)."""
     out = np.empty((height, width, 3), np.uint8)
@@ -314,6 +331,20 @@ class PanoramaEngine:
         self._check(self._L.mst_compose(self._h, ptrs, strides, pano.ctypes.data, pano.strides[0],
                                         mask.ctypes.data if want_mask else None, w))
         return pano, mask
+
+    def pipeline_submit(self, frames, pano):
+        """Queue one frame set of the three-stage host pipeline (frames / pano: uint8 arrays, ideally PinnedArray
+        views); returns at once.  Keep the arrays alive and untouched until the matching pipeline_wait()."""
+        n = len(frames)
+        ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        strides = (C.c_size_t * n)(*[f.strides[0] for f in frames])
+        self._check(self._L.mst_pipeline_submit(self._h, ptrs, strides, pano.ctypes.data, pano.strides[0]))
+
+    def pipeline_wait(self):
+        """Block until the oldest submitted frame is done -> (address of its panorama buffer, canvas rect)."""
+        p, r = C.c_void_p(), capi.Rect()
+        self._check(self._L.mst_pipeline_wait(self._h, C.byref(p), C.byref(r)))
+        return p.value, r.tuple()
 
     def compose_device(self, frame_ptrs, frame_strides, pano_ptr, pano_stride, mask_ptr=None, mask_stride=0,
                        stream=None):

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import helpers as H
+import stitchingvideo_amd as S
 from stitchingvideo_amd import rig as rigmod
 
 pytestmark = pytest.mark.gpu
@@ -312,6 +313,64 @@ def test_recalibration_that_changes_the_canvas_size_while_composing():
     pano, _ = eng.compose(host)
     assert np.array_equal(pano, pano_b) and eng.canvas() == rect_b
     eng.close()
+
+
+def test_host_pipeline_three_stage_overlap_matches_oracle():
+    """mst_pipeline_submit / mst_pipeline_wait: H2D of t+1, kernels of t, D2H of t-1 on three streams over a ring of three
+    slots, page-locked host buffers.  Panoramas come back in submission order, each equal to the oracle's; a
+    recalibration in the middle changes the canvas of the frames submitted after it and of no other."""
+    rig_a = rigmod.build_rig(rigmod.scaled_config("C3", 8))
+    cfg_b = rigmod.scaled_config("C3", 8)
+    cfg_b["focal"] *= 1.1
+    rig_b = rigmod.build_rig(cfg_b)
+    eng = H.make_engine(rig_a)
+    n_frames = 9
+    host = [rigmod.frames_for(rig_a, i) for i in range(n_frames)]
+    pinned_frames = []
+    for fr in host:
+        row = []
+        for f in fr:
+            pa = S.PinnedArray(f.shape)
+            pa.array[...] = f
+            row.append(pa)
+        pinned_frames.append(row)
+    ra = H.oracle_compose(rig_a, host[0])[0]
+    rb = H.oracle_compose(rig_b, host[0])[0]
+    big = (max(ra[3], rb[3]), max(ra[2], rb[2]), 3)
+    panos = [S.PinnedArray(big) for _ in range(3)]
+    results = []
+
+    def wait_one():
+        addr, rect = eng.pipeline_wait()
+        slot = [i for i, p in enumerate(panos) if p.array.ctypes.data == addr][0]
+        w, h = rect[2], rect[3]
+        flat = panos[slot].array.reshape(-1)[:h * w * 3].reshape(h, w, 3)
+        results.append((rect, flat.copy()))
+
+    import ctypes as C
+    with pytest.raises(capi_err()):
+        eng.pipeline_wait()                                   # nothing submitted
+    for t in range(n_frames):
+        if t == 5:
+            eng.update(rig_b["scale"], rig_b["cameras"])      # takes effect for frames submitted from now on
+        if t >= 3:
+            wait_one()                                        # ring of three: free the oldest slot first
+        (_, _, cw, ch), _ = eng.acquire()
+        pano = panos[t % 3].array.reshape(-1)[:ch * cw * 3].reshape(ch, cw, 3)
+        eng.pipeline_submit([p.array for p in pinned_frames[t]], pano)
+    while len(results) < n_frames:
+        wait_one()
+    for t, (rect, pano) in enumerate(results):
+        rig = rig_a if t < 5 else rig_b
+        orect, opano, _ = H.oracle_compose(rig, host[t])
+        assert rect == orect, t
+        assert np.array_equal(pano, opano), "frame %d" % t
+    eng.close()
+
+
+def capi_err():
+    from stitchingvideo_amd import _capi
+    return _capi.StitchError
 
 
 def test_profile_entry_points_report_every_launch():
