@@ -1119,9 +1119,39 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
 // 16-byte access even where the top level's width is odd (the pad column takes the pair's second pixel there)
 __host__ __device__ inline int region_pitch(const Region& r) { return (r.x1 - r.x0 + 1) & ~1; }
 
+// The regions of a canvas tile at every level, worked out once per block (lane l of the first wave derives level l)
+// and kept in LDS: the phases below used to re-derive them -- a scalar loop over the levels -- for every 64-quad
+// chunk and every collapse step, which made 29 % of this kernel's instructions scalar bookkeeping.  Row l:
+// x0, y0, x1, y1 of the region, and ceil(2^20 / quads per row) for the quad index -> (row, column) split.
+constexpr int kRegionRow = 8;
+__device__ __forceinline__ void fill_region_table(const BlendArgs& a, int tx, int ty, int* __restrict__ s_reg)
+{
+    const int l = static_cast<int>(threadIdx.x);
+    if (l < a.nlev) {
+        const Region r = blend_region(a, tx, ty, l);
+        const int qw = max(1, (r.x1 - r.x0 + 1) >> 1);
+        s_reg[l * kRegionRow + 0] = r.x0; s_reg[l * kRegionRow + 1] = r.y0;
+        s_reg[l * kRegionRow + 2] = r.x1; s_reg[l * kRegionRow + 3] = r.y1;
+        s_reg[l * kRegionRow + 4] = ((1 << 20) + qw - 1) / qw;
+    }
+}
+__device__ __forceinline__ Region table_region(const int* __restrict__ s_reg, int l)
+{
+    const int4 v = *reinterpret_cast<const int4*>(s_reg + l * kRegionRow);
+    Region r;
+    r.x0 = __builtin_amdgcn_readfirstlane(v.x); r.y0 = __builtin_amdgcn_readfirstlane(v.y);
+    r.x1 = __builtin_amdgcn_readfirstlane(v.z); r.y1 = __builtin_amdgcn_readfirstlane(v.w);
+    return r;
+}
+
 struct QuadIter {
     Region r;
     int rw, qw, nq, pitch;
+    uint32_t inv = 0;            // ceil(2^20 / qw) when known: q / qw == (q * inv) >> 20 for q < 4096, qw <= 64
+    __device__ __forceinline__ QuadIter(const int* __restrict__ s_reg, int l) : QuadIter(table_region(s_reg, l))
+    {
+        inv = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_reg[l * kRegionRow + 4]));
+    }
     __device__ __forceinline__ QuadIter(const Region& reg) : r(reg)
     {
         rw = r.x1 - r.x0;
@@ -1131,7 +1161,9 @@ struct QuadIter {
     }
     __device__ __forceinline__ void at(int q, int& x, int& y, bool valid[4]) const
     {
-        const int qy = q / qw, qx = q - __mul24(qy, qw);
+        // (the multiply form needs q < 4096 and qw <= 64: a 128 x 64 tile has 2048 quads in rows of 64 at most)
+        const int qy = (inv != 0 && C_TW <= 128 && C_TW * C_TH <= 4 * 4096) ? static_cast<int>((static_cast<uint32_t>(q) * inv) >> 20) : q / qw;
+        const int qx = q - __mul24(qy, qw);
         x = r.x0 + 2 * qx;
         y = r.y0 + 2 * qy;
 #pragma unroll
@@ -1157,9 +1189,9 @@ struct QuadIter {
 // phase 1: normalised band of one coarse level into its LDS region
 template <bool TOP, bool PURE, bool W16 = false>
 __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int l, int tx, int ty,
-                                           uint32_t cam_bits, uint2* __restrict__ lds)
+                                           uint32_t cam_bits, uint2* __restrict__ lds, const int* __restrict__ s_reg)
 {
-    const QuadIter it(blend_region(a, tx, ty, l));
+    const QuadIter it(s_reg, l);
     uint2* s_out = lds + a.lds_off[l];
     for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
         int x, y;
@@ -1189,8 +1221,8 @@ __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, con
 // cameras on its coarsest levels only): `owned_levels` (bit l) / `owner_bits` send those levels down the integer path.
 template <bool PURE, bool W16 = false>
 __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, const BlendArgs& a, int top, int tx, int ty,
-                                            uint32_t cam_bits, uint2* __restrict__ lds, uint32_t owned_levels = 0,
-                                            uint32_t owner_bits = 0)
+                                            uint32_t cam_bits, uint2* __restrict__ lds, const int* __restrict__ s_reg,
+                                            uint32_t owned_levels = 0, uint32_t owner_bits = 0)
 {
     constexpr int kWaves = C_THREADS / 64;
     const int lane = static_cast<int>(threadIdx.x & 63u);
@@ -1199,7 +1231,7 @@ __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, co
     int total = 0;
 #pragma unroll
     for (int k = 1; k < kMaxLevels; ++k) {
-        nch[k] = k <= top ? (QuadIter(blend_region(a, tx, ty, k)).nq + 63) >> 6 : 0;
+        nch[k] = k <= top ? (QuadIter(s_reg, k).nq + 63) >> 6 : 0;
         total += nch[k];
     }
     for (int chunk = wave; chunk < total; chunk += kWaves) {
@@ -1209,7 +1241,7 @@ __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, co
             if (l == 0 && chunk < acc + nch[k]) { l = k; first = acc; }
             acc += nch[k];
         }
-        const QuadIter it(blend_region(a, tx, ty, l));
+        const QuadIter it(s_reg, l);
         uint2* s_out = lds + a.lds_off[l];
         const int q = ((chunk - first) << 6) + lane;
         if (q >= it.nq) continue;
@@ -1243,10 +1275,11 @@ __device__ __forceinline__ void dump_level(const BlendArgs& a, int l, int px, in
 }
 
 // phase 2: restoreImageFromLaplacePyr inside LDS: level l <- saturate(pyrUp(level l+1) + level l)
-__device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx, int ty, uint2* __restrict__ lds)
+__device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx, int ty, uint2* __restrict__ lds,
+                                               const int* __restrict__ s_reg)
 {
-    const QuadIter it(blend_region(a, tx, ty, l));
-    const Region ur = blend_region(a, tx, ty, l + 1);
+    const QuadIter it(s_reg, l);
+    const Region ur = table_region(s_reg, l + 1);
     const uint2* s_up = lds + a.lds_off[l + 1];
     uint2* s_io = lds + a.lds_off[l];
     for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
@@ -1362,13 +1395,14 @@ __device__ __forceinline__ int pano_store_mode(const BlendArgs& a, const uint8_t
 // evaluated, and no validity predicate or per-quad index division is left.
 __device__ __forceinline__ void final_level_pure_full(const CamDesc* __restrict__ cams, const BlendArgs& a, int tx, int ty,
                                                       uint32_t cam_bits, const uint2* __restrict__ lds,
-                                                      uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask)
+                                                      uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask,
+                                                      const int* __restrict__ s_reg)
 {
     static_assert(C_TW == 128 && (C_TW / 2) * (C_TH / 2) % C_THREADS == 0, "thread <-> quad column mapping");
     constexpr int kIters = (C_TW / 2) * (C_TH / 2) / C_THREADS;
     constexpr int kRowStep = 2 * C_THREADS / (C_TW / 2);        // canvas rows between two quads of a thread
-    const Region r = blend_region(a, tx, ty, 0);
-    const Region ur = blend_region(a, tx, ty, 1);
+    const Region r = table_region(s_reg, 0);
+    const Region ur = table_region(s_reg, 1);
     const uint2* s_up = lds + a.lds_off[1];
     const int upitch = region_pitch(ur);
     const CamDesc& c = cams[__builtin_ctz(cam_bits)];
@@ -1435,13 +1469,13 @@ __device__ __forceinline__ void final_level_pure_full(const CamDesc* __restrict_
 template <bool TOP, bool PURE, bool W16 = false>
 __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int tx, int ty,
                                             uint32_t cam_bits, const uint2* __restrict__ lds, uint8_t* __restrict__ pano,
-                                            uint8_t* __restrict__ pano_mask)
+                                            uint8_t* __restrict__ pano_mask, const int* __restrict__ s_reg)
 {
-    const QuadIter it(blend_region(a, tx, ty, 0));
+    const QuadIter it(s_reg, 0);
     Region ur = it.r;
     const uint2* s_up = nullptr;
     if (!TOP) {
-        ur = blend_region(a, tx, ty, 1);
+        ur = table_region(s_reg, 1);
         s_up = lds + a.lds_off[1];
     }
     const bool blocked = !PURE && !(MST_ABLATE_C & 256) && it.blockable();
@@ -1510,31 +1544,34 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend(const CamDesc*
     const int top = a.nlev - 1;
     MST_STAMP(1, 0);
     MST_STAMP_VAL(1, 8, static_cast<unsigned long long>(entry));
+    __shared__ __attribute__((aligned(16))) int s_reg[kMaxLevels * kRegionRow];     // 352 bytes: keeps the dynamic base 16-aligned
+    fill_region_table(a, tx, ty, s_reg);
+    __syncthreads();
     if (top == 0) {
-        if (pure) final_level<true, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
-        else final_level<true, false, W16>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
+        if (pure) final_level<true, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask, s_reg);
+        else final_level<true, false, W16>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask, s_reg);
         return;
     }
     // phase 1: every coarse band, independent of each other -> no barrier until all are in LDS
     if (MST_ABLATE_C & 128) {
         if (pure) {
-            band_level<true, true>(cams, a, top, tx, ty, cam_bits, lds);
-            for (int l = top - 1; l >= 1; --l) band_level<false, true>(cams, a, l, tx, ty, cam_bits, lds);
+            band_level<true, true>(cams, a, top, tx, ty, cam_bits, lds, s_reg);
+            for (int l = top - 1; l >= 1; --l) band_level<false, true>(cams, a, l, tx, ty, cam_bits, lds, s_reg);
         } else {
-            band_level<true, false>(cams, a, top, tx, ty, cam_bits, lds);
-            for (int l = top - 1; l >= 1; --l) band_level<false, false>(cams, a, l, tx, ty, cam_bits, lds);
+            band_level<true, false>(cams, a, top, tx, ty, cam_bits, lds, s_reg);
+            for (int l = top - 1; l >= 1; --l) band_level<false, false>(cams, a, l, tx, ty, cam_bits, lds, s_reg);
         }
     } else if (pure) {
-        band_levels<true>(cams, a, top, tx, ty, cam_bits, lds);
+        band_levels<true>(cams, a, top, tx, ty, cam_bits, lds, s_reg);
     } else {
-        band_levels<false, W16>(cams, a, top, tx, ty, cam_bits, lds, owned_levels, owner_bits);
+        band_levels<false, W16>(cams, a, top, tx, ty, cam_bits, lds, s_reg, owned_levels, owner_bits);
     }
     MST_STAMP(1, 1);
     __syncthreads();
     MST_STAMP(1, 2);
     // phase 2: collapse coarse to fine (LDS only)
     if (a.dbg_C[top]) {
-        const QuadIter it(blend_region(a, tx, ty, top));
+        const QuadIter it(s_reg, top);
         const uint2* s = lds + a.lds_off[top];
         for (int i = threadIdx.x; i < it.rw * (it.r.y1 - it.r.y0); i += C_THREADS) {
             const int py = it.r.y0 + i / it.rw, px = it.r.x0 + i % it.rw;
@@ -1544,19 +1581,19 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend(const CamDesc*
         }
     }
     for (int l = top - 1; l >= 1; --l) {
-        if (!(MST_ABLATE_C & 2)) collapse_level(a, l, tx, ty, lds);
+        if (!(MST_ABLATE_C & 2)) collapse_level(a, l, tx, ty, lds, s_reg);
         __syncthreads();
     }
     // phase 3
     MST_STAMP(1, 3);
-    const Region r0 = blend_region(a, tx, ty, 0);
+    const Region r0 = table_region(s_reg, 0);
     const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
     // level 0 owned outright (true of every pure tile, and of most tiles near -- but not on -- a seam)
     const bool own0 = pure || (owned_levels & 1u);
     const uint32_t bits0 = pure ? cam_bits : owner_bits;
-    if (own0 && full && !(MST_ABLATE_C & 64)) final_level_pure_full(cams, a, tx, ty, bits0, lds, pano, pano_mask);
-    else if (own0) final_level<false, true>(cams, a, tx, ty, bits0, lds, pano, pano_mask);
-    else final_level<false, false, W16>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask);
+    if (own0 && full && !(MST_ABLATE_C & 64)) final_level_pure_full(cams, a, tx, ty, bits0, lds, pano, pano_mask, s_reg);
+    else if (own0) final_level<false, true>(cams, a, tx, ty, bits0, lds, pano, pano_mask, s_reg);
+    else final_level<false, false, W16>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask, s_reg);
     MST_STAMP(1, 4);
 }
 
