@@ -313,6 +313,18 @@ int  mst_warp(int device, int warp_kind, float scale, const float K[9], const fl
  * GAIN_BLOCKS: gain_map gain_h x gain_w; GAIN: scalar `gain`. */
 int  mst_exposure_apply(int device, int expos_kind, uint8_t *image, int width, int height,
                         size_t stride, const float *gain_map, int gain_w, int gain_h, float gain);
+/* ExposureCompensator::feed -- the calibration-side half (exposure_compensate.cpp:63-147, 165-222; the driver's
+ * BlockFeed, DRV:251-306): gains from the overlaps of the seam-scale warped images.  images[i]: CV_8UC3 of
+ * sizes_wh[2i] x sizes_wh[2i+1] at canvas corner corners_xy[2i..]; masks[i]: CV_8U, 255 = valid.
+ * GAIN: gains[num_images] (doubles, GainCompensator::gains()).  GAIN_BLOCKS: gain_maps[i] receives the camera's
+ * block gain map, mst_gain_map_size floats (block size 32 x 32 in the reference, exposure_compensate.hpp:96) -- exactly
+ * what mst_camera.gain_map takes.  The overlap statistics run on the device (one thread per pair of overlapping
+ * blocks, in the reference's summation order), the normal equations, cv::solve and the smoothing on the host. */
+int  mst_gain_map_size(int image_width, int image_height, int block_width, int block_height, int *gain_w, int *gain_h);
+int  mst_exposure_feed(int device, int expos_kind, int num_images, const int32_t *corners_xy,
+                       const uint8_t *const *images, const size_t *image_strides, const int32_t *sizes_wh,
+                       const uint8_t *const *masks, const size_t *mask_strides, int block_width, int block_height,
+                       double *gains, float *const *gain_maps);
 /* MultiBandBlender::prepare + feed integer geometry -- host only.
  * out[0..3] = tl_new.x, tl_new.y, br_new.x, br_new.y; out[4..7] = top, left, bottom, right */
 int  mst_multiband_geometry(mst_rect canvas, int num_bands, mst_rect image, mst_rect *padded_canvas,

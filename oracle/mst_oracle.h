@@ -119,6 +119,18 @@ void mo_blocks_gain_apply(uint8_t *img, int w, int h, size_t stride,
                           const float *gain_map, int gw, int gh);
 void mo_gain_apply(uint8_t *img, int w, int h, size_t stride, int cn, double gain);
 
+/* exposure ESTIMATION (calibration side): GainCompensator::feed / BlocksGainCompensator::feed
+ * (exposure_compensate.cpp:73-147, 165-222).  Images are CV_8UC3, masks CV_8U (level 255), corners_xy / sizes_wh
+ * hold n (x, y) / (w, h) pairs. */
+int  mo_solve_lu_64f(const double *A, const double *b, int n, double *x);
+void mo_smooth_gain_map(float *m, int w, int h);
+void mo_gain_feed(int n, const int *corners_xy, const uint8_t *const *images, const size_t *image_strides,
+                  const int *sizes_wh, const uint8_t *const *masks, const size_t *mask_strides, double *gains);
+void mo_gain_map_size(int w, int h, int bl_width, int bl_height, int *gw, int *gh);
+void mo_blocks_gain_feed(int n, const int *corners_xy, const uint8_t *const *images, const size_t *image_strides,
+                         const int *sizes_wh, const uint8_t *const *masks, const size_t *mask_strides,
+                         int bl_width, int bl_height, float *const *gain_maps);
+
 /* ---- core/imgproc primitives used by the blenders --------------------------- */
 void mo_convert_8u_16s(const uint8_t *src, size_t sstride, int16_t *dst, size_t dstride_elems,
                        int w_elems, int h);

@@ -509,6 +509,29 @@ int mst_exposure_apply(int device, int expos_kind, uint8_t* image, int width, in
     });
 }
 
+int mst_gain_map_size(int image_width, int image_height, int block_width, int block_height, int* gain_w, int* gain_h)
+{
+    return guarded(nullptr, [&] {
+        require(image_width > 0 && image_height > 0 && block_width > 0 && block_height > 0 && gain_w && gain_h, "bad sizes");
+        mst::gain_map_size(image_width, image_height, block_width, block_height, gain_w, gain_h);
+    });
+}
+
+int mst_exposure_feed(int device, int expos_kind, int num_images, const int32_t* corners_xy, const uint8_t* const* images,
+                      const size_t* image_strides, const int32_t* sizes_wh, const uint8_t* const* masks,
+                      const size_t* mask_strides, int block_width, int block_height, double* gains, float* const* gain_maps)
+{
+    return guarded(nullptr, [&] {
+        require(expos_kind == MST_EXPOS_GAIN || expos_kind == MST_EXPOS_GAIN_BLOCKS, "feed exists for GAIN and GAIN_BLOCKS");
+        require(num_images >= 1 && num_images <= MST_MAX_CAMERAS, "num_images out of range");
+        require(corners_xy && images && image_strides && sizes_wh && masks && mask_strides, "null argument");
+        require(expos_kind == MST_EXPOS_GAIN ? gains != nullptr : gain_maps != nullptr, "null output");
+        require(expos_kind == MST_EXPOS_GAIN || (block_width > 0 && block_height > 0), "bad block size");
+        mst::exposure_feed(device, expos_kind, num_images, corners_xy, images, image_strides, sizes_wh, masks, mask_strides,
+                           block_width, block_height, gains, gain_maps);
+    });
+}
+
 int mst_multiband_geometry(mst_rect canvas, int num_bands, mst_rect image, mst_rect* padded_canvas, int* used_bands,
                            int out[8])
 {

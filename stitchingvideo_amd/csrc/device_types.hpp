@@ -126,6 +126,12 @@ struct PayloadRect {
     uint32_t off;
 };
 
+// Exposure-gain estimation (GainCompensator::feed): images and masks on the device, and one overlapping pair of
+// (block) images: its overlap rectangle's origin inside each parent image, and its size.
+struct FeedImage { const uint8_t* img; const uint8_t* mask; uint32_t istride, mstride; };
+struct FeedPair { int32_t a, b, ax, ay, bx, by, w, h, i, j; };
+struct FeedStat { double sum_a, sum_b; int32_t count; int32_t pad; };
+
 // Work lists (static per calibration): only tiles whose output can reach the panorama are launched.
 struct TileList {
     const uint32_t* tiles;         // cam << 24 | ty << 12 | tx

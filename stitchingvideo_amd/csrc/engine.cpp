@@ -106,6 +106,8 @@ template int16_t* DevicePool::upload<int16_t>(const int16_t*, size_t, hipStream_
 template uint16_t* DevicePool::upload<uint16_t>(const uint16_t*, size_t, hipStream_t);
 template UndistortCam* DevicePool::upload<UndistortCam>(const UndistortCam*, size_t, hipStream_t);
 template PayloadRect* DevicePool::upload<PayloadRect>(const PayloadRect*, size_t, hipStream_t);
+template FeedImage* DevicePool::upload<FeedImage>(const FeedImage*, size_t, hipStream_t);
+template FeedPair* DevicePool::upload<FeedPair>(const FeedPair*, size_t, hipStream_t);
 
 CalibState::~CalibState()
 {

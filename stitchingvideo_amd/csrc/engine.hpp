@@ -215,6 +215,12 @@ private:
 void fill_camera_desc(DevicePool& pool, hipStream_t s, const Projector& proj, const Rect& roi, int src_w, int src_h,
                       int expos_kind, const float* gain_map, int gw, int gh, float gain, CamDesc& d);
 
+// exposure-gain estimation (exposure_feed.cpp): GAIN -> gains[n]; GAIN_BLOCKS -> gain_maps[i] of gain_map_size floats
+void gain_map_size(int w, int h, int bl_w, int bl_h, int* gw, int* gh);
+void exposure_feed(int device, int expos_kind, int n, const int32_t* corners_xy, const uint8_t* const* images,
+                   const size_t* image_strides, const int32_t* sizes_wh, const uint8_t* const* masks,
+                   const size_t* mask_strides, int bl_w, int bl_h, double* gains, float* const* gain_maps);
+
 void check_hip(hipError_t e, const char* what);
 void select_device(int device);
 

@@ -371,6 +371,38 @@ __global__ __launch_bounds__(64) void k_dt_rows(const int32_t* __restrict__ g, i
     }
 }
 
+// GainCompensator::feed's overlap statistics (exposure_compensate.cpp:92-120): one thread per overlapping pair,
+// walking the overlap row by row exactly as the reference does, so that Isum1 / Isum2 -- sums of correctly rounded
+// double square roots -- are accumulated in the reference's order.  Pairs are small (32 x 32 blocks) and many.
+__global__ __launch_bounds__(64) void k_overlap_stats(const FeedImage* __restrict__ imgs, const FeedPair* __restrict__ pairs,
+                                                      int n_pairs, FeedStat* __restrict__ out)
+{
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n_pairs) return;
+    const FeedPair p = pairs[k];
+    const FeedImage ia = imgs[p.a], ib = imgs[p.b];
+    int count = 0;
+    double s1 = 0., s2 = 0.;
+    for (int y = 0; y < p.h; ++y) {
+        const uint8_t* r1 = ia.img + static_cast<size_t>(p.ay + y) * ia.istride + static_cast<size_t>(p.ax) * 3;
+        const uint8_t* r2 = ib.img + static_cast<size_t>(p.by + y) * ib.istride + static_cast<size_t>(p.bx) * 3;
+        const uint8_t* m1 = ia.mask + static_cast<size_t>(p.ay + y) * ia.mstride + p.ax;
+        const uint8_t* m2 = ib.mask + static_cast<size_t>(p.by + y) * ib.mstride + p.bx;
+        for (int x = 0; x < p.w; ++x) {
+            if (m1[x] != 255 || m2[x] != 255) continue;
+            ++count;
+            const int b1 = r1[3 * x], g1 = r1[3 * x + 1], c1 = r1[3 * x + 2];
+            const int b2 = r2[3 * x], g2 = r2[3 * x + 1], c2 = r2[3 * x + 2];
+            s1 += sqrt(static_cast<double>(b1 * b1 + g1 * g1 + c1 * c1));
+            s2 += sqrt(static_cast<double>(b2 * b2 + g2 * g2 + c2 * c2));
+        }
+    }
+    out[k].sum_a = s1;
+    out[k].sum_b = s2;
+    out[k].count = count;
+    out[k].pad = 0;
+}
+
 // Camera-sharded hand-off: copy the rectangles of one camera's payload between its pyramid levels and a
 // packed buffer.  PACK: pyramid -> buffer (the sending rank), else buffer -> pyramid (the blending rank).
 template <bool PACK>
@@ -562,6 +594,12 @@ void launch_feather_weight_map(const uint8_t* d_mask, int w, int h, float sharpn
 {
     hipLaunchKernelGGL(k_dt_columns, dim3((w + 255) / 256), dim3(256), 0, s, d_mask, w, h, d_tmp);
     hipLaunchKernelGGL(k_dt_rows, dim3((h + 63) / 64), dim3(64), 0, s, d_tmp, w, h, sharpness, d_weight);
+}
+
+void launch_overlap_stats(const FeedImage* d_imgs, const FeedPair* d_pairs, int n_pairs, FeedStat* d_out, hipStream_t s)
+{
+    if (n_pairs <= 0) return;
+    hipLaunchKernelGGL(k_overlap_stats, dim3((n_pairs + 63) / 64), dim3(64), 0, s, d_imgs, d_pairs, n_pairs, d_out);
 }
 
 void launch_payload_copy(const CamDesc* d_cam, const PayloadRect* d_rects, int n_rects, uint32_t* d_buf, bool pack, hipStream_t s)

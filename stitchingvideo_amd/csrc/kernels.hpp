@@ -28,6 +28,8 @@ void launch_mask_fixup(const CamDesc* d_cam, const uint8_t* d_seam, int sw, int 
 // FeatherBlender's createWeightMap(mask, sharpness) (blenders.cpp:427-432); d_tmp: w * h ints of scratch
 void launch_feather_weight_map(const uint8_t* d_mask, int w, int h, float sharpness, int32_t* d_tmp, float* d_weight,
                                hipStream_t s);
+// GainCompensator::feed overlap statistics, one thread per overlapping pair (exposure_feed.cpp)
+void launch_overlap_stats(const FeedImage* d_imgs, const FeedPair* d_pairs, int n_pairs, FeedStat* d_out, hipStream_t s);
 // camera-sharded hand-off: pack (pyramid -> buffer) or unpack (buffer -> pyramid) one camera's payload rectangles
 void launch_payload_copy(const CamDesc* d_cam, const PayloadRect* d_rects, int n_rects, uint32_t* d_buf, bool pack, hipStream_t s);
 void launch_weight_class(const float* d_w, uint8_t* d_out, size_t n, float unit, hipStream_t s);   // see k_weight_class

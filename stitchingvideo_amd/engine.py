@@ -105,23 +105,60 @@ BLEND_KINDS = {"no": capi.BLEND_NO, "feather": capi.BLEND_FEATHER, "multiband": 
 EXPOS_KINDS = {"no": capi.EXPOS_NO, "gain": capi.EXPOS_GAIN, "gain_blocks": capi.EXPOS_GAIN_BLOCKS}
 
 
-class GainCompensator:
-    """apply(): image *= gain (exposure_compensate.cpp:150-153)."""
+def _feed(device, kind, corners, images, masks, block=(32, 32)):
+    """ExposureCompensator::feed (exposure_compensate.cpp:63-147,165-222) -> gains (list) or gain maps (list of arrays)."""
+    n = len(images)
+    imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+    msk = [np.ascontiguousarray(m, np.uint8) for m in masks]
+    for im, m in zip(imgs, msk):
+        if im.ndim != 3 or im.shape[2] != 3 or m.shape != im.shape[:2]:
+            raise capi.StitchError(capi.ERR_INVALID_ARG, "feed expects CV_8UC3 images and CV_8U masks of the same size")
+    L = capi.load()
+    cxy = (C.c_int * (2 * n))(*[int(v) for p in corners for v in p])
+    swh = (C.c_int * (2 * n))(*[v for im in imgs for v in (im.shape[1], im.shape[0])])
+    ip = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+    istr = (C.c_size_t * n)(*[im.strides[0] for im in imgs])
+    mp = (C.c_void_p * n)(*[m.ctypes.data for m in msk])
+    mstr = (C.c_size_t * n)(*[m.strides[0] for m in msk])
+    if kind == capi.EXPOS_GAIN:
+        gains = (C.c_double * n)()
+        capi.check(L.mst_exposure_feed(device, kind, n, cxy, ip, istr, swh, mp, mstr, 0, 0, gains, None))
+        return list(gains)
+    maps = []
+    for im in imgs:
+        gw, gh = C.c_int(), C.c_int()
+        capi.check(L.mst_gain_map_size(im.shape[1], im.shape[0], block[0], block[1], C.byref(gw), C.byref(gh)))
+        maps.append(np.empty((gh.value, gw.value), np.float32))
+    gp = (C.c_void_p * n)(*[g.ctypes.data for g in maps])
+    capi.check(L.mst_exposure_feed(device, kind, n, cxy, ip, istr, swh, mp, mstr, block[0], block[1], None, gp))
+    return maps
 
-    def __init__(self, gains, device=0):
+
+class GainCompensator:
+    """feed(): gains from the overlaps (exposure_compensate.cpp:73-147); apply(): image *= gain (:150-153)."""
+
+    def __init__(self, gains=(), device=0):
         self.gains = list(gains)
         self.device = device
+
+    def feed(self, corners, images, masks):
+        self.gains = _feed(self.device, capi.EXPOS_GAIN, corners, images, masks)
 
     def apply(self, index, corner, image, mask=None):
         _exposure_apply(self.device, capi.EXPOS_GAIN, image, None, float(self.gains[index]))
 
 
 class BlocksGainCompensator:
-    """apply(): bilinearly up-sized block gain map (exposure_compensate.cpp:225-246)."""
+    """feed(): per-block gains, smoothed twice (exposure_compensate.cpp:165-222); apply(): bilinearly up-sized block
+    gain map (:225-246)."""
 
-    def __init__(self, gain_maps, device=0):
+    def __init__(self, gain_maps=(), device=0, bl_width=32, bl_height=32):
         self.gain_maps = [np.ascontiguousarray(g, np.float32) for g in gain_maps]
         self.device = device
+        self.block = (bl_width, bl_height)
+
+    def feed(self, corners, images, masks):
+        self.gain_maps = _feed(self.device, capi.EXPOS_GAIN_BLOCKS, corners, images, masks, self.block)
 
     def apply(self, index, corner, image, mask=None):
         _exposure_apply(self.device, capi.EXPOS_GAIN_BLOCKS, image, self.gain_maps[index], 1.0)

@@ -280,6 +280,48 @@ def create_weight_map(mask, sharpness):
     return dst
 
 
+def _feed_args(corners, images, masks):
+    n = len(images)
+    imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+    msk = [np.ascontiguousarray(m, np.uint8) for m in masks]
+    cxy = (C.c_int * (2 * n))(*[int(v) for p in corners for v in p])
+    swh = (C.c_int * (2 * n))(*[v for im in imgs for v in (im.shape[1], im.shape[0])])
+    ip = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+    istr = (C.c_size_t * n)(*[im.strides[0] for im in imgs])
+    mp = (C.c_void_p * n)(*[m.ctypes.data for m in msk])
+    mstr = (C.c_size_t * n)(*[m.strides[0] for m in msk])
+    return n, imgs, msk, cxy, swh, ip, istr, mp, mstr
+
+
+def gain_feed(corners, images, masks):
+    """GainCompensator::feed -> gains (list of float)."""
+    n, imgs, msk, cxy, swh, ip, istr, mp, mstr = _feed_args(corners, images, masks)
+    g = (C.c_double * n)()
+    lib().mo_gain_feed(n, cxy, ip, istr, swh, mp, mstr, g)
+    return list(g)
+
+
+def blocks_gain_feed(corners, images, masks, block=(32, 32)):
+    """BlocksGainCompensator::feed -> list of float32 gain maps."""
+    n, imgs, msk, cxy, swh, ip, istr, mp, mstr = _feed_args(corners, images, masks)
+    maps = []
+    for im in imgs:
+        gw, gh = C.c_int(), C.c_int()
+        lib().mo_gain_map_size(im.shape[1], im.shape[0], block[0], block[1], C.byref(gw), C.byref(gh))
+        maps.append(np.empty((gh.value, gw.value), np.float32))
+    gp = (C.c_void_p * n)(*[g.ctypes.data for g in maps])
+    lib().mo_blocks_gain_feed(n, cxy, ip, istr, swh, mp, mstr, block[0], block[1], gp)
+    return maps
+
+
+def solve_lu(A, b):
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros(len(b), np.float64)
+    ok = lib().mo_solve_lu_64f(_ptr(A), _ptr(b), len(b), _ptr(x))
+    return ok, x
+
+
 def dilate3x3(mask):
     mask = np.ascontiguousarray(mask, np.uint8)
     dst = np.empty_like(mask)

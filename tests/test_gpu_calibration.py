@@ -78,3 +78,48 @@ def test_feather_weight_map_on_device(sharpness):
     assert eng.canvas() == rect
     assert np.array_equal(mask, omask) and np.array_equal(pano, opano), H.diff_report(pano, opano)
     eng.close()
+
+
+def _seam_scale_inputs(name, div, rng, exposure_spread=0.25):
+    """Seam-scale warped images + masks of a rig, with a different exposure per camera (what the compensators are for)."""
+    rig = rigmod.build_rig(rigmod.scaled_config(name, div), seams=False)
+    frames = rigmod.frames_for(rig, 1)
+    images, masks, corners = [], [], []
+    for i, (c, f) in enumerate(zip(rig["cameras"], frames)):
+        g = 1.0 + exposure_spread * np.sin(1.7 * i)
+        fe = np.clip(np.rint(f.astype(np.float64) * g), 0, 255).astype(np.uint8)
+        _, warped = O.warp(H.WARP_O[rig["warp"]], rig["scale"], c["K"], c["R"], fe, O.INTER_LINEAR, O.BORDER_REFLECT)
+        images.append(warped)
+        m = c["mask"].copy()
+        m[rng.uniform(size=m.shape) < 0.01] = 0                  # a few holes: the intersection test matters
+        masks.append(m)
+        corners.append(rig["corners"][i])
+    return corners, images, masks
+
+
+@pytest.mark.parametrize("name,div", [("C3", 8), ("C2", 6), ("C4", 10)])
+def test_gain_compensator_feed_matches_oracle(name, div):
+    """GainCompensator::feed: overlap statistics on the device (one thread per pair, the reference's summation
+    order), normal equations + cv::solve on the host -- gains bit-identical to the oracle's doubles."""
+    corners, images, masks = _seam_scale_inputs(name, div, np.random.default_rng(3))
+    comp = S.GainCompensator()
+    comp.feed(corners, images, masks)
+    want = O.gain_feed(corners, images, masks)
+    assert np.array_equal(np.asarray(comp.gains).view(np.uint64), np.asarray(want).view(np.uint64)), (comp.gains, want)
+    assert max(comp.gains) - min(comp.gains) > 0.02               # the exposure spread was seen
+
+
+@pytest.mark.parametrize("name,div,block", [("C3", 8, (32, 32)), ("C2", 6, (32, 32)), ("C5", 16, (16, 24))])
+def test_blocks_gain_compensator_feed_matches_oracle(name, div, block):
+    """BlocksGainCompensator::feed: every block an image (hundreds of them, thousands of overlapping pairs), LU solve,
+    two smoothing passes -- float gain maps bit-identical to the oracle's; and they round-trip through apply()."""
+    corners, images, masks = _seam_scale_inputs(name, div, np.random.default_rng(8))
+    comp = S.BlocksGainCompensator(bl_width=block[0], bl_height=block[1])
+    comp.feed(corners, images, masks)
+    want = O.blocks_gain_feed(corners, images, masks, block)
+    assert len(comp.gain_maps) == len(want)
+    for got, w in zip(comp.gain_maps, want):
+        assert got.shape == w.shape and np.array_equal(got.view(np.uint32), w.view(np.uint32))
+    img = images[0].copy()
+    comp.apply(0, corners[0], img)
+    assert np.array_equal(img, O.blocks_gain_apply(images[0], want[0]))

@@ -247,3 +247,28 @@ def test_feather_and_multiband_accumulate_semantics():
     b = O.Blender(O.BLEND_MULTI_BAND, num_bands=9)
     b.prepare([(0, 0)], [(20, 10)])
     assert b.num_bands() == 5
+
+
+def test_exposure_feed_known_answers():
+    """GainCompensator::feed on hand-checkable inputs: identical overlapping images -> equal gains; cv::solve's LU
+    against numpy on a well-conditioned system; the two-image closed form."""
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 3, 4, 9):
+        A = rng.uniform(-1, 1, size=(n, n)) + np.eye(n) * 4
+        b = rng.uniform(-1, 1, size=n)
+        ok, x = O.solve_lu(A, b)
+        assert ok and np.allclose(A @ x, b, atol=1e-12)
+    ok, x = O.solve_lu(np.zeros((4, 4)), np.ones(4))
+    assert not ok and not x.any()
+    # two images with the same content over a shared overlap: I(0,1) == I(1,0) -> gains equal (and ~1: beta pulls to 1)
+    img = rng.integers(30, 200, size=(40, 60, 3), dtype=np.uint8)
+    m = np.full((40, 60), 255, np.uint8)
+    g = O.gain_feed([(0, 0), (20, 0)], [img, np.roll(img, -20, axis=1)], [m, m])
+    assert abs(g[0] - g[1]) < 1e-9 and abs(g[0] - 1.0) < 1e-6
+    # brighter second image -> its gain below the first one's
+    bright = np.clip(np.roll(img, -20, axis=1).astype(int) * 3 // 2, 0, 255).astype(np.uint8)
+    g = O.gain_feed([(0, 0), (20, 0)], [img, bright], [m, m])
+    assert g[1] < g[0]
+    # gain maps: constant gains stay constant under the [1/4 1/2 1/4] smoothing (weights sum to one exactly)
+    maps = O.blocks_gain_feed([(0, 0)], [img], [m], block=(16, 16))
+    assert maps[0].shape == (3, 4) and np.all(maps[0] == maps[0][0, 0])
