@@ -313,6 +313,12 @@ int  mst_warp(int device, int warp_kind, float scale, const float K[9], const fl
  * GAIN_BLOCKS: gain_map gain_h x gain_w; GAIN: scalar `gain`. */
 int  mst_exposure_apply(int device, int expos_kind, uint8_t *image, int width, int height,
                         size_t stride, const float *gain_map, int gain_w, int gain_h, float gain);
+/* VoronoiSeamFinder::find (--seam voronoi, CLI:106; seam_finders.cpp:74-85,108-160) on the device: for every
+ * overlapping pair i < j, in order, the overlap pixels go to the image whose un-contested region is nearer in the L1
+ * metric.  masks[i]: CV_8U of sizes_wh[2i] x sizes_wh[2i+1] at corner corners_xy[2i..] (host memory), updated in
+ * place.  (The graph-cut and dynamic-programming seam finders stay on the host: out of scope) */
+int  mst_seam_voronoi(int device, int num_images, const int32_t *corners_xy, const int32_t *sizes_wh,
+                      uint8_t *const *masks, const size_t *mask_strides);
 /* ExposureCompensator::feed -- the calibration-side half (exposure_compensate.cpp:63-147, 165-222; the driver's
  * BlockFeed, DRV:251-306): gains from the overlaps of the seam-scale warped images.  images[i]: CV_8UC3 of
  * sizes_wh[2i] x sizes_wh[2i+1] at canvas corner corners_xy[2i..]; masks[i]: CV_8U, 255 = valid.

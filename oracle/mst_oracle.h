@@ -152,6 +152,9 @@ void mo_dilate3x3_8u(const uint8_t *src, int w, int h, uint8_t *dst);
 void mo_resize_linear_8u(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh);
 void mo_mask_fixup(const uint8_t *seam_mask, int sw, int sh, const uint8_t *mask_warped, int w, int h, uint8_t *out);
 
+/* ---- VoronoiSeamFinder (seam_finders.cpp:74-85, 108-160): masks tightly packed, updated in place ---- */
+void mo_voronoi_seams(int n, const int *corners_xy, const int *sizes_wh, uint8_t *const *masks);
+
 /* ---- util (a10) -------------------------------------------------------------- */
 mo_rect mo_result_roi(const int *corners_xy, const int *sizes_wh, int n);
 int mo_overlap_roi(int tl1x, int tl1y, int tl2x, int tl2y, int w1, int h1, int w2, int h2, mo_rect *roi);

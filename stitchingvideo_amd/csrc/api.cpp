@@ -509,6 +509,16 @@ int mst_exposure_apply(int device, int expos_kind, uint8_t* image, int width, in
     });
 }
 
+int mst_seam_voronoi(int device, int num_images, const int32_t* corners_xy, const int32_t* sizes_wh, uint8_t* const* masks,
+                     const size_t* mask_strides)
+{
+    return guarded(nullptr, [&] {
+        require(num_images >= 1 && num_images <= MST_MAX_CAMERAS, "num_images out of range");
+        require(corners_xy && sizes_wh && masks && mask_strides, "null argument");
+        mst::voronoi_seams(device, num_images, corners_xy, sizes_wh, masks, mask_strides);
+    });
+}
+
 int mst_gain_map_size(int image_width, int image_height, int block_width, int block_height, int* gain_w, int* gain_h)
 {
     return guarded(nullptr, [&] {

@@ -221,6 +221,10 @@ void exposure_feed(int device, int expos_kind, int n, const int32_t* corners_xy,
                    const size_t* image_strides, const int32_t* sizes_wh, const uint8_t* const* masks,
                    const size_t* mask_strides, int bl_w, int bl_h, double* gains, float* const* gain_maps);
 
+// VoronoiSeamFinder::find on the device (seams.cpp): masks (host, CV_8U of sizes_wh) updated in place
+void voronoi_seams(int device, int n, const int32_t* corners_xy, const int32_t* sizes_wh, uint8_t* const* masks,
+                   const size_t* mask_strides);
+
 void check_hip(hipError_t e, const char* what);
 void select_device(int device);
 

@@ -348,6 +348,8 @@ __global__ __launch_bounds__(256) void k_dt_columns(const uint8_t* __restrict__ 
 // Pass 2: per row, min over columns of g + |dx| (and the frame columns left and right), then the float scaling of
 // distanceTransform (* 2^-16), `weight * sharpness` and threshold(..., 1, THRESH_TRUNC).  One wave per row: a
 // running minimum is a scan, done here as two sequential sweeps by lane 0's neighbours in chunks.
+// RAW: the distance itself (distanceTransform's output: value * 2^-16), for the Voronoi seam finder
+template <bool RAW>
 __global__ __launch_bounds__(64) void k_dt_rows(const int32_t* __restrict__ g, int w, int h, float sharpness,
                                                 float* __restrict__ weight)
 {
@@ -366,9 +368,44 @@ __global__ __launch_bounds__(64) void k_dt_rows(const int32_t* __restrict__ g, i
         run = min(row[x], run + kDtStep);
         const int v = min(run, __float_as_int(out[x]));
         float d = static_cast<float>(v) * (1.f / 65536.f);
-        d = d * sharpness + 0.f;
-        out[x] = d > 1.f ? 1.f : d;
+        if (!RAW) {
+            d = d * sharpness + 0.f;
+            d = d > 1.f ? 1.f : d;
+        }
+        out[x] = d;
     }
+}
+
+// VoronoiSeamFinder::findInPair (seam_finders.cpp:108-160), step 1: cut the two sub-masks around the overlap (with the
+// reference's 10-pixel gap), drop the collision, and write the distance transforms' inputs `unique == 0`.
+struct VoronoiPair {
+    uint8_t* m1; uint8_t* m2;       // the two masks (tight), updated in place by step 3
+    int32_t w1, h1, w2, h2;
+    int32_t ox1, oy1, ox2, oy2;     // roi.tl - tl1, roi.tl - tl2
+    int32_t rw, rh, gap;
+};
+__global__ __launch_bounds__(256) void k_voronoi_cut(VoronoiPair p, uint8_t* __restrict__ inv1, uint8_t* __restrict__ inv2)
+{
+    const int x = blockIdx.x * kTileW + threadIdx.x, y = blockIdx.y * kTileH + threadIdx.y;
+    const int sw = p.rw + 2 * p.gap, sh = p.rh + 2 * p.gap;
+    if (x >= sw || y >= sh) return;
+    const int x1 = p.ox1 + x - p.gap, y1 = p.oy1 + y - p.gap, x2 = p.ox2 + x - p.gap, y2 = p.oy2 + y - p.gap;
+    const int s1 = (x1 >= 0 && y1 >= 0 && x1 < p.w1 && y1 < p.h1) ? p.m1[static_cast<size_t>(y1) * p.w1 + x1] : 0;
+    const int s2 = (x2 >= 0 && y2 >= 0 && x2 < p.w2 && y2 < p.h2) ? p.m2[static_cast<size_t>(y2) * p.w2 + x2] : 0;
+    const bool collision = s1 != 0 && s2 != 0;
+    const size_t i = static_cast<size_t>(y) * sw + x;
+    inv1[i] = (collision || s1 == 0) ? 255 : 0;          // unique1 == 0
+    inv2[i] = (collision || s2 == 0) ? 255 : 0;
+}
+// step 3: `seam = dist1 < dist2` over the overlap: the nearer image keeps the pixel
+__global__ __launch_bounds__(256) void k_voronoi_apply(VoronoiPair p, const float* __restrict__ d1, const float* __restrict__ d2)
+{
+    const int x = blockIdx.x * kTileW + threadIdx.x, y = blockIdx.y * kTileH + threadIdx.y;
+    if (x >= p.rw || y >= p.rh) return;
+    const int sw = p.rw + 2 * p.gap;
+    const size_t i = static_cast<size_t>(y + p.gap) * sw + (x + p.gap);
+    if (d1[i] < d2[i]) p.m2[static_cast<size_t>(p.oy2 + y) * p.w2 + (p.ox2 + x)] = 0;
+    else p.m1[static_cast<size_t>(p.oy1 + y) * p.w1 + (p.ox1 + x)] = 0;
 }
 
 // GainCompensator::feed's overlap statistics (exposure_compensate.cpp:92-120): one thread per overlapping pair,
@@ -593,7 +630,21 @@ void launch_feather_weight_map(const uint8_t* d_mask, int w, int h, float sharpn
                                hipStream_t s)
 {
     hipLaunchKernelGGL(k_dt_columns, dim3((w + 255) / 256), dim3(256), 0, s, d_mask, w, h, d_tmp);
-    hipLaunchKernelGGL(k_dt_rows, dim3((h + 63) / 64), dim3(64), 0, s, d_tmp, w, h, sharpness, d_weight);
+    hipLaunchKernelGGL(k_dt_rows<false>, dim3((h + 63) / 64), dim3(64), 0, s, d_tmp, w, h, sharpness, d_weight);
+}
+
+void launch_voronoi_pair(uint8_t* d_m1, int w1, int h1, int ox1, int oy1, uint8_t* d_m2, int w2, int h2, int ox2, int oy2,
+                         int rw, int rh, uint8_t* d_inv1, uint8_t* d_inv2, int32_t* d_tmp, float* d_dist1, float* d_dist2,
+                         hipStream_t s)
+{
+    VoronoiPair p{d_m1, d_m2, w1, h1, w2, h2, ox1, oy1, ox2, oy2, rw, rh, 10};
+    const int sw = rw + 2 * p.gap, sh = rh + 2 * p.gap;
+    hipLaunchKernelGGL(k_voronoi_cut, grid2d(sw, sh), block2d(), 0, s, p, d_inv1, d_inv2);
+    hipLaunchKernelGGL(k_dt_columns, dim3((sw + 255) / 256), dim3(256), 0, s, d_inv1, sw, sh, d_tmp);
+    hipLaunchKernelGGL(k_dt_rows<true>, dim3((sh + 63) / 64), dim3(64), 0, s, d_tmp, sw, sh, 0.f, d_dist1);
+    hipLaunchKernelGGL(k_dt_columns, dim3((sw + 255) / 256), dim3(256), 0, s, d_inv2, sw, sh, d_tmp);
+    hipLaunchKernelGGL(k_dt_rows<true>, dim3((sh + 63) / 64), dim3(64), 0, s, d_tmp, sw, sh, 0.f, d_dist2);
+    hipLaunchKernelGGL(k_voronoi_apply, grid2d(rw, rh), block2d(), 0, s, p, d_dist1, d_dist2);
 }
 
 void launch_overlap_stats(const FeedImage* d_imgs, const FeedPair* d_pairs, int n_pairs, FeedStat* d_out, hipStream_t s)

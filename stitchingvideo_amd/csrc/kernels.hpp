@@ -32,6 +32,11 @@ void launch_feather_weight_map(const uint8_t* d_mask, int w, int h, float sharpn
 void launch_overlap_stats(const FeedImage* d_imgs, const FeedPair* d_pairs, int n_pairs, FeedStat* d_out, hipStream_t s);
 // camera-sharded hand-off: pack (pyramid -> buffer) or unpack (buffer -> pyramid) one camera's payload rectangles
 void launch_payload_copy(const CamDesc* d_cam, const PayloadRect* d_rects, int n_rects, uint32_t* d_buf, bool pack, hipStream_t s);
+// VoronoiSeamFinder::findInPair for one overlapping pair (masks tight on the device, updated in place); scratch:
+// (rw + 20) * (rh + 20) bytes / ints / floats in d_inv1, d_inv2 / d_tmp / d_dist1, d_dist2
+void launch_voronoi_pair(uint8_t* d_m1, int w1, int h1, int ox1, int oy1, uint8_t* d_m2, int w2, int h2, int ox2, int oy2,
+                         int rw, int rh, uint8_t* d_inv1, uint8_t* d_inv2, int32_t* d_tmp, float* d_dist1, float* d_dist2,
+                         hipStream_t s);
 void launch_weight_class(const float* d_w, uint8_t* d_out, size_t n, float unit, hipStream_t s);   // see k_weight_class
 void launch_band_weight_sum(const CamDesc* d_cams, int n_cams, int level, float* d_ws, int cw, int ch,
                             hipStream_t s);

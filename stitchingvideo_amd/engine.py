@@ -105,6 +105,24 @@ BLEND_KINDS = {"no": capi.BLEND_NO, "feather": capi.BLEND_FEATHER, "multiband": 
 EXPOS_KINDS = {"no": capi.EXPOS_NO, "gain": capi.EXPOS_GAIN, "gain_blocks": capi.EXPOS_GAIN_BLOCKS}
 
 
+class VoronoiSeamFinder:
+    """cv::detail::VoronoiSeamFinder (seam_finders.hpp:97-104): find(sizes, corners, masks) updates the masks in place."""
+
+    def __init__(self, device=0):
+        self.device = device
+
+    def find(self, sizes, corners, masks):
+        n = len(masks)
+        for m, (w, h) in zip(masks, sizes):
+            if m.dtype != np.uint8 or m.shape != (h, w) or not m.flags.c_contiguous or not m.flags.writeable:
+                raise capi.StitchError(capi.ERR_INVALID_ARG, "masks must be writable C-contiguous CV_8U of the given sizes")
+        cxy = (C.c_int * (2 * n))(*[int(v) for p in corners for v in p])
+        swh = (C.c_int * (2 * n))(*[int(v) for s in sizes for v in s])
+        mp = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
+        mstr = (C.c_size_t * n)(*[m.strides[0] for m in masks])
+        capi.check(capi.load().mst_seam_voronoi(self.device, n, cxy, swh, mp, mstr))
+
+
 def _feed(device, kind, corners, images, masks, block=(32, 32)):
     """ExposureCompensator::feed (exposure_compensate.cpp:63-147,165-222) -> gains (list) or gain maps (list of arrays)."""
     n = len(images)

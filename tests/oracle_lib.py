@@ -322,6 +322,17 @@ def solve_lu(A, b):
     return ok, x
 
 
+def voronoi_seams(corners, masks):
+    """VoronoiSeamFinder::find -> new list of masks."""
+    n = len(masks)
+    out = [np.ascontiguousarray(m, np.uint8).copy() for m in masks]
+    cxy = (C.c_int * (2 * n))(*[int(v) for p in corners for v in p])
+    swh = (C.c_int * (2 * n))(*[v for m in out for v in (m.shape[1], m.shape[0])])
+    mp = (C.c_void_p * n)(*[m.ctypes.data for m in out])
+    lib().mo_voronoi_seams(n, cxy, swh, mp)
+    return out
+
+
 def dilate3x3(mask):
     mask = np.ascontiguousarray(mask, np.uint8)
     dst = np.empty_like(mask)

@@ -123,3 +123,17 @@ def test_blocks_gain_compensator_feed_matches_oracle(name, div, block):
     img = images[0].copy()
     comp.apply(0, corners[0], img)
     assert np.array_equal(img, O.blocks_gain_apply(images[0], want[0]))
+
+
+@pytest.mark.parametrize("name,div", [("C3", 8), ("C2", 4), ("C4", 8), ("C5", 16)])
+def test_voronoi_seam_finder_on_device(name, div):
+    """VoronoiSeamFinder::find: pairs in the reference's order, masks updated in place; the device result equals the
+    oracle's C restatement (which in turn equals rig.py's independent scipy one, tests/test_oracle_kat.py)."""
+    rig = rigmod.build_rig(rigmod.scaled_config(name, div), seams=False)
+    masks = [c["mask"].copy() for c in rig["cameras"]]
+    want = O.voronoi_seams(rig["corners"], masks)
+    S.VoronoiSeamFinder().find(rig["sizes"], rig["corners"], masks)
+    for i, (a, b) in enumerate(zip(masks, want)):
+        assert np.array_equal(a, b), (i, H.diff_report(a, b))
+    cover = sum(int((m != 0).sum()) for m in masks)
+    assert 0 < cover < sum(m.size for m in masks)

@@ -272,3 +272,13 @@ def test_exposure_feed_known_answers():
     # gain maps: constant gains stay constant under the [1/4 1/2 1/4] smoothing (weights sum to one exactly)
     maps = O.blocks_gain_feed([(0, 0)], [img], [m], block=(16, 16))
     assert maps[0].shape == (3, 4) and np.all(maps[0] == maps[0][0, 0])
+
+
+def test_voronoi_seams_two_restatements_agree():
+    """The oracle's C VoronoiSeamFinder against rig.py's scipy-based one (written independently for the rig builder)."""
+    from stitchingvideo_amd import rig as rigmod
+    for name, div in (("C3", 8), ("C2", 4), ("C4", 10)):
+        cfg = rigmod.scaled_config(name, div)
+        open_rig, cut_rig = rigmod.build_rig(cfg, seams=False), rigmod.build_rig(cfg, seams=True)
+        got = O.voronoi_seams(open_rig["corners"], [c["mask"] for c in open_rig["cameras"]])
+        assert all(np.array_equal(a, c["mask"]) for a, c in zip(got, cut_rig["cameras"]))
