@@ -100,20 +100,28 @@ struct UndistortCam {
     int32_t w, h;                  // frame size (the maps are frame-sized: the reference undistorts in place size)
 };
 
-// Arguments of the fused canvas kernel (k_blend), passed by value.
+// Arguments of the canvas kernels (k_blend_coarse: levels 1 .. top -> collapsed level-1 canvas; k_blend_fine: level 0
+// -> panorama), passed by value.
 struct BlendArgs {
     int32_t nlev, n_cams;
     int32_t cw[kMaxLevels], ch[kMaxLevels];   // padded canvas pyramid level sizes
     int32_t final_w, final_h;                 // dst_roi_final_
     uint8_t* pano[kMaxBatch]; uint32_t pano_stride;          // one panorama (and optional mask) per frame set
     uint8_t* pano_mask[kMaxBatch]; uint32_t mask_stride;
-    const uint32_t* block_cams;               // per block: bit i set = camera i has non-zero weight under the tile
-    const uint32_t* block_pure;               // per block: bit l set = level l of the tile is owned by ONE camera with
-                                              // weight exactly 1 (integer band path); that camera's index << 16
+    uint64_t* c1[kMaxBatch];                   // collapsed level-1 canvas of each frame set: ch[1] x cw[1], 8 bytes a pixel
+    // k_blend_fine, per panorama tile: bit i = camera i has a non-zero level-0 weight under the tile; bit 31 = the
+    // tile's level 0 is owned by ONE camera with weight exactly 1 (integer band path) -- then only that camera's bit
+    const uint32_t* block_cams;
     const uint32_t* block_order;              // tile index (ty * tiles_x + tx) handled by block i
     int32_t tiles_x;
-    int32_t n_tiles, n_sets;                  // canvas tiles and frame sets of this launch (filled in by launch_blend)
-    int32_t lds_off[kMaxLevels];              // LDS offset (in pixels) of each level's region buffer
+    // k_blend_coarse, per level-1 tile: camera bits over the levels 1 .. top (bit 31: every level owned by the one
+    // camera); coarse_pure: bit l set = level l of the tile is owned by ONE camera, that camera's index << 16
+    const uint32_t* coarse_cams;
+    const uint32_t* coarse_pure;
+    const uint32_t* coarse_order;
+    int32_t coarse_tiles_x;
+    int32_t n_tiles, n_coarse_tiles, n_sets;  // tiles and frame sets of this launch (filled in by launch_blend)
+    int32_t lds_off[kMaxLevels];              // k_blend_coarse: LDS offset (in pixels) of each level's region buffer
     int16_t* dbg_C[kMaxLevels];               // optional dump of the collapsed levels (MST_FLAG_DEBUG)
     float alpha;                              // (float)(1./255.)
     int32_t weights_16s;                      // MultiBandBlender weight_type CV_16S: integer weights, >> 8 accumulate

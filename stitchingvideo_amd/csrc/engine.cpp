@@ -566,8 +566,17 @@ void Engine::update(const mst_calibration& calib)
         for (int l = 0; l <= nb; ++l) ba.lds_off[l] = plan.lds_off[l];
         if (plan.lds_bytes > 64 * 1024) throw Error{MST_ERR_INVALID_ARG, "canvas kernel LDS budget exceeded"};
         ba.block_cams = st->pool.upload(plan.block_cams, s);
-        ba.block_pure = st->pool.upload(plan.block_pure, s);
         ba.block_order = st->pool.upload(plan.block_order, s);
+        ba.coarse_tiles_x = plan.coarse_tiles_x;
+        if (nb >= 1) {
+            ba.coarse_cams = st->pool.upload(plan.coarse_cams, s);
+            ba.coarse_pure = st->pool.upload(plan.coarse_pure, s);
+            ba.coarse_order = st->pool.upload(plan.coarse_order, s);
+            // the collapsed level-1 canvas k_blend_coarse hands to k_blend_fine, one per buffer set
+            st->c1.assign(st->num_sets, nullptr);
+            for (int k = 0; k < st->num_sets; ++k)
+                st->c1[k] = st->pool.alloc<uint64_t>(static_cast<size_t>(cv.cw[1]) * cv.ch[1]);
+        }
         st->warp_list.tiles = st->pool.upload(plan.warp_tiles, s);
         st->warp_list.count = static_cast<int32_t>(plan.warp_tiles.size());
         st->warp_list.first = 0;
@@ -725,7 +734,10 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         }
         ba.pano_stride = static_cast<uint32_t>(pano_stride);
         ba.mask_stride = static_cast<uint32_t>(mask_stride);
-        launch_blend(desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, count, st->plan.lds_bytes, s);
+        if (!st->c1.empty())
+            for (int f = 0; f < count; ++f) ba.c1[f] = st->c1[first_set + f];
+        launch_blend(desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, st->plan.coarse_tiles_x * st->plan.coarse_tiles_y,
+                     count, st->plan.lds_bytes, s);
         mark("k_blend");
         if (overlap) {
             check_hip(hipEventRecord(ev_canvas_done_[slot], s), "hipEventRecord");
@@ -836,8 +848,9 @@ void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t
     ba.pano[0] = static_cast<uint8_t*>(d_pano); ba.pano_stride = static_cast<uint32_t>(pano_stride);
     ba.pano_mask[0] = static_cast<uint8_t*>(d_mask); ba.mask_stride = static_cast<uint32_t>(mask_stride);
     if (stage_set_ >= st->num_sets) throw Error{MST_ERR_INVALID_ARG, "stage set beyond mst_config.max_batch"};
-    launch_blend(st->d_desc + static_cast<size_t>(stage_set_) * st->n, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, 1,
-                 st->plan.lds_bytes, s);
+    if (!st->c1.empty()) ba.c1[0] = st->c1[stage_set_];
+    launch_blend(st->d_desc + static_cast<size_t>(stage_set_) * st->n, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y,
+                 st->plan.coarse_tiles_x * st->plan.coarse_tiles_y, 1, st->plan.lds_bytes, s);
     check_hip(hipGetLastError(), "canvas stage kernel");
     set_in_flight(std::move(st));
 }

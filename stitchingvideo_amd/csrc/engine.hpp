@@ -93,6 +93,7 @@ struct CalibState {
     UndistortCam* d_ucams = nullptr;
     bool any_undistort = false;
     int undist_max_w = 0, undist_max_h = 0;
+    std::vector<uint64_t*> c1;               // per buffer set: collapsed level-1 canvas (k_blend_coarse -> k_blend_fine)
     std::vector<uint8_t*> undist_frames;   // num_sets x n engine-owned undistorted frames (nullptr: camera has no maps)
     uint32_t* warp_table = nullptr;     // per-tile backward-map table (frame-invariant), see kernels_mb.hip
     uint32_t* warp_blobs = nullptr;     // per tile: calibration constants of kernel A (gain rows, row weights, table origin)

@@ -47,8 +47,10 @@ void mb_tile_dims(int* a_tw0, int* a_th0, int* b_t, int* c_tw, int* c_th);
 int  mb_read_stamps(int which, unsigned long long* out, size_t n);                // diagnostic builds (-DMST_STAMPS) only
 int  mb_read_stamps(int which, unsigned long long* out, size_t n);                // diagnostic builds (-DMST_STAMPS) only
 int  mb_chain_depth();                                                           // levels per k_pyr_chain launch
-void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4]);   // x0, y0, x1, y1
-int  mb_blend_region_lds_pixels(const BlendArgs& a, int tx, int ty, int level);      // LDS footprint of that region
+void mb_coarse_tile_dims(int* tw, int* th);                                        // k_blend_coarse tiles, in level-1 pixels
+// region of tile (tx, ty) -- a panorama tile (base 0) or a level-1 tile (base 1) -- at `level` >= base: x0, y0, x1, y1
+void mb_blend_region(const BlendArgs& a, int base, int tx, int ty, int level, int out[4]);
+int  mb_blend_region_lds_pixels(const BlendArgs& a, int base, int tx, int ty, int level);   // LDS footprint of that region
 size_t mb_warp_table_entries(int num_tiles);                                         // 32-bit entries for `num_tiles` tiles
 size_t mb_warp_blob_entries(int num_tiles);                                          // 32-bit words of per-tile constants
 // per calibration: the backward-map table and the per-tile constants of every launched tile of kernel A
@@ -58,7 +60,8 @@ void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, ui
 void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
                      int batch, const uint32_t* d_table, const uint32_t* d_blobs, hipStream_t s);
 void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s);
-void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int batch, size_t lds_bytes, hipStream_t s);
+void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
+                  hipStream_t s);
 
 // ---- per-frame hot path: feather / paste (fully fused: warp + gain + blend in one kernel) ----
 void launch_feather_compose(const CamDesc* d_cams, int n_cams, const FrameArgs& frames, const float* d_ws,

@@ -42,7 +42,7 @@ using namespace dev;
 #if defined(MST_STAMPS)
 // Diagnostic build only (-DMST_STAMPS, tools/stamps.sh): per block, shader-clock stamps at the phase boundaries of
 // kernels A and C, written to a buffer nothing else reads and copied out by mst_debug_stamps().  Never timed.
-__device__ unsigned long long g_stamps[2][1 << 17];
+__device__ unsigned long long g_stamps[3][1 << 17];       // k_warp_pyr, k_blend_coarse, k_blend_fine
 __device__ __forceinline__ unsigned long long stamp_now()
 {
     unsigned long long t;
@@ -800,6 +800,13 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
 #define MST_C_TH 64        // 128x64 canvas tiles: 84.5 us vs 87.8 us for 128x32 (C3, MI355X)
 #endif
 constexpr int C_TW = 128, C_TH = MST_C_TH;
+#ifndef MST_CC_TW
+#define MST_CC_TW 128      // k_blend_coarse: tile size in level-1 pixels
+#endif
+#ifndef MST_CC_TH
+#define MST_CC_TH 64
+#endif
+constexpr int CC_TW = MST_CC_TW, CC_TH = MST_CC_TH;
 #ifndef MST_C_THREADS
 #define MST_C_THREADS 256
 #endif
@@ -807,14 +814,17 @@ constexpr int C_THREADS = MST_C_THREADS;
 
 struct Region { int x0, y0, x1, y1; };
 
-__host__ __device__ inline Region blend_region(const BlendArgs& a, int tx, int ty, int level)
+// The canvas is cut into C_TW x C_TH tiles at level `base` (0: the panorama tiles of k_blend_fine, 1: the level-1
+// tiles of k_blend_coarse); a tile's region at a coarser level is what pyrUp needs of that level to rebuild the tile.
+__host__ __device__ inline Region blend_region(const BlendArgs& a, int base, int tx, int ty, int level)
 {
     Region r;
     auto lo = [](int v, int m) { return v < m ? v : m; };
     auto hi = [](int v, int m) { return v > m ? v : m; };
-    r.x0 = tx * C_TW; r.y0 = ty * C_TH;
-    r.x1 = lo(r.x0 + C_TW, a.cw[0]); r.y1 = lo(r.y0 + C_TH, a.ch[0]);
-    for (int l = 1; l <= level; ++l) {
+    const int tw = base ? CC_TW : C_TW, th = base ? CC_TH : C_TH;
+    r.x0 = tx * tw; r.y0 = ty * th;
+    r.x1 = lo(r.x0 + tw, a.cw[base]); r.y1 = lo(r.y0 + th, a.ch[base]);
+    for (int l = base + 1; l <= level; ++l) {
         r.x0 = hi(0, ((r.x0 >> 1) - 1) & ~1);
         r.y0 = hi(0, ((r.y0 >> 1) - 1) & ~1);
         r.x1 = lo(a.cw[l], (((r.x1 - 1) >> 1) + 3) & ~1);
@@ -900,7 +910,13 @@ __device__ __forceinline__ void pyrup_quad_s16(const uint2 v[3][3], int out[4][3
     }
 }
 
-__device__ __forceinline__ void pyrup_quad_lds(const uint2* __restrict__ s, int rx0, int ry0, int pitch, int sw, int sh,
+// a pixel of the collapsed level-1 canvas in global memory (HIP's uint2 class cannot be used through address-space pointers)
+typedef uint32_t __attribute__((ext_vector_type(2))) GPix;
+typedef const GPix MST_GLOBAL* C1Ptr;
+template <typename T> __device__ __forceinline__ uint2 as_u2(const T& t) { return make_uint2(t.x, t.y); }
+
+template <typename Ptr>      // LDS (collapse inside a tile) or global memory (the collapsed level-1 canvas)
+__device__ __forceinline__ void pyrup_quad_lds(Ptr s, int rx0, int ry0, int pitch, int sw, int sh,
                                                int j, int i, int out[4][3])
 {
     int jm, jp, im, ip;
@@ -911,8 +927,8 @@ __device__ __forceinline__ void pyrup_quad_lds(const uint2* __restrict__ s, int 
     uint2 v[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        const uint2* p = s + __mul24(rows[r], pitch);
-        v[r][0] = p[c0]; v[r][1] = p[c1]; v[r][2] = p[c2];
+        const Ptr p = s + __mul24(rows[r], pitch);
+        v[r][0] = as_u2(p[c0]); v[r][1] = as_u2(p[c1]); v[r][2] = as_u2(p[c2]);
     }
     pyrup_quad_s16(v, out);
 }
@@ -1124,11 +1140,11 @@ __host__ __device__ inline int region_pitch(const Region& r) { return (r.x1 - r.
 // chunk and every collapse step, which made 29 % of this kernel's instructions scalar bookkeeping.  Row l:
 // x0, y0, x1, y1 of the region, and ceil(2^20 / quads per row) for the quad index -> (row, column) split.
 constexpr int kRegionRow = 8;
-__device__ __forceinline__ void fill_region_table(const BlendArgs& a, int tx, int ty, int* __restrict__ s_reg)
+__device__ __forceinline__ void fill_region_table(const BlendArgs& a, int base, int tx, int ty, int* __restrict__ s_reg)
 {
     const int l = static_cast<int>(threadIdx.x);
-    if (l < a.nlev) {
-        const Region r = blend_region(a, tx, ty, l);
+    if (l >= base && l < a.nlev) {
+        const Region r = blend_region(a, base, tx, ty, l);
         const int qw = max(1, (r.x1 - r.x0 + 1) >> 1);
         s_reg[l * kRegionRow + 0] = r.x0; s_reg[l * kRegionRow + 1] = r.y0;
         s_reg[l * kRegionRow + 2] = r.x1; s_reg[l * kRegionRow + 3] = r.y1;
@@ -1162,7 +1178,7 @@ struct QuadIter {
     __device__ __forceinline__ void at(int q, int& x, int& y, bool valid[4]) const
     {
         // (the multiply form needs q < 4096 and qw <= 64: a 128 x 64 tile has 2048 quads in rows of 64 at most)
-        const int qy = (inv != 0 && C_TW <= 128 && C_TW * C_TH <= 4 * 4096) ? static_cast<int>((static_cast<uint32_t>(q) * inv) >> 20) : q / qw;
+        const int qy = (inv != 0 && C_TW <= 128 && C_TW * C_TH <= 4 * 4096 && CC_TW <= 128 && CC_TW * CC_TH <= 4 * 4096) ? static_cast<int>((static_cast<uint32_t>(q) * inv) >> 20) : q / qw;
         const int qx = q - __mul24(qy, qw);
         x = r.x0 + 2 * qx;
         y = r.y0 + 2 * qy;
@@ -1222,7 +1238,7 @@ __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, con
 template <bool PURE, bool W16 = false>
 __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, const BlendArgs& a, int top, int tx, int ty,
                                             uint32_t cam_bits, uint2* __restrict__ lds, const int* __restrict__ s_reg,
-                                            uint32_t owned_levels = 0, uint32_t owner_bits = 0)
+                                            int first, uint32_t owned_levels = 0, uint32_t owner_bits = 0)
 {
     constexpr int kWaves = C_THREADS / 64;
     const int lane = static_cast<int>(threadIdx.x & 63u);
@@ -1231,7 +1247,7 @@ __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, co
     int total = 0;
 #pragma unroll
     for (int k = 1; k < kMaxLevels; ++k) {
-        nch[k] = k <= top ? (QuadIter(s_reg, k).nq + 63) >> 6 : 0;
+        nch[k] = (k >= first && k <= top) ? (QuadIter(s_reg, k).nq + 63) >> 6 : 0;
         total += nch[k];
     }
     for (int chunk = wave; chunk < total; chunk += kWaves) {
@@ -1388,96 +1404,204 @@ __device__ __forceinline__ int pano_store_mode(const BlendArgs& a, const uint8_t
     return (al & 1u) == 0 ? 1 : 0;
 }
 
-// phase 3 for a tile that is pure (see band_quad), not the top level, covers a whole C_TW x C_TH region and lies
-// inside the final crop: every quad is valid, the quad columns are fixed per thread, and the trip count is a
-// compile-time constant -- so the loop is fully unrolled with the loads of the next quad (Gaussian quad, 3x3
-// pyrUp sources from global memory, 3x3 collapsed level-1 values from LDS) issued before the current quad is
-// evaluated, and no validity predicate or per-quad index division is left.
-__device__ __forceinline__ void final_level_pure_full(const CamDesc* __restrict__ cams, const BlendArgs& a, int tx, int ty,
-                                                      uint32_t cam_bits, const uint2* __restrict__ lds,
-                                                      uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask,
-                                                      const int* __restrict__ s_reg)
+// values of the lanes beside this one within a DPP row of 16 lanes (row_shr:1 / row_shl:1; the row's first / last
+// lane keeps its own value).  (The wavefront-wide shifts wave_shr / wave_shl assemble for gfx950 but do not cross
+// the 16-lane rows there: measured, tests/test_gpu_edge_cases.py caught it.)
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v)      // lane i <- lane i - 1
 {
-    static_assert(C_TW == 128 && (C_TW / 2) * (C_TH / 2) % C_THREADS == 0, "thread <-> quad column mapping");
-    constexpr int kIters = (C_TW / 2) * (C_TH / 2) / C_THREADS;
-    constexpr int kRowStep = 2 * C_THREADS / (C_TW / 2);        // canvas rows between two quads of a thread
-    const Region r = table_region(s_reg, 0);
-    const Region ur = table_region(s_reg, 1);
-    const uint2* s_up = lds + a.lds_off[1];
-    const int upitch = region_pitch(ur);
-    const CamDesc& c = cams[__builtin_ctz(cam_bits)];
-    const int lw = c.lw[0], sw = c.lw[1], sh = c.lh[1];
-    const int x = r.x0 + 2 * static_cast<int>(threadIdx.x & (C_TW / 2 - 1));
-    const int y0 = r.y0 + 2 * static_cast<int>(threadIdx.x / (C_TW / 2));
-    const int lx = x - c.ox[0];
-    int jm, jp, cjm, cjp;
-    const int j = lx >> 1, cj = x >> 1;
-    up_idx(j, sw, jm, jp);
-    up_idx(cj, a.cw[1], cjm, cjp);
-    const int uc[3] = {cjm - ur.x0, cj - ur.x0, cjp - ur.x0};
-    const uint32_t MST_GLOBAL* __restrict__ g0p = gp(c.G[0]);
-    const uint32_t MST_GLOBAL* __restrict__ g1p = gp(c.G[1]);
-    const int store_mode = pano_store_mode(a, pano, true);      // x0 is a multiple of C_TW, a lane's x = x0 + 2 * (lane)
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x111, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v)      // lane i <- lane i + 1
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x101, 0xF, 0xF, false));
+}
 
-    struct Stage { uint32_t g[4]; uint32_t nb[3][3]; uint2 u[3][3]; };
-    auto load = [&](Stage& st, int y) {
-        const int ly = y - c.oy[0];
-        const uint32_t off = __umul24(ly, lw) + lx;
-        st.g[0] = g0p[off]; st.g[1] = g0p[off + 1]; st.g[2] = g0p[off + lw]; st.g[3] = g0p[off + lw + 1];
-        int im, ip, cim, cip;
-        const int i = ly >> 1, ci = y >> 1;
-        up_idx(i, sh, im, ip);
-        up_idx(ci, a.ch[1], cim, cip);
-        const int rr[3] = {__mul24(im, sw), __mul24(i, sw), __mul24(ip, sw)};
-        const int ur_[3] = {__mul24(cim - ur.y0, upitch), __mul24(ci - ur.y0, upitch), __mul24(cip - ur.y0, upitch)};
+// v - sign(v)
+__device__ __forceinline__ int toward_zero(int v)
+{
+    int sgn;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(sgn) : "v"(v));
+    return v - sgn;
+}
+
+// Level L (0 in k_blend_fine, 1 in k_blend_coarse) of a tile that is owned by one camera (see band_quad), is not the
+// top level and covers a whole 128 x 64 region (for level 0: inside the final crop).  Every quad is valid; a wave
+// takes a strip of the tile one quad row wide (64 quads: lane == quad column) and walks down it.  cv::pyrUp is
+// separable, and both of its sources here -- the camera's Gaussian level L + 1 and the collapsed canvas level
+// L + 1 -- advance by exactly one source row per quad row.  So a lane
+//   * loads ONE source pixel of each per quad row (its own column; the two columns beside it come from the lanes
+//     beside it over DPP, and only the first and last lane of each 16-lane DPP row fetch an outer column -- one
+//     masked load instruction), not a 3 x 3 block,
+//   * filters that row horizontally once and keeps the last three filtered rows in registers,
+// and the vertical taps then only combine registers.  Per quad: 6 loads instead of 20, a third of the horizontal
+// filter work; the loads of the next row are issued before the current quad row is evaluated.
+// `up` is the collapsed level L + 1: the global level-1 canvas (L == 0; pitch cw[1], origin 0) or the tile's LDS
+// region of level 2 (L == 1).  Output: the panorama (L == 0; 12-byte stores, see store_quad) or the collapsed
+// level-1 canvas (L == 1).
+template <int L, typename UpPtr>
+__device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, const BlendArgs& a, const Region& r,
+                                            uint32_t cam_bits, UpPtr up, int up_x0, int up_y0, int up_pitch,
+                                            uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask, uint64_t* __restrict__ c1_out)
+{
+    static_assert(C_TW == 128 && (C_TH / 2) % (C_THREADS / 64) == 0 && CC_TW == C_TW && CC_TH == C_TH, "one wave per quad row of the tile");
+    constexpr int kRows = (C_TH / 2) / (C_THREADS / 64);        // quad rows per wave
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const CamDesc& c = cams[__builtin_ctz(cam_bits)];
+    const int lw = c.lw[L], sw = c.lw[L + 1], sh = c.lh[L + 1], uw = a.cw[L + 1], uh = a.ch[L + 1];
+    const int x = r.x0 + 2 * lane, y0 = r.y0 + 2 * kRows * wave;
+    const int lx = x - c.ox[L], ly0 = y0 - c.oy[L];
+    const int j = lx >> 1, cj = x >> 1;
+    int jm, jp, cjm, cjp;
+    up_idx(j, sw, jm, jp);
+    up_idx(cj, uw, cjm, cjp);
+    const bool first = (lane & 15) == 0, last = (lane & 15) == 15, edge = first || last;
+    const int je = first ? jm : jp, cje = (first ? cjm : cjp) - up_x0;    // the outer column an edge lane fetches itself
+    const int cjc = cj - up_x0;
+    const uint32_t MST_GLOBAL* __restrict__ gup = gp(c.G[L + 1]);
+    const GPix MST_GLOBAL* gq = (const GPix MST_GLOBAL*)(c.G[L] + (__umul24(ly0, lw) + lx));   // this lane's quad, upper row
+    const bool odd = (lane & 1) != 0;
+
+    struct Raw { uint32_t g, ge; uint2 u, ue; };                 // one source row as loaded: own column, outer column
+    struct RowG { uint32_t hebr, hobr, heg, hog; };              // horizontally filtered: even / odd output column
+    struct RowC { int he[3], ho[3]; };
+    auto load_row = [&](Raw& w, int gi, int ci) {                // source row gi of the camera's level, ci of the canvas'
+        const int go = __mul24(gi, sw), co = __mul24(ci - up_y0, up_pitch);
+        w.g = gup[go + j];
+        w.u = as_u2(up[co + cjc]);
+        w.ge = 0u; w.ue = make_uint2(0u, 0u);
+        if (edge) { w.ge = gup[go + je]; w.ue = as_u2(up[co + cje]); }
+    };
+    auto filter_row = [&](const Raw& w, RowG& g, RowC& u) {
+        // (the shifts first, on every lane: a lane switched off by a branch would not be readable by its neighbour)
+        const uint32_t gb = from_lane_below(w.g), ga = from_lane_above(w.g);
+        const uint32_t uxb = from_lane_below(w.u.x), uyb = from_lane_below(w.u.y);
+        const uint32_t uxa = from_lane_above(w.u.x), uya = from_lane_above(w.u.y);
+        const uint32_t gl = first ? w.ge : gb, gr = last ? w.ge : ga;
+        g.hebr = lanes_br(gl) + 6u * lanes_br(w.g) + lanes_br(gr);
+        g.hobr = 4u * (lanes_br(w.g) + lanes_br(gr));
+        g.heg = lane_g(gl) + 6u * lane_g(w.g) + lane_g(gr);
+        g.hog = 4u * (lane_g(w.g) + lane_g(gr));
+        const uint32_t ulx = first ? w.ue.x : uxb, uly = first ? w.ue.y : uyb;
+        const uint32_t urx = last ? w.ue.x : uxa, ury = last ? w.ue.y : uya;
+        const int av[3] = {s16_lo(ulx), s16_hi(ulx), s16_lo(uly)};
+        const int bv[3] = {s16_lo(w.u.x), s16_hi(w.u.x), s16_lo(w.u.y)};
+        const int cv[3] = {s16_lo(urx), s16_hi(urx), s16_lo(ury)};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            st.nb[k][0] = g1p[rr[k] + jm]; st.nb[k][1] = g1p[rr[k] + j]; st.nb[k][2] = g1p[rr[k] + jp];
-            st.u[k][0] = s_up[ur_[k] + uc[0]]; st.u[k][1] = s_up[ur_[k] + uc[1]]; st.u[k][2] = s_up[ur_[k] + uc[2]];
+        for (int ch = 0; ch < 3; ++ch) {
+            u.he[ch] = av[ch] + 6 * bv[ch] + cv[ch];
+            u.ho[ch] = 4 * (bv[ch] + cv[ch]);
         }
     };
-    auto finish = [&](const Stage& st, int y) {
+
+    // the three source rows of the strip's first quad row (clamped like cv::pyrUp's border); afterwards one new row each
+    const int i0 = ly0 >> 1, ci0 = y0 >> 1;
+    RowG rg[3];
+    RowC rc[3];
+    {
+        int im, ip, cim, cip;
+        up_idx(i0, sh, im, ip);
+        up_idx(ci0, uh, cim, cip);
+        Raw w0, w1, w2;
+        load_row(w0, im, cim); load_row(w1, i0, ci0); load_row(w2, ip, cip);
+        filter_row(w0, rg[0], rc[0]); filter_row(w1, rg[1], rc[1]); filter_row(w2, rg[2], rc[2]);
+    }
+    GPix q0 = gq[0], q1 = *(const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)gq + lw);
+    // output pointers of this lane, advanced by two rows per quad row
+    uint8_t* po = nullptr;           // L == 0: even lanes write the upper row of a lane pair's two quads, odd lanes the lower
+    uint8_t* pm = nullptr;
+    GPix MST_GLOBAL* co = nullptr;   // L == 1
+    if (L == 0) {
+        po = pano + __umul24(y0 + (odd ? 1 : 0), a.pano_stride) + (odd ? x - 2 : x) * 3;
+        if (pano_mask) pm = pano_mask + __umul24(y0, a.mask_stride) + x;
+    } else {
+        co = (GPix MST_GLOBAL*)c1_out + __mul24(y0, a.cw[L]) + x;
+    }
+#pragma unroll
+    for (int t = 0; t < kRows; ++t) {
+        Raw wn;
+        GPix n0, n1;
+        if (t + 1 < kRows) {          // next quad row: its new source row (i + 2, clamped) and its Gaussian quad
+            load_row(wn, min(i0 + t + 2, sh - 1), min(ci0 + t + 2, uh - 1));
+            gq = (const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)gq + 2 * lw);
+            n0 = gq[0];
+            n1 = *(const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)gq + lw);
+        }
+        const uint32_t g[4] = {q0.x, q0.y, q1.x, q1.y};
         uint32_t ubr[4], ug[4];
-        pyrup_quad_packed(st.nb, ubr, ug);
-        int up[4][3];
-        pyrup_quad_s16(st.u, up);
-        uint32_t o8[4][3];
-        const bool all[4] = {true, true, true, true};
+        ubr[0] = rg[0].hebr + 6u * rg[1].hebr + rg[2].hebr;  ug[0] = rg[0].heg + 6u * rg[1].heg + rg[2].heg;
+        ubr[1] = rg[0].hobr + 6u * rg[1].hobr + rg[2].hobr;  ug[1] = rg[0].hog + 6u * rg[1].hog + rg[2].hog;
+        ubr[2] = 4u * (rg[1].hebr + rg[2].hebr);             ug[2] = 4u * (rg[1].heg + rg[2].heg);
+        ubr[3] = 4u * (rg[1].hobr + rg[2].hobr);             ug[3] = 4u * (rg[1].hog + rg[2].hog);
+        int upv[4][3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            upv[0][ch] = sat_s16((rc[0].he[ch] + 6 * rc[1].he[ch] + rc[2].he[ch] + 32) >> 6);
+            upv[1][ch] = sat_s16((rc[0].ho[ch] + 6 * rc[1].ho[ch] + rc[2].ho[ch] + 32) >> 6);
+            upv[2][ch] = sat_s16((4 * (rc[1].he[ch] + rc[2].he[ch]) + 32) >> 6);
+            upv[3][ch] = sat_s16((4 * (rc[1].ho[ch] + rc[2].ho[ch]) + 32) >> 6);
+        }
+        int v[4][3];                 // collapsed level L
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int lb = static_cast<int>(st.g[q] & 0xFF) - static_cast<int>(ubr[q] & 0xFFFF);
-            const int lg = static_cast<int>((st.g[q] >> 8) & 0xFF) - static_cast<int>(ug[q]);
-            const int lr = static_cast<int>((st.g[q] >> 16) & 0xFF) - static_cast<int>(ubr[q] >> 16);
-            const int n[3] = {lb - (lb > 0) + (lb < 0), lg - (lg > 0) + (lg < 0), lr - (lr > 0) + (lr < 0)};
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) o8[q][ch] = static_cast<uint32_t>(sat_u8(sat_s16(up[q][ch] + n[ch])));
+            const uint32_t pbr = ((ubr[q] + 0x00200020u) >> 6) & 0x03FF03FFu, pg = (ug[q] + 32u) >> 6;
+            const int lb = static_cast<int>(g[q] & 0xFF) - static_cast<int>(pbr & 0xFFFF);
+            const int lg = static_cast<int>((g[q] >> 8) & 0xFF) - static_cast<int>(pg);
+            const int lr = static_cast<int>((g[q] >> 16) & 0xFF) - static_cast<int>(pbr >> 16);
+            // normalised band of an owned pixel: lap - sign(lap) (see band_quad); cv::add saturates
+            v[q][0] = sat_s16(upv[q][0] + toward_zero(lb));
+            v[q][1] = sat_s16(upv[q][1] + toward_zero(lg));
+            v[q][2] = sat_s16(upv[q][2] + toward_zero(lr));
         }
-        store_quad(a, pano, pano_mask, x, y, all, o8, all, store_mode);
-    };
-    Stage sa, sb;
-    load(sa, y0);
+        if (L == 0) {
+            uint32_t o8[4][3];
 #pragma unroll
-    for (int it = 0; it < kIters; it += 2) {
-        if (it + 1 < kIters) load(sb, y0 + (it + 1) * kRowStep);
-        finish(sa, y0 + it * kRowStep);
-        if (it + 2 < kIters) load(sa, y0 + (it + 2) * kRowStep);
-        if (it + 1 < kIters) finish(sb, y0 + (it + 1) * kRowStep);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) o8[q][ch] = static_cast<uint32_t>(sat_u8(v[q][ch]));
+            // 6 bytes per quad row: B0 G0 R0 B1 | G1 R1; lane pairs swap so that each lane holds one row of four pixels
+            const uint32_t lo0 = o8[0][0] | o8[0][1] << 8 | o8[0][2] << 16 | o8[1][0] << 24, hi0 = o8[1][1] | o8[1][2] << 8;
+            const uint32_t lo1 = o8[2][0] | o8[2][1] << 8 | o8[2][2] << 16 | o8[3][0] << 24, hi1 = o8[3][1] | o8[3][2] << 8;
+            const uint32_t rlo = lane_swap1(odd ? lo0 : lo1), rhi = lane_swap1(odd ? hi0 : hi1);
+            const uint32_t flo = odd ? rlo : lo0, fhi = odd ? rhi : hi0;
+            const uint32_t slo = odd ? lo1 : rlo, shi = odd ? hi1 : rhi;
+            uint3 w;
+            w.x = flo;
+            w.y = (fhi & 0xFFFFu) | slo << 16;
+            w.z = slo >> 16 | shi << 16;
+            *reinterpret_cast<uint3*>(po) = w;
+            po += 2 * a.pano_stride;
+            if (pm) {
+                pm[0] = 255; pm[1] = 255; pm[a.mask_stride] = 255; pm[a.mask_stride + 1] = 255;
+                pm += 2 * a.mask_stride;
+            }
+        } else {
+            typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+#pragma unroll
+            for (int ry = 0; ry < 2; ++ry) {
+                const uint2 p0 = pack3(v[2 * ry][0], v[2 * ry][1], v[2 * ry][2]);
+                const uint2 p1 = pack3(v[2 * ry + 1][0], v[2 * ry + 1][1], v[2 * ry + 1][2]);
+                *reinterpret_cast<u32x4 MST_GLOBAL*>(co + __mul24(ry, a.cw[L])) = u32x4{p0.x, p0.y, p1.x, p1.y};
+                if (a.dbg_C[L]) { dump_level(a, L, x, y0 + 2 * t + ry, v[2 * ry]); dump_level(a, L, x + 1, y0 + 2 * t + ry, v[2 * ry + 1]); }
+            }
+            co += 2 * a.cw[L];
+        }
+        if (t + 1 < kRows) {
+            rg[0] = rg[1]; rg[1] = rg[2];
+            rc[0] = rc[1]; rc[1] = rc[2];
+            filter_row(wn, rg[2], rc[2]);
+            q0 = n0; q1 = n1;
+        }
     }
 }
 
-// phase 3: level 0 band + pyrUp of collapsed level 1 -> crop, mask, convertTo(8U), panorama
+// level 0 band + pyrUp of the collapsed level-1 canvas -> crop, mask, convertTo(8U), panorama
 template <bool TOP, bool PURE, bool W16 = false>
-__device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int tx, int ty,
-                                            uint32_t cam_bits, const uint2* __restrict__ lds, uint8_t* __restrict__ pano,
-                                            uint8_t* __restrict__ pano_mask, const int* __restrict__ s_reg)
+__device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, const BlendArgs& a, const Region& r,
+                                            uint32_t cam_bits, C1Ptr __restrict__ s_up,
+                                            uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask)
 {
-    const QuadIter it(s_reg, 0);
-    Region ur = it.r;
-    const uint2* s_up = nullptr;
-    if (!TOP) {
-        ur = table_region(s_reg, 1);
-        s_up = lds + a.lds_off[1];
-    }
+    const QuadIter it(r);
     const bool blocked = !PURE && !(MST_ABLATE_C & 256) && it.blockable();
     // lane pairs hold horizontally adjacent quads when a quad row has an even number of quads (row-major order) or in
     // the 8 x 8 blocked order; the region starts on a multiple of C_TW
@@ -1497,7 +1621,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
         int up[4][3];
         if (MST_ABLATE_C & 4) {
             for (int k = 0; k < 4; ++k) up[k][0] = up[k][1] = up[k][2] = x - y + k;
-        } else if (!TOP) pyrup_quad_lds(s_up, ur.x0, ur.y0, region_pitch(ur), a.cw[1], a.ch[1], x >> 1, y >> 1, up);
+        } else if (!TOP) pyrup_quad_lds(s_up, 0, 0, a.cw[1], a.cw[1], a.ch[1], x >> 1, y >> 1, up);
         uint32_t o8[4][3];
         bool m[4];
 #pragma unroll
@@ -1513,88 +1637,181 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
     }
 }
 
+// The base level of k_blend_coarse (level 1): its band is formed like any other, the collapsed level above comes out
+// of LDS, and the sum -- the collapsed level-1 canvas -- goes to global memory for k_blend_fine (8 bytes a pixel).
+template <bool TOP, bool PURE, bool W16 = false>
+__device__ __forceinline__ void coarse_base_level(const CamDesc* __restrict__ cams, const BlendArgs& a, uint32_t cam_bits,
+                                                  const uint2* __restrict__ lds, const int* __restrict__ s_reg,
+                                                  uint2* __restrict__ c1)
+{
+    constexpr int l = 1;
+    const QuadIter it(s_reg, l);
+    Region ur = it.r;
+    const uint2* s_up = nullptr;
+    if (!TOP) {
+        ur = table_region(s_reg, l + 1);
+        s_up = lds + a.lds_off[l + 1];
+    }
+    const int cw = a.cw[l];
+    const bool wide = (cw & 1) == 0;       // rows start 16-byte aligned (c1 is), x is even
+    for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
+        int x, y;
+        bool valid[4];
+        it.at(q, x, y, valid);
+        int n[4][3];
+        float ws[4];
+        band_quad<TOP, false, PURE, W16>(cams, a, l, x, y, valid, cam_bits, n, ws);
+        int up[4][3];
+        if (!TOP) pyrup_quad_lds(s_up, ur.x0, ur.y0, region_pitch(ur), a.cw[l + 1], a.ch[l + 1], x >> 1, y >> 1, up);
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry) {
+            if (!valid[2 * ry]) continue;
+            int v[2][3];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    v[k][ch] = TOP ? n[2 * ry + k][ch] : sat_s16(up[2 * ry + k][ch] + n[2 * ry + k][ch]);   // cv::add saturates
+            const int py = y + ry;
+            GPix MST_GLOBAL* o = (GPix MST_GLOBAL*)c1 + __mul24(py, cw) + x;
+            const uint2 p0 = pack3(v[0][0], v[0][1], v[0][2]), p1 = pack3(v[1][0], v[1][1], v[1][2]);
+            if (wide && valid[2 * ry + 1]) {
+                typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+                const u32x4 w = {p0.x, p0.y, p1.x, p1.y};
+                *reinterpret_cast<u32x4 MST_GLOBAL*>(o) = w;
+            } else {
+                o[0] = GPix{p0.x, p0.y};
+                if (valid[2 * ry + 1]) o[1] = GPix{p1.x, p1.y};
+            }
+            if (a.dbg_C[l]) {
+                dump_level(a, l, x, py, v[0]);
+                if (valid[2 * ry + 1]) dump_level(a, l, x + 1, py, v[1]);
+            }
+        }
+    }
+}
+
 // W16 (weight_type CV_16S) is a separate instantiation: its integer divides would otherwise set the register
 // allocation (and spill) for the default kernel as well.
 #ifndef MST_C_WAVES
 #define MST_C_WAVES 1      // minimum waves per SIMD the register allocation must allow (occupancy experiments)
 #endif
-template <bool W16>
-__global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend(const CamDesc* __restrict__ cams_all, BlendArgs a)
+
+// 1-D grids over (tile, frame set).  Blocks are dealt to the XCDs round-robin, so XCD k = blockIdx.x % 8 sees the
+// blocks j = blockIdx.x / 8 in order: consecutive j are the frame sets of one tile (the weight pyramids and masks a
+// seam tile reads are frame-invariant: fetched into that XCD's L2 once, shared by the other sets), and tiles go to
+// the XCDs round-robin in launch order, which keeps "most expensive first" true on every XCD.
+__device__ __forceinline__ bool tile_of_block(int n_tiles, int n_sets, int& q, int& set)
 {
-    // 1-D grid over (tile, frame set).  Blocks are dealt to the XCDs round-robin, so XCD k = blockIdx.x % 8 sees the
-    // blocks j = blockIdx.x / 8 in order: consecutive j are the frame sets of one tile (the weight pyramids and
-    // masks a seam tile reads are frame-invariant: fetched into that XCD's L2 once, shared by the other sets), and
-    // tiles go to the XCDs round-robin in launch order, which keeps "most expensive first" true on every XCD.
     const int xj = blockIdx.x >> 3, xk = blockIdx.x & 7;
-    const int q = (xj / a.n_sets) * 8 + xk, set = xj % a.n_sets;
-    if (q >= a.n_tiles) return;
+    q = (xj / n_sets) * 8 + xk;
+    set = xj % n_sets;
+    return q < n_tiles;
+}
+
+// Canvas kernel 1 of 2: levels 1 .. top of the canvas pyramid, one block per CC_TW x CC_TH tile of LEVEL 1.
+//   phase 1  bands of the levels 2 .. top over the tile's regions (tile + pyrUp halo), normalised, into LDS
+//   phase 2  restoreImageFromLaplacePyr inside LDS down to level 2
+//   phase 3  level-1 band + pyrUp(level 2) -> the collapsed level-1 canvas in global memory
+// Level 1 and above hold a quarter of the pixels but -- with the halo every level adds around a tile -- took three
+// quarters of the time of the single canvas kernel this replaces: tiles four times as large in panorama terms
+// halve the halo at every level, and level 0 runs as a streaming kernel of its own with no LDS and no barrier.
+template <bool W16>
+__global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_coarse(const CamDesc* __restrict__ cams_all, BlendArgs a)
+{
+    int q, set;
+    if (!tile_of_block(a.n_coarse_tiles, a.n_sets, q, set)) return;
     const CamDesc* __restrict__ cams = cams_all + set * a.n_cams;
-    uint8_t* __restrict__ pano = a.pano[set];
-    uint8_t* __restrict__ pano_mask = a.pano_mask[set];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* lds = reinterpret_cast<uint2*>(smem);
-    const uint32_t tile = a.block_order[q];
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const uint32_t entry = a.block_cams[tile];
-    const bool pure = (MST_ABLATE_C & 32) ? true : (entry >> 31) != 0;   // see band_quad: one camera, weight exactly 1 everywhere
+    const uint32_t tile = a.coarse_order[q];
+    const int tx = tile % a.coarse_tiles_x, ty = tile / a.coarse_tiles_x;
+    const uint32_t entry = a.coarse_cams[tile];
+    const bool pure = (entry >> 31) != 0;            // see band_quad: one camera, weight exactly 1 on every level
     const uint32_t cam_bits = entry & 0x7FFFFFFFu;
     // levels of this tile owned by one camera with weight exactly 1 (bit l), and that camera
-    const uint32_t own = (MST_ABLATE_C & 512) ? 0u : a.block_pure[tile];
+    const uint32_t own = (MST_ABLATE_C & 512) ? 0u : a.coarse_pure[tile];
     const uint32_t owned_levels = own & 0xFFFFu, owner_bits = 1u << (own >> 16);
     const int top = a.nlev - 1;
     MST_STAMP(1, 0);
     MST_STAMP_VAL(1, 8, static_cast<unsigned long long>(entry));
     __shared__ __attribute__((aligned(16))) int s_reg[kMaxLevels * kRegionRow];     // 352 bytes: keeps the dynamic base 16-aligned
-    fill_region_table(a, tx, ty, s_reg);
+    fill_region_table(a, 1, tx, ty, s_reg);
     __syncthreads();
-    if (top == 0) {
-        if (pure) final_level<true, true>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask, s_reg);
-        else final_level<true, false, W16>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask, s_reg);
+    if (top >= 2) {
+        // phase 1: every band above level 1, independent of each other -> no barrier until all are in LDS
+        if (pure) band_levels<true>(cams, a, top, tx, ty, cam_bits, lds, s_reg, 2);
+        else band_levels<false, W16>(cams, a, top, tx, ty, cam_bits, lds, s_reg, 2, owned_levels, owner_bits);
+        MST_STAMP(1, 1);
+        __syncthreads();
+        MST_STAMP(1, 2);
+        // phase 2: collapse coarse to fine (LDS only)
+        if (a.dbg_C[top]) {
+            const QuadIter it(s_reg, top);
+            const uint2* s = lds + a.lds_off[top];
+            for (int i = threadIdx.x; i < it.rw * (it.r.y1 - it.r.y0); i += C_THREADS) {
+                const int py = it.r.y0 + i / it.rw, px = it.r.x0 + i % it.rw;
+                const uint2 n = s[(py - it.r.y0) * it.pitch + (px - it.r.x0)];
+                const int v[3] = {s16_lo(n.x), s16_hi(n.x), s16_lo(n.y)};
+                dump_level(a, top, px, py, v);
+            }
+        }
+        for (int l = top - 1; l >= 2; --l) {
+            collapse_level(a, l, tx, ty, lds, s_reg);
+            __syncthreads();
+        }
+    }
+    MST_STAMP(1, 3);
+    // phase 3: level 1, owned outright on every pure tile and on most tiles near -- but not on -- a seam
+    const bool own1 = pure || (owned_levels & 2u);
+    const uint32_t bits1 = pure ? cam_bits : owner_bits;
+    uint2* c1 = reinterpret_cast<uint2*>(a.c1[set]);
+    if (top == 1) {
+        if (own1) coarse_base_level<true, true>(cams, a, bits1, lds, s_reg, c1);
+        else coarse_base_level<true, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
+    } else {
+        const Region r1 = table_region(s_reg, 1), ur = table_region(s_reg, 2);
+        const bool full = r1.x1 - r1.x0 == CC_TW && r1.y1 - r1.y0 == CC_TH && (a.cw[1] & 1) == 0;
+        if (own1 && full && !(MST_ABLATE_C & 64))
+            owned_strip<1>(cams, a, r1, bits1, static_cast<const uint2*>(lds + a.lds_off[2]), ur.x0, ur.y0, region_pitch(ur),
+                           nullptr, nullptr, a.c1[set]);
+        else if (own1) coarse_base_level<false, true>(cams, a, bits1, lds, s_reg, c1);
+        else coarse_base_level<false, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
+    }
+    MST_STAMP(1, 4);
+}
+
+// Canvas kernel 2 of 2: level 0, one block per C_TW x C_TH tile of the panorama: level-0 band + pyrUp of the
+// collapsed level-1 canvas (k_blend_coarse) -> crop, mask, convertTo(8U) -> panorama.  No LDS, no barrier.
+template <bool W16>
+__global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_fine(const CamDesc* __restrict__ cams_all, BlendArgs a)
+{
+    int q, set;
+    if (!tile_of_block(a.n_tiles, a.n_sets, q, set)) return;
+    const CamDesc* __restrict__ cams = cams_all + set * a.n_cams;
+    uint8_t* __restrict__ pano = a.pano[set];
+    uint8_t* __restrict__ pano_mask = a.pano_mask[set];
+    const uint32_t tile = a.block_order[q];
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const uint32_t entry = a.block_cams[tile];       // bit 31: level 0 owned by ONE camera with weight exactly 1
+    const bool own0 = (MST_ABLATE_C & 512) ? false : (entry >> 31) != 0;
+    const uint32_t cam_bits = entry & 0x7FFFFFFFu;   // (that camera alone when owned)
+    const Region r0 = blend_region(a, 0, tx, ty, 0);
+    const C1Ptr c1 = (C1Ptr)a.c1[set];
+    MST_STAMP(2, 0);
+    MST_STAMP_VAL(2, 8, static_cast<unsigned long long>(entry));
+    if (a.nlev == 1) {
+        if (own0) final_level<true, true>(cams, a, r0, cam_bits, c1, pano, pano_mask);
+        else final_level<true, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
         return;
     }
-    // phase 1: every coarse band, independent of each other -> no barrier until all are in LDS
-    if (MST_ABLATE_C & 128) {
-        if (pure) {
-            band_level<true, true>(cams, a, top, tx, ty, cam_bits, lds, s_reg);
-            for (int l = top - 1; l >= 1; --l) band_level<false, true>(cams, a, l, tx, ty, cam_bits, lds, s_reg);
-        } else {
-            band_level<true, false>(cams, a, top, tx, ty, cam_bits, lds, s_reg);
-            for (int l = top - 1; l >= 1; --l) band_level<false, false>(cams, a, l, tx, ty, cam_bits, lds, s_reg);
-        }
-    } else if (pure) {
-        band_levels<true>(cams, a, top, tx, ty, cam_bits, lds, s_reg);
-    } else {
-        band_levels<false, W16>(cams, a, top, tx, ty, cam_bits, lds, s_reg, owned_levels, owner_bits);
-    }
-    MST_STAMP(1, 1);
-    __syncthreads();
-    MST_STAMP(1, 2);
-    // phase 2: collapse coarse to fine (LDS only)
-    if (a.dbg_C[top]) {
-        const QuadIter it(s_reg, top);
-        const uint2* s = lds + a.lds_off[top];
-        for (int i = threadIdx.x; i < it.rw * (it.r.y1 - it.r.y0); i += C_THREADS) {
-            const int py = it.r.y0 + i / it.rw, px = it.r.x0 + i % it.rw;
-            const uint2 n = s[(py - it.r.y0) * it.pitch + (px - it.r.x0)];
-            const int v[3] = {s16_lo(n.x), s16_hi(n.x), s16_lo(n.y)};
-            dump_level(a, top, px, py, v);
-        }
-    }
-    for (int l = top - 1; l >= 1; --l) {
-        if (!(MST_ABLATE_C & 2)) collapse_level(a, l, tx, ty, lds, s_reg);
-        __syncthreads();
-    }
-    // phase 3
-    MST_STAMP(1, 3);
-    const Region r0 = table_region(s_reg, 0);
     const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
-    // level 0 owned outright (true of every pure tile, and of most tiles near -- but not on -- a seam)
-    const bool own0 = pure || (owned_levels & 1u);
-    const uint32_t bits0 = pure ? cam_bits : owner_bits;
-    if (own0 && full && !(MST_ABLATE_C & 64)) final_level_pure_full(cams, a, tx, ty, bits0, lds, pano, pano_mask, s_reg);
-    else if (own0) final_level<false, true>(cams, a, tx, ty, bits0, lds, pano, pano_mask, s_reg);
-    else final_level<false, false, W16>(cams, a, tx, ty, cam_bits, lds, pano, pano_mask, s_reg);
-    MST_STAMP(1, 4);
+    if (own0 && full && !(MST_ABLATE_C & 64) && pano_store_mode(a, pano, true) == 2)
+        owned_strip<0>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (own0) final_level<false, true>(cams, a, r0, cam_bits, c1, pano, pano_mask);
+    else final_level<false, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
+    MST_STAMP_VAL(2, 9, static_cast<unsigned long long>(full));
+    MST_STAMP(2, 1);
 }
 
 }  // namespace
@@ -1620,7 +1837,7 @@ int mb_chain_depth() { return B_KMAX; }
 int mb_read_stamps(int which, unsigned long long* out, size_t n)
 {
 #if defined(MST_STAMPS)
-    if (which < 0 || which > 1 || n > (size_t{1} << 17)) return -1;
+    if (which < 0 || which > 2 || n > (size_t{1} << 17)) return -1;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long),
                                static_cast<size_t>(which) * sizeof(unsigned long long) * (size_t{1} << 17),
                                hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
@@ -1630,15 +1847,17 @@ int mb_read_stamps(int which, unsigned long long* out, size_t n)
 #endif
 }
 
-void mb_blend_region(const BlendArgs& a, int tx, int ty, int level, int out[4])
+void mb_coarse_tile_dims(int* tw, int* th) { *tw = CC_TW; *th = CC_TH; }
+
+void mb_blend_region(const BlendArgs& a, int base, int tx, int ty, int level, int out[4])
 {
-    const Region r = blend_region(a, tx, ty, level);
+    const Region r = blend_region(a, base, tx, ty, level);
     out[0] = r.x0; out[1] = r.y0; out[2] = r.x1; out[3] = r.y1;
 }
 
-int mb_blend_region_lds_pixels(const BlendArgs& a, int tx, int ty, int level)
+int mb_blend_region_lds_pixels(const BlendArgs& a, int base, int tx, int ty, int level)
 {
-    const Region r = blend_region(a, tx, ty, level);
+    const Region r = blend_region(a, base, tx, ty, level);
     return region_pitch(r) * (r.y1 - r.y0);
 }
 
@@ -1673,16 +1892,23 @@ void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, i
     else hipLaunchKernelGGL(k_pyr_chain<2>, dim3(list.count, batch), dim3(B_THREADS), 0, s, d_cams, list, base, n_cams);
 }
 
-void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, int batch, size_t lds_bytes, hipStream_t s)
+void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
+                  hipStream_t s)
 {
     static const size_t pad = tuning_env("MST_C_PAD_LDS");
     if (num_blocks <= 0 || batch <= 0) return;
     BlendArgs a = a_in;
     a.n_tiles = num_blocks;
+    a.n_coarse_tiles = num_coarse;
     a.n_sets = batch;
+    if (a.nlev > 1) {
+        const int grid = ((num_coarse + 7) / 8) * 8 * batch;
+        if (a.weights_16s) hipLaunchKernelGGL(k_blend_coarse<true>, dim3(grid), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
+        else hipLaunchKernelGGL(k_blend_coarse<false>, dim3(grid), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
+    }
     const int grid = ((num_blocks + 7) / 8) * 8 * batch;
-    if (a.weights_16s) hipLaunchKernelGGL(k_blend<true>, dim3(grid), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
-    else hipLaunchKernelGGL(k_blend<false>, dim3(grid), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
+    if (a.weights_16s) hipLaunchKernelGGL(k_blend_fine<true>, dim3(grid), dim3(C_THREADS), 0, s, d_cams, a);
+    else hipLaunchKernelGGL(k_blend_fine<false>, dim3(grid), dim3(C_THREADS), 0, s, d_cams, a);
 }
 
 }  // namespace mst

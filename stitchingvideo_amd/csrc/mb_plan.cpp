@@ -247,11 +247,16 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
         plan.payload_cam_start.push_back(static_cast<int>(plan.payload_rects.size()));
     }
     mark("warp + chain tile lists");
-    // ---- kernel C: canvas tiles, camera bit masks, LDS layout
+    // ---- canvas kernels: panorama tiles (k_blend_fine, level 0) and level-1 tiles (k_blend_coarse, levels 1 .. top)
+    int cc_tw, cc_th;
+    mb_coarse_tile_dims(&cc_tw, &cc_th);
     plan.blend_tiles_x = (blend.cw[0] + c_tw - 1) / c_tw;
     plan.blend_tiles_y = (blend.ch[0] + c_th - 1) / c_th;
     plan.block_cams.assign(static_cast<size_t>(plan.blend_tiles_x) * plan.blend_tiles_y, 0u);
-    plan.block_pure.assign(plan.block_cams.size(), 0u);
+    plan.coarse_tiles_x = nlev > 1 ? (blend.cw[1] + cc_tw - 1) / cc_tw : 0;
+    plan.coarse_tiles_y = nlev > 1 ? (blend.ch[1] + cc_th - 1) / cc_th : 0;
+    plan.coarse_cams.assign(static_cast<size_t>(plan.coarse_tiles_x) * plan.coarse_tiles_y, 0u);
+    plan.coarse_pure.assign(plan.coarse_cams.size(), 0u);
     std::vector<int> max_area(nlev, 0);
     // any non-zero weight of camera c at level l inside [x0,x1) x [y0,y1) of the canvas level?  all exactly `unit`
     // (and the camera's window covering the rectangle)?
@@ -278,33 +283,50 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                 if (!(w[static_cast<size_t>(y) * d.lw[l] + x] & 2u)) return false;
         return true;
     };
-    std::vector<std::vector<int>> row_area(plan.blend_tiles_y, std::vector<int>(nlev, 0));
+    auto covers = [&](int c, int l, int rx0, int ry0, int rx1, int ry1) {       // camera window over the whole rectangle?
+        const CamDesc& d = desc[c];
+        return rx0 - d.ox[l] >= 0 && ry0 - d.oy[l] >= 0 && rx1 - d.ox[l] <= d.lw[l] && ry1 - d.oy[l] <= d.lh[l];
+    };
+    // Panorama tiles.  A tile whose level 0 is owned by ONE camera with a weight of exactly 1.0f everywhere inside the
+    // final crop (pixels outside are never stored), and no other camera with a non-zero weight there, takes the
+    // integer-only band path (bit 31 + that camera's bit alone).
     parallel_for(plan.blend_tiles_y, 64, [&](int ty) {
-        std::vector<int>& max_area = row_area[ty];
         for (int tx = 0; tx < plan.blend_tiles_x; ++tx) {
+            int r[4];
+            mb_blend_region(blend, 0, tx, ty, 0, r);
             uint32_t bits = 0;
-            // Levels on which the tile's region is owned by ONE camera with a weight of exactly 1.0f everywhere (and no
-            // other camera has a non-zero weight there): kernel C forms those bands on its integer-only path.  Level 0
-            // only counts the part of the region inside the final crop (pixels outside are never stored).  A tile whose
-            // levels are all owned by the same camera is "pure" (bit 31 of block_cams): no float arithmetic at all.
-            uint32_t level_mask = 0;
+            for (int c = 0; c < n; ++c)
+                if (any_nonzero(c, 0, r[0], r[1], r[2], r[3])) bits |= 1u << c;
+            const int cx1 = std::min(r[2], blend.final_w), cy1 = std::min(r[3], blend.final_h);
+            if (r[0] < cx1 && r[1] < cy1) {
+                uint32_t lbits = 0;
+                for (int c = 0; c < n; ++c)
+                    if (any_nonzero(c, 0, r[0], r[1], cx1, cy1)) lbits |= 1u << c;
+                if (lbits != 0 && (lbits & (lbits - 1)) == 0) {
+                    const int c = __builtin_ctz(lbits);
+                    if (all_unit(c, 0, r[0], r[1], cx1, cy1) && covers(c, 0, r[0], r[1], r[2], r[3])) bits = lbits | 0x80000000u;
+                }
+            }
+            plan.block_cams[static_cast<size_t>(ty) * plan.blend_tiles_x + tx] = bits;
+        }
+    });
+    // Level-1 tiles.  Levels on which the tile's region (tile + pyrUp halo) is owned by ONE camera with a weight of
+    // exactly 1.0f everywhere and no other camera has a non-zero weight there go down the integer path as well; a
+    // tile whose levels are all owned by the same camera is "pure" (bit 31 of coarse_cams): no float arithmetic.
+    std::vector<std::vector<int>> row_area(plan.coarse_tiles_y, std::vector<int>(nlev, 0));
+    parallel_for(plan.coarse_tiles_y, 64, [&](int ty) {
+        std::vector<int>& max_area = row_area[ty];
+        for (int tx = 0; tx < plan.coarse_tiles_x; ++tx) {
+            uint32_t bits = 0, level_mask = 0;
             int owner = -1;
-            for (int l = 0; l < nlev; ++l) {
+            for (int l = 1; l < nlev; ++l) {
                 int r[4];
-                mb_blend_region(blend, tx, ty, l, r);
-                max_area[l] = std::max(max_area[l], mb_blend_region_lds_pixels(blend, tx, ty, l));
+                mb_blend_region(blend, 1, tx, ty, l, r);
+                max_area[l] = std::max(max_area[l], mb_blend_region_lds_pixels(blend, 1, tx, ty, l));
                 uint32_t lbits = 0;
                 for (int c = 0; c < n; ++c)
                     if (any_nonzero(c, l, r[0], r[1], r[2], r[3])) lbits |= 1u << c;
                 bits |= lbits;
-                if (l == 0) {           // ownership of level 0 is judged inside the crop
-                    r[2] = std::min(r[2], blend.final_w);
-                    r[3] = std::min(r[3], blend.final_h);
-                    if (r[0] >= r[2] || r[1] >= r[3]) continue;
-                    lbits = 0;
-                    for (int c = 0; c < n; ++c)
-                        if (any_nonzero(c, l, r[0], r[1], r[2], r[3])) lbits |= 1u << c;
-                }
                 if (lbits != 0 && (lbits & (lbits - 1)) == 0) {
                     const int c = __builtin_ctz(lbits);
                     if ((owner < 0 || owner == c) && all_unit(c, l, r[0], r[1], r[2], r[3])) {
@@ -313,37 +335,44 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                     }
                 }
             }
-            const size_t ti = static_cast<size_t>(ty) * plan.blend_tiles_x + tx;
-            // all levels owned, and by the one camera that has weights under the tile at all -> the pure tile of old
-            // (level 0 judged over the whole region there as well, as the pure path's band covers all of it)
-            if (owner >= 0 && level_mask == (1u << nlev) - 1u && bits == (1u << owner)) {
-                int r[4];
-                mb_blend_region(blend, tx, ty, 0, r);
-                if (all_unit(owner, 0, r[0], r[1], r[2], r[3])) bits |= 0x80000000u;
-            }
-            plan.block_cams[ti] = bits;
-            plan.block_pure[ti] = owner >= 0 ? (level_mask | static_cast<uint32_t>(owner) << 16) : 0u;
+            const size_t ti = static_cast<size_t>(ty) * plan.coarse_tiles_x + tx;
+            if (owner >= 0 && level_mask == ((1u << nlev) - 2u) && bits == (1u << owner)) bits |= 0x80000000u;
+            plan.coarse_cams[ti] = bits;
+            plan.coarse_pure[ti] = owner >= 0 ? (level_mask | static_cast<uint32_t>(owner) << 16) : 0u;
         }
     });
     mark("canvas tiles");
+    if (timing) {
+        int owned = 0, pure = 0, own1 = 0;
+        for (uint32_t e : plan.block_cams) owned += e >> 31;
+        for (uint32_t e : plan.coarse_cams) pure += e >> 31;
+        for (uint32_t e : plan.coarse_pure) own1 += (e >> 1) & 1u;
+        std::fprintf(stderr, "[mst_update]   plan: %zu panorama tiles (%d with level 0 owned), %zu level-1 tiles (%d pure, %d with level 1 owned)\n",
+                     plan.block_cams.size(), owned, plan.coarse_cams.size(), pure, own1);
+    }
     for (const std::vector<int>& ra : row_area)
         for (int l = 0; l < nlev; ++l) max_area[l] = std::max(max_area[l], ra[l]);
-    // launch order: every canvas tile is resident at once on a 256-CU part, so the dispatcher's round-robin
-    // placement is the only load balancing there is -- hand out the expensive tiles (several cameras under the
-    // tile, float path) first so that they land on different CUs, then the single-camera integer-path tiles
-    plan.block_order.resize(plan.block_cams.size());
-    for (size_t i = 0; i < plan.block_order.size(); ++i) plan.block_order[i] = static_cast<uint32_t>(i);
-    auto cost = [&](uint32_t tile) {
-        const uint32_t e = plan.block_cams[tile];
-        const int cams_under = __builtin_popcount(e & 0x7FFFFFFFu);
-        if (e >> 31) return 4;                          // relative: integer path everywhere
-        const bool l0_owned = plan.block_pure[tile] & 1u;       // float bands on some coarse levels only
-        return (l0_owned ? 6 : 10) + 2 * cams_under;
+    // launch order: every tile is resident at once on a 256-CU part, so the dispatcher's round-robin placement is
+    // the only load balancing there is -- hand out the expensive tiles (several cameras under the tile, float
+    // path) first so that they land on different CUs, then the single-camera integer-path tiles
+    auto ordered = [](const std::vector<uint32_t>& entries, auto cost) {
+        std::vector<uint32_t> order(entries.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = static_cast<uint32_t>(i);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
+        return order;
     };
-    std::stable_sort(plan.block_order.begin(), plan.block_order.end(),
-                     [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
+    plan.block_order = ordered(plan.block_cams, [&](uint32_t tile) {
+        const uint32_t e = plan.block_cams[tile];
+        return (e >> 31) ? 4 : 10 + 2 * __builtin_popcount(e);
+    });
+    plan.coarse_order = ordered(plan.coarse_cams, [&](uint32_t tile) {
+        const uint32_t e = plan.coarse_cams[tile];
+        if (e >> 31) return 4;                                  // relative: integer path everywhere
+        const bool l1_owned = plan.coarse_pure[tile] & 2u;      // float bands on some coarser levels only
+        return (l1_owned ? 6 : 10) + 2 * __builtin_popcount(e);
+    });
     int off = 0;
-    for (int l = 1; l < nlev; ++l) {
+    for (int l = 2; l < nlev; ++l) {
         plan.lds_off[l] = off;
         off += (max_area[l] + 1) & ~1;
     }

@@ -32,10 +32,13 @@ struct MbPlanHost {
     std::vector<int> warp_cam_start;                          // n+1 offsets into warp_tiles
     struct ChainStep { int base, k; std::vector<uint32_t> tiles; std::vector<int> cam_start; };
     std::vector<ChainStep> chain;                             // kernel B launches
-    std::vector<uint32_t> block_cams;                         // kernel C, one entry per canvas tile
-    std::vector<uint32_t> block_pure;                         // kernel C: levels owned by one camera | owner << 16
-    std::vector<uint32_t> block_order;                        // kernel C, tile index launched as block i
+    std::vector<uint32_t> block_cams;                         // k_blend_fine, one entry per panorama tile (BlendArgs)
+    std::vector<uint32_t> block_order;                        // k_blend_fine, tile index launched as block i
     int blend_tiles_x = 0, blend_tiles_y = 0;
+    std::vector<uint32_t> coarse_cams;                        // k_blend_coarse, one entry per level-1 tile
+    std::vector<uint32_t> coarse_pure;                        // levels owned by one camera | owner << 16
+    std::vector<uint32_t> coarse_order;
+    int coarse_tiles_x = 0, coarse_tiles_y = 0;
     // camera-sharded hand-off: per camera, the interiors of its launched tiles at every level (what the canvas kernel
     // can read of that camera and nothing else), packed back to back
     std::vector<PayloadRect> payload_rects;                   // grouped by camera

@@ -9,9 +9,9 @@ import csv,sys,re,collections
 rows=list(csv.DictReader(open(sys.argv[1])))
 d=collections.defaultdict(list)
 for r in rows:
-    m=re.search(r"(k_[a-z0-9_]+(<\d+>)?)",r["Kernel_Name"])
+    m=re.search(r"(k_[a-z0-9_]+(<\w+>)?)",r["Kernel_Name"])
     if not m: continue
-    key=(m.group(1), r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
+    key=(m.group(1), r["Grid_Size_X"], r["Workgroup_Size_X"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
     d[key].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
 print("%-18s %9s %5s %7s %5s %5s %6s %9s %9s"%("kernel","grid","wg","lds","vgpr","sgpr","calls","avg_us","min_us"))
 for k,v in sorted(d.items()):

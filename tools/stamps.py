@@ -28,7 +28,8 @@ L = capi.load()
 L.mst_debug_stamps.restype = C.c_int
 L.mst_debug_stamps.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
 for which, name, labels in ((0, "A k_warp_pyr", ["prologue", "pixel loop", "barrier+drain", "pyrDown"]),
-                            (1, "C k_blend", ["phase1 bands", "barrier", "collapse", "final level"])):
+                            (1, "C k_blend_coarse", ["phase1 bands", "barrier", "collapse", "level 1"]),
+                            (2, "C k_blend_fine", ["level 0"])):
     buf = np.zeros(1 << 17, np.uint64)
     rc = L.mst_debug_stamps(which, buf.ctypes.data, buf.size)
     if rc:
@@ -36,10 +37,18 @@ for which, name, labels in ((0, "A k_warp_pyr", ["prologue", "pixel loop", "barr
     st = buf.reshape(-1, 16).astype(np.int64)
     live = st[:, 0] != 0
     st = st[live]
-    d = np.diff(st[:, :5], axis=1)
-    total = st[:, 4] - st[:, 0]
+    last = 1 if which == 2 else 4
+    d = np.diff(st[:, :last + 1], axis=1)
+    total = st[:, last] - st[:, 0]
     print("%s: %d blocks stamped, mean lifetime %.0f cycles (p10 %.0f, p90 %.0f)" % (name, len(st), total.mean(), np.percentile(total, 10), np.percentile(total, 90)))
-    if which == 1:
+    if which == 2:
+        entry = st[:, 8]
+        own, full = (entry >> 31) & 1, st[:, 9]
+        ncam = np.array([bin(int(e) & 0x7FFFFFFF).count("1") for e in entry])
+        classes = [("owned, full", (own == 1) & (full == 1)), ("owned, edge", (own == 1) & (full == 0)),
+                   ("1 cam, not owned", (own == 0) & (ncam == 1)), ("2 cams", (own == 0) & (ncam == 2)),
+                   (">=3 cams", (own == 0) & (ncam >= 3)), ("no camera", ncam == 0)]
+    elif which == 1:
         entry = st[:, 8]
         pure = (entry >> 31) & 1
         ncam = np.array([bin(int(e) & 0x7FFFFFFF).count("1") for e in entry])
