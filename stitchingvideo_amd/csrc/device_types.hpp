@@ -110,7 +110,8 @@ struct BlendArgs {
     uint8_t* pano_mask[kMaxBatch]; uint32_t mask_stride;
     uint64_t* c1[kMaxBatch];                   // collapsed level-1 canvas of each frame set: ch[1] x cw[1], 8 bytes a pixel
     // k_blend_fine, per panorama tile: bit i = camera i has a non-zero level-0 weight under the tile; bit 31 = the
-    // tile's level 0 is owned by ONE camera with weight exactly 1 (integer band path) -- then only that camera's bit
+    // tile's level 0 is owned by ONE camera with weight exactly 1 (integer band path) -- then only that camera's bit;
+    // bit 30 = one or two cameras with 0/1 weights, never both non-zero on a pixel (integer path with masks)
     const uint32_t* block_cams;
     const uint32_t* block_order;              // tile index (ty * tiles_x + tx) handled by block i
     int32_t tiles_x;

@@ -794,17 +794,20 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
 }
 
 // ======================================================================================================
-// C: all bands of one canvas tile in one block
+// C: the canvas -- k_blend_coarse (levels 1 .. top of a level-1 tile in one block) and k_blend_fine (level 0)
 // ======================================================================================================
+// Tile heights, C3 on MI355X, canvas stage per frame set (8 sets per launch) / one-set-at-a-time panoramas per s:
+//   fine 64, coarse 64: 33.1 us / 7.5 k      fine 64, coarse 32: 32.5 us / 8.5 k      fine 32, coarse 32: 30.3 us / 8.8 k
+//   fine 32, coarse 16: 32.4 us / 9.5 k      fine 16, coarse 16: 35.9 us / 9.4 k
 #ifndef MST_C_TH
-#define MST_C_TH 64        // 128x64 canvas tiles: 84.5 us vs 87.8 us for 128x32 (C3, MI355X)
+#define MST_C_TH 32        // k_blend_fine: 128 x 32 panorama tiles
 #endif
 constexpr int C_TW = 128, C_TH = MST_C_TH;
 #ifndef MST_CC_TW
 #define MST_CC_TW 128      // k_blend_coarse: tile size in level-1 pixels
 #endif
 #ifndef MST_CC_TH
-#define MST_CC_TH 64
+#define MST_CC_TH 32
 #endif
 constexpr int CC_TW = MST_CC_TW, CC_TH = MST_CC_TH;
 #ifndef MST_C_THREADS
@@ -1438,50 +1441,88 @@ __device__ __forceinline__ int toward_zero(int v)
 // `up` is the collapsed level L + 1: the global level-1 canvas (L == 0; pitch cw[1], origin 0) or the tile's LDS
 // region of level 2 (L == 1).  Output: the panorama (L == 0; 12-byte stores, see store_quad) or the collapsed
 // level-1 canvas (L == 1).
-template <int L, typename UpPtr>
+//
+// NC / MASKED (level 0 only): the tile lies under NC cameras (1 or 2) whose level-0 weights are all exactly 0 or 1
+// and never both non-zero on a pixel (seam masks; image borders), every window covering the whole tile (checked
+// per calibration, mb_plan.cpp).  A pixel's band is then its one covering camera's lap - sign(lap), or 0 under no
+// camera (where dst_mask_ is 0 and the panorama pixel with it): still integers only, the masks pick per pixel.
+template <int L, int NC, bool MASKED, typename UpPtr>
 __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, const BlendArgs& a, const Region& r,
                                             uint32_t cam_bits, UpPtr up, int up_x0, int up_y0, int up_pitch,
                                             uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask, uint64_t* __restrict__ c1_out)
 {
-    static_assert(C_TW == 128 && (C_TH / 2) % (C_THREADS / 64) == 0 && CC_TW == C_TW && CC_TH == C_TH, "one wave per quad row of the tile");
-    constexpr int kRows = (C_TH / 2) / (C_THREADS / 64);        // quad rows per wave
+    constexpr int kTileH = L == 0 ? C_TH : CC_TH;
+    static_assert(C_TW == 128 && CC_TW == 128 && (kTileH / 2) % (C_THREADS / 64) == 0, "one wave per quad row of the tile");
+    static_assert(L == 0 || (NC == 1 && !MASKED), "masks are level-0 weights");
+    constexpr int kRows = (kTileH / 2) / (C_THREADS / 64);      // quad rows per wave
     const int lane = static_cast<int>(threadIdx.x & 63u);
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    const CamDesc& c = cams[__builtin_ctz(cam_bits)];
-    const int lw = c.lw[L], sw = c.lw[L + 1], sh = c.lh[L + 1], uw = a.cw[L + 1], uh = a.ch[L + 1];
+    const int uw = a.cw[L + 1], uh = a.ch[L + 1];
     const int x = r.x0 + 2 * lane, y0 = r.y0 + 2 * kRows * wave;
-    const int lx = x - c.ox[L], ly0 = y0 - c.oy[L];
-    const int j = lx >> 1, cj = x >> 1;
-    int jm, jp, cjm, cjp;
-    up_idx(j, sw, jm, jp);
+    const int cj = x >> 1;
+    int cjm, cjp;
     up_idx(cj, uw, cjm, cjp);
     const bool first = (lane & 15) == 0, last = (lane & 15) == 15, edge = first || last;
-    const int je = first ? jm : jp, cje = (first ? cjm : cjp) - up_x0;    // the outer column an edge lane fetches itself
+    const int cje = (first ? cjm : cjp) - up_x0;                 // the outer column an edge lane fetches itself
     const int cjc = cj - up_x0;
-    const uint32_t MST_GLOBAL* __restrict__ gup = gp(c.G[L + 1]);
-    const GPix MST_GLOBAL* gq = (const GPix MST_GLOBAL*)(c.G[L] + (__umul24(ly0, lw) + lx));   // this lane's quad, upper row
     const bool odd = (lane & 1) != 0;
 
-    struct Raw { uint32_t g, ge; uint2 u, ue; };                 // one source row as loaded: own column, outer column
+    struct Cam {
+        const uint32_t MST_GLOBAL* gup;      // Gaussian level L + 1
+        const GPix MST_GLOBAL* gq;           // this lane's quad of level L, upper row (advanced as the strip is walked)
+        const uint8_t MST_GLOBAL* mq;        // MASKED: this lane's quad of the bordered level-0 mask
+        int lw, sw, sh, i0, j, je;
+    } cam[NC];
+    {
+        uint32_t bits = cam_bits;
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            const CamDesc& c = cams[__builtin_ctz(bits)];
+            bits &= bits - 1;
+            Cam& k = cam[n];
+            k.lw = c.lw[L]; k.sw = c.lw[L + 1]; k.sh = c.lh[L + 1];
+            const int lx = x - c.ox[L], ly0 = y0 - c.oy[L];
+            k.i0 = ly0 >> 1;
+            k.j = lx >> 1;
+            int jm, jp;
+            up_idx(k.j, k.sw, jm, jp);
+            k.je = first ? jm : jp;
+            k.gup = gp(c.G[L + 1]);
+            const uint32_t off = __umul24(ly0, k.lw) + lx;
+            k.gq = (const GPix MST_GLOBAL*)(c.G[L] + off);
+            k.mq = MASKED ? gp(c.mask_b) + off : nullptr;
+        }
+    }
+
+    struct RawG { uint32_t g, ge; };                             // one source row as loaded: own column, outer column
+    struct RawC { uint2 u, ue; };
     struct RowG { uint32_t hebr, hobr, heg, hog; };              // horizontally filtered: even / odd output column
     struct RowC { int he[3], ho[3]; };
-    auto load_row = [&](Raw& w, int gi, int ci) {                // source row gi of the camera's level, ci of the canvas'
-        const int go = __mul24(gi, sw), co = __mul24(ci - up_y0, up_pitch);
-        w.g = gup[go + j];
-        w.u = as_u2(up[co + cjc]);
-        w.ge = 0u; w.ue = make_uint2(0u, 0u);
-        if (edge) { w.ge = gup[go + je]; w.ue = as_u2(up[co + cje]); }
+    auto load_g = [&](RawG& w, const Cam& k, int gi) {           // source row gi of the camera's level L + 1
+        const int go = __mul24(gi, k.sw);
+        w.g = k.gup[go + k.j];
+        w.ge = 0u;
+        if (edge) w.ge = k.gup[go + k.je];
     };
-    auto filter_row = [&](const Raw& w, RowG& g, RowC& u) {
-        // (the shifts first, on every lane: a lane switched off by a branch would not be readable by its neighbour)
+    auto load_c = [&](RawC& w, int ci) {                         // source row ci of the collapsed canvas level L + 1
+        const int co = __mul24(ci - up_y0, up_pitch);
+        if (MST_ABLATE_C & 8192) { w.u = make_uint2(co + cjc, co * 3 + cjc); w.ue = w.u; return; }   // timing experiments
+        w.u = as_u2(up[co + cjc]);
+        w.ue = make_uint2(0u, 0u);
+        if (edge) w.ue = as_u2(up[co + cje]);
+    };
+    // (the DPP shifts first, on every lane: a lane switched off by a branch would not be readable by its neighbour)
+    auto filter_g = [&](const RawG& w, RowG& g) {
         const uint32_t gb = from_lane_below(w.g), ga = from_lane_above(w.g);
-        const uint32_t uxb = from_lane_below(w.u.x), uyb = from_lane_below(w.u.y);
-        const uint32_t uxa = from_lane_above(w.u.x), uya = from_lane_above(w.u.y);
         const uint32_t gl = first ? w.ge : gb, gr = last ? w.ge : ga;
         g.hebr = lanes_br(gl) + 6u * lanes_br(w.g) + lanes_br(gr);
         g.hobr = 4u * (lanes_br(w.g) + lanes_br(gr));
         g.heg = lane_g(gl) + 6u * lane_g(w.g) + lane_g(gr);
         g.hog = 4u * (lane_g(w.g) + lane_g(gr));
+    };
+    auto filter_c = [&](const RawC& w, RowC& u) {
+        const uint32_t uxb = from_lane_below(w.u.x), uyb = from_lane_below(w.u.y);
+        const uint32_t uxa = from_lane_above(w.u.x), uya = from_lane_above(w.u.y);
         const uint32_t ulx = first ? w.ue.x : uxb, uly = first ? w.ue.y : uyb;
         const uint32_t urx = last ? w.ue.x : uxa, ury = last ? w.ue.y : uya;
         const int av[3] = {s16_lo(ulx), s16_hi(ulx), s16_lo(uly)};
@@ -1493,20 +1534,42 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
             u.ho[ch] = 4 * (bv[ch] + cv[ch]);
         }
     };
+    struct Quad { GPix q0, q1; uint32_t m; };                    // Gaussian quad (two rows) and its four mask bytes
+    auto load_quad = [&](Quad& q, const Cam& k) {
+        if (MST_ABLATE_C & 2048) {         // timing experiments: no Gaussian quad loads
+            q.q0 = GPix{static_cast<uint32_t>(x * 3 + k.j), static_cast<uint32_t>(x * 5 + k.j)};
+            q.q1 = GPix{static_cast<uint32_t>(x * 7 + k.j), static_cast<uint32_t>(x * 11 + k.j)};
+        } else {
+            q.q0 = k.gq[0];
+            q.q1 = *(const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)k.gq + k.lw);
+        }
+        q.m = 0xFFFFFFFFu;
+        if (MASKED)
+            q.m = static_cast<uint32_t>(*(const uint16_t MST_GLOBAL*)k.mq) |
+                  static_cast<uint32_t>(*(const uint16_t MST_GLOBAL*)(k.mq + k.lw)) << 16;
+    };
 
     // the three source rows of the strip's first quad row (clamped like cv::pyrUp's border); afterwards one new row each
-    const int i0 = ly0 >> 1, ci0 = y0 >> 1;
-    RowG rg[3];
+    const int ci0 = y0 >> 1;
+    RowG rg[NC][3];
     RowC rc[3];
+    Quad qd[NC];
     {
-        int im, ip, cim, cip;
-        up_idx(i0, sh, im, ip);
+        int cim, cip;
         up_idx(ci0, uh, cim, cip);
-        Raw w0, w1, w2;
-        load_row(w0, im, cim); load_row(w1, i0, ci0); load_row(w2, ip, cip);
-        filter_row(w0, rg[0], rc[0]); filter_row(w1, rg[1], rc[1]); filter_row(w2, rg[2], rc[2]);
+        RawC w0, w1, w2;
+        load_c(w0, cim); load_c(w1, ci0); load_c(w2, cip);
+        filter_c(w0, rc[0]); filter_c(w1, rc[1]); filter_c(w2, rc[2]);
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            int im, ip;
+            up_idx(cam[n].i0, cam[n].sh, im, ip);
+            RawG g0, g1, g2;
+            load_g(g0, cam[n], im); load_g(g1, cam[n], cam[n].i0); load_g(g2, cam[n], ip);
+            filter_g(g0, rg[n][0]); filter_g(g1, rg[n][1]); filter_g(g2, rg[n][2]);
+            load_quad(qd[n], cam[n]);
+        }
     }
-    GPix q0 = gq[0], q1 = *(const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)gq + lw);
     // output pointers of this lane, advanced by two rows per quad row
     uint8_t* po = nullptr;           // L == 0: even lanes write the upper row of a lane pair's two quads, odd lanes the lower
     uint8_t* pm = nullptr;
@@ -1519,20 +1582,19 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
     }
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
-        Raw wn;
-        GPix n0, n1;
-        if (t + 1 < kRows) {          // next quad row: its new source row (i + 2, clamped) and its Gaussian quad
-            load_row(wn, min(i0 + t + 2, sh - 1), min(ci0 + t + 2, uh - 1));
-            gq = (const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)gq + 2 * lw);
-            n0 = gq[0];
-            n1 = *(const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)gq + lw);
+        RawC wc;
+        RawG wg[NC];
+        Quad qn[NC];
+        if (t + 1 < kRows) {          // next quad row: its new source rows (i + 2, clamped) and its Gaussian quads
+            load_c(wc, min(ci0 + t + 2, uh - 1));
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                load_g(wg[n], cam[n], min(cam[n].i0 + t + 2, cam[n].sh - 1));
+                cam[n].gq = (const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)cam[n].gq + 2 * cam[n].lw);
+                if (MASKED) cam[n].mq += 2 * cam[n].lw;
+                load_quad(qn[n], cam[n]);
+            }
         }
-        const uint32_t g[4] = {q0.x, q0.y, q1.x, q1.y};
-        uint32_t ubr[4], ug[4];
-        ubr[0] = rg[0].hebr + 6u * rg[1].hebr + rg[2].hebr;  ug[0] = rg[0].heg + 6u * rg[1].heg + rg[2].heg;
-        ubr[1] = rg[0].hobr + 6u * rg[1].hobr + rg[2].hobr;  ug[1] = rg[0].hog + 6u * rg[1].hog + rg[2].hog;
-        ubr[2] = 4u * (rg[1].hebr + rg[2].hebr);             ug[2] = 4u * (rg[1].heg + rg[2].heg);
-        ubr[3] = 4u * (rg[1].hobr + rg[2].hobr);             ug[3] = 4u * (rg[1].hog + rg[2].hog);
         int upv[4][3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -1541,24 +1603,47 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
             upv[2][ch] = sat_s16((4 * (rc[1].he[ch] + rc[2].he[ch]) + 32) >> 6);
             upv[3][ch] = sat_s16((4 * (rc[1].ho[ch] + rc[2].ho[ch]) + 32) >> 6);
         }
-        int v[4][3];                 // collapsed level L
+        int band[4][3];              // normalised band of level L
+        uint32_t many = 0;           // MASKED: a byte per quad pixel, non-zero under a camera
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t pbr = ((ubr[q] + 0x00200020u) >> 6) & 0x03FF03FFu, pg = (ug[q] + 32u) >> 6;
-            const int lb = static_cast<int>(g[q] & 0xFF) - static_cast<int>(pbr & 0xFFFF);
-            const int lg = static_cast<int>((g[q] >> 8) & 0xFF) - static_cast<int>(pg);
-            const int lr = static_cast<int>((g[q] >> 16) & 0xFF) - static_cast<int>(pbr >> 16);
-            // normalised band of an owned pixel: lap - sign(lap) (see band_quad); cv::add saturates
-            v[q][0] = sat_s16(upv[q][0] + toward_zero(lb));
-            v[q][1] = sat_s16(upv[q][1] + toward_zero(lg));
-            v[q][2] = sat_s16(upv[q][2] + toward_zero(lr));
+        for (int n = 0; n < NC; ++n) {
+            const RowG* g3 = rg[n];
+            uint32_t ubr[4], ug[4];
+            ubr[0] = g3[0].hebr + 6u * g3[1].hebr + g3[2].hebr;  ug[0] = g3[0].heg + 6u * g3[1].heg + g3[2].heg;
+            ubr[1] = g3[0].hobr + 6u * g3[1].hobr + g3[2].hobr;  ug[1] = g3[0].hog + 6u * g3[1].hog + g3[2].hog;
+            ubr[2] = 4u * (g3[1].hebr + g3[2].hebr);             ug[2] = 4u * (g3[1].heg + g3[2].heg);
+            ubr[3] = 4u * (g3[1].hobr + g3[2].hobr);             ug[3] = 4u * (g3[1].hog + g3[2].hog);
+            const uint32_t g[4] = {qd[n].q0.x, qd[n].q0.y, qd[n].q1.x, qd[n].q1.y};
+            many |= qd[n].m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t pbr = ((ubr[q] + 0x00200020u) >> 6) & 0x03FF03FFu, pg = (ug[q] + 32u) >> 6;
+                const int lb = static_cast<int>(g[q] & 0xFF) - static_cast<int>(pbr & 0xFFFF);
+                const int lg = static_cast<int>((g[q] >> 8) & 0xFF) - static_cast<int>(pg);
+                const int lr = static_cast<int>((g[q] >> 16) & 0xFF) - static_cast<int>(pbr >> 16);
+                // normalised band of an owned pixel: lap - sign(lap) (see band_quad)
+                const int nb[3] = {toward_zero(lb), toward_zero(lg), toward_zero(lr)};
+                const bool mine = !MASKED || ((qd[n].m >> (8 * q)) & 0xFFu) != 0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    if (n == 0) band[q][ch] = mine ? nb[ch] : 0;
+                    else if (mine) band[q][ch] = nb[ch];
+                }
+            }
         }
+        int v[4][3];                 // collapsed level L; cv::add saturates
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) v[q][ch] = sat_s16(upv[q][ch] + band[q][ch]);
         if (L == 0) {
             uint32_t o8[4][3];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                const bool m = !MASKED || ((many >> (8 * q)) & 0xFFu) != 0;                // dst_mask_
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) o8[q][ch] = static_cast<uint32_t>(sat_u8(v[q][ch]));
+                for (int ch = 0; ch < 3; ++ch) o8[q][ch] = m ? static_cast<uint32_t>(sat_u8(v[q][ch])) : 0u;
+            }
             // 6 bytes per quad row: B0 G0 R0 B1 | G1 R1; lane pairs swap so that each lane holds one row of four pixels
             const uint32_t lo0 = o8[0][0] | o8[0][1] << 8 | o8[0][2] << 16 | o8[1][0] << 24, hi0 = o8[1][1] | o8[1][2] << 8;
             const uint32_t lo1 = o8[2][0] | o8[2][1] << 8 | o8[2][2] << 16 | o8[3][0] << 24, hi1 = o8[3][1] | o8[3][2] << 8;
@@ -1569,10 +1654,12 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
             w.x = flo;
             w.y = (fhi & 0xFFFFu) | slo << 16;
             w.z = slo >> 16 | shi << 16;
-            *reinterpret_cast<uint3*>(po) = w;
+            if (!(MST_ABLATE_C & 4096) || w.x == 0x12345678u) *reinterpret_cast<uint3*>(po) = w;
             po += 2 * a.pano_stride;
             if (pm) {
-                pm[0] = 255; pm[1] = 255; pm[a.mask_stride] = 255; pm[a.mask_stride + 1] = 255;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    pm[(q >> 1) * a.mask_stride + (q & 1)] = (!MASKED || ((many >> (8 * q)) & 0xFFu) != 0) ? 255 : 0;
                 pm += 2 * a.mask_stride;
             }
         } else {
@@ -1587,10 +1674,14 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
             co += 2 * a.cw[L];
         }
         if (t + 1 < kRows) {
-            rg[0] = rg[1]; rg[1] = rg[2];
             rc[0] = rc[1]; rc[1] = rc[2];
-            filter_row(wn, rg[2], rc[2]);
-            q0 = n0; q1 = n1;
+            filter_c(wc, rc[2]);
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                rg[n][0] = rg[n][1]; rg[n][1] = rg[n][2];
+                filter_g(wg[n], rg[n][2]);
+                qd[n] = qn[n];
+            }
         }
     }
 }
@@ -1773,7 +1864,7 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_coarse(const C
         const Region r1 = table_region(s_reg, 1), ur = table_region(s_reg, 2);
         const bool full = r1.x1 - r1.x0 == CC_TW && r1.y1 - r1.y0 == CC_TH && (a.cw[1] & 1) == 0;
         if (own1 && full && !(MST_ABLATE_C & 64))
-            owned_strip<1>(cams, a, r1, bits1, static_cast<const uint2*>(lds + a.lds_off[2]), ur.x0, ur.y0, region_pitch(ur),
+            owned_strip<1, 1, false>(cams, a, r1, bits1, static_cast<const uint2*>(lds + a.lds_off[2]), ur.x0, ur.y0, region_pitch(ur),
                            nullptr, nullptr, a.c1[set]);
         else if (own1) coarse_base_level<false, true>(cams, a, bits1, lds, s_reg, c1);
         else coarse_base_level<false, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
@@ -1795,7 +1886,7 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_fine(const Cam
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const uint32_t entry = a.block_cams[tile];       // bit 31: level 0 owned by ONE camera with weight exactly 1
     const bool own0 = (MST_ABLATE_C & 512) ? false : (entry >> 31) != 0;
-    const uint32_t cam_bits = entry & 0x7FFFFFFFu;   // (that camera alone when owned)
+    const uint32_t cam_bits = entry & 0x3FFFFFFFu;   // (that camera alone when owned)
     const Region r0 = blend_region(a, 0, tx, ty, 0);
     const C1Ptr c1 = (C1Ptr)a.c1[set];
     MST_STAMP(2, 0);
@@ -1806,8 +1897,11 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_fine(const Cam
         return;
     }
     const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
-    if (own0 && full && !(MST_ABLATE_C & 64) && pano_store_mode(a, pano, true) == 2)
-        owned_strip<0>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    const bool strip = full && !(MST_ABLATE_C & 64) && pano_store_mode(a, pano, true) == 2;
+    const bool binary = !(MST_ABLATE_C & 512) && (entry >> 30) & 1u;      // 0/1 weights, disjoint, windows cover the tile
+    if (own0 && strip) owned_strip<0, 1, false>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (binary && strip && (cam_bits & (cam_bits - 1)) == 0) owned_strip<0, 1, true>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (binary && strip) owned_strip<0, 2, true>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
     else if (own0) final_level<false, true>(cams, a, r0, cam_bits, c1, pano, pano_mask);
     else final_level<false, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
     MST_STAMP_VAL(2, 9, static_cast<unsigned long long>(full));

@@ -307,6 +307,24 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                     if (all_unit(c, 0, r[0], r[1], cx1, cy1) && covers(c, 0, r[0], r[1], r[2], r[3])) bits = lbits | 0x80000000u;
                 }
             }
+            // bit 30: one or two cameras, every weight exactly 0 or 1 and never two non-zero on a pixel, both windows
+            // over the whole tile -> the integer strip path with per-pixel masks (a whole tile inside the crop only)
+            const int nc = __builtin_popcount(bits & 0x3FFFFFFFu);
+            if (!(bits >> 31) && nc >= 1 && nc <= 2 && r[2] - r[0] == c_tw && r[3] - r[1] == c_th && r[2] <= blend.final_w &&
+                r[3] <= blend.final_h) {
+                int cs[2] = {__builtin_ctz(bits), nc == 2 ? __builtin_ctz(bits & (bits - 1)) : -1};
+                bool ok = true;
+                for (int k = 0; k < nc; ++k) ok = ok && covers(cs[k], 0, r[0], r[1], r[2], r[3]);
+                for (int y = r[1]; ok && y < r[3]; ++y) {
+                    const uint8_t* w0 = weight_class[cs[0]][0].data() + static_cast<size_t>(y - desc[cs[0]].oy[0]) * desc[cs[0]].lw[0] - desc[cs[0]].ox[0];
+                    const uint8_t* w1 = nc == 2 ? weight_class[cs[1]][0].data() + static_cast<size_t>(y - desc[cs[1]].oy[0]) * desc[cs[1]].lw[0] - desc[cs[1]].ox[0] : nullptr;
+                    for (int x = r[0]; x < r[2]; ++x) {
+                        const uint8_t a0 = w0[x], a1 = w1 ? w1[x] : 0;
+                        if ((a0 == 1) | (a1 == 1) | ((a0 & a1 & 1) != 0)) { ok = false; break; }   // fractional, or both non-zero
+                    }
+                }
+                if (ok) bits |= 0x40000000u;
+            }
             plan.block_cams[static_cast<size_t>(ty) * plan.blend_tiles_x + tx] = bits;
         }
     });
@@ -343,12 +361,12 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
     });
     mark("canvas tiles");
     if (timing) {
-        int owned = 0, pure = 0, own1 = 0;
-        for (uint32_t e : plan.block_cams) owned += e >> 31;
+        int owned = 0, pure = 0, own1 = 0, binary = 0;
+        for (uint32_t e : plan.block_cams) { owned += e >> 31; binary += (e >> 30) & 1u; }
         for (uint32_t e : plan.coarse_cams) pure += e >> 31;
         for (uint32_t e : plan.coarse_pure) own1 += (e >> 1) & 1u;
-        std::fprintf(stderr, "[mst_update]   plan: %zu panorama tiles (%d with level 0 owned), %zu level-1 tiles (%d pure, %d with level 1 owned)\n",
-                     plan.block_cams.size(), owned, plan.coarse_cams.size(), pure, own1);
+        std::fprintf(stderr, "[mst_update]   plan: %zu panorama tiles (%d with level 0 owned, %d more with 0/1 masks), %zu level-1 tiles (%d pure, %d with level 1 owned)\n",
+                     plan.block_cams.size(), owned, binary, plan.coarse_cams.size(), pure, own1);
     }
     for (const std::vector<int>& ra : row_area)
         for (int l = 0; l < nlev; ++l) max_area[l] = std::max(max_area[l], ra[l]);
@@ -363,7 +381,9 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
     };
     plan.block_order = ordered(plan.block_cams, [&](uint32_t tile) {
         const uint32_t e = plan.block_cams[tile];
-        return (e >> 31) ? 4 : 10 + 2 * __builtin_popcount(e);
+        if (e >> 31) return 4;
+        const int nc = __builtin_popcount(e & 0x3FFFFFFFu);
+        return (e >> 30) ? 4 + 2 * nc : 10 + 2 * nc;
     });
     plan.coarse_order = ordered(plan.coarse_cams, [&](uint32_t tile) {
         const uint32_t e = plan.coarse_cams[tile];
