@@ -336,6 +336,31 @@ def main():
                                    "frames_per_s": round(1000.0 / ms1, 2),
                                    "roofline_frac": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
+    # ---- two launch sequences in flight (MST_FLAG_OVERLAP_FRAMES): the warp + chain kernels of sequence t + 1 run
+    # beside the canvas kernels of sequence t on a second stream and a second set of pyramid buffers.  Reported
+    # beside `value`, not as `value`: per-kernel durations under overlap are not comparable with a kernel trace.
+    if rank == 0 and world == 1 and not by_camera and not args.no_latency_leg and blend == "multiband" and batch > 1 \
+            and not args.overlap:
+        eng2 = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
+                                overlap_frames=True, max_batch=batch)
+        eng2.update(rig["scale"], rig["cameras"])
+        eng2.acquire()
+        calls2 = [eng2.make_device_batch_call(*tables(first), [p.data_ptr() for p in panos], pano.stride(0), stream=stream)
+                  for first in range(n_sets)]
+        for i in range(10):
+            calls2[i % len(calls2)]()
+        torch.cuda.synchronize()
+        n2 = max(20, int(0.5 / max(t_seq, 1e-6)))
+        t0 = time.perf_counter()
+        for i in range(n2):
+            calls2[i % len(calls2)]()
+        torch.cuda.synchronize()
+        w2 = time.perf_counter() - t0
+        out["overlapped"] = {"launch_sequences_in_flight": 2, "frame_sets_per_launch": batch, "frames": n2 * batch,
+                             "frames_per_s": round(n2 * batch / w2, 2),
+                             "roofline_frac": round(alg_bytes * n2 * batch / w2 / 1e9 / HBM_PEAK_GBS, 5)}
+        eng2.close()
+
     # ---- host buffers: the PCIe-inclusive rate (never `value`): serial mst_compose vs the three-stage pipeline ----
     if rank == 0 and world == 1 and not by_camera and not args.no_latency_leg and blend == "multiband":
         try:

@@ -1271,6 +1271,9 @@ __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, co
         float ws[4];
         if (MST_ABLATE_C & 1) {
             for (int k = 0; k < 4; ++k) n[k][0] = n[k][1] = n[k][2] = x + y + k;
+        } else if (!PURE && ((owned_levels >> l) & 1u)) {        // (wave-uniform) this level of the tile is owned outright
+            if (l == top) band_quad<true, false, true>(cams, a, l, x, y, valid, owner_bits, n, ws);
+            else band_quad<false, false, true>(cams, a, l, x, y, valid, owner_bits, n, ws);
         } else if (l == top) {
             band_quad<true, false, PURE, W16>(cams, a, l, x, y, valid, cam_bits, n, ws);
         } else {
@@ -1889,6 +1892,27 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_fine(const Cam
     const uint32_t cam_bits = entry & 0x3FFFFFFFu;   // (that camera alone when owned)
     const Region r0 = blend_region(a, 0, tx, ty, 0);
     const C1Ptr c1 = (C1Ptr)a.c1[set];
+    if (cam_bits == 0) {            // under no camera at all: dst_mask_ is 0 and the panorama with it
+        const int w = min(r0.x1, a.final_w) - r0.x0, h = min(r0.y1, a.final_h) - r0.y0;
+        if (pano_store_mode(a, pano, true) == 2 && (w & 3) == 0) {          // dword stores
+            const int wd = w * 3 / 4;
+            for (int i = threadIdx.x; i < wd * max(h, 0); i += C_THREADS) {
+                const int y = i / wd, b = i - y * wd;
+                reinterpret_cast<uint32_t*>(pano + __umul24(r0.y0 + y, a.pano_stride) + r0.x0 * 3)[b] = 0u;
+            }
+        } else {
+            for (int i = threadIdx.x; i < max(w, 0) * 3 * max(h, 0); i += C_THREADS) {
+                const int y = i / (w * 3), b = i - y * (w * 3);
+                pano[__umul24(r0.y0 + y, a.pano_stride) + r0.x0 * 3 + b] = 0;
+            }
+        }
+        if (pano_mask)
+            for (int i = threadIdx.x; i < max(w, 0) * max(h, 0); i += C_THREADS) {
+                const int y = i / w, b = i - y * w;
+                pano_mask[__umul24(r0.y0 + y, a.mask_stride) + r0.x0 + b] = 0;
+            }
+        return;
+    }
     MST_STAMP(2, 0);
     MST_STAMP_VAL(2, 8, static_cast<unsigned long long>(entry));
     if (a.nlev == 1) {

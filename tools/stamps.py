@@ -43,11 +43,12 @@ for which, name, labels in ((0, "A k_warp_pyr", ["prologue", "pixel loop", "barr
     print("%s: %d blocks stamped, mean lifetime %.0f cycles (p10 %.0f, p90 %.0f)" % (name, len(st), total.mean(), np.percentile(total, 10), np.percentile(total, 90)))
     if which == 2:
         entry = st[:, 8]
-        own, full = (entry >> 31) & 1, st[:, 9]
-        ncam = np.array([bin(int(e) & 0x7FFFFFFF).count("1") for e in entry])
+        own, binary, full = (entry >> 31) & 1, (entry >> 30) & 1, st[:, 9]
+        ncam = np.array([bin(int(e) & 0x3FFFFFFF).count("1") for e in entry])
         classes = [("owned, full", (own == 1) & (full == 1)), ("owned, edge", (own == 1) & (full == 0)),
-                   ("1 cam, not owned", (own == 0) & (ncam == 1)), ("2 cams", (own == 0) & (ncam == 2)),
-                   (">=3 cams", (own == 0) & (ncam >= 3)), ("no camera", ncam == 0)]
+                   ("0/1 masks, 1 cam", (binary == 1) & (ncam == 1)), ("0/1 masks, 2 cams", (binary == 1) & (ncam == 2)),
+                   ("generic, 1 cam", (own == 0) & (binary == 0) & (ncam == 1)), ("generic, 2 cams", (own == 0) & (binary == 0) & (ncam == 2)),
+                   ("generic, >=3 cams", (own == 0) & (binary == 0) & (ncam >= 3)), ("no camera", ncam == 0)]
     elif which == 1:
         entry = st[:, 8]
         pure = (entry >> 31) & 1

@@ -60,7 +60,7 @@ if len(sys.argv) > 2 and counters:
                 "stitchingvideo_amd/csrc/kernels_common.hpp", "stitchingvideo_amd/csrc/device_types.hpp"]:
         h.update(open(os.path.join(ROOT, rel), "rb").read())
     batch = 8
-    launches = {"k_warp_pyr": 1, "k_pyr_chain": 2, "k_blend": 1}
+    launches = {"k_warp_pyr": 1, "k_pyr_chain": 2, "k_blend_coarse": 1, "k_blend_fine": 1}
     per = {}
     for k, d in counters.items():
         base = k.split("<")[0]
