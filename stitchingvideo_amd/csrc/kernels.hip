@@ -84,13 +84,22 @@ __global__ __launch_bounds__(256) void k_warp_u8(const CamDesc* __restrict__ cam
 // loads, the others resolve the constant border tap by tap.
 constexpr int kRemapPx = 4;
 __global__ __launch_bounds__(256) void k_remap_fixed(const UndistortCam* __restrict__ ucams, int n_cams, FrameBatch src,
-                                                     FrameBatch dst)
+                                                     FrameBatch dst, int bx, int by, int n_sets)
 {
-    const int set = blockIdx.z / n_cams, cam = blockIdx.z - set * n_cams;
+    // 1-D grid over (camera, block row, block column, frame set), frame set fastest, walked in XCD runs (blocks are
+    // dealt to the 8 XCDs round-robin: XCD k = blockIdx.x % 8 takes one contiguous run): the frame sets of a block
+    // are dispatched together onto one XCD, so its 6 bytes per pixel of maps -- frame-invariant, and as large a
+    // stream as the frames themselves -- come from HBM once per launch instead of once per frame set.
+    const int total = bx * by * n_cams * n_sets;
+    const int q8 = total >> 3, r8 = total & 7, xk = blockIdx.x & 7, xj = blockIdx.x >> 3;
+    int idx1 = xk * q8 + min(xk, r8) + xj;
+    const int set = idx1 % n_sets; idx1 /= n_sets;
+    const int bxi = idx1 % bx; idx1 /= bx;
+    const int byi = idx1 % by, cam = idx1 / by;
     const UndistortCam u = ucams[cam];
     const uint8_t* __restrict__ s = src.f[set].ptr[cam];
     if (!u.map1 || !s) return;                      // no maps, or a camera that is not part of this call
-    const int x0 = (blockIdx.x * kTileW + threadIdx.x) * kRemapPx, y = blockIdx.y * kTileH + threadIdx.y;
+    const int x0 = (bxi * kTileW + threadIdx.x) * kRemapPx, y = byi * kTileH + threadIdx.y;
     if (x0 >= u.w || y >= u.h) return;
     const uint32_t sstride = src.f[set].stride[cam], dstride = dst.f[set].stride[cam];
     uint8_t* __restrict__ drow = const_cast<uint8_t*>(dst.f[set].ptr[cam]) + static_cast<size_t>(y) * dstride;
@@ -590,9 +599,10 @@ void launch_remap_fixed(const UndistortCam* d_ucams, int n_cams, int max_w, int 
                         const FrameBatch& dst, int batch, hipStream_t s)
 {
     if (n_cams <= 0 || batch <= 0 || max_w <= 0 || max_h <= 0) return;
-    dim3 grid = grid2d((max_w + kRemapPx - 1) / kRemapPx, max_h);
-    grid.z = static_cast<unsigned>(n_cams * batch);
-    hipLaunchKernelGGL(k_remap_fixed, grid, block2d(), 0, s, d_ucams, n_cams, src, dst);
+    const dim3 g2 = grid2d((max_w + kRemapPx - 1) / kRemapPx, max_h);
+    const int bx = static_cast<int>(g2.x), by = static_cast<int>(g2.y);
+    hipLaunchKernelGGL(k_remap_fixed, dim3(static_cast<unsigned>(bx * by * n_cams * batch)), block2d(), 0, s, d_ucams, n_cams, src,
+                       dst, bx, by, batch);
 }
 
 void launch_exposure_apply(const CamDesc* d_cam, uint8_t* d_img, size_t stride, int w, int h, hipStream_t s)

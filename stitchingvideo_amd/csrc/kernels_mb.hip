@@ -77,6 +77,18 @@ __device__ __forceinline__ uint32_t pyrdown_finish(uint32_t vbr, uint32_t vg)
     return (((vbr + 0x00800080u) >> 8) & 0x00FF00FFu) | (((vg + 128u) >> 8) << 8);
 }
 
+// values of the lanes beside this one within a DPP row of 16 lanes (row_shr:1 / row_shl:1; the row's first / last
+// lane keeps its own value).  (The wavefront-wide shifts wave_shr / wave_shl assemble for gfx950 but do not cross
+// the 16-lane rows there: measured, tests/test_gpu_edge_cases.py caught it.)
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v)      // lane i <- lane i - 1
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x111, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v)      // lane i <- lane i + 1
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x101, 0xF, 0xF, false));
+}
+
 // Workgroups are dealt to the 8 XCDs round-robin (each XCD has its own L2), so block b works on list entry
 // xcd_run_index(b, n): XCD k = b % 8 walks one contiguous run of the list, and tiles that are neighbours in the
 // image (shared source rows, shared pyramid halos) meet in one L2.  A bijection on [0, n) for every n.
@@ -807,13 +819,17 @@ constexpr int C_TW = 128, C_TH = MST_C_TH;
 #define MST_CC_TW 128      // k_blend_coarse: tile size in level-1 pixels
 #endif
 #ifndef MST_CC_TH
-#define MST_CC_TH 32
+#define MST_CC_TH 64
 #endif
 constexpr int CC_TW = MST_CC_TW, CC_TH = MST_CC_TH;
 #ifndef MST_C_THREADS
 #define MST_C_THREADS 256
 #endif
-constexpr int C_THREADS = MST_C_THREADS;
+constexpr int C_THREADS = MST_C_THREADS;       // k_blend_fine
+#ifndef MST_CC_THREADS
+#define MST_CC_THREADS 512     // k_blend_coarse: eight waves share the latency-bound upper levels of a tile
+#endif
+constexpr int CC_THREADS = MST_CC_THREADS;
 
 struct Region { int x0, y0, x1, y1; };
 
@@ -1205,32 +1221,6 @@ struct QuadIter {
     }
 };
 
-// phase 1: normalised band of one coarse level into its LDS region
-template <bool TOP, bool PURE, bool W16 = false>
-__device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, const BlendArgs& a, int l, int tx, int ty,
-                                           uint32_t cam_bits, uint2* __restrict__ lds, const int* __restrict__ s_reg)
-{
-    const QuadIter it(s_reg, l);
-    uint2* s_out = lds + a.lds_off[l];
-    for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
-        int x, y;
-        bool valid[4];
-        it.at(q, x, y, valid);
-        int n[4][3];
-        float ws[4];
-        if (MST_ABLATE_C & 1) {
-            for (int k = 0; k < 4; ++k) n[k][0] = n[k][1] = n[k][2] = x + y + k;
-        } else {
-            band_quad<TOP, false, PURE, W16>(cams, a, l, x, y, valid, cam_bits, n, ws);
-        }
-        // (x, region origin and region width are even: both pixels of a quad row are valid or invalid together)
-#pragma unroll
-        for (int ry = 0; ry < 2; ++ry)
-            if (valid[2 * ry])
-                lds_store_pair(s_out, __mul24(y + ry - it.r.y0, it.pitch) + (x - it.r.x0), n[2 * ry], n[2 * ry + 1]);
-    }
-}
-
 // phase 1 for all coarse levels at once.  The levels above 1 hold only a few dozen quads per tile, so looping
 // over them one after the other leaves most of the block idle while each level's load -> band chain runs its
 // course, five times in a row.  Here the quads of every level form one index space cut into 64-quad chunks
@@ -1238,12 +1228,12 @@ __device__ __forceinline__ void band_level(const CamDesc* __restrict__ cams, con
 // The level of a chunk is wave-uniform, which keeps every descriptor access scalar.
 // Tiles that are not pure still own most of their levels outright (a tile a few hundred pixels from a seam mixes
 // cameras on its coarsest levels only): `owned_levels` (bit l) / `owner_bits` send those levels down the integer path.
-template <bool PURE, bool W16 = false>
+template <int NT, bool PURE, bool W16 = false>
 __device__ __forceinline__ void band_levels(const CamDesc* __restrict__ cams, const BlendArgs& a, int top, int tx, int ty,
                                             uint32_t cam_bits, uint2* __restrict__ lds, const int* __restrict__ s_reg,
                                             int first, uint32_t owned_levels = 0, uint32_t owner_bits = 0)
 {
-    constexpr int kWaves = C_THREADS / 64;
+    constexpr int kWaves = NT / 64;
     const int lane = static_cast<int>(threadIdx.x & 63u);
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     int nch[kMaxLevels];          // chunks per level; only ever indexed by unrolled constants
@@ -1297,6 +1287,7 @@ __device__ __forceinline__ void dump_level(const BlendArgs& a, int l, int px, in
 }
 
 // phase 2: restoreImageFromLaplacePyr inside LDS: level l <- saturate(pyrUp(level l+1) + level l)
+template <int NT>
 __device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx, int ty, uint2* __restrict__ lds,
                                                const int* __restrict__ s_reg)
 {
@@ -1304,7 +1295,7 @@ __device__ __forceinline__ void collapse_level(const BlendArgs& a, int l, int tx
     const Region ur = table_region(s_reg, l + 1);
     const uint2* s_up = lds + a.lds_off[l + 1];
     uint2* s_io = lds + a.lds_off[l];
-    for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
+    for (int q = threadIdx.x; q < it.nq; q += NT) {
         int x, y;
         bool valid[4];
         it.at(q, x, y, valid);
@@ -1410,18 +1401,6 @@ __device__ __forceinline__ int pano_store_mode(const BlendArgs& a, const uint8_t
     return (al & 1u) == 0 ? 1 : 0;
 }
 
-// values of the lanes beside this one within a DPP row of 16 lanes (row_shr:1 / row_shl:1; the row's first / last
-// lane keeps its own value).  (The wavefront-wide shifts wave_shr / wave_shl assemble for gfx950 but do not cross
-// the 16-lane rows there: measured, tests/test_gpu_edge_cases.py caught it.)
-__device__ __forceinline__ uint32_t from_lane_below(uint32_t v)      // lane i <- lane i - 1
-{
-    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x111, 0xF, 0xF, false));
-}
-__device__ __forceinline__ uint32_t from_lane_above(uint32_t v)      // lane i <- lane i + 1
-{
-    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x101, 0xF, 0xF, false));
-}
-
 // v - sign(v)
 __device__ __forceinline__ int toward_zero(int v)
 {
@@ -1449,15 +1428,15 @@ __device__ __forceinline__ int toward_zero(int v)
 // and never both non-zero on a pixel (seam masks; image borders), every window covering the whole tile (checked
 // per calibration, mb_plan.cpp).  A pixel's band is then its one covering camera's lap - sign(lap), or 0 under no
 // camera (where dst_mask_ is 0 and the panorama pixel with it): still integers only, the masks pick per pixel.
-template <int L, int NC, bool MASKED, typename UpPtr>
+template <int L, int NC, bool MASKED, int NT, typename UpPtr>
 __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, const BlendArgs& a, const Region& r,
                                             uint32_t cam_bits, UpPtr up, int up_x0, int up_y0, int up_pitch,
                                             uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask, uint64_t* __restrict__ c1_out)
 {
     constexpr int kTileH = L == 0 ? C_TH : CC_TH;
-    static_assert(C_TW == 128 && CC_TW == 128 && (kTileH / 2) % (C_THREADS / 64) == 0, "one wave per quad row of the tile");
+    static_assert(C_TW == 128 && CC_TW == 128 && (kTileH / 2) % (NT / 64) == 0, "one wave per quad row of the tile");
     static_assert(L == 0 || (NC == 1 && !MASKED), "masks are level-0 weights");
-    constexpr int kRows = (kTileH / 2) / (C_THREADS / 64);      // quad rows per wave
+    constexpr int kRows = (kTileH / 2) / (NT / 64);              // quad rows per wave
     const int lane = static_cast<int>(threadIdx.x & 63u);
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int uw = a.cw[L + 1], uh = a.ch[L + 1];
@@ -1733,7 +1712,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
 
 // The base level of k_blend_coarse (level 1): its band is formed like any other, the collapsed level above comes out
 // of LDS, and the sum -- the collapsed level-1 canvas -- goes to global memory for k_blend_fine (8 bytes a pixel).
-template <bool TOP, bool PURE, bool W16 = false>
+template <int NT, bool TOP, bool PURE, bool W16 = false>
 __device__ __forceinline__ void coarse_base_level(const CamDesc* __restrict__ cams, const BlendArgs& a, uint32_t cam_bits,
                                                   const uint2* __restrict__ lds, const int* __restrict__ s_reg,
                                                   uint2* __restrict__ c1)
@@ -1748,7 +1727,7 @@ __device__ __forceinline__ void coarse_base_level(const CamDesc* __restrict__ ca
     }
     const int cw = a.cw[l];
     const bool wide = (cw & 1) == 0;       // rows start 16-byte aligned (c1 is), x is even
-    for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
+    for (int q = threadIdx.x; q < it.nq; q += NT) {
         int x, y;
         bool valid[4];
         it.at(q, x, y, valid);
@@ -1811,7 +1790,7 @@ __device__ __forceinline__ bool tile_of_block(int n_tiles, int n_sets, int& q, i
 // quarters of the time of the single canvas kernel this replaces: tiles four times as large in panorama terms
 // halve the halo at every level, and level 0 runs as a streaming kernel of its own with no LDS and no barrier.
 template <bool W16>
-__global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_coarse(const CamDesc* __restrict__ cams_all, BlendArgs a)
+__global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const CamDesc* __restrict__ cams_all, BlendArgs a)
 {
     int q, set;
     if (!tile_of_block(a.n_coarse_tiles, a.n_sets, q, set)) return;
@@ -1834,8 +1813,8 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_coarse(const C
     __syncthreads();
     if (top >= 2) {
         // phase 1: every band above level 1, independent of each other -> no barrier until all are in LDS
-        if (pure) band_levels<true>(cams, a, top, tx, ty, cam_bits, lds, s_reg, 2);
-        else band_levels<false, W16>(cams, a, top, tx, ty, cam_bits, lds, s_reg, 2, owned_levels, owner_bits);
+        if (pure) band_levels<CC_THREADS, true>(cams, a, top, tx, ty, cam_bits, lds, s_reg, 2);
+        else band_levels<CC_THREADS, false, W16>(cams, a, top, tx, ty, cam_bits, lds, s_reg, 2, owned_levels, owner_bits);
         MST_STAMP(1, 1);
         __syncthreads();
         MST_STAMP(1, 2);
@@ -1843,7 +1822,7 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_coarse(const C
         if (a.dbg_C[top]) {
             const QuadIter it(s_reg, top);
             const uint2* s = lds + a.lds_off[top];
-            for (int i = threadIdx.x; i < it.rw * (it.r.y1 - it.r.y0); i += C_THREADS) {
+            for (int i = threadIdx.x; i < it.rw * (it.r.y1 - it.r.y0); i += CC_THREADS) {
                 const int py = it.r.y0 + i / it.rw, px = it.r.x0 + i % it.rw;
                 const uint2 n = s[(py - it.r.y0) * it.pitch + (px - it.r.x0)];
                 const int v[3] = {s16_lo(n.x), s16_hi(n.x), s16_lo(n.y)};
@@ -1851,7 +1830,7 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_coarse(const C
             }
         }
         for (int l = top - 1; l >= 2; --l) {
-            collapse_level(a, l, tx, ty, lds, s_reg);
+            collapse_level<CC_THREADS>(a, l, tx, ty, lds, s_reg);
             __syncthreads();
         }
     }
@@ -1861,16 +1840,16 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_coarse(const C
     const uint32_t bits1 = pure ? cam_bits : owner_bits;
     uint2* c1 = reinterpret_cast<uint2*>(a.c1[set]);
     if (top == 1) {
-        if (own1) coarse_base_level<true, true>(cams, a, bits1, lds, s_reg, c1);
-        else coarse_base_level<true, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
+        if (own1) coarse_base_level<CC_THREADS, true, true>(cams, a, bits1, lds, s_reg, c1);
+        else coarse_base_level<CC_THREADS, true, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
     } else {
         const Region r1 = table_region(s_reg, 1), ur = table_region(s_reg, 2);
         const bool full = r1.x1 - r1.x0 == CC_TW && r1.y1 - r1.y0 == CC_TH && (a.cw[1] & 1) == 0;
         if (own1 && full && !(MST_ABLATE_C & 64))
-            owned_strip<1, 1, false>(cams, a, r1, bits1, static_cast<const uint2*>(lds + a.lds_off[2]), ur.x0, ur.y0, region_pitch(ur),
+            owned_strip<1, 1, false, CC_THREADS>(cams, a, r1, bits1, static_cast<const uint2*>(lds + a.lds_off[2]), ur.x0, ur.y0, region_pitch(ur),
                            nullptr, nullptr, a.c1[set]);
-        else if (own1) coarse_base_level<false, true>(cams, a, bits1, lds, s_reg, c1);
-        else coarse_base_level<false, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
+        else if (own1) coarse_base_level<CC_THREADS, false, true>(cams, a, bits1, lds, s_reg, c1);
+        else coarse_base_level<CC_THREADS, false, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
     }
     MST_STAMP(1, 4);
 }
@@ -1923,9 +1902,9 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_fine(const Cam
     const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
     const bool strip = full && !(MST_ABLATE_C & 64) && pano_store_mode(a, pano, true) == 2;
     const bool binary = !(MST_ABLATE_C & 512) && (entry >> 30) & 1u;      // 0/1 weights, disjoint, windows cover the tile
-    if (own0 && strip) owned_strip<0, 1, false>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
-    else if (binary && strip && (cam_bits & (cam_bits - 1)) == 0) owned_strip<0, 1, true>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
-    else if (binary && strip) owned_strip<0, 2, true>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    if (own0 && strip) owned_strip<0, 1, false, C_THREADS>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (binary && strip && (cam_bits & (cam_bits - 1)) == 0) owned_strip<0, 1, true, C_THREADS>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (binary && strip) owned_strip<0, 2, true, C_THREADS>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
     else if (own0) final_level<false, true>(cams, a, r0, cam_bits, c1, pano, pano_mask);
     else final_level<false, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
     MST_STAMP_VAL(2, 9, static_cast<unsigned long long>(full));
@@ -2021,8 +2000,8 @@ void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, 
     a.n_sets = batch;
     if (a.nlev > 1) {
         const int grid = ((num_coarse + 7) / 8) * 8 * batch;
-        if (a.weights_16s) hipLaunchKernelGGL(k_blend_coarse<true>, dim3(grid), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
-        else hipLaunchKernelGGL(k_blend_coarse<false>, dim3(grid), dim3(C_THREADS), lds_bytes + pad, s, d_cams, a);
+        if (a.weights_16s) hipLaunchKernelGGL(k_blend_coarse<true>, dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, a);
+        else hipLaunchKernelGGL(k_blend_coarse<false>, dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, a);
     }
     const int grid = ((num_blocks + 7) / 8) * 8 * batch;
     if (a.weights_16s) hipLaunchKernelGGL(k_blend_fine<true>, dim3(grid), dim3(C_THREADS), 0, s, d_cams, a);
