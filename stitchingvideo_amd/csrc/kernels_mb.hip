@@ -818,16 +818,17 @@ constexpr int C_TW = 128, C_TH = MST_C_TH;
 #ifndef MST_CC_TW
 #define MST_CC_TW 128      // k_blend_coarse: tile size in level-1 pixels
 #endif
-#ifndef MST_CC_TH
-#define MST_CC_TH 64
-#endif
-constexpr int CC_TW = MST_CC_TW, CC_TH = MST_CC_TH;
+constexpr int CC_TW = MST_CC_TW;
+// k_blend_coarse tile height (level-1 rows) is chosen per calibration (BlendArgs::cc_th): 32 for batched launches, 16 when
+// frame sets are composed one at a time (four times as many, shorter blocks: 9.5 k instead of 8.8 k panoramas/s
+// one at a time, 3 % slower in batches of 8)
+constexpr int CC_TH_MAX = 32;
 #ifndef MST_C_THREADS
 #define MST_C_THREADS 256
 #endif
 constexpr int C_THREADS = MST_C_THREADS;       // k_blend_fine
 #ifndef MST_CC_THREADS
-#define MST_CC_THREADS 512     // k_blend_coarse: eight waves share the latency-bound upper levels of a tile
+#define MST_CC_THREADS 256
 #endif
 constexpr int CC_THREADS = MST_CC_THREADS;
 
@@ -840,7 +841,7 @@ __host__ __device__ inline Region blend_region(const BlendArgs& a, int base, int
     Region r;
     auto lo = [](int v, int m) { return v < m ? v : m; };
     auto hi = [](int v, int m) { return v > m ? v : m; };
-    const int tw = base ? CC_TW : C_TW, th = base ? CC_TH : C_TH;
+    const int tw = base ? CC_TW : C_TW, th = base ? a.cc_th : C_TH;
     r.x0 = tx * tw; r.y0 = ty * th;
     r.x1 = lo(r.x0 + tw, a.cw[base]); r.y1 = lo(r.y0 + th, a.ch[base]);
     for (int l = base + 1; l <= level; ++l) {
@@ -1197,7 +1198,7 @@ struct QuadIter {
     __device__ __forceinline__ void at(int q, int& x, int& y, bool valid[4]) const
     {
         // (the multiply form needs q < 4096 and qw <= 64: a 128 x 64 tile has 2048 quads in rows of 64 at most)
-        const int qy = (inv != 0 && C_TW <= 128 && C_TW * C_TH <= 4 * 4096 && CC_TW <= 128 && CC_TW * CC_TH <= 4 * 4096) ? static_cast<int>((static_cast<uint32_t>(q) * inv) >> 20) : q / qw;
+        const int qy = (inv != 0 && C_TW <= 128 && C_TW * C_TH <= 4 * 4096 && CC_TW <= 128 && CC_TW * CC_TH_MAX <= 4 * 4096) ? static_cast<int>((static_cast<uint32_t>(q) * inv) >> 20) : q / qw;
         const int qx = q - __mul24(qy, qw);
         x = r.x0 + 2 * qx;
         y = r.y0 + 2 * qy;
@@ -1428,12 +1429,12 @@ __device__ __forceinline__ int toward_zero(int v)
 // and never both non-zero on a pixel (seam masks; image borders), every window covering the whole tile (checked
 // per calibration, mb_plan.cpp).  A pixel's band is then its one covering camera's lap - sign(lap), or 0 under no
 // camera (where dst_mask_ is 0 and the panorama pixel with it): still integers only, the masks pick per pixel.
-template <int L, int NC, bool MASKED, int NT, typename UpPtr>
+template <int L, int NC, bool MASKED, int NT, int TH, typename UpPtr>
 __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, const BlendArgs& a, const Region& r,
                                             uint32_t cam_bits, UpPtr up, int up_x0, int up_y0, int up_pitch,
                                             uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask, uint64_t* __restrict__ c1_out)
 {
-    constexpr int kTileH = L == 0 ? C_TH : CC_TH;
+    constexpr int kTileH = TH;
     static_assert(C_TW == 128 && CC_TW == 128 && (kTileH / 2) % (NT / 64) == 0, "one wave per quad row of the tile");
     static_assert(L == 0 || (NC == 1 && !MASKED), "masks are level-0 weights");
     constexpr int kRows = (kTileH / 2) / (NT / 64);              // quad rows per wave
@@ -1782,14 +1783,14 @@ __device__ __forceinline__ bool tile_of_block(int n_tiles, int n_sets, int& q, i
     return q < n_tiles;
 }
 
-// Canvas kernel 1 of 2: levels 1 .. top of the canvas pyramid, one block per CC_TW x CC_TH tile of LEVEL 1.
+// Canvas kernel 1 of 2: levels 1 .. top of the canvas pyramid, one block per CC_TW x TH tile of LEVEL 1.
 //   phase 1  bands of the levels 2 .. top over the tile's regions (tile + pyrUp halo), normalised, into LDS
 //   phase 2  restoreImageFromLaplacePyr inside LDS down to level 2
 //   phase 3  level-1 band + pyrUp(level 2) -> the collapsed level-1 canvas in global memory
 // Level 1 and above hold a quarter of the pixels but -- with the halo every level adds around a tile -- took three
 // quarters of the time of the single canvas kernel this replaces: tiles four times as large in panorama terms
 // halve the halo at every level, and level 0 runs as a streaming kernel of its own with no LDS and no barrier.
-template <bool W16>
+template <bool W16, int TH>
 __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const CamDesc* __restrict__ cams_all, BlendArgs a)
 {
     int q, set;
@@ -1844,9 +1845,9 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
         else coarse_base_level<CC_THREADS, true, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
     } else {
         const Region r1 = table_region(s_reg, 1), ur = table_region(s_reg, 2);
-        const bool full = r1.x1 - r1.x0 == CC_TW && r1.y1 - r1.y0 == CC_TH && (a.cw[1] & 1) == 0;
+        const bool full = r1.x1 - r1.x0 == CC_TW && r1.y1 - r1.y0 == TH && (a.cw[1] & 1) == 0;
         if (own1 && full && !(MST_ABLATE_C & 64))
-            owned_strip<1, 1, false, CC_THREADS>(cams, a, r1, bits1, static_cast<const uint2*>(lds + a.lds_off[2]), ur.x0, ur.y0, region_pitch(ur),
+            owned_strip<1, 1, false, CC_THREADS, TH>(cams, a, r1, bits1, static_cast<const uint2*>(lds + a.lds_off[2]), ur.x0, ur.y0, region_pitch(ur),
                            nullptr, nullptr, a.c1[set]);
         else if (own1) coarse_base_level<CC_THREADS, false, true>(cams, a, bits1, lds, s_reg, c1);
         else coarse_base_level<CC_THREADS, false, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
@@ -1902,9 +1903,9 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_fine(const Cam
     const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
     const bool strip = full && !(MST_ABLATE_C & 64) && pano_store_mode(a, pano, true) == 2;
     const bool binary = !(MST_ABLATE_C & 512) && (entry >> 30) & 1u;      // 0/1 weights, disjoint, windows cover the tile
-    if (own0 && strip) owned_strip<0, 1, false, C_THREADS>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
-    else if (binary && strip && (cam_bits & (cam_bits - 1)) == 0) owned_strip<0, 1, true, C_THREADS>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
-    else if (binary && strip) owned_strip<0, 2, true, C_THREADS>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    if (own0 && strip) owned_strip<0, 1, false, C_THREADS, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (binary && strip && (cam_bits & (cam_bits - 1)) == 0) owned_strip<0, 1, true, C_THREADS, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (binary && strip) owned_strip<0, 2, true, C_THREADS, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
     else if (own0) final_level<false, true>(cams, a, r0, cam_bits, c1, pano, pano_mask);
     else final_level<false, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
     MST_STAMP_VAL(2, 9, static_cast<unsigned long long>(full));
@@ -1944,7 +1945,9 @@ int mb_read_stamps(int which, unsigned long long* out, size_t n)
 #endif
 }
 
-void mb_coarse_tile_dims(int* tw, int* th) { *tw = CC_TW; *th = CC_TH; }
+int mb_coarse_tile_width() { return CC_TW; }
+
+int mb_coarse_tile_height(int max_batch) { return max_batch <= 2 ? 16 : 32; }
 
 void mb_blend_region(const BlendArgs& a, int base, int tx, int ty, int level, int out[4])
 {
@@ -2000,8 +2003,10 @@ void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, 
     a.n_sets = batch;
     if (a.nlev > 1) {
         const int grid = ((num_coarse + 7) / 8) * 8 * batch;
-        if (a.weights_16s) hipLaunchKernelGGL(k_blend_coarse<true>, dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, a);
-        else hipLaunchKernelGGL(k_blend_coarse<false>, dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, a);
+#define MST_LAUNCH_COARSE(W, TH) hipLaunchKernelGGL((k_blend_coarse<W, TH>), dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, a)
+        if (a.cc_th == 16) { if (a.weights_16s) MST_LAUNCH_COARSE(true, 16); else MST_LAUNCH_COARSE(false, 16); }
+        else { if (a.weights_16s) MST_LAUNCH_COARSE(true, 32); else MST_LAUNCH_COARSE(false, 32); }
+#undef MST_LAUNCH_COARSE
     }
     const int grid = ((num_blocks + 7) / 8) * 8 * batch;
     if (a.weights_16s) hipLaunchKernelGGL(k_blend_fine<true>, dim3(grid), dim3(C_THREADS), 0, s, d_cams, a);

@@ -248,8 +248,7 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
     }
     mark("warp + chain tile lists");
     // ---- canvas kernels: panorama tiles (k_blend_fine, level 0) and level-1 tiles (k_blend_coarse, levels 1 .. top)
-    int cc_tw, cc_th;
-    mb_coarse_tile_dims(&cc_tw, &cc_th);
+    const int cc_tw = mb_coarse_tile_width(), cc_th = blend.cc_th;
     plan.blend_tiles_x = (blend.cw[0] + c_tw - 1) / c_tw;
     plan.blend_tiles_y = (blend.ch[0] + c_th - 1) / c_th;
     plan.block_cams.assign(static_cast<size_t>(plan.blend_tiles_x) * plan.blend_tiles_y, 0u);

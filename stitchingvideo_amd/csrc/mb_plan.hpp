@@ -52,7 +52,7 @@ struct MbPlanHost {
 // weight_class[c][l]: one byte per pixel of camera c's weight pyramid level l -- bit 0: the weight is non-zero,
 // bit 1: it is exactly the weight of a fully owned pixel (1.0f; 256 with CV_16S weights) -- classified on the
 // device (k_weight_class), so that the plan never needs the float pyramids on the host.  `blend` must have
-// nlev/cw/ch/final_w/final_h filled in.
+// nlev/cw/ch/final_w/final_h/cc_th filled in.
 void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<uint8_t>>>& weight_class,
                    const BlendArgs& blend, MbPlanHost& plan);
 
