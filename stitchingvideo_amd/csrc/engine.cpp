@@ -737,9 +737,13 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         ba.mask_stride = static_cast<uint32_t>(mask_stride);
         if (!st->c1.empty())
             for (int f = 0; f < count; ++f) ba.c1[f] = st->c1[first_set + f];
-        launch_blend(desc, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y, st->plan.coarse_tiles_x * st->plan.coarse_tiles_y,
-                     count, st->plan.lds_bytes, s);
-        mark("k_blend");
+        const int n_fine = st->plan.blend_tiles_x * st->plan.blend_tiles_y, n_coarse = st->plan.coarse_tiles_x * st->plan.coarse_tiles_y;
+        if (ba.nlev > 1) {
+            launch_blend(desc, ba, n_fine, n_coarse, count, st->plan.lds_bytes, s, 1);
+            mark("k_blend_coarse");
+        }
+        launch_blend(desc, ba, n_fine, n_coarse, count, st->plan.lds_bytes, s, 2);
+        mark("k_blend_fine");
         if (overlap) {
             check_hip(hipEventRecord(ev_canvas_done_[slot], s), "hipEventRecord");
             canvas_pending_[slot] = true;

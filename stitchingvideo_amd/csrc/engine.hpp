@@ -99,7 +99,7 @@ struct CalibState {
     uint32_t* warp_blobs = nullptr;     // per tile: calibration constants of kernel A (gain rows, row weights, table origin)
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step
     PayloadRect* d_payload_rects = nullptr;   // camera-sharded hand-off (plan.payload_*)
-    BlendArgs blend{};                  // kernel C (pano pointers filled per frame)
+    BlendArgs blend{};                  // canvas kernels (pano pointers filled per frame)
     // feather
     float* d_feather_ws = nullptr;
     // output rectangle (== canvas unless the driver LUT crop is active)

@@ -61,8 +61,9 @@ void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, ui
 void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
                      int batch, const uint32_t* d_table, const uint32_t* d_blobs, hipStream_t s);
 void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s);
+// which: bit 0 = k_blend_coarse (levels 1 .. top -> collapsed level-1 canvas), bit 1 = k_blend_fine (level 0 -> panorama)
 void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
-                  hipStream_t s);
+                  hipStream_t s, int which = 3);
 
 // ---- per-frame hot path: feather / paste (fully fused: warp + gain + blend in one kernel) ----
 void launch_feather_compose(const CamDesc* d_cams, int n_cams, const FrameArgs& frames, const float* d_ws,

@@ -6,10 +6,11 @@
 //                    (RotationWarper::warp, ExposureCompensator::apply, convertTo(16S),
 //                     copyMakeBorder, first pyrDown: stitcher.cpp:275-285, blenders.cpp:272-274,481)
 //   B  k_pyr_chain   per camera tile: two further pyrDown levels inside LDS per launch (blenders.cpp:481)
-//   C  k_blend       per canvas tile, all bands in one block: Laplacian = G_l - pyrUp(G_l+1)
-//                    (blenders.cpp:482-487), short(lap * w) accumulate over cameras (:306-330),
-//                    normalise by the re-summed weights (:383-405), collapse inside LDS (:520-530),
-//                    crop + mask + convertTo(8U) (:369-376, stitcher.cpp:313).
+//   C1 k_blend_coarse  per level-1 canvas tile, every band above level 0 in one block: Laplacian = G_l - pyrUp(G_l+1)
+//                    (blenders.cpp:482-487), short(lap * w) accumulate over cameras (:306-330), normalise by the
+//                    re-summed weights (:383-405), collapse inside LDS (:520-530) -> collapsed level-1 canvas.
+//   C2 k_blend_fine  per panorama tile: level-0 band + pyrUp of the collapsed level 1, crop + mask +
+//                    convertTo(8U) (:369-376, stitcher.cpp:313).  No LDS, no barrier.
 //
 // Data layout: every Gaussian level of a CV_8U-sourced pyramid stays within [0,255], so a pixel is
 // one dword B | G<<8 | R<<16.  The [1 4 6 4 1] sums are evaluated two channels at a time in the 16-bit
@@ -19,13 +20,15 @@
 // Work lists: only tiles whose output can reach the panorama (non-zero blend weight somewhere down
 // the chain) are launched; the lists are built once per calibration on the host (mb_plan.cpp).
 //
-// Tuning notes (MI355X, rocprofv3, profiles/): per frame set the path moves ~310 MB
-// (5x the compulsory bytes) and issues ~45 M VALU wave-instructions; kernel A runs close to what HBM delivers
-// for its access pattern (~4.4 TB/s), kernels B and C are bound by instruction issue with few ready waves and by
-// dependent-load latency.  What paid off, in order: never launching tiles that cannot reach the panorama,
-// packed pixels + SWAR pyramids, the per-calibration map table with BORDER_REFLECT folded into it, integer
-// paths wherever the weights are exactly 0/1, keeping the software pipelines intact through the compiler
-// (global address space, no branches around in-flight loads, full unrolling), and batching frame sets.
+// Tuning notes (MI355X, rocprofv3, profiles/): per frame set the path moves ~259 MB at the
+// fabric (4.2x the compulsory bytes) and issues ~33 M VALU wave-instructions.  Kernel A and the coarse canvas kernel
+// are bound by instruction issue (50-65 % VALU-busy with the other pipes partly loaded), the level-0 canvas kernel by
+// memory (4.9 TB/s), the pyrDown chain by dependent round trips per block.  What paid off, in order: never launching
+// tiles that cannot reach the panorama, packed pixels + SWAR pyramids, the per-calibration map table with
+// BORDER_REFLECT folded into it, integer paths wherever the weights are exactly 0/1, register-rolling quad-row
+// strips with DPP neighbour exchange for those paths (6 loads per quad instead of 20), keeping the software
+// pipelines intact through the compiler (global address space, no branches around in-flight loads, full
+// unrolling), and batching frame sets.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -78,8 +81,11 @@ __device__ __forceinline__ uint32_t pyrdown_finish(uint32_t vbr, uint32_t vg)
 }
 
 // values of the lanes beside this one within a DPP row of 16 lanes (row_shr:1 / row_shl:1; the row's first / last
-// lane keeps its own value).  (The wavefront-wide shifts wave_shr / wave_shl assemble for gfx950 but do not cross
-// the 16-lane rows there: measured, tests/test_gpu_edge_cases.py caught it.)
+// lane keeps its own value).  Callers fetch the outer neighbour of every row's end lanes themselves (one masked
+// load whether there are two such lanes or eight).  A DPP read of a lane that a branch has switched off returns the
+// reader's own `old` value, so the shifts must be executed by all lanes BEFORE any select: `edge ? loaded : shift(v)`
+// evaluates shift() under the branch and silently hands the end lanes' neighbours stale data
+// (tests/test_gpu_edge_cases.py caught exactly that).
 __device__ __forceinline__ uint32_t from_lane_below(uint32_t v)      // lane i <- lane i - 1
 {
     return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x111, 0xF, 0xF, false));
@@ -1993,7 +1999,7 @@ void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, i
 }
 
 void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
-                  hipStream_t s)
+                  hipStream_t s, int which)
 {
     static const size_t pad = tuning_env("MST_C_PAD_LDS");
     if (num_blocks <= 0 || batch <= 0) return;
@@ -2001,13 +2007,14 @@ void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, 
     a.n_tiles = num_blocks;
     a.n_coarse_tiles = num_coarse;
     a.n_sets = batch;
-    if (a.nlev > 1) {
+    if (a.nlev > 1 && (which & 1)) {
         const int grid = ((num_coarse + 7) / 8) * 8 * batch;
 #define MST_LAUNCH_COARSE(W, TH) hipLaunchKernelGGL((k_blend_coarse<W, TH>), dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, a)
         if (a.cc_th == 16) { if (a.weights_16s) MST_LAUNCH_COARSE(true, 16); else MST_LAUNCH_COARSE(false, 16); }
         else { if (a.weights_16s) MST_LAUNCH_COARSE(true, 32); else MST_LAUNCH_COARSE(false, 32); }
 #undef MST_LAUNCH_COARSE
     }
+    if (!(which & 2)) return;
     const int grid = ((num_blocks + 7) / 8) * 8 * batch;
     if (a.weights_16s) hipLaunchKernelGGL(k_blend_fine<true>, dim3(grid), dim3(C_THREADS), 0, s, d_cams, a);
     else hipLaunchKernelGGL(k_blend_fine<false>, dim3(grid), dim3(C_THREADS), 0, s, d_cams, a);

@@ -389,7 +389,7 @@ def test_profile_entry_points_report_every_launch():
     single = eng.profile_stages(ptrs[0], strides[0], panos[0].data_ptr(), panos[0].stride(0))
     batch = eng.profile_stages_batch(ptrs, strides, [p.data_ptr() for p in panos], panos[0].stride(0))
     for stages in (single, batch):
-        assert [n for n, _ in stages] == ["k_warp_pyr", "k_pyr_chain", "k_pyr_chain", "k_blend"]
+        assert [n for n, _ in stages] == ["k_warp_pyr", "k_pyr_chain", "k_pyr_chain", "k_blend_coarse", "k_blend_fine"]
         assert all(0.0 < ms < 50.0 for _, ms in stages)
     eng.synchronize()
     for i in range(2):

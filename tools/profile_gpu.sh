@@ -11,6 +11,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python3 $PWD/bench.py --steps 10 --warmup 3 --min-time 0.1 --no-cpu-baseline --no-latency-leg $EXTRA"
 REPO=$PWD
+echo "$BENCH" | sed "s|$PWD/||" > "$OUT/command.txt"
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1 || echo "stats pass failed"
 pass() {   # name, counters...

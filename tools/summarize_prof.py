@@ -18,7 +18,12 @@ def short(name):
     return name[:40]
 
 
-print("# rocprofv3 summary of: python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline")
+cmd = "python3 bench.py (see tools/profile_gpu.sh)"
+try:
+    cmd = open(os.path.join(root, "command.txt")).read().strip()
+except OSError:
+    pass
+print("# rocprofv3 --kernel-trace --stats (+ separate --pmc passes) of: %s" % cmd)
 for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
     print("\n## kernel stats (%s)" % os.path.relpath(f, root))
     rows = list(csv.DictReader(open(f)))
