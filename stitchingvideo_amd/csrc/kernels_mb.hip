@@ -1837,7 +1837,7 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
             }
         }
         for (int l = top - 1; l >= 2; --l) {
-            collapse_level<CC_THREADS>(a, l, tx, ty, lds, s_reg);
+            if (!(MST_ABLATE_C & 2)) collapse_level<CC_THREADS>(a, l, tx, ty, lds, s_reg);       // (timing experiments)
             __syncthreads();
         }
     }
