@@ -79,3 +79,28 @@ def test_full_size_c4_camera_sharded_two_engines():
     p1, m1 = e1.compose(frames)
     assert np.array_equal(p1, opano) and np.array_equal(m1, omask)
     e0.close(); e1.close()
+
+
+def test_full_size_c3_in_the_bench_configuration():
+    """C3 exactly as bench.py times it: an engine created with max_batch = 8 (which also selects the taller canvas
+    tiles of the batched mode) composing eight frame sets in one launch sequence -- every panorama against the
+    oracle (two distinct frame sets, alternated)."""
+    import torch
+    rig = rigmod.build_rig(rigmod.CONFIGS["C3"])
+    eng = H.make_engine(rig, max_batch=8)
+    _, _, cw, ch = eng.canvas()
+    assert (cw, ch) == (7852, 1020)                          # SURVEY.md 8d
+    dev = torch.device("cuda", 0)
+    host = [rigmod.frames_for(rig, i) for i in range(2)]
+    dfr = [[torch.from_numpy(f).to(dev) for f in fr] for fr in host]
+    order = [0, 1, 1, 0, 1, 0, 0, 1]
+    panos = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in order]
+    masks = [torch.zeros((ch, cw), dtype=torch.uint8, device=dev) for _ in order]
+    eng.compose_device_batch([[t.data_ptr() for t in dfr[k]] for k in order], [[t.stride(0) for t in dfr[k]] for k in order],
+                             [p.data_ptr() for p in panos], panos[0].stride(0), [m.data_ptr() for m in masks], masks[0].stride(0))
+    eng.synchronize()
+    expect = [H.oracle_compose(rig, fr, threads=THREADS) for fr in host]
+    for i, k in enumerate(order):
+        assert np.array_equal(masks[i].cpu().numpy(), expect[k][2]), "frame set %d mask" % i
+        assert np.array_equal(panos[i].cpu().numpy(), expect[k][1]), "frame set %d: %s" % (i, H.diff_report(panos[i].cpu().numpy(), expect[k][1]))
+    eng.close()
