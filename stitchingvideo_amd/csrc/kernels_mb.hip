@@ -610,7 +610,13 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
             const uint2 lo = *reinterpret_cast<const uint2*>(&s_l0[2 + r][2 + 4 * g]);
             const uint2 hi = *reinterpret_cast<const uint2*>(&s_l0[2 + r][4 + 4 * g]);
             typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+#if !defined(MST_NO_NT_STORE)
+            // (non-temporal: level 0 is next read a whole batch later, by k_blend_fine; keeping it out of the caches
+            // leaves them to the frames and the map table: k_warp_pyr 287.5 -> 274.0 us per 8 frame sets)
+            __builtin_nontemporal_store(u32x4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<u32x4 MST_GLOBAL*>(g0out + __umul24(gy, bw) + gx4));
+#else
             *reinterpret_cast<u32x4 MST_GLOBAL*>(g0out + __umul24(gy, bw) + gx4) = u32x4{lo.x, lo.y, hi.x, hi.y};
+#endif
         }
     }
     if (nlev < 2 || (MST_ABLATE_A & 4)) return;
@@ -1529,8 +1535,18 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
             q.q0 = GPix{static_cast<uint32_t>(x * 3 + k.j), static_cast<uint32_t>(x * 5 + k.j)};
             q.q1 = GPix{static_cast<uint32_t>(x * 7 + k.j), static_cast<uint32_t>(x * 11 + k.j)};
         } else {
-            q.q0 = k.gq[0];
-            q.q1 = *(const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)k.gq + k.lw);
+#if !defined(MST_NO_NT_LOAD)
+            // level 0 of a camera is read exactly once per frame set: streamed past the caches (non-temporal), which leaves
+            // them to the level-1 rows the strips above and below re-read (k_blend_fine 169.6 -> 160.4 us per 8 frame sets)
+            if (L == 0) {
+                q.q0 = __builtin_nontemporal_load(k.gq);
+                q.q1 = __builtin_nontemporal_load((const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)k.gq + k.lw));
+            } else
+#endif
+            {
+                q.q0 = k.gq[0];
+                q.q1 = *(const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)k.gq + k.lw);
+            }
         }
         q.m = 0xFFFFFFFFu;
         if (MASKED)
@@ -1643,7 +1659,10 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
             w.x = flo;
             w.y = (fhi & 0xFFFFu) | slo << 16;
             w.z = slo >> 16 | shi << 16;
-            if (!(MST_ABLATE_C & 4096) || w.x == 0x12345678u) *reinterpret_cast<uint3*>(po) = w;
+            if (!(MST_ABLATE_C & 4096) || w.x == 0x12345678u) {
+                // (a plain store: marked non-temporal it costs 5 % of this kernel, measured)
+                *reinterpret_cast<uint3*>(po) = w;
+            }
             po += 2 * a.pano_stride;
             if (pm) {
 #pragma unroll
@@ -1657,7 +1676,11 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
             for (int ry = 0; ry < 2; ++ry) {
                 const uint2 p0 = pack3(v[2 * ry][0], v[2 * ry][1], v[2 * ry][2]);
                 const uint2 p1 = pack3(v[2 * ry + 1][0], v[2 * ry + 1][1], v[2 * ry + 1][2]);
+#if !defined(MST_NO_NT_STORE)      // (read again a kernel later, eight frame sets away: k_blend_coarse 86.5 -> 83.9 us)
+                __builtin_nontemporal_store(u32x4{p0.x, p0.y, p1.x, p1.y}, reinterpret_cast<u32x4 MST_GLOBAL*>(co + __mul24(ry, a.cw[L])));
+#else
                 *reinterpret_cast<u32x4 MST_GLOBAL*>(co + __mul24(ry, a.cw[L])) = u32x4{p0.x, p0.y, p1.x, p1.y};
+#endif
                 if (a.dbg_C[L]) { dump_level(a, L, x, y0 + 2 * t + ry, v[2 * ry]); dump_level(a, L, x + 1, y0 + 2 * t + ry, v[2 * ry + 1]); }
             }
             co += 2 * a.cw[L];
@@ -1758,7 +1781,11 @@ __device__ __forceinline__ void coarse_base_level(const CamDesc* __restrict__ ca
             if (wide && valid[2 * ry + 1]) {
                 typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
                 const u32x4 w = {p0.x, p0.y, p1.x, p1.y};
+#if !defined(MST_NO_NT_STORE)
+                __builtin_nontemporal_store(w, reinterpret_cast<u32x4 MST_GLOBAL*>(o));
+#else
                 *reinterpret_cast<u32x4 MST_GLOBAL*>(o) = w;
+#endif
             } else {
                 o[0] = GPix{p0.x, p0.y};
                 if (valid[2 * ry + 1]) o[1] = GPix{p1.x, p1.y};
