@@ -2,9 +2,15 @@
 #include "mb_plan.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 
 #include "kernels.hpp"
@@ -24,17 +30,110 @@ int reflect101(int p, int len)
     return p;
 }
 
-// run f(i) for i in [0, count) on up to `max_threads` host threads (the plan is a few dozen independent passes over
-// byte maps: per camera, per canvas tile row)
+// A small persistent pool for the loops below (the plan is a few dozen independent passes over byte maps -- per
+// camera, per stripe of rows -- and used to create and join a set of std::threads for every one of them, a third of
+// its run time).  A loop is published as a job with an atomic index; the caller works on its own job like any
+// worker, so nested loops (cameras outside, stripes inside) always make progress, and waits only for the items
+// other threads have already taken.
+class LoopPool {
+public:
+    struct Job {
+        std::function<void(int)> body;
+        int count = 0;
+        std::atomic<int> next{0}, done{0};
+    };
+    static LoopPool& instance() { static LoopPool p; return p; }
+    void run(int count, int max_threads, std::function<void(int)> body)
+    {
+        if (count <= 0) return;
+        if (count == 1 || max_threads <= 1 || workers_.empty()) { for (int i = 0; i < count; ++i) body(i); return; }
+        auto job = std::make_shared<Job>();
+        job->body = std::move(body);
+        job->count = count;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            jobs_.push_back(job);
+        }
+        cv_.notify_all();
+        work_on(*job);
+        while (job->done.load(std::memory_order_acquire) < count) std::this_thread::yield();
+        std::lock_guard<std::mutex> lk(mu_);
+        jobs_.erase(std::find(jobs_.begin(), jobs_.end(), job));
+    }
+private:
+    LoopPool()
+    {
+        const int hw = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+        const int n = std::min(hw, 32) - 1;                 // the caller is a worker too
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { worker(); });
+    }
+    ~LoopPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread& t : workers_) t.join();
+    }
+    static void work_on(Job& j)
+    {
+        for (;;) {
+            const int i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.count) return;
+            j.body(i);
+            j.done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void worker()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            std::shared_ptr<Job> pick;
+            for (const std::shared_ptr<Job>& j : jobs_)
+                if (j->next.load(std::memory_order_relaxed) < j->count) { pick = j; break; }
+            if (pick) {
+                lk.unlock();
+                work_on(*pick);
+                lk.lock();
+                continue;
+            }
+            if (stop_) return;
+            cv_.wait(lk);
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::shared_ptr<Job>> jobs_;
+    std::vector<std::thread> workers_;
+    bool stop_ = false;
+};
+
+// run f(i) for i in [0, count) on the pool (the caller included)
 template <typename F> void parallel_for(int count, int max_threads, F&& f)
 {
-    const int hw = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
-    const int workers = std::max(1, std::min(std::min(count, max_threads), hw));
-    if (workers == 1) { for (int i = 0; i < count; ++i) f(i); return; }
-    std::vector<std::thread> pool;
-    for (int w = 0; w < workers; ++w)
-        pool.emplace_back([&, w] { for (int i = w; i < count; i += workers) f(i); });
-    for (std::thread& t : pool) t.join();
+    LoopPool::instance().run(count, max_threads, std::function<void(int)>(std::forward<F>(f)));
+}
+
+// index of the first non-zero byte of row[x .. n), or n: whole zero words are skipped eight bytes at a time (the byte
+// maps of a wrap-around camera are mostly zero)
+inline int next_set(const uint8_t* row, int x, int n)
+{
+    while (x < n && (reinterpret_cast<uintptr_t>(row + x) & 7u)) {
+        if (row[x]) return x;
+        ++x;
+    }
+    while (x + 8 <= n) {
+        uint64_t w;
+        std::memcpy(&w, row + x, 8);
+        if (w) return x + (__builtin_ctzll(w) >> 3);
+        x += 8;
+    }
+    while (x < n) {
+        if (row[x]) return x;
+        ++x;
+    }
+    return n;
 }
 
 // rows of a level cut into stripes for the passes below: each worker owns the OUTPUT rows of its stripe, reads the
@@ -62,8 +161,7 @@ void mark_parents(const std::vector<uint8_t>& fine, int fw, int fh, std::vector<
             const int i = y >> 1;
             up_idx(i, ch, im, ip);
             const int ys[3] = {im, i, ip};
-            for (int x = 0; x < fw; ++x) {
-                if (!row[x]) continue;
+            for (int x = next_set(row, 0, fw); x < fw; x = next_set(row, x + 1, fw)) {
                 int jm, jp;
                 const int j = x >> 1;
                 up_idx(j, cw, jm, jp);
@@ -94,8 +192,7 @@ void mark_footprint(const std::vector<uint8_t>& coarse, int cw, int ch, std::vec
             bool mine = false;
             for (int t = 0; t < 5; ++t) { ys[t] = reflect101(2 * y + t - 2, fh); mine |= ys[t] >= f0 && ys[t] < f1; }
             if (!mine) continue;
-            for (int x = 0; x < cw; ++x) {
-                if (!row[x]) continue;
+            for (int x = next_set(row, 0, cw); x < cw; x = next_set(row, x + 1, cw)) {
                 int xs[5];
                 for (int t = 0; t < 5; ++t) xs[t] = reflect101(2 * x + t - 2, fw);
                 for (int yy : ys) {
@@ -165,8 +262,11 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                 uint8_t* urow = used.data() + static_cast<size_t>(ty) * tiles_x;
                 for (int y = ty * a_th0; y < std::min(d.lh[0], (ty + 1) * a_th0); ++y) {
                     const uint8_t* row = need0.data() + static_cast<size_t>(y) * d.lw[0];
-                    for (int x = 0; x < d.lw[0]; ++x)
-                        if (row[x]) urow[x / a_tw0] = 1;
+                    for (int x = next_set(row, 0, d.lw[0]); x < d.lw[0];) {
+                        const int t = x / a_tw0;
+                        urow[t] = 1;
+                        x = next_set(row, (t + 1) * a_tw0, d.lw[0]);       // the rest of this tile's columns cannot add anything
+                    }
                 }
             });
             for (int ty = 0; ty < tiles_y; ++ty)
@@ -201,8 +301,11 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                 for (int y = 0; y < d.lh[l]; ++y) {
                     const uint8_t* row = need.data() + static_cast<size_t>(y) * d.lw[l];
                     uint8_t* urow = used.data() + static_cast<size_t>(y >> shift) * tiles_x;
-                    for (int x = 0; x < d.lw[l]; ++x)
-                        if (row[x]) urow[x >> shift] = 1;
+                    for (int x = next_set(row, 0, d.lw[l]); x < d.lw[l];) {
+                        const int t = x >> shift;
+                        urow[t] = 1;
+                        x = next_set(row, std::min(d.lw[l], (t + 1) << shift), d.lw[l]);
+                    }
                 }
             }
             for (int ty = 0; ty < tiles_y; ++ty)
@@ -267,8 +370,7 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
         const std::vector<uint8_t>& nz = plan.cams[c].nz[l];
         for (int y = y0; y < y1; ++y) {
             const uint8_t* row = nz.data() + static_cast<size_t>(y) * d.lw[l];
-            for (int x = x0; x < x1; ++x)
-                if (row[x]) return true;
+            if (next_set(row, x0, x1) < x1) return true;
         }
         return false;
     };

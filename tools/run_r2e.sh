@@ -14,3 +14,4 @@ for f in ('bench_batch1','bench_undistort'):
     d=json.load(open('gpurun_out/r2e/%s.json'%f)); print(f, d['value'], [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']])"
 bash tools/profile_gpu.sh r02 > gpurun_out/r2e/profile.log 2>&1
 tail -5 gpurun_out/r2e/profile.log
+python tools/time_update.py 2>&1 | tail -4
