@@ -560,6 +560,7 @@ void Engine::update(const mst_calibration& calib)
         ba.alpha = static_cast<float>(1. / 255.);
         ba.weights_16s = cfg_.weight_type == MST_WEIGHT_16S ? 1 : 0;
         ba.cc_th = mb_coarse_tile_height(cfg_.max_batch);
+        ba.fine_threads = mb_fine_threads(cfg_.max_batch);
         build_mb_plan(st->desc, wh, ba, st->plan);
         clk.mark("work-list plan (host)");
         const MbPlanHost& plan = st->plan;

@@ -835,10 +835,10 @@ constexpr int CC_TW = MST_CC_TW;
 // frame sets are composed one at a time (four times as many, shorter blocks: 9.5 k instead of 8.8 k panoramas/s
 // one at a time, 3 % slower in batches of 8)
 constexpr int CC_TH_MAX = 32;
-#ifndef MST_C_THREADS
-#define MST_C_THREADS 256
-#endif
-constexpr int C_THREADS = MST_C_THREADS;       // k_blend_fine
+// k_blend_fine block size, chosen per calibration like the coarse tile height (BlendArgs::fine_threads): 128 for batched
+// launches -- two waves of eight quad rows, a wave re-reads 2 source rows in 10 instead of 4 in 12, which shows once the
+// level-0 loads stream past the caches (157.6 -> 147.7 us per 8 frame sets) -- and 256 (four waves of four rows: half
+// the dependent steps per block) when frame sets are composed one at a time
 #ifndef MST_CC_THREADS
 #define MST_CC_THREADS 256
 #endif
@@ -1699,7 +1699,7 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
 }
 
 // level 0 band + pyrUp of the collapsed level-1 canvas -> crop, mask, convertTo(8U), panorama
-template <bool TOP, bool PURE, bool W16 = false>
+template <int NT, bool TOP, bool PURE, bool W16 = false>
 __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, const BlendArgs& a, const Region& r,
                                             uint32_t cam_bits, C1Ptr __restrict__ s_up,
                                             uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask)
@@ -1709,7 +1709,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
     // lane pairs hold horizontally adjacent quads when a quad row has an even number of quads (row-major order) or in
     // the 8 x 8 blocked order; the region starts on a multiple of C_TW
     const int store_mode = pano_store_mode(a, pano, blocked || (it.qw & 1) == 0);
-    for (int q = threadIdx.x; q < it.nq; q += C_THREADS) {
+    for (int q = threadIdx.x; q < it.nq; q += NT) {
         int x, y;
         bool valid[4];
         if (blocked) it.at_blocked(q, x, y, valid);
@@ -1890,8 +1890,8 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
 
 // Canvas kernel 2 of 2: level 0, one block per C_TW x C_TH tile of the panorama: level-0 band + pyrUp of the
 // collapsed level-1 canvas (k_blend_coarse) -> crop, mask, convertTo(8U) -> panorama.  No LDS, no barrier.
-template <bool W16>
-__global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_fine(const CamDesc* __restrict__ cams_all, BlendArgs a)
+template <bool W16, int NT>
+__global__ __launch_bounds__(NT, MST_C_WAVES) void k_blend_fine(const CamDesc* __restrict__ cams_all, BlendArgs a)
 {
     int q, set;
     if (!tile_of_block(a.n_tiles, a.n_sets, q, set)) return;
@@ -1909,18 +1909,18 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_fine(const Cam
         const int w = min(r0.x1, a.final_w) - r0.x0, h = min(r0.y1, a.final_h) - r0.y0;
         if (pano_store_mode(a, pano, true) == 2 && (w & 3) == 0) {          // dword stores
             const int wd = w * 3 / 4;
-            for (int i = threadIdx.x; i < wd * max(h, 0); i += C_THREADS) {
+            for (int i = threadIdx.x; i < wd * max(h, 0); i += NT) {
                 const int y = i / wd, b = i - y * wd;
                 reinterpret_cast<uint32_t*>(pano + __umul24(r0.y0 + y, a.pano_stride) + r0.x0 * 3)[b] = 0u;
             }
         } else {
-            for (int i = threadIdx.x; i < max(w, 0) * 3 * max(h, 0); i += C_THREADS) {
+            for (int i = threadIdx.x; i < max(w, 0) * 3 * max(h, 0); i += NT) {
                 const int y = i / (w * 3), b = i - y * (w * 3);
                 pano[__umul24(r0.y0 + y, a.pano_stride) + r0.x0 * 3 + b] = 0;
             }
         }
         if (pano_mask)
-            for (int i = threadIdx.x; i < max(w, 0) * max(h, 0); i += C_THREADS) {
+            for (int i = threadIdx.x; i < max(w, 0) * max(h, 0); i += NT) {
                 const int y = i / w, b = i - y * w;
                 pano_mask[__umul24(r0.y0 + y, a.mask_stride) + r0.x0 + b] = 0;
             }
@@ -1929,18 +1929,18 @@ __global__ __launch_bounds__(C_THREADS, MST_C_WAVES) void k_blend_fine(const Cam
     MST_STAMP(2, 0);
     MST_STAMP_VAL(2, 8, static_cast<unsigned long long>(entry));
     if (a.nlev == 1) {
-        if (own0) final_level<true, true>(cams, a, r0, cam_bits, c1, pano, pano_mask);
-        else final_level<true, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
+        if (own0) final_level<NT, true, true>(cams, a, r0, cam_bits, c1, pano, pano_mask);
+        else final_level<NT, true, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
         return;
     }
     const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
     const bool strip = full && !(MST_ABLATE_C & 64) && pano_store_mode(a, pano, true) == 2;
     const bool binary = !(MST_ABLATE_C & 512) && (entry >> 30) & 1u;      // 0/1 weights, disjoint, windows cover the tile
-    if (own0 && strip) owned_strip<0, 1, false, C_THREADS, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
-    else if (binary && strip && (cam_bits & (cam_bits - 1)) == 0) owned_strip<0, 1, true, C_THREADS, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
-    else if (binary && strip) owned_strip<0, 2, true, C_THREADS, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
-    else if (own0) final_level<false, true>(cams, a, r0, cam_bits, c1, pano, pano_mask);
-    else final_level<false, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
+    if (own0 && strip) owned_strip<0, 1, false, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (binary && strip && (cam_bits & (cam_bits - 1)) == 0) owned_strip<0, 1, true, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (binary && strip) owned_strip<0, 2, true, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (own0) final_level<NT, false, true>(cams, a, r0, cam_bits, c1, pano, pano_mask);
+    else final_level<NT, false, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
     MST_STAMP_VAL(2, 9, static_cast<unsigned long long>(full));
     MST_STAMP(2, 1);
 }
@@ -1981,6 +1981,8 @@ int mb_read_stamps(int which, unsigned long long* out, size_t n)
 int mb_coarse_tile_width() { return CC_TW; }
 
 int mb_coarse_tile_height(int max_batch) { return max_batch <= 2 ? 16 : 32; }
+
+int mb_fine_threads(int max_batch) { return max_batch <= 2 ? 256 : 128; }
 
 void mb_blend_region(const BlendArgs& a, int base, int tx, int ty, int level, int out[4])
 {
@@ -2043,8 +2045,10 @@ void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, 
     }
     if (!(which & 2)) return;
     const int grid = ((num_blocks + 7) / 8) * 8 * batch;
-    if (a.weights_16s) hipLaunchKernelGGL(k_blend_fine<true>, dim3(grid), dim3(C_THREADS), 0, s, d_cams, a);
-    else hipLaunchKernelGGL(k_blend_fine<false>, dim3(grid), dim3(C_THREADS), 0, s, d_cams, a);
+#define MST_LAUNCH_FINE(W, NT) hipLaunchKernelGGL((k_blend_fine<W, NT>), dim3(grid), dim3(NT), 0, s, d_cams, a)
+    if (a.fine_threads == 128) { if (a.weights_16s) MST_LAUNCH_FINE(true, 128); else MST_LAUNCH_FINE(false, 128); }
+    else { if (a.weights_16s) MST_LAUNCH_FINE(true, 256); else MST_LAUNCH_FINE(false, 256); }
+#undef MST_LAUNCH_FINE
 }
 
 }  // namespace mst
