@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--shard", default="frames", choices=["frames", "cameras"],
                     help="N > 1 headline: frames = every rank stitches its own frame sets (default, no collective); "
                          "cameras = camera i on rank i %% N, payload sent to rank 0 over RCCL, rank 0 blends (SURVEY 8e)")
+    ap.add_argument("--pano-row-pad", type=int, default=0, help="extra bytes per panorama row (stride experiments)")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the one-frame-set-per-sequence measurement (profiling runs)")
     ap.add_argument("--no-camera-leg", action="store_true", help="N > 1: skip the camera-sharded secondary measurement")
     ap.add_argument("--camera-leg", action="store_true", help="run the camera-sharded measurement at N = 1 too (stage split only)")
@@ -177,7 +178,9 @@ def main():
         fr = rigmod.frames_for(rig, frame_index=sharding.global_frame_index(rank, world, s))
         host_sets.append(fr)
         dev_sets.append([torch.from_numpy(f).to(dev) for f in fr])
-    panos = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(batch)]
+    # (--pano-row-pad: rows of cw * 3 + pad bytes, to time panorama strides that are not a multiple of four)
+    pano_rows = [torch.empty((ch, cw * 3 + args.pano_row_pad), dtype=torch.uint8, device=dev) for _ in range(batch)]
+    panos = [p[:, :cw * 3].view(ch, cw, 3) if args.pano_row_pad == 0 else p for p in pano_rows]
     pano = panos[0]
     # a real (non-null) stream, made torch's current one: torch.cuda.Event brackets the launches and RCCL's
     # point-to-point operations (camera-sharded mode) order against the same stream as the kernels

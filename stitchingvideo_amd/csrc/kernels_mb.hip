@@ -1576,11 +1576,13 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
         }
     }
     // output pointers of this lane, advanced by two rows per quad row
+    bool aligned_rows = true;
     uint8_t* po = nullptr;           // L == 0: even lanes write the upper row of a lane pair's two quads, odd lanes the lower
     uint8_t* pm = nullptr;
     GPix MST_GLOBAL* co = nullptr;   // L == 1
     if (L == 0) {
         po = pano + __umul24(y0 + (odd ? 1 : 0), a.pano_stride) + (odd ? x - 2 : x) * 3;
+        aligned_rows = pano_store_mode(a, pano, true) == 2;
         if (pano_mask) pm = pano_mask + __umul24(y0, a.mask_stride) + x;
     } else {
         co = (GPix MST_GLOBAL*)c1_out + __mul24(y0, a.cw[L]) + x;
@@ -1660,8 +1662,12 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
             w.y = (fhi & 0xFFFFu) | slo << 16;
             w.z = slo >> 16 | shi << 16;
             if (!(MST_ABLATE_C & 4096) || w.x == 0x12345678u) {
-                // (a plain store: marked non-temporal it costs 5 % of this kernel, measured)
-                *reinterpret_cast<uint3*>(po) = w;
+                // (a plain store: marked non-temporal it costs 5 % of this kernel, measured).  A panorama whose base or row
+                // stride is not a multiple of four -- a tight cv::Mat of a width that is not -- takes the same 12 bytes as
+                // one unaligned access: gfx950 under HSA serves unaligned global accesses.
+                struct __attribute__((packed, aligned(1))) Bytes12 { uint32_t x, y, z; };
+                if (aligned_rows) *reinterpret_cast<uint3*>(po) = w;
+                else *reinterpret_cast<Bytes12*>(po) = Bytes12{w.x, w.y, w.z};
             }
             po += 2 * a.pano_stride;
             if (pm) {
@@ -1934,7 +1940,7 @@ __global__ __launch_bounds__(NT, MST_C_WAVES) void k_blend_fine(const CamDesc* _
         return;
     }
     const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
-    const bool strip = full && !(MST_ABLATE_C & 64) && pano_store_mode(a, pano, true) == 2;
+    const bool strip = full && !(MST_ABLATE_C & 64);
     const bool binary = !(MST_ABLATE_C & 512) && (entry >> 30) & 1u;      // 0/1 weights, disjoint, windows cover the tile
     if (own0 && strip) owned_strip<0, 1, false, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
     else if (binary && strip && (cam_bits & (cam_bits - 1)) == 0) owned_strip<0, 1, true, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);

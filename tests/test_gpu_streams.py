@@ -401,3 +401,33 @@ def test_profile_entry_points_report_every_launch():
     eng.synchronize()
     assert np.array_equal(panos[1].cpu().numpy(), H.oracle_compose(rig, host[1])[1])
     eng.close()
+
+
+@pytest.mark.parametrize("base_off,row_pad,mask_off,mask_pad", [(0, 1, 0, 1), (1, 2, 3, 0), (2, 3, 1, 5), (3, 0, 0, 0), (0, 4, 2, 2)])
+def test_unaligned_panorama_and_mask_buffers(base_off, row_pad, mask_off, mask_pad):
+    """A tight cv::Mat of a canvas whose width is not a multiple of four has rows (and, after the first, row starts)
+    off the 4-byte grid: the fast level-0 path then writes its 12-byte runs unaligned.  Same panorama, bit for bit,
+    and nothing outside the rows is touched."""
+    import torch
+    rig = rigmod.build_rig(rigmod.scaled_config("C3", 4))            # several whole 128 x 32 tiles
+    eng = H.make_engine(rig, max_batch=4)
+    _, _, cw, ch = eng.canvas()
+    dev = torch.device("cuda", 0)
+    frames = rigmod.frames_for(rig, 3)
+    dfr = [torch.from_numpy(f).to(dev) for f in frames]
+    stride, mstride = cw * 3 + row_pad, cw + mask_pad
+    pbuf = torch.full((base_off + ch * stride + 16,), 0x5A, dtype=torch.uint8, device=dev)
+    mbuf = torch.full((mask_off + ch * mstride + 16,), 0x5A, dtype=torch.uint8, device=dev)
+    eng.compose_device([t.data_ptr() for t in dfr], [t.stride(0) for t in dfr], pbuf.data_ptr() + base_off, stride,
+                       mbuf.data_ptr() + mask_off, mstride)
+    eng.synchronize()
+    _, opano, omask = H.oracle_compose(rig, frames)
+    got = pbuf.cpu().numpy()
+    rows = got[base_off:base_off + ch * stride].reshape(ch, stride)
+    assert np.array_equal(rows[:, :cw * 3].reshape(ch, cw, 3), opano)
+    assert (rows[:, cw * 3:] == 0x5A).all() and (got[:base_off] == 0x5A).all() and (got[base_off + ch * stride:] == 0x5A).all()
+    gm = mbuf.cpu().numpy()
+    mrows = gm[mask_off:mask_off + ch * mstride].reshape(ch, mstride)
+    assert np.array_equal(mrows[:, :cw], omask)
+    assert (mrows[:, cw:] == 0x5A).all() and (gm[:mask_off] == 0x5A).all() and (gm[mask_off + ch * mstride:] == 0x5A).all()
+    eng.close()
