@@ -519,8 +519,6 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     gs.rx = reflect<0>(reflect<1>(lx0 + col, bw) - c.left, c.roi_w);
     MST_STAMP(0, 1);
 
-    const int gx = lx0 + col;
-    const bool col_interior = col >= 2 && col < A_LW - 2 && gx < bw;
     const int row0 = half * A_ROWS_PER_THREAD;
     // software pipeline over two explicit register sets: the gather of the next pixel is in flight while
     // the current one is blended (A_ROWS_PER_THREAD is even; the last prefetch re-reads the last row)
@@ -529,13 +527,10 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     // the gathers is not free even though nothing waits for it explicitly: the memory counter retires in issue
     // order, so every gather issued after a store could only be consumed once that store had been acknowledged by
     // L2 -- which tied the loop to the write latency (11.6 of this kernel's 37.5 us per frame set, by ablation).
-    const bool store_in_loop = (bw & 3) != 0;                 // rows not 16-byte aligned (one band): keep the simple form
-    auto emit = [&](int row, uint32_t px) {
-        s_l0[row][col] = px;
-        const int gy = ly0 + row;
-        if (store_in_loop && col_interior && row >= 2 && row < A_LH - 2 && gy < bh)
-            g0out[__umul24(gy, bw) + gx] = px;
-    };
+    // (Nor a store behind a uniform condition: the branch alone cuts the loop body into basic blocks and pins the
+    // loads behind it.  Levels whose rows are not 16-byte aligned -- one band -- take a dword-wide pass instead.)
+    const bool wide_rows = (bw & 3) == 0;
+    auto emit = [&](int row, uint32_t px) { s_l0[row][col] = px; };
     const int row_last = row0 + A_ROWS_PER_THREAD - 1;
     const uint32_t* __restrict__ tcol = tab + col;
     auto entry = [&](int row) -> MapPx {
@@ -598,7 +593,13 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     }
     MST_STAMP(0, 2);
     __syncthreads();
-    if (!store_in_loop && !(MST_ABLATE_A & 128)) {
+    if (!wide_rows) {
+        for (int i = tid; i < A_TH0 * A_TW0; i += 256) {
+            const int r = i / A_TW0, cc = i - r * A_TW0;
+            const int gy = ly0 + 2 + r, gxx = lx0 + 2 + cc;
+            if (gy < bh && gxx < bw) g0out[__umul24(gy, bw) + gxx] = s_l0[2 + r][2 + cc];
+        }
+    } else if (!(MST_ABLATE_A & 128)) {
         // interior of the tile, four pixels (16 bytes) per lane: a tile row is 31 such groups, and because the level
         // width is a multiple of four and the tile origin a multiple of 124, a group lies inside the level as a whole
         // or not at all, and is 16-byte aligned in global memory (8-byte aligned in LDS: the interior starts at column 2)
