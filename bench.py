@@ -321,14 +321,9 @@ def main():
                          "dominant_kernel": dominant, "kernels": kernels},
         }
         if batch > 1 and not args.no_latency_leg:
-            # latency mode: one frame set per launch sequence, as the reference's StitchingAll() -- an engine created for
-            # that (max_batch = 1 also selects the shorter canvas tiles, see mst_config.max_batch)
-            eng1 = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
-                                    max_batch=1)
-            eng1.update(rig["scale"], rig["cameras"])
-            eng1.acquire()
-            one = [eng1.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),
-                                         pano.stride(0), stream=stream) for ds in dev_sets]
+            # latency mode on the same engine: one frame set per launch sequence, as the reference's StitchingAll()
+            one = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),
+                                        pano.stride(0), stream=stream) for ds in dev_sets]
             for i in range(20):
                 one[i % len(one)]()
             torch.cuda.synchronize()
@@ -343,7 +338,6 @@ def main():
             out["latency_mode"] = {"frame_sets_per_launch": 1, "frames": n1, "ms_per_frame": round(ms1, 5),
                                    "frames_per_s": round(1000.0 / ms1, 2),
                                    "roofline_frac": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-            eng1.close()
 
     # ---- two launch sequences in flight (MST_FLAG_OVERLAP_FRAMES): the warp + chain kernels of sequence t + 1 run
     # beside the canvas kernels of sequence t on a second stream and a second set of pyramid buffers.  Reported

@@ -130,9 +130,7 @@ typedef struct mst_config {
     uint32_t flags;              /* MST_FLAG_* */
     float    upblack, downblack, leftblack, rightblack;   /* DRV:47 crop margins (LUT path) */
     int32_t  max_batch;          /* frame sets per mst_compose_device_batch call, 0/1 = none, <= MST_MAX_BATCH;
-                                  * multi-band keeps one set of Gaussian pyramids per frame set of a batch.  Also a
-                                  * tuning hint: with max_batch <= 2 the canvas kernels use shorter tiles (more, shorter
-                                  * blocks), which suits one frame set per launch sequence; results are identical */
+                                  * multi-band keeps one set of Gaussian pyramids per frame set of a batch */
     int32_t  weight_type;        /* MST_WEIGHT_*: MultiBandBlender's weight_type (blenders.hpp:101), default CV_32F */
     float    warp_a, warp_b;     /* A, B of CompressedRectilinear* / Panini* warpers when warp_kind carries
                                   * MST_WARP_AB_CUSTOM (detail/warpers.hpp:232-305) */

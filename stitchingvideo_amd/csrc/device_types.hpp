@@ -121,8 +121,8 @@ struct BlendArgs {
     const uint32_t* coarse_pure;
     const uint32_t* coarse_order;
     int32_t coarse_tiles_x;
-    int32_t cc_th;                            // height of a k_blend_coarse tile in level-1 rows (16 or 32)
-    int32_t fine_threads;                     // k_blend_fine block size (256 or 128)
+    int32_t cc_th;                            // height of a k_blend_coarse tile in level-1 rows (16 or 32) and
+    int32_t fine_threads;                     // k_blend_fine block size (256 or 128): chosen per launch by the engine
     int32_t n_tiles, n_coarse_tiles, n_sets;  // tiles and frame sets of this launch (filled in by launch_blend)
     int32_t lds_off[kMaxLevels];              // k_blend_coarse: LDS offset (in pixels) of each level's region buffer
     int16_t* dbg_C[kMaxLevels];               // optional dump of the collapsed levels (MST_FLAG_DEBUG)

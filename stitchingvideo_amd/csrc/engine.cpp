@@ -184,6 +184,23 @@ void fill_camera_desc(DevicePool& pool, hipStream_t s, const Projector& proj, co
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
 }
 
+BlendArgs CalibState::blend_for(int frame_sets, int* n_coarse, size_t* lds_bytes) const
+{
+    const int v = mb_launch_variant(frame_sets);
+    const MbPlanHost::CoarseTiles& ct = plan.coarse[v];
+    BlendArgs ba = blend;
+    ba.cc_th = ct.th;
+    ba.fine_threads = mb_fine_threads(v);
+    ba.coarse_cams = coarse_dev[v].cams;
+    ba.coarse_pure = coarse_dev[v].pure;
+    ba.coarse_order = coarse_dev[v].order;
+    ba.coarse_tiles_x = ct.tiles_x;
+    for (int l = 0; l < kMaxLevels; ++l) ba.lds_off[l] = ct.lds_off[l];
+    *n_coarse = ct.tiles_x * ct.tiles_y;
+    *lds_bytes = ct.lds_bytes;
+    return ba;
+}
+
 // ---- StageTimer --------------------------------------------------------------------------------
 
 StageTimer::~StageTimer()
@@ -559,21 +576,22 @@ void Engine::update(const mst_calibration& calib)
         ba.final_w = cv.final_w; ba.final_h = cv.final_h;
         ba.alpha = static_cast<float>(1. / 255.);
         ba.weights_16s = cfg_.weight_type == MST_WEIGHT_16S ? 1 : 0;
-        ba.cc_th = mb_coarse_tile_height(cfg_.max_batch);
-        ba.fine_threads = mb_fine_threads(cfg_.max_batch);
         build_mb_plan(st->desc, wh, ba, st->plan);
         clk.mark("work-list plan (host)");
         const MbPlanHost& plan = st->plan;
         ba.tiles_x = plan.blend_tiles_x;
-        for (int l = 0; l <= nb; ++l) ba.lds_off[l] = plan.lds_off[l];
-        if (plan.lds_bytes > 64 * 1024) throw Error{MST_ERR_INVALID_ARG, "canvas kernel LDS budget exceeded"};
         ba.block_cams = st->pool.upload(plan.block_cams, s);
         ba.block_order = st->pool.upload(plan.block_order, s);
-        ba.coarse_tiles_x = plan.coarse_tiles_x;
+        for (int v = 0; v < 2; ++v) {
+            const MbPlanHost::CoarseTiles& ct = plan.coarse[v];
+            if (ct.lds_bytes > 64 * 1024) throw Error{MST_ERR_INVALID_ARG, "canvas kernel LDS budget exceeded"};
+            if (nb >= 1) {
+                st->coarse_dev[v].cams = st->pool.upload(ct.cams, s);
+                st->coarse_dev[v].pure = st->pool.upload(ct.pure, s);
+                st->coarse_dev[v].order = st->pool.upload(ct.order, s);
+            }
+        }
         if (nb >= 1) {
-            ba.coarse_cams = st->pool.upload(plan.coarse_cams, s);
-            ba.coarse_pure = st->pool.upload(plan.coarse_pure, s);
-            ba.coarse_order = st->pool.upload(plan.coarse_order, s);
             // the collapsed level-1 canvas k_blend_coarse hands to k_blend_fine, one per buffer set
             st->c1.assign(st->num_sets, nullptr);
             for (int k = 0; k < st->num_sets; ++k)
@@ -729,7 +747,9 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
             mark("k_pyr_chain");
         }
         if (overlap && !split_after_warp) cross();
-        BlendArgs ba = st->blend;
+        int n_coarse = 0;
+        size_t lds_bytes = 0;
+        BlendArgs ba = st->blend_for(count, &n_coarse, &lds_bytes);
         for (int f = 0; f < count; ++f) {
             ba.pano[f] = static_cast<uint8_t*>(d_panos[f]);
             ba.pano_mask[f] = d_masks ? static_cast<uint8_t*>(d_masks[f]) : nullptr;
@@ -738,12 +758,12 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         ba.mask_stride = static_cast<uint32_t>(mask_stride);
         if (!st->c1.empty())
             for (int f = 0; f < count; ++f) ba.c1[f] = st->c1[first_set + f];
-        const int n_fine = st->plan.blend_tiles_x * st->plan.blend_tiles_y, n_coarse = st->plan.coarse_tiles_x * st->plan.coarse_tiles_y;
+        const int n_fine = st->plan.blend_tiles_x * st->plan.blend_tiles_y;
         if (ba.nlev > 1) {
-            launch_blend(desc, ba, n_fine, n_coarse, count, st->plan.lds_bytes, s, 1);
+            launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 1);
             mark("k_blend_coarse");
         }
-        launch_blend(desc, ba, n_fine, n_coarse, count, st->plan.lds_bytes, s, 2);
+        launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 2);
         mark("k_blend_fine");
         if (overlap) {
             check_hip(hipEventRecord(ev_canvas_done_[slot], s), "hipEventRecord");
@@ -850,13 +870,15 @@ void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t
     if (pano_stride * static_cast<size_t>(st->out_h) > 0xFFFFFFFFull)
         throw Error{MST_ERR_INVALID_ARG, "panoramas of 4 GiB and more are not supported (32-bit byte offsets)"};
     hipStream_t s = stream ? stream : stream_;
-    BlendArgs ba = st->blend;
+    int n_coarse = 0;
+    size_t lds_bytes = 0;
+    BlendArgs ba = st->blend_for(1, &n_coarse, &lds_bytes);
     ba.pano[0] = static_cast<uint8_t*>(d_pano); ba.pano_stride = static_cast<uint32_t>(pano_stride);
     ba.pano_mask[0] = static_cast<uint8_t*>(d_mask); ba.mask_stride = static_cast<uint32_t>(mask_stride);
     if (stage_set_ >= st->num_sets) throw Error{MST_ERR_INVALID_ARG, "stage set beyond mst_config.max_batch"};
     if (!st->c1.empty()) ba.c1[0] = st->c1[stage_set_];
     launch_blend(st->d_desc + static_cast<size_t>(stage_set_) * st->n, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y,
-                 st->plan.coarse_tiles_x * st->plan.coarse_tiles_y, 1, st->plan.lds_bytes, s);
+                 n_coarse, 1, lds_bytes, s);
     check_hip(hipGetLastError(), "canvas stage kernel");
     set_in_flight(std::move(st));
 }

@@ -93,6 +93,10 @@ struct CalibState {
     UndistortCam* d_ucams = nullptr;
     bool any_undistort = false;
     int undist_max_w = 0, undist_max_h = 0;
+    struct CoarseDev { const uint32_t* cams = nullptr; const uint32_t* pure = nullptr; const uint32_t* order = nullptr; };
+    CoarseDev coarse_dev[2];               // k_blend_coarse tile tables of plan.coarse[v] on the device
+    // `blend` completed for a launch of `frame_sets` frame sets: the tile tables / LDS layout of its launch variant
+    BlendArgs blend_for(int frame_sets, int* n_coarse, size_t* lds_bytes) const;
     std::vector<uint64_t*> c1;               // per buffer set: collapsed level-1 canvas (k_blend_coarse -> k_blend_fine)
     std::vector<uint8_t*> undist_frames;   // num_sets x n engine-owned undistorted frames (nullptr: camera has no maps)
     uint32_t* warp_table = nullptr;     // per-tile backward-map table (frame-invariant), see kernels_mb.hip

@@ -48,8 +48,10 @@ int  mb_read_stamps(int which, unsigned long long* out, size_t n);              
 int  mb_read_stamps(int which, unsigned long long* out, size_t n);                // diagnostic builds (-DMST_STAMPS) only
 int  mb_chain_depth();                                                           // levels per k_pyr_chain launch
 int mb_coarse_tile_width();                                                        // k_blend_coarse tiles, in level-1 pixels
-int mb_coarse_tile_height(int max_batch);                                          // (BlendArgs::cc_th: 16 or 32)
-int mb_fine_threads(int max_batch);                                                // (BlendArgs::fine_threads: 256 or 128)
+// Launch variants of the canvas kernels: 0 for one or two frame sets per launch sequence, 1 for batches
+int mb_launch_variant(int frame_sets);
+int mb_coarse_tile_height(int variant);                                            // (BlendArgs::cc_th: 16 or 32)
+int mb_fine_threads(int variant);                                                  // (BlendArgs::fine_threads: 256 or 128)
 // region of tile (tx, ty) -- a panorama tile (base 0) or a level-1 tile (base 1) -- at `level` >= base: x0, y0, x1, y1
 void mb_blend_region(const BlendArgs& a, int base, int tx, int ty, int level, int out[4]);
 int  mb_blend_region_lds_pixels(const BlendArgs& a, int base, int tx, int ty, int level);   // LDS footprint of that region

@@ -832,11 +832,11 @@ constexpr int C_TW = 128, C_TH = MST_C_TH;
 #define MST_CC_TW 128      // k_blend_coarse: tile size in level-1 pixels
 #endif
 constexpr int CC_TW = MST_CC_TW;
-// k_blend_coarse tile height (level-1 rows) is chosen per calibration (BlendArgs::cc_th): 32 for batched launches, 16 when
-// frame sets are composed one at a time (four times as many, shorter blocks: 9.5 k instead of 8.8 k panoramas/s
-// one at a time, 3 % slower in batches of 8)
+// k_blend_coarse tile height (level-1 rows) is chosen per launch (BlendArgs::cc_th; both tile tables are planned at
+// calibration): 32 for batched launches, 16 for one or two frame sets (four times as many, shorter blocks: 9.5 k instead
+// of 8.8 k panoramas/s one at a time, 3 % slower in batches of 8)
 constexpr int CC_TH_MAX = 32;
-// k_blend_fine block size, chosen per calibration like the coarse tile height (BlendArgs::fine_threads): 128 for batched
+// k_blend_fine block size, chosen per launch like the coarse tile height (BlendArgs::fine_threads): 128 for batched
 // launches -- two waves of eight quad rows, a wave re-reads 2 source rows in 10 instead of 4 in 12, which shows once the
 // level-0 loads stream past the caches (157.6 -> 147.7 us per 8 frame sets) -- and 256 (four waves of four rows: half
 // the dependent steps per block) when frame sets are composed one at a time
@@ -1987,9 +1987,11 @@ int mb_read_stamps(int which, unsigned long long* out, size_t n)
 
 int mb_coarse_tile_width() { return CC_TW; }
 
-int mb_coarse_tile_height(int max_batch) { return max_batch <= 2 ? 16 : 32; }
+int mb_coarse_tile_height(int variant) { return variant == 0 ? 16 : 32; }
 
-int mb_fine_threads(int max_batch) { return max_batch <= 2 ? 256 : 128; }
+int mb_launch_variant(int frame_sets) { return frame_sets <= 2 ? 0 : 1; }
+
+int mb_fine_threads(int variant) { return variant == 0 ? 256 : 128; }
 
 void mb_blend_region(const BlendArgs& a, int base, int tx, int ty, int level, int out[4])
 {

@@ -351,15 +351,10 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
     }
     mark("warp + chain tile lists");
     // ---- canvas kernels: panorama tiles (k_blend_fine, level 0) and level-1 tiles (k_blend_coarse, levels 1 .. top)
-    const int cc_tw = mb_coarse_tile_width(), cc_th = blend.cc_th;
+    const int cc_tw = mb_coarse_tile_width();
     plan.blend_tiles_x = (blend.cw[0] + c_tw - 1) / c_tw;
     plan.blend_tiles_y = (blend.ch[0] + c_th - 1) / c_th;
     plan.block_cams.assign(static_cast<size_t>(plan.blend_tiles_x) * plan.blend_tiles_y, 0u);
-    plan.coarse_tiles_x = nlev > 1 ? (blend.cw[1] + cc_tw - 1) / cc_tw : 0;
-    plan.coarse_tiles_y = nlev > 1 ? (blend.ch[1] + cc_th - 1) / cc_th : 0;
-    plan.coarse_cams.assign(static_cast<size_t>(plan.coarse_tiles_x) * plan.coarse_tiles_y, 0u);
-    plan.coarse_pure.assign(plan.coarse_cams.size(), 0u);
-    std::vector<int> max_area(nlev, 0);
     // any non-zero weight of camera c at level l inside [x0,x1) x [y0,y1) of the canvas level?  all exactly `unit`
     // (and the camera's window covering the rectangle)?
     auto any_nonzero = [&](int c, int l, int rx0, int ry0, int rx1, int ry1) {
@@ -429,48 +424,6 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
             plan.block_cams[static_cast<size_t>(ty) * plan.blend_tiles_x + tx] = bits;
         }
     });
-    // Level-1 tiles.  Levels on which the tile's region (tile + pyrUp halo) is owned by ONE camera with a weight of
-    // exactly 1.0f everywhere and no other camera has a non-zero weight there go down the integer path as well; a
-    // tile whose levels are all owned by the same camera is "pure" (bit 31 of coarse_cams): no float arithmetic.
-    std::vector<std::vector<int>> row_area(plan.coarse_tiles_y, std::vector<int>(nlev, 0));
-    parallel_for(plan.coarse_tiles_y, 64, [&](int ty) {
-        std::vector<int>& max_area = row_area[ty];
-        for (int tx = 0; tx < plan.coarse_tiles_x; ++tx) {
-            uint32_t bits = 0, level_mask = 0;
-            int owner = -1;
-            for (int l = 1; l < nlev; ++l) {
-                int r[4];
-                mb_blend_region(blend, 1, tx, ty, l, r);
-                max_area[l] = std::max(max_area[l], mb_blend_region_lds_pixels(blend, 1, tx, ty, l));
-                uint32_t lbits = 0;
-                for (int c = 0; c < n; ++c)
-                    if (any_nonzero(c, l, r[0], r[1], r[2], r[3])) lbits |= 1u << c;
-                bits |= lbits;
-                if (lbits != 0 && (lbits & (lbits - 1)) == 0) {
-                    const int c = __builtin_ctz(lbits);
-                    if ((owner < 0 || owner == c) && all_unit(c, l, r[0], r[1], r[2], r[3])) {
-                        owner = c;
-                        level_mask |= 1u << l;
-                    }
-                }
-            }
-            const size_t ti = static_cast<size_t>(ty) * plan.coarse_tiles_x + tx;
-            if (owner >= 0 && level_mask == ((1u << nlev) - 2u) && bits == (1u << owner)) bits |= 0x80000000u;
-            plan.coarse_cams[ti] = bits;
-            plan.coarse_pure[ti] = owner >= 0 ? (level_mask | static_cast<uint32_t>(owner) << 16) : 0u;
-        }
-    });
-    mark("canvas tiles");
-    if (timing) {
-        int owned = 0, pure = 0, own1 = 0, binary = 0;
-        for (uint32_t e : plan.block_cams) { owned += e >> 31; binary += (e >> 30) & 1u; }
-        for (uint32_t e : plan.coarse_cams) pure += e >> 31;
-        for (uint32_t e : plan.coarse_pure) own1 += (e >> 1) & 1u;
-        std::fprintf(stderr, "[mst_update]   plan: %zu panorama tiles (%d with level 0 owned, %d more with 0/1 masks), %zu level-1 tiles (%d pure, %d with level 1 owned)\n",
-                     plan.block_cams.size(), owned, binary, plan.coarse_cams.size(), pure, own1);
-    }
-    for (const std::vector<int>& ra : row_area)
-        for (int l = 0; l < nlev; ++l) max_area[l] = std::max(max_area[l], ra[l]);
     // launch order: every tile is resident at once on a 256-CU part, so the dispatcher's round-robin placement is
     // the only load balancing there is -- hand out the expensive tiles (several cameras under the tile, float
     // path) first so that they land on different CUs, then the single-camera integer-path tiles
@@ -486,18 +439,77 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
         const int nc = __builtin_popcount(e & 0x3FFFFFFFu);
         return (e >> 30) ? 4 + 2 * nc : 10 + 2 * nc;
     });
-    plan.coarse_order = ordered(plan.coarse_cams, [&](uint32_t tile) {
-        const uint32_t e = plan.coarse_cams[tile];
-        if (e >> 31) return 4;                                  // relative: integer path everywhere
-        const bool l1_owned = plan.coarse_pure[tile] & 2u;      // float bands on some coarser levels only
-        return (l1_owned ? 6 : 10) + 2 * __builtin_popcount(e);
-    });
-    int off = 0;
-    for (int l = 2; l < nlev; ++l) {
-        plan.lds_off[l] = off;
-        off += (max_area[l] + 1) & ~1;
+    // Level-1 tiles, once per tile height the launcher may pick (MbPlanHost::coarse).  Levels on which the tile's region
+    // (tile + pyrUp halo) is owned by ONE camera with a weight of exactly 1.0f everywhere and no other camera has a
+    // non-zero weight there go down the integer path as well; a tile whose levels are all owned by the same camera
+    // is "pure" (bit 31 of cams): no float arithmetic.
+    int pure_tiles = 0, own1_tiles = 0;
+    for (int v = 0; v < 2; ++v) {
+        MbPlanHost::CoarseTiles& ct = plan.coarse[v];
+        ct = MbPlanHost::CoarseTiles{};
+        ct.th = mb_coarse_tile_height(v);
+        if (nlev <= 1) continue;
+        BlendArgs geo = blend;
+        geo.cc_th = ct.th;
+        ct.tiles_x = (blend.cw[1] + cc_tw - 1) / cc_tw;
+        ct.tiles_y = (blend.ch[1] + ct.th - 1) / ct.th;
+        ct.cams.assign(static_cast<size_t>(ct.tiles_x) * ct.tiles_y, 0u);
+        ct.pure.assign(ct.cams.size(), 0u);
+        std::vector<std::vector<int>> row_area(ct.tiles_y, std::vector<int>(nlev, 0));
+        parallel_for(ct.tiles_y, 64, [&](int ty) {
+            std::vector<int>& max_area = row_area[ty];
+            for (int tx = 0; tx < ct.tiles_x; ++tx) {
+                uint32_t bits = 0, level_mask = 0;
+                int owner = -1;
+                for (int l = 1; l < nlev; ++l) {
+                    int r[4];
+                    mb_blend_region(geo, 1, tx, ty, l, r);
+                    max_area[l] = std::max(max_area[l], mb_blend_region_lds_pixels(geo, 1, tx, ty, l));
+                    uint32_t lbits = 0;
+                    for (int c = 0; c < n; ++c)
+                        if (any_nonzero(c, l, r[0], r[1], r[2], r[3])) lbits |= 1u << c;
+                    bits |= lbits;
+                    if (lbits != 0 && (lbits & (lbits - 1)) == 0) {
+                        const int c = __builtin_ctz(lbits);
+                        if ((owner < 0 || owner == c) && all_unit(c, l, r[0], r[1], r[2], r[3])) {
+                            owner = c;
+                            level_mask |= 1u << l;
+                        }
+                    }
+                }
+                const size_t ti = static_cast<size_t>(ty) * ct.tiles_x + tx;
+                if (owner >= 0 && level_mask == ((1u << nlev) - 2u) && bits == (1u << owner)) bits |= 0x80000000u;
+                ct.cams[ti] = bits;
+                ct.pure[ti] = owner >= 0 ? (level_mask | static_cast<uint32_t>(owner) << 16) : 0u;
+            }
+        });
+        std::vector<int> max_area(nlev, 0);
+        for (const std::vector<int>& ra : row_area)
+            for (int l = 0; l < nlev; ++l) max_area[l] = std::max(max_area[l], ra[l]);
+        ct.order = ordered(ct.cams, [&](uint32_t tile) {
+            const uint32_t e = ct.cams[tile];
+            if (e >> 31) return 4;                                  // relative: integer path everywhere
+            const bool l1_owned = ct.pure[tile] & 2u;               // float bands on some coarser levels only
+            return (l1_owned ? 6 : 10) + 2 * __builtin_popcount(e);
+        });
+        int off = 0;
+        for (int l = 2; l < nlev; ++l) {
+            ct.lds_off[l] = off;
+            off += (max_area[l] + 1) & ~1;
+        }
+        ct.lds_bytes = static_cast<size_t>(off) * 8;
+        if (v == 1) {
+            for (uint32_t e : ct.cams) pure_tiles += e >> 31;
+            for (uint32_t e : ct.pure) own1_tiles += (e >> 1) & 1u;
+        }
     }
-    plan.lds_bytes = static_cast<size_t>(off) * 8;
+    mark("canvas tiles");
+    if (timing) {
+        int owned = 0, binary = 0;
+        for (uint32_t e : plan.block_cams) { owned += e >> 31; binary += (e >> 30) & 1u; }
+        std::fprintf(stderr, "[mst_update]   plan: %zu panorama tiles (%d with level 0 owned, %d more with 0/1 masks), %zu level-1 tiles (%d pure, %d with level 1 owned)\n",
+                     plan.block_cams.size(), owned, binary, plan.coarse[1].cams.size(), pure_tiles, own1_tiles);
+    }
 }
 
 }  // namespace mst

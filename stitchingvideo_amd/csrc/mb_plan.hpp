@@ -35,24 +35,28 @@ struct MbPlanHost {
     std::vector<uint32_t> block_cams;                         // k_blend_fine, one entry per panorama tile (BlendArgs)
     std::vector<uint32_t> block_order;                        // k_blend_fine, tile index launched as block i
     int blend_tiles_x = 0, blend_tiles_y = 0;
-    std::vector<uint32_t> coarse_cams;                        // k_blend_coarse, one entry per level-1 tile
-    std::vector<uint32_t> coarse_pure;                        // levels owned by one camera | owner << 16
-    std::vector<uint32_t> coarse_order;
-    int coarse_tiles_x = 0, coarse_tiles_y = 0;
+    // k_blend_coarse tiles for each tile height the launcher chooses between (index 0: 16 level-1 rows, for one or two
+    // frame sets per launch; 1: 32 rows, for batches): per tile the camera bits over levels 1 .. top (bit 31: every
+    // level owned by the one camera), the levels owned by one camera | owner << 16, the launch order, the LDS layout
+    struct CoarseTiles {
+        int th = 0, tiles_x = 0, tiles_y = 0;
+        std::vector<uint32_t> cams, pure, order;
+        int lds_off[kMaxLevels] = {};
+        size_t lds_bytes = 0;
+    };
+    CoarseTiles coarse[2];
     // camera-sharded hand-off: per camera, the interiors of its launched tiles at every level (what the canvas kernel
     // can read of that camera and nothing else), packed back to back
     std::vector<PayloadRect> payload_rects;                   // grouped by camera
     std::vector<int> payload_cam_start;                       // n+1 offsets into payload_rects
     std::vector<uint32_t> payload_px;                         // pixels (dwords) per camera
-    int lds_off[kMaxLevels] = {};
-    size_t lds_bytes = 0;
     std::vector<MbCameraNeed> cams;
 };
 
 // weight_class[c][l]: one byte per pixel of camera c's weight pyramid level l -- bit 0: the weight is non-zero,
 // bit 1: it is exactly the weight of a fully owned pixel (1.0f; 256 with CV_16S weights) -- classified on the
 // device (k_weight_class), so that the plan never needs the float pyramids on the host.  `blend` must have
-// nlev/cw/ch/final_w/final_h/cc_th filled in.
+// nlev/cw/ch/final_w/final_h filled in.
 void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<uint8_t>>>& weight_class,
                    const BlendArgs& blend, MbPlanHost& plan);
 
