@@ -1813,13 +1813,28 @@ __device__ __forceinline__ void coarse_base_level(const CamDesc* __restrict__ ca
 
 // 1-D grids over (tile, frame set).  Blocks are dealt to the XCDs round-robin, so XCD k = blockIdx.x % 8 sees the
 // blocks j = blockIdx.x / 8 in order: consecutive j are the frame sets of one tile (the weight pyramids and masks a
-// seam tile reads are frame-invariant: fetched into that XCD's L2 once, shared by the other sets), and tiles go to
-// the XCDs round-robin in launch order, which keeps "most expensive first" true on every XCD.
-__device__ __forceinline__ bool tile_of_block(int n_tiles, int n_sets, int& q, int& set)
+// seam tile reads are frame-invariant: fetched into that XCD's L2 once, shared by the other sets).  Tiles go to the
+// XCDs in groups of C_XCD_GROUP consecutive entries of the launch order: entries of one cost class are neighbours
+// along a tile row, and a tile reads one column of its left and right neighbours' level-1 rows (pyrUp halo) -- a
+// whole memory sector for 8 bytes -- which an XCD that also works on the neighbour already has in its L2.  "Most
+// expensive first" still holds on every XCD up to the group size.
+#ifndef MST_C_XCD_GROUP
+#define MST_C_XCD_GROUP 8          // k_blend_fine: 139.7 / 137.9 / 134.0 / 130.7 us per 8 frame sets with groups of 1 / 2 / 4 / 8
+#endif
+#ifndef MST_CC_XCD_GROUP
+#define MST_CC_XCD_GROUP 1         // k_blend_coarse (few, long blocks: balance matters more): 85.1 / 85.0 / 86.5 / 88.6 us
+#endif
+constexpr int C_XCD_GROUP = MST_C_XCD_GROUP, CC_XCD_GROUP = MST_CC_XCD_GROUP;
+template <int G> __host__ __device__ inline int canvas_grid(int n_tiles, int n_sets)
+{
+    return ((n_tiles + 8 * G - 1) / (8 * G)) * 8 * G * n_sets;
+}
+template <int G> __device__ __forceinline__ bool tile_of_block(int n_tiles, int n_sets, int& q, int& set)
 {
     const int xj = blockIdx.x >> 3, xk = blockIdx.x & 7;
-    q = (xj / n_sets) * 8 + xk;
-    set = xj % n_sets;
+    const int m = xj / n_sets;                        // this XCD's m-th tile
+    set = xj - m * n_sets;
+    q = (m / G) * (8 * G) + xk * G + m % G;
     return q < n_tiles;
 }
 
@@ -1834,7 +1849,7 @@ template <bool W16, int TH>
 __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const CamDesc* __restrict__ cams_all, BlendArgs a)
 {
     int q, set;
-    if (!tile_of_block(a.n_coarse_tiles, a.n_sets, q, set)) return;
+    if (!tile_of_block<CC_XCD_GROUP>(a.n_coarse_tiles, a.n_sets, q, set)) return;
     const CamDesc* __restrict__ cams = cams_all + set * a.n_cams;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* lds = reinterpret_cast<uint2*>(smem);
@@ -1901,7 +1916,7 @@ template <bool W16, int NT>
 __global__ __launch_bounds__(NT, MST_C_WAVES) void k_blend_fine(const CamDesc* __restrict__ cams_all, BlendArgs a)
 {
     int q, set;
-    if (!tile_of_block(a.n_tiles, a.n_sets, q, set)) return;
+    if (!tile_of_block<C_XCD_GROUP>(a.n_tiles, a.n_sets, q, set)) return;
     const CamDesc* __restrict__ cams = cams_all + set * a.n_cams;
     uint8_t* __restrict__ pano = a.pano[set];
     uint8_t* __restrict__ pano_mask = a.pano_mask[set];
@@ -2046,14 +2061,14 @@ void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, 
     a.n_coarse_tiles = num_coarse;
     a.n_sets = batch;
     if (a.nlev > 1 && (which & 1)) {
-        const int grid = ((num_coarse + 7) / 8) * 8 * batch;
+        const int grid = canvas_grid<CC_XCD_GROUP>(num_coarse, batch);
 #define MST_LAUNCH_COARSE(W, TH) hipLaunchKernelGGL((k_blend_coarse<W, TH>), dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, a)
         if (a.cc_th == 16) { if (a.weights_16s) MST_LAUNCH_COARSE(true, 16); else MST_LAUNCH_COARSE(false, 16); }
         else { if (a.weights_16s) MST_LAUNCH_COARSE(true, 32); else MST_LAUNCH_COARSE(false, 32); }
 #undef MST_LAUNCH_COARSE
     }
     if (!(which & 2)) return;
-    const int grid = ((num_blocks + 7) / 8) * 8 * batch;
+    const int grid = canvas_grid<C_XCD_GROUP>(num_blocks, batch);
 #define MST_LAUNCH_FINE(W, NT) hipLaunchKernelGGL((k_blend_fine<W, NT>), dim3(grid), dim3(NT), 0, s, d_cams, a)
     if (a.fine_threads == 128) { if (a.weights_16s) MST_LAUNCH_FINE(true, 128); else MST_LAUNCH_FINE(false, 128); }
     else { if (a.weights_16s) MST_LAUNCH_FINE(true, 256); else MST_LAUNCH_FINE(false, 256); }
