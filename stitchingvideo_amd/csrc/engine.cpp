@@ -576,7 +576,7 @@ void Engine::update(const mst_calibration& calib)
         ba.final_w = cv.final_w; ba.final_h = cv.final_h;
         ba.alpha = static_cast<float>(1. / 255.);
         ba.weights_16s = cfg_.weight_type == MST_WEIGHT_16S ? 1 : 0;
-        build_mb_plan(st->desc, wh, ba, st->plan);
+        build_mb_plan(st->desc, wh, ba, (cfg_.flags & MST_FLAG_DEBUG) != 0, st->plan);
         clk.mark("work-list plan (host)");
         const MbPlanHost& plan = st->plan;
         ba.tiles_x = plan.blend_tiles_x;

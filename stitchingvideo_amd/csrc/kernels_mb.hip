@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_warp_table(const CamDesc* __restrict__ 
     __shared__ int s_ry[A_LH];
     __shared__ int s_min[2];
     const uint32_t t = list.tiles[blockIdx.x];
-    const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
+    const int cam = (t >> 24) & 0x7F, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
     const int bw = c.lw[0], bh = c.lh[0];
     const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     const CamDesc* __restrict__ cams = cams_all + set * n_cams;
     const FrameArgs& frames = batch.f[set];
     const uint32_t t = list.tiles[li];
-    const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
+    const int cam = (t >> 24) & 0x7F, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
     const int bw = c.lw[0], bh = c.lh[0], nlev = c.nlev;
     const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;    // level-0 origin of the halo'd tile
@@ -593,7 +593,9 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     }
     MST_STAMP(0, 2);
     __syncthreads();
-    if (!wide_rows) {
+    const bool store0 = !(t >> 31) || (MST_ABLATE_A & 256);    // (bit 31: nothing reads this tile's level 0 from memory, see mb_plan.cpp)
+    if (!store0) {
+    } else if (!wide_rows) {
         for (int i = tid; i < A_TH0 * A_TW0; i += 256) {
             const int r = i / A_TW0, cc = i - r * A_TW0;
             const int gy = ly0 + 2 + r, gxx = lx0 + 2 + cc;
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
     uint32_t* const s_e0 = s_all;
 
     const uint32_t t = list.tiles[xcd_run_index(blockIdx.x, list.count)];
-    const int cam = t >> 24, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
+    const int cam = (t >> 24) & 0x7F, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
     const int tid = threadIdx.x;
 

@@ -209,7 +209,7 @@ void mark_footprint(const std::vector<uint8_t>& coarse, int cw, int ch, std::vec
 
 
 void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<uint8_t>>>& weight_class,
-                   const BlendArgs& blend, MbPlanHost& plan)
+                   const BlendArgs& blend, bool keep_level0, MbPlanHost& plan)
 {
     const int n = static_cast<int>(desc.size());
     const int nlev = blend.nlev, nb = nlev - 1;
@@ -256,23 +256,32 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
         parallel_for(n, 16, [&](int c) {
             const CamDesc& d = desc[c];
             const int tiles_x = (d.lw[0] + a_tw0 - 1) / a_tw0, tiles_y = (d.lh[0] + a_th0 - 1) / a_th0;
-            std::vector<uint8_t> used(static_cast<size_t>(tiles_x) * tiles_y, 0);
+            // used: some pixel of the tile is needed; weighted: some pixel has a level-0 weight.  A tile that is needed only
+            // as pyrDown input (bit 31 of its list entry) keeps its level 0 on chip: nothing ever reads it from memory.
+            std::vector<uint8_t> used(static_cast<size_t>(tiles_x) * tiles_y, 0), weighted(used.size(), 0);
             const std::vector<uint8_t>& need0 = plan.cams[c].need[0];
+            const std::vector<uint8_t>& nz0 = plan.cams[c].nz[0];
             parallel_for(tiles_y, 32, [&](int ty) {                       // a tile row's flags belong to one worker
-                uint8_t* urow = used.data() + static_cast<size_t>(ty) * tiles_x;
-                for (int y = ty * a_th0; y < std::min(d.lh[0], (ty + 1) * a_th0); ++y) {
-                    const uint8_t* row = need0.data() + static_cast<size_t>(y) * d.lw[0];
-                    for (int x = next_set(row, 0, d.lw[0]); x < d.lw[0];) {
-                        const int t = x / a_tw0;
-                        urow[t] = 1;
-                        x = next_set(row, (t + 1) * a_tw0, d.lw[0]);       // the rest of this tile's columns cannot add anything
+                for (int pass = 0; pass < 2; ++pass) {
+                    uint8_t* urow = (pass ? weighted : used).data() + static_cast<size_t>(ty) * tiles_x;
+                    const std::vector<uint8_t>& map = pass ? nz0 : need0;
+                    for (int y = ty * a_th0; y < std::min(d.lh[0], (ty + 1) * a_th0); ++y) {
+                        const uint8_t* row = map.data() + static_cast<size_t>(y) * d.lw[0];
+                        for (int x = next_set(row, 0, d.lw[0]); x < d.lw[0];) {
+                            const int t = x / a_tw0;
+                            urow[t] = 1;
+                            x = next_set(row, (t + 1) * a_tw0, d.lw[0]);   // the rest of this tile's columns cannot add anything
+                        }
                     }
                 }
             });
             for (int ty = 0; ty < tiles_y; ++ty)
-                for (int tx = 0; tx < tiles_x; ++tx)
-                    if (used[static_cast<size_t>(ty) * tiles_x + tx])
-                        per_cam[c].push_back(static_cast<uint32_t>(c) << 24 | static_cast<uint32_t>(ty) << 12 | tx);
+                for (int tx = 0; tx < tiles_x; ++tx) {
+                    const size_t ti = static_cast<size_t>(ty) * tiles_x + tx;
+                    if (used[ti])
+                        per_cam[c].push_back(static_cast<uint32_t>(c) << 24 | static_cast<uint32_t>(ty) << 12 | tx |
+                                             ((weighted[ti] || keep_level0) ? 0u : 0x80000000u));
+                }
         });
         for (int c = 0; c < n; ++c) {
             plan.warp_cam_start.push_back(static_cast<int>(plan.warp_tiles.size()));
@@ -335,7 +344,7 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
             for (int i = plan.warp_cam_start[c]; i < plan.warp_cam_start[c + 1]; ++i) {
                 const uint32_t t = plan.warp_tiles[i];
                 const int ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
-                add(0, tx * a_tw0, ty * a_th0, a_tw0, a_th0);
+                if (!(t >> 31)) add(0, tx * a_tw0, ty * a_th0, a_tw0, a_th0);      // (level 0 the canvas never reads is not shipped either)
                 if (nlev >= 2) add(1, tx * a_tw1, ty * a_th1, a_tw1, a_th1);
             }
             for (const MbPlanHost::ChainStep& step : plan.chain)

@@ -28,7 +28,8 @@ struct MbCameraNeed {
 };
 
 struct MbPlanHost {
-    std::vector<uint32_t> warp_tiles;                         // kernel A, grouped by camera
+    std::vector<uint32_t> warp_tiles;                         // kernel A, grouped by camera: cam << 24 | ty << 12 | tx, bit 31 =
+                                                              // level 0 of the tile is not stored (no level-0 weight under it)
     std::vector<int> warp_cam_start;                          // n+1 offsets into warp_tiles
     struct ChainStep { int base, k; std::vector<uint32_t> tiles; std::vector<int> cam_start; };
     std::vector<ChainStep> chain;                             // kernel B launches
@@ -56,8 +57,9 @@ struct MbPlanHost {
 // weight_class[c][l]: one byte per pixel of camera c's weight pyramid level l -- bit 0: the weight is non-zero,
 // bit 1: it is exactly the weight of a fully owned pixel (1.0f; 256 with CV_16S weights) -- classified on the
 // device (k_weight_class), so that the plan never needs the float pyramids on the host.  `blend` must have
-// nlev/cw/ch/final_w/final_h filled in.
+// nlev/cw/ch/final_w/final_h filled in.  keep_level0 (MST_FLAG_DEBUG): store the warped level 0 of every launched tile,
+// also of those no panorama pixel reads it from (mst_debug_read then shows all of it).
 void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<uint8_t>>>& weight_class,
-                   const BlendArgs& blend, MbPlanHost& plan);
+                   const BlendArgs& blend, bool keep_level0, MbPlanHost& plan);
 
 }  // namespace mst
