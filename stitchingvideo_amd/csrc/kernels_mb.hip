@@ -20,15 +20,16 @@
 // Work lists: only tiles whose output can reach the panorama (non-zero blend weight somewhere down
 // the chain) are launched; the lists are built once per calibration on the host (mb_plan.cpp).
 //
-// Tuning notes (MI355X, rocprofv3, profiles/): per frame set the path moves ~259 MB at the
-// fabric (4.2x the compulsory bytes) and issues ~33 M VALU wave-instructions.  Kernel A and the coarse canvas kernel
+// Tuning notes (MI355X, rocprofv3, profiles/): per frame set the path moves ~240 MB at the
+// fabric (3.9x the compulsory bytes) and issues ~33 M VALU wave-instructions.  Kernel A and the coarse canvas kernel
 // are bound by instruction issue (50-65 % VALU-busy with the other pipes partly loaded), the level-0 canvas kernel by
-// memory (4.9 TB/s), the pyrDown chain by dependent round trips per block.  What paid off, in order: never launching
+// memory (5-6 TB/s), the pyrDown chain by dependent round trips per block.  What paid off, in order: never launching
 // tiles that cannot reach the panorama, packed pixels + SWAR pyramids, the per-calibration map table with
 // BORDER_REFLECT folded into it, integer paths wherever the weights are exactly 0/1, register-rolling quad-row
 // strips with DPP neighbour exchange for those paths (6 loads per quad instead of 20), keeping the software
 // pipelines intact through the compiler (global address space, no branches around in-flight loads, full
-// unrolling), and batching frame sets.
+// unrolling), batching frame sets, and telling the caches what streams (non-temporal level-0 traffic) and which
+// blocks share lines (launch order dealt to the XCDs in groups of neighbours).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
