@@ -337,7 +337,8 @@ int  mst_multiband_geometry(mst_rect canvas, int num_bands, mst_rect image, mst_
                             int *used_bands, int out[8]);
 
 /* ---- introspection for parity tests ------------------------------------------------------ */
-#define MST_DBG_CAM_WARPED_S16   1   /* bordered level-0 image of camera c, planar 3 x h x w int16 */
+#define MST_DBG_CAM_WARPED_S16   1   /* bordered level-0 image of camera c, planar 3 x h x w int16 (pixels no panorama pixel
+                                       can depend on read 0; without MST_FLAG_DEBUG so do tiles that only feed level 1) */
 #define MST_DBG_CAM_GAUSS_S16    2   /* Gaussian level `level` of camera c, planar int16 */
 #define MST_DBG_CAM_WEIGHT_F32   3   /* weight pyramid level of camera c, h x w float */
 #define MST_DBG_BAND_WEIGHT_F32  4   /* dst_band_weights_[level], h x w float */

@@ -116,7 +116,8 @@ __device__ __forceinline__ int xcd_run_index(int b, int n)
 #define MST_A_TH0 32
 #endif
 #ifndef MST_ABLATE_A
-#define MST_ABLATE_A 0     // timing experiments only: 1 no gather, 2 no gain, 4 no pyrDown, 8 no map, 16 no blend math
+#define MST_ABLATE_A 0     // timing experiments only: 1 no gather, 2 no gain, 4 no pyrDown, 8 no map, 16 no blend math,
+                           // 32 every window on the fast path, 128 no level-0 store pass, 256 store level 0 of every tile
 #endif
 constexpr int A_TW0 = 124, A_TH0 = MST_A_TH0;  // level-0 interior of a tile
 constexpr int A_LW = A_TW0 + 4, A_LH = A_TH0 + 4;   // with the 2-pixel pyrDown halo: 128 x 36
@@ -1165,8 +1166,10 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
 }
 
 #ifndef MST_ABLATE_C
-#define MST_ABLATE_C 0     // timing experiments only: 1 no coarse bands, 2 no collapse, 4 no final pyrUp, 8 no final band,
-#endif                     // 16 no panorama stores, 32 every tile on the single-camera integer path
+#define MST_ABLATE_C 0     // timing experiments only (results are wrong): 1 no coarse bands, 2 no collapse, 4 no final pyrUp,
+#endif                     // 8 no final band, 16 no panorama stores (generic path), 64 no strips, 256 no blocked quad order,
+                           // 512 no ownership, 1024 no wide stores; strips: 2048 no level-0 loads, 4096 no panorama
+                           // stores, 8192 no collapsed-level loads
 // LDS row pitch (in pixels) of a level region: its width rounded up to even, so that a quad row is one aligned
 // 16-byte access even where the top level's width is odd (the pad column takes the pair's second pixel there)
 __host__ __device__ inline int region_pitch(const Region& r) { return (r.x1 - r.x0 + 1) & ~1; }
