@@ -225,7 +225,8 @@ def main():
     torch.cuda.synchronize()
     t_seq = (time.perf_counter() - t0) / probe
     t_seq = sharding.max_over_ranks([t_seq], device=dev)[0]
-    reps = max(1, int(math.ceil(args.min_time / max(args.steps, 1) / max(t_seq, 1e-6))))
+    # (sized 25 % long: the probe runs right after the first launches and reads slower than the steady state)
+    reps = max(1, int(math.ceil(1.25 * args.min_time / max(args.steps, 1) / max(t_seq, 1e-6))))
 
     for i in range(args.warmup):
         run(reps, i * reps)
