@@ -83,6 +83,44 @@ struct FrameBatch {
     FrameArgs f[kMaxBatch];
 };
 
+// ---- single-pass composites (Blender::NO, the driver's LUT, FeatherBlender): kernels_compose.hip ------------------
+// The output (the canvas, or its cropped part on the LUT path) is cut into kCompTW x kCompTH tiles.  A tile is fed by
+// one SEGMENT per camera that contributes to it; a segment carries, per tile pixel, the backward map in cv::remap's
+// fixed-point form relative to the segment's window origin (one dword), the exposure gain (one float) and, for the
+// feather blend, the camera's blend weight (one float).  All of it is frame-invariant: built by mst_update.
+constexpr int kCompTW = 128, kCompTH = 32, kCompPx = kCompTW * kCompTH;
+constexpr int kCompModePaste = 0, kCompModeLut = 1, kCompModeFeather = 2;
+struct ComposeSeg {
+    int32_t cam;
+    int32_t bx, by;              // smallest window coordinate over the segment's pixels (source pixels)
+    uint32_t flags;              // bit 0: every contributing weight is exactly 1.0f (feather)
+};
+struct ComposeTile {
+    uint32_t seg_first;          // first segment (and, * kCompPx, first table entry) of the tile
+    uint32_t seg_count;
+    uint32_t flags;              // bit 0: some pixel needs the general per-pixel path (border taps, huge gains, far windows)
+    uint32_t tx_ty;              // tx | ty << 16
+};
+constexpr uint32_t kCompTileGeneral = 1u;
+constexpr uint32_t kCompSegUnit = 1u;
+struct ComposeArgs {
+    const CamDesc* cams;
+    int32_t n_cams, mode;
+    const ComposeTile* tiles;    // in launch order (most segments first)
+    const ComposeSeg* segs;
+    const uint32_t* table;       // per segment kCompPx entries: fx | fy << 6 | dx << 12 | dy << 22 | valid << 31
+    const float* gain;           // per segment kCompPx floats
+    const float* weight;         // feather: per segment kCompPx floats
+    const float* wsum;           // feather: per tile (canvas order) kCompPx floats: dst_weight_map_
+    const uint8_t* mask_plane;   // out_h x out_w: the blender's dst_mask (static per calibration)
+    int32_t n_tiles, n_sets;
+    int32_t out_w, out_h, crop_x, crop_y;      // output rectangle inside the canvas
+    int32_t canvas_w, canvas_h, tiles_x;
+    const float* feather_ws;     // canvas-sized weight sum (general path)
+    uint8_t* pano[kMaxBatch]; uint32_t pano_stride;
+    uint8_t* pano_mask[kMaxBatch]; uint32_t mask_stride;
+};
+
 struct CanvasDesc {
     int32_t n_cams;
     int32_t nlev;

@@ -106,6 +106,8 @@ template int16_t* DevicePool::upload<int16_t>(const int16_t*, size_t, hipStream_
 template uint16_t* DevicePool::upload<uint16_t>(const uint16_t*, size_t, hipStream_t);
 template UndistortCam* DevicePool::upload<UndistortCam>(const UndistortCam*, size_t, hipStream_t);
 template PayloadRect* DevicePool::upload<PayloadRect>(const PayloadRect*, size_t, hipStream_t);
+template ComposeTile* DevicePool::upload<ComposeTile>(const ComposeTile*, size_t, hipStream_t);
+template ComposeSeg* DevicePool::upload<ComposeSeg>(const ComposeSeg*, size_t, hipStream_t);
 template FeedImage* DevicePool::upload<FeedImage>(const FeedImage*, size_t, hipStream_t);
 template FeedPair* DevicePool::upload<FeedPair>(const FeedPair*, size_t, hipStream_t);
 
@@ -630,6 +632,8 @@ void Engine::update(const mst_calibration& calib)
                 st->crop_x + st->out_w > st->canvas.width || st->crop_y + st->out_h > st->canvas.height)
                 throw Error{MST_ERR_INVALID_ARG, "crop margins leave no output"};
         }
+        build_compose_plan(*st, s);
+        clk.mark("compose tables");
     }
     check_hip(hipGetLastError(), "calibration kernels");
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(calibration)");
@@ -643,6 +647,79 @@ void Engine::update(const mst_calibration& calib)
         current_ = std::move(st);     // takes effect at the next compose / acquire (Upflag / UpdateMat)
     }
     old.reset();                      // if nobody else holds it: torn down here, on the calibration thread
+}
+
+
+// Per-calibration tables of the single-pass composites (kernels_compose.hip): which cameras reach each 128 x 32 output
+// tile (classified on the device, one dword per tile back to the host), one segment per (tile, camera), the
+// segments' map / gain / weight tables, the static mask plane.  This is what the reference's driver builds as its
+// per-pixel LUT in prepareSize / feedSize (DRV:94-148), extended to the feather blend.
+void Engine::build_compose_plan(CalibState& st, hipStream_t s)
+{
+    ComposeArgs& ca = st.compose;
+    ca = ComposeArgs{};
+    ca.cams = st.d_desc;
+    ca.n_cams = st.n;
+    ca.mode = cfg_.blend_kind == MST_BLEND_FEATHER ? kCompModeFeather
+              : ((cfg_.flags & MST_FLAG_DRIVER_LUT) ? kCompModeLut : kCompModePaste);
+    ca.out_w = st.out_w; ca.out_h = st.out_h; ca.crop_x = st.crop_x; ca.crop_y = st.crop_y;
+    ca.canvas_w = st.canvas.width; ca.canvas_h = st.canvas.height;
+    ca.feather_ws = st.d_feather_ws;
+    const int tiles_x = (st.out_w + kCompTW - 1) / kCompTW, tiles_y = (st.out_h + kCompTH - 1) / kCompTH;
+    if (tiles_x > 0xFFFF || tiles_y > 0xFFFF) throw Error{MST_ERR_INVALID_ARG, "output too large for the tile tables"};
+    ca.tiles_x = tiles_x;
+    const int n_canvas_tiles = tiles_x * tiles_y;
+    uint32_t* d_bits = st.pool.alloc<uint32_t>(n_canvas_tiles);
+    launch_compose_classify(ca, n_canvas_tiles, d_bits, s);
+    check_hip(hipGetLastError(), "k_compose_classify");
+    std::vector<uint32_t> bits(n_canvas_tiles);
+    check_hip(hipMemcpyAsync(bits.data(), d_bits, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H tile cameras)");
+    check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(tile cameras)");
+    // launch order: tiles with the most segments first (the longest blocks start earliest)
+    std::vector<int> order(n_canvas_tiles);
+    for (int i = 0; i < n_canvas_tiles; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return __builtin_popcount(bits[a]) > __builtin_popcount(bits[b]); });
+    std::vector<ComposeTile> tiles(n_canvas_tiles);
+    std::vector<ComposeSeg> segs;
+    std::vector<uint32_t> seg_tile;
+    for (int k = 0; k < n_canvas_tiles; ++k) {
+        const int ti = order[k];
+        ComposeTile& t = tiles[k];
+        t.seg_first = static_cast<uint32_t>(segs.size());
+        t.seg_count = 0;
+        t.flags = 0;
+        t.tx_ty = static_cast<uint32_t>(ti % tiles_x) | static_cast<uint32_t>(ti / tiles_x) << 16;
+        for (int c = 0; c < st.n; ++c)
+            if (bits[ti] >> c & 1u) {
+                segs.push_back(ComposeSeg{c, 0, 0, 0u});
+                seg_tile.push_back(static_cast<uint32_t>(k));
+                ++t.seg_count;
+            }
+    }
+    const int n_segs = static_cast<int>(segs.size());
+    if (static_cast<size_t>(n_segs) * kCompPx > 0xFFFFFFFFull) throw Error{MST_ERR_INVALID_ARG, "too many tile segments"};
+    ComposeTile* d_tiles = st.pool.upload(tiles.data(), tiles.size(), s);
+    ComposeSeg* d_segs = st.pool.upload(segs.data(), std::max<size_t>(segs.size(), 1), s);
+    uint32_t* d_seg_tile = st.pool.upload(seg_tile.data(), std::max<size_t>(seg_tile.size(), 1), s);
+    const size_t entries = std::max<size_t>(static_cast<size_t>(n_segs) * kCompPx, 4);
+    uint32_t* d_table = st.pool.alloc<uint32_t>(entries);
+    float* d_gain = st.pool.alloc<float>(entries);
+    float* d_weight = ca.mode == kCompModeFeather ? st.pool.alloc<float>(entries) : nullptr;
+    ca.tiles = d_tiles; ca.segs = d_segs; ca.table = d_table; ca.gain = d_gain; ca.weight = d_weight;
+    ca.n_tiles = n_canvas_tiles;
+    check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");     // tiles / segs / seg_tile are pageable and local
+    launch_compose_table(ca, cfg_.warp_kind & 0xFF, n_segs, d_segs, d_tiles, d_seg_tile, d_table, d_gain, d_weight, s);
+    check_hip(hipGetLastError(), "k_compose_table");
+    if (ca.mode == kCompModeFeather) {
+        float* d_wsum = st.pool.alloc<float>(static_cast<size_t>(n_canvas_tiles) * kCompPx);
+        launch_compose_wsum(ca, n_canvas_tiles, d_wsum, s);
+        ca.wsum = d_wsum;
+    }
+    uint8_t* d_plane = st.pool.alloc<uint8_t>(static_cast<size_t>(st.out_w) * st.out_h + 16);
+    launch_compose_mask(ca, d_plane, s);
+    ca.mask_plane = d_plane;
+    check_hip(hipGetLastError(), "compose calibration kernels");
+    st.compose_segments = n_segs;
 }
 
 void Engine::compose_device(const void* const* d_frames, const size_t* strides, void* d_pano, size_t pano_stride,
@@ -771,20 +848,16 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         }
     } else {
         undistort(0, s);
+        ComposeArgs ca = st->compose;
+        ca.n_sets = count;
         for (int f = 0; f < count; ++f) {
-            uint8_t* pano = static_cast<uint8_t*>(d_panos[f]);
-            uint8_t* pmask = d_masks ? static_cast<uint8_t*>(d_masks[f]) : nullptr;
-            if (st->blend_kind == MST_BLEND_FEATHER) {
-                launch_feather_compose(st->d_desc, st->n, fb.f[f], st->d_feather_ws, st->canvas.width, st->canvas.height,
-                                       pano, pano_stride, pmask, mask_stride, s);
-                mark("k_feather_compose");
-            } else {
-                launch_paste_compose(st->d_desc, st->n, fb.f[f], st->canvas.width, st->canvas.height, st->crop_x,
-                                     st->crop_y, st->out_w, st->out_h, (cfg_.flags & MST_FLAG_DRIVER_LUT) ? 1 : 0, pano,
-                                     pano_stride, pmask, mask_stride, s);
-                mark("k_paste_compose");
-            }
+            ca.pano[f] = static_cast<uint8_t*>(d_panos[f]);
+            ca.pano_mask[f] = d_masks ? static_cast<uint8_t*>(d_masks[f]) : nullptr;
         }
+        ca.pano_stride = static_cast<uint32_t>(pano_stride);
+        ca.mask_stride = static_cast<uint32_t>(mask_stride);
+        launch_compose(ca, fb, s);
+        mark("k_compose");
     }
     check_hip(hipGetLastError(), "compose kernels");
     set_in_flight(std::move(st));

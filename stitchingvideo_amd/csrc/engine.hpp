@@ -106,6 +106,9 @@ struct CalibState {
     BlendArgs blend{};                  // canvas kernels (pano pointers filled per frame)
     // feather
     float* d_feather_ws = nullptr;
+    // single-pass composites (no blend / driver LUT / feather): tile and segment tables, see kernels_compose.hip
+    ComposeArgs compose{};
+    int compose_segments = 0;
     // output rectangle (== canvas unless the driver LUT crop is active)
     int crop_x = 0, crop_y = 0, out_w = 0, out_h = 0;
     uint64_t generation = 0;            // 1, 2, ... in mst_update order (mst_acquire_calibration)
@@ -170,6 +173,7 @@ private:
     void compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
                           void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
                           hipStream_t stream, StageTimer* timer);
+    void build_compose_plan(CalibState& st, hipStream_t s);     // mst_update, blend kinds NO and FEATHER
     void set_in_flight(std::shared_ptr<CalibState> st);   // keeps `st` alive; the previous one goes to retired_
     void drop_retired();                                   // calibration thread / destructor: tear old states down
     mst_config cfg_;

@@ -1,5 +1,5 @@
 // kernels.hip -- hand-written HIP kernels for gfx950 (CDNA4, wave64): stage-level entry points,
-// calibration-time static products, and the single-kernel feather / paste composites.
+// and calibration-time static products.
 // The multi-band frame path lives in kernels_mb.hip.
 //
 // All of these are HBM-bound integer/byte image operators: no MFMA.  Arithmetic follows the
@@ -14,9 +14,7 @@
 //   k_weight_level0       mask.convertTo(32F,1/255) + copyMakeBorder(CONSTANT)   R64/src/blenders.cpp:287,295
 //   k_pyrdown_f32         cv::pyrDown CV_32F (weights)      R64/src/blenders.cpp:298
 //   k_band_weight_sum     dst_band_weights_ accumulation    R64/src/blenders.cpp:324
-//   k_feather_compose     FeatherBlender::feed/blend        R64/src/blenders.cpp:123-155
-//   k_paste_compose       Blender::feed/blend               R64/src/blenders.cpp:81-112
-//                         feedSize/feedSizeRemap (LUT)      DRV:117-177
+// (the single-pass feather / no-blend / driver-LUT composites live in kernels_compose.hip)
 #include "kernels.hpp"
 #include "kernels_common.hpp"
 
@@ -496,70 +494,6 @@ __global__ __launch_bounds__(256) void k_feather_weight_sum(const CamDesc* __res
     ws[static_cast<size_t>(y) * cw + x] = acc;
 }
 
-// ------------------------------------------------------------------------------------------
-// per-frame hot path: feather and paste -- one fused kernel each (source pixels in, panorama out)
-// ------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(256) void k_feather_compose(const CamDesc* __restrict__ cams, int n_cams,
-                                                         FrameArgs frames, const float* __restrict__ ws_map,
-                                                         int cw, int ch, uint8_t* __restrict__ pano,
-                                                         size_t pano_stride, uint8_t* __restrict__ pano_mask,
-                                                         size_t mask_stride)
-{
-    const int x = blockIdx.x * kTileW + threadIdx.x, y = blockIdx.y * kTileH + threadIdx.y;
-    if (x >= cw || y >= ch) return;
-    int acc[3] = {0, 0, 0};
-    for (int i = 0; i < n_cams; ++i) {
-        const CamDesc& c = cams[i];
-        const int lx = x - c.corner_x, ly = y - c.corner_y;
-        if (static_cast<unsigned>(lx) >= static_cast<unsigned>(c.roi_w) ||
-            static_cast<unsigned>(ly) >= static_cast<unsigned>(c.roi_h))
-            continue;
-        const float w = gp(c.feather_w)[static_cast<size_t>(ly) * c.roi_w + lx];
-        if (w == 0.f) continue;
-        int v[3];
-        warped_pixel(c, frames.ptr[i], frames.stride[i], lx, ly, v);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) acc[p] = wrap_s16(acc[p] + trunc_s16(static_cast<float>(v[p]) * w));
-    }
-    const float wsum = ws_map[static_cast<size_t>(y) * cw + x];
-    const bool m = wsum > kWeightEps;
-    const float ws = wsum + kWeightEps;
-    uint8_t* o = pano + static_cast<size_t>(y) * pano_stride + x * 3;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) o[p] = m ? static_cast<uint8_t>(sat_u8(trunc_s16(static_cast<float>(acc[p]) / ws))) : 0;
-    if (pano_mask) pano_mask[static_cast<size_t>(y) * mask_stride + x] = m ? 255 : 0;
-}
-
-__global__ __launch_bounds__(256) void k_paste_compose(const CamDesc* __restrict__ cams, int n_cams, FrameArgs frames,
-                                                       int cw, int ch, int crop_x, int crop_y, int out_w, int out_h,
-                                                       int driver_lut, uint8_t* __restrict__ pano, size_t pano_stride,
-                                                       uint8_t* __restrict__ pano_mask, size_t mask_stride)
-{
-    const int ox = blockIdx.x * kTileW + threadIdx.x, oy = blockIdx.y * kTileH + threadIdx.y;
-    if (ox >= out_w || oy >= out_h) return;
-    const int x = ox + crop_x, y = oy + crop_y;
-    int owner = -1, olx = 0, oly = 0, mask_or = 0;
-    for (int i = 0; i < n_cams; ++i) {          // later cameras overwrite earlier ones (feed order)
-        const CamDesc& c = cams[i];
-        const int lx = x - c.corner_x, ly = y - c.corner_y;
-        if (static_cast<unsigned>(lx) >= static_cast<unsigned>(c.roi_w) ||
-            static_cast<unsigned>(ly) >= static_cast<unsigned>(c.roi_h))
-            continue;
-        const int mv = gp(c.mask)[static_cast<size_t>(ly) * c.roi_w + lx];
-        mask_or |= mv;
-        if (mv) { owner = i; olx = lx; oly = ly; }
-    }
-    int v[3] = {0, 0, 0};
-    if (owner < 0 && driver_lut) { owner = 0; olx = 0; oly = 0; }   // zero-initialised LUT entry (DRV:107-112)
-    if (owner >= 0) warped_pixel(cams[owner], frames.ptr[owner], frames.stride[owner], olx, oly, v);
-    uint8_t* o = pano + static_cast<size_t>(oy) * pano_stride + ox * 3;
-    o[0] = static_cast<uint8_t>(v[0]);
-    o[1] = static_cast<uint8_t>(v[1]);
-    o[2] = static_cast<uint8_t>(v[2]);
-    if (pano_mask) pano_mask[static_cast<size_t>(oy) * mask_stride + ox] = static_cast<uint8_t>(mask_or);
-}
-
 inline dim3 grid2d(int w, int h) { return dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH); }
 inline dim3 block2d() { return dim3(kTileW, kTileH); }
 
@@ -684,22 +618,6 @@ void launch_band_weight_sum(const CamDesc* d_cams, int n_cams, int level, float*
 void launch_feather_weight_sum(const CamDesc* d_cams, int n_cams, float* d_ws, int cw, int ch, hipStream_t s)
 {
     hipLaunchKernelGGL(k_feather_weight_sum, grid2d(cw, ch), block2d(), 0, s, d_cams, n_cams, d_ws, cw, ch);
-}
-
-void launch_feather_compose(const CamDesc* d_cams, int n_cams, const FrameArgs& frames, const float* d_ws, int cw,
-                            int ch, uint8_t* d_pano, size_t pano_stride, uint8_t* d_pano_mask, size_t mask_stride,
-                            hipStream_t s)
-{
-    hipLaunchKernelGGL(k_feather_compose, grid2d(cw, ch), block2d(), 0, s, d_cams, n_cams, frames, d_ws, cw, ch,
-                       d_pano, pano_stride, d_pano_mask, mask_stride);
-}
-
-void launch_paste_compose(const CamDesc* d_cams, int n_cams, const FrameArgs& frames, int cw, int ch, int crop_x,
-                          int crop_y, int out_w, int out_h, int driver_lut, uint8_t* d_pano, size_t pano_stride,
-                          uint8_t* d_pano_mask, size_t mask_stride, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_paste_compose, grid2d(out_w, out_h), block2d(), 0, s, d_cams, n_cams, frames, cw, ch,
-                       crop_x, crop_y, out_w, out_h, driver_lut, d_pano, pano_stride, d_pano_mask, mask_stride);
 }
 
 }  // namespace mst

@@ -68,13 +68,15 @@ void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, i
 void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
                   hipStream_t s, int which = 3);
 
-// ---- per-frame hot path: feather / paste (fully fused: warp + gain + blend in one kernel) ----
-void launch_feather_compose(const CamDesc* d_cams, int n_cams, const FrameArgs& frames, const float* d_ws,
-                            int cw, int ch, uint8_t* d_pano, size_t pano_stride, uint8_t* d_pano_mask,
-                            size_t mask_stride, hipStream_t s);
-// driver_lut: 0 = Blender::NO semantics; 1 = feedSizeRemap semantics (crop, no mask test)
-void launch_paste_compose(const CamDesc* d_cams, int n_cams, const FrameArgs& frames, int cw, int ch,
-                          int crop_x, int crop_y, int out_w, int out_h, int driver_lut, uint8_t* d_pano,
-                          size_t pano_stride, uint8_t* d_pano_mask, size_t mask_stride, hipStream_t s);
+// ---- per-frame hot path: no-blend / driver LUT / feather composites (kernels_compose.hip) ----
+// calibration: bit i of d_out[canvas tile] = camera i contributes to the tile
+void launch_compose_classify(const ComposeArgs& a, int n_canvas_tiles, uint32_t* d_out, hipStream_t s);
+void launch_compose_mask(const ComposeArgs& a, uint8_t* d_plane, hipStream_t s);            // the blender's dst_mask
+void launch_compose_wsum(const ComposeArgs& a, int n_canvas_tiles, float* d_out, hipStream_t s);   // feather: tiled dst_weight_map_
+// calibration: per segment the map / gain / weight tables, window origin and flags; sets the tiles' general-path flag
+void launch_compose_table(const ComposeArgs& a, int kind, int n_segs, ComposeSeg* d_segs, ComposeTile* d_tiles,
+                          const uint32_t* d_seg_tile, uint32_t* d_table, float* d_gain, float* d_weight, hipStream_t s);
+// per frame: a.n_sets frame sets in one launch (a.pano[f], frames.f[f])
+void launch_compose(const ComposeArgs& a, const FrameBatch& frames, hipStream_t s);
 
 }  // namespace mst

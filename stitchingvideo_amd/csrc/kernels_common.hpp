@@ -212,6 +212,67 @@ __device__ __forceinline__ void sample_linear_reflect_c3(const uint8_t* __restri
         out[k] = blend_taps(t, p00[k], p01[k], p10[k], p11[k]);
 }
 
+// ---- backward map in cv::remap's fixed-point form (shared by the multi-band and the single-pass kernels) ----------
+// The backward map of one destination pixel in the fixed-point form cv::remap uses: integer source
+// coordinate of the 2x2 window, 5-bit fractions (0..32 after border folding), and whether the window can be
+// read with the two 12-byte loads.
+struct MapPx {
+    int sx, sy, fx, fy;
+    bool fast;
+};
+
+// KIND 3 stands for every non-separable projector: its map comes from the host-built xmap / ymap (rx, ry index it)
+template <int KIND>
+__device__ __forceinline__ MapPx map_px(const CamDesc& c, const float kr[9], int src_w, int src_h, const ColEntry& ce,
+                                        const RowEntry& re, int rx, int ry)
+{
+    float X, Y, Z, mx, my;
+    if (KIND == 3) {
+        backward_map(c, rx, ry, mx, my);
+    } else {
+        if (KIND == 1) {
+            const float x_ = re.ra * ce.ca, z_ = re.ra * ce.cb;
+            X = (kr[0] * x_ + re.b[0]) + kr[2] * z_;
+            Y = (kr[3] * x_ + re.b[1]) + kr[5] * z_;
+            Z = (kr[6] * x_ + re.b[2]) + kr[8] * z_;
+        } else {
+            X = (ce.a[0] + re.b[0]) + ce.c[0];
+            Y = (ce.a[1] + re.b[1]) + ce.c[1];
+            Z = (ce.a[2] + re.b[2]) + ce.c[2];
+        }
+        if (KIND == 0 || Z > 0) { mx = X / Z; my = Y / Z; }
+        else { mx = -1.f; my = -1.f; }
+    }
+    const int fsx = cv_round(mx * 32.f), fsy = cv_round(my * 32.f);
+    int sx = sat_s16(fsx >> 5), sy = sat_s16(fsy >> 5);
+    int fx = fsx & 31, fy = fsy & 31;
+    // fast = the 2x2 window lies inside the source and its two 12-byte reads stay inside the frame: they may
+    // run up to 8 bytes past the pixel pair, which is still this frame (next row) except on the last row
+    auto window_ok = [&](int x, int y) {
+        return x >= 0 && x < src_w - 1 && y >= 0 && y < src_h - 1 && (x < src_w - 3 || y < src_h - 2);
+    };
+    bool fast = window_ok(sx, sy);
+    if (!fast) {
+        // BORDER_REFLECT folds both taps of an axis onto neighbouring (or the same) source pixels, so the
+        // sample is again a 2x2 window with the two weights of the axis swapped or merged: the integer sum
+        // sum(v * wx * wy) is the same one remap forms.  Only windows that cannot be read with the 12-byte
+        // loads (the last pixels of the frame, one-pixel sources) stay on the per-tap path.
+        const int x0 = reflect<0>(sx, src_w), x1 = reflect<0>(sx + 1, src_w);
+        const int y0 = reflect<0>(sy, src_h), y1 = reflect<0>(sy + 1, src_h);
+        int xs = min(x0, x1), ys = min(y0, y1);
+        if (xs == src_w - 1) --xs;                  // both taps on the last pixel: window [len-2, len-1], all weight high
+        if (ys == src_h - 1) --ys;
+        const int wxl = (x0 == xs ? 32 - fx : 0) + (x1 == xs ? fx : 0);
+        const int wyl = (y0 == ys ? 32 - fy : 0) + (y1 == ys ? fy : 0);
+        if (window_ok(xs, ys)) {
+            sx = xs; sy = ys; fx = 32 - wxl; fy = 32 - wyl; fast = true;
+        }
+    }
+    MapPx m;
+    m.sx = sx; m.sy = sy; m.fx = fx; m.fy = fy; m.fast = fast;
+    return m;
+}
+
 __device__ __forceinline__ float gain_at(const CamDesc& c, int x, int y)
 {
     if (c.expos == 2) {

@@ -1,0 +1,476 @@
+// kernels_compose.hip -- the single-pass composites as tiled, table-driven HIP kernels for gfx950:
+//
+//   Blender::NO   prepare / feed / blend                       R64/src/blenders.cpp:65-112
+//   driver LUT    prepareSize / feedSize / feedSizeRemap       R64/stitching_detailed.cpp:94-177 (crop: DRV:153,169,702)
+//   FeatherBlender prepare / feed / blend                      R64/src/blenders.cpp:115-155
+//
+// each fused with the per-frame stages in front of it (RotationWarper::warp = cv::remap INTER_LINEAR +
+// BORDER_REFLECT, detail/warpers_inl.hpp:88-99; ExposureCompensator::apply, exposure_compensate.cpp:150-153,
+// 225-246; convertTo(16S), stitcher.cpp:285) and the final convertTo(8U) (stitcher.cpp:313): source frames in,
+// panorama out, nothing in between touches memory.
+//
+// What the reference recomputes per frame and what is frame-invariant are separated the way its own driver does it
+// (the LUT of DRV:94-148 is exactly a per-calibration "which camera, which source pixel" table): mst_update cuts the
+// output into 128 x 32 tiles and gives every tile one SEGMENT per camera that reaches it.  A segment holds, per
+// pixel, the backward map in cv::remap's fixed-point form (window offset from the segment's window origin and the
+// two 5-bit fractions: one dword), the exposure gain (one float; BlocksGainCompensator's resize() evaluated once
+// instead of once per frame) and for the feather blend the camera's weight.  Per frame a lane then handles four
+// adjacent panorama pixels of a row: one 16-byte table load and one 16-byte gain load, eight aligned 12-byte
+// gathers, the separable v_dot4 bilinear form, and one 12-byte panorama store; the frame sets of a batch that share a
+// tile run back to back on one XCD, so the tables come out of that XCD's L2 for all but the first.
+//
+// Measured on MI355X (tools/ubench/sampler.hip): this loop is bound by the memory pipeline (gather + streaming
+// loads + stores through one in-order queue per wave), not by instruction issue -- halving the VALU count changed
+// nothing, four pixels per lane (a quarter of the streaming instructions) and keeping stores out from between the
+// gathers of a row did.  Unaligned 8-byte gathers (no funnel shift) are slower than aligned 12-byte ones.
+//
+// Tiles whose pixels cannot all take that form -- a window on the frame's last pixels that the 12-byte reads would
+// overrun, a window further than 1023 x 511 pixels from the segment origin, a gain of 8e6 and more -- run the
+// general per-pixel path (the round-1 kernels' arithmetic, kept below as device functions).
+#include <algorithm>
+#include <climits>
+
+#include "kernels.hpp"
+#include "kernels_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mst {
+
+using namespace dev;
+
+namespace {
+
+typedef uint32_t __attribute__((ext_vector_type(3))) u32x3;
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+typedef uint32_t __attribute__((aligned(1))) u32_any;      // a dword at any byte address (gfx950 serves unaligned accesses)
+struct __attribute__((packed, aligned(1))) Bytes12 { uint32_t x, y, z; };
+
+__device__ __forceinline__ int xcd_run_index(int b, int n)      // see kernels_mb.hip
+{
+    const int q = n >> 3, r = n & 7, k = b & 7, j = b >> 3;
+    return k * q + min(k, r) + j;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// per-pixel semantics (shared by the table builders and the general path)
+// ------------------------------------------------------------------------------------------------------
+
+// Blender::feed: later cameras overwrite earlier ones where their mask is set; dst_mask |= mask
+__device__ __forceinline__ int paste_owner(const CamDesc* __restrict__ cams, int n_cams, int x, int y, int& olx, int& oly,
+                                           int& mask_or)
+{
+    int owner = -1;
+    mask_or = 0;
+    olx = oly = 0;
+    for (int i = 0; i < n_cams; ++i) {
+        const CamDesc& c = cams[i];
+        const int lx = x - c.corner_x, ly = y - c.corner_y;
+        if (static_cast<unsigned>(lx) >= static_cast<unsigned>(c.roi_w) ||
+            static_cast<unsigned>(ly) >= static_cast<unsigned>(c.roi_h))
+            continue;
+        const int mv = gp(c.mask)[static_cast<size_t>(ly) * c.roi_w + lx];
+        mask_or |= mv;
+        if (mv) { owner = i; olx = lx; oly = ly; }
+    }
+    return owner;
+}
+
+// one panorama pixel of the no-blend / LUT composite, the general way (canvas coordinates)
+__device__ __forceinline__ void paste_pixel(const ComposeArgs& a, const FrameArgs& frames, int x, int y, int v[3], int& mask_or)
+{
+    int olx, oly;
+    int owner = paste_owner(a.cams, a.n_cams, x, y, olx, oly, mask_or);
+    v[0] = v[1] = v[2] = 0;
+    if (owner < 0 && a.mode == kCompModeLut) { owner = 0; olx = 0; oly = 0; }   // zero-initialised LUT entry (DRV:107-112)
+    if (owner >= 0) warped_pixel(a.cams[owner], frames.ptr[owner], frames.stride[owner], olx, oly, v);
+}
+
+// one panorama pixel of the feather blend, the general way
+__device__ __forceinline__ void feather_pixel(const ComposeArgs& a, const FrameArgs& frames, int x, int y, int v[3], bool& m)
+{
+    int acc[3] = {0, 0, 0};
+    for (int i = 0; i < a.n_cams; ++i) {
+        const CamDesc& c = a.cams[i];
+        const int lx = x - c.corner_x, ly = y - c.corner_y;
+        if (static_cast<unsigned>(lx) >= static_cast<unsigned>(c.roi_w) ||
+            static_cast<unsigned>(ly) >= static_cast<unsigned>(c.roi_h))
+            continue;
+        const float w = gp(c.feather_w)[static_cast<size_t>(ly) * c.roi_w + lx];
+        if (w == 0.f) continue;
+        int s[3];
+        warped_pixel(c, frames.ptr[i], frames.stride[i], lx, ly, s);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) acc[p] = wrap_s16(acc[p] + trunc_s16(static_cast<float>(s[p]) * w));
+    }
+    const float wsum = gp(a.feather_ws)[static_cast<size_t>(y) * a.canvas_w + x];
+    m = wsum > kWeightEps;
+    const float ws = wsum + kWeightEps;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) v[p] = m ? sat_u8(trunc_s16(static_cast<float>(acc[p]) / ws)) : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// calibration: which cameras reach a tile, the segment tables, the static mask plane
+// ------------------------------------------------------------------------------------------------------
+
+// Does camera `cam` contribute to canvas pixel (x, y), and at which roi position?  Paste / LUT: it owns the pixel
+// (LUT: pixels nobody owns read camera 0 at roi (0, 0)); feather: the pixel lies in its roi with a non-zero weight.
+__device__ __forceinline__ bool contributes(const ComposeArgs& a, int cam, int x, int y, int& lx, int& ly)
+{
+    if (a.mode == kCompModeFeather) {
+        const CamDesc& c = a.cams[cam];
+        lx = x - c.corner_x; ly = y - c.corner_y;
+        if (static_cast<unsigned>(lx) >= static_cast<unsigned>(c.roi_w) ||
+            static_cast<unsigned>(ly) >= static_cast<unsigned>(c.roi_h))
+            return false;
+        return gp(c.feather_w)[static_cast<size_t>(ly) * c.roi_w + lx] != 0.f;
+    }
+    int mask_or;
+    int owner = paste_owner(a.cams, a.n_cams, x, y, lx, ly, mask_or);
+    if (owner < 0 && a.mode == kCompModeLut) { owner = 0; lx = 0; ly = 0; }
+    return owner == cam;
+}
+
+// bit i of out[tile] = camera i contributes to some pixel of the tile (tiles in canvas order)
+__global__ __launch_bounds__(256) void k_compose_classify(ComposeArgs a, uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t s_bits;
+    if (threadIdx.x == 0) s_bits = 0;
+    __syncthreads();
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    uint32_t bits = 0;
+    for (int i = threadIdx.x; i < kCompPx; i += 256) {
+        const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
+        if (ox >= a.out_w || oy >= a.out_h) continue;
+        const int x = ox + a.crop_x, y = oy + a.crop_y;
+        if (a.mode == kCompModeFeather) {
+            for (int c = 0; c < a.n_cams; ++c) {
+                int lx, ly;
+                if (contributes(a, c, x, y, lx, ly)) bits |= 1u << c;
+            }
+        } else {
+            int lx, ly, mask_or;
+            int owner = paste_owner(a.cams, a.n_cams, x, y, lx, ly, mask_or);
+            if (owner < 0 && a.mode == kCompModeLut) owner = 0;
+            if (owner >= 0) bits |= 1u << owner;
+        }
+    }
+    if (bits) atomicOr(&s_bits, bits);
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = s_bits;
+}
+
+// the blender's dst_mask, static per calibration: Blender::feed ORs the camera masks (blenders.cpp:98-100); the
+// feather blend's is `dst_weight_map_ > WEIGHT_EPS` (blenders.cpp:153)
+__global__ __launch_bounds__(256) void k_compose_mask(ComposeArgs a, uint8_t* __restrict__ plane)
+{
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= a.out_w || oy >= a.out_h) return;
+    const int x = ox + a.crop_x, y = oy + a.crop_y;
+    int m;
+    if (a.mode == kCompModeFeather) {
+        m = gp(a.feather_ws)[static_cast<size_t>(y) * a.canvas_w + x] > kWeightEps ? 255 : 0;
+    } else {
+        int lx, ly;
+        (void)paste_owner(a.cams, a.n_cams, x, y, lx, ly, m);
+    }
+    plane[static_cast<size_t>(oy) * a.out_w + ox] = static_cast<uint8_t>(m);
+}
+
+// dst_weight_map_ in tile order (feather): [canvas tile][row][column]
+__global__ __launch_bounds__(256) void k_compose_wsum(ComposeArgs a, float* __restrict__ out)
+{
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    for (int i = threadIdx.x; i < kCompPx; i += 256) {
+        const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
+        float w = 0.f;
+        if (ox < a.out_w && oy < a.out_h) w = gp(a.feather_ws)[static_cast<size_t>(oy + a.crop_y) * a.canvas_w + ox + a.crop_x];
+        out[static_cast<size_t>(blockIdx.x) * kCompPx + i] = w;
+    }
+}
+
+// One block per segment: the table, gain and weight entries of its 128 x 32 pixels, the segment's window origin and
+// flags, and the owning tile's "general path" flag.  seg_tile[s]: index of the segment's tile in `tiles`.
+constexpr uint32_t kEntryValid = 1u << 31;
+template <int KIND>
+__global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg* __restrict__ segs, ComposeTile* __restrict__ tiles,
+                                                       const uint32_t* __restrict__ seg_tile, uint32_t* __restrict__ table,
+                                                       float* __restrict__ gain, float* __restrict__ weight)
+{
+    __shared__ int s_min[2];
+    __shared__ uint32_t s_flags[2];      // [0]: general pixels seen, [1]: a contributing weight != 1
+    const int s = blockIdx.x;
+    const ComposeTile t = tiles[seg_tile[s]];
+    const int cam = segs[s].cam;
+    const CamDesc& c = a.cams[cam];
+    const int tx = t.tx_ty & 0xFFFF, ty = t.tx_ty >> 16;
+    if (threadIdx.x == 0) { s_min[0] = INT_MAX; s_min[1] = INT_MAX; s_flags[0] = 0; s_flags[1] = 0; }
+    __syncthreads();
+    float kr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) kr[i] = c.kr[i];
+    constexpr int kPer = kCompPx / 256;
+    // pass 1: the maps, their smallest window coordinate
+    int x_lo = INT_MAX, y_lo = INT_MAX;
+    uint32_t valid_bits = 0;
+    for (int j = 0; j < kPer; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
+        if (ox >= a.out_w || oy >= a.out_h) continue;
+        int lx, ly;
+        if (!contributes(a, cam, ox + a.crop_x, oy + a.crop_y, lx, ly)) continue;
+        valid_bits |= 1u << j;
+        const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, load_global(c.cols + lx), load_global(c.rows + ly), lx, ly);
+        if (m.fast) { x_lo = min(x_lo, m.sx); y_lo = min(y_lo, m.sy); }
+    }
+    if (x_lo != INT_MAX) { atomicMin(&s_min[0], x_lo); atomicMin(&s_min[1], y_lo); }
+    __syncthreads();
+    const int bx = s_min[0] == INT_MAX ? 0 : s_min[0], by = s_min[1] == INT_MAX ? 0 : s_min[1];
+    // pass 2: pack
+    bool general = false, not_unit = false;
+    for (int j = 0; j < kPer; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        uint32_t e = 0;
+        float g = 1.f, w = 0.f;
+        if (valid_bits >> j & 1u) {
+            const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
+            int lx, ly;
+            (void)contributes(a, cam, ox + a.crop_x, oy + a.crop_y, lx, ly);
+            const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, load_global(c.cols + lx), load_global(c.rows + ly), lx, ly);
+            const uint32_t dx = static_cast<uint32_t>(m.sx - bx), dy = static_cast<uint32_t>(m.sy - by);
+            g = c.expos == 0 ? 1.f : gain_at(c, lx, ly);
+            if (a.mode == kCompModeFeather) {
+                w = gp(c.feather_w)[static_cast<size_t>(ly) * c.roi_w + lx];
+                not_unit |= w != 1.0f;
+            }
+            if (m.fast && dx < 1024u && dy < 512u && !(g >= 8.0e6f))
+                e = static_cast<uint32_t>(m.fx) | static_cast<uint32_t>(m.fy) << 6 | dx << 12 | dy << 22 | kEntryValid;
+            else
+                general = true;
+        }
+        const size_t o = static_cast<size_t>(s) * kCompPx + i;
+        table[o] = e;
+        gain[o] = g;
+        if (weight) weight[o] = w;
+    }
+    if (general) atomicOr(&s_flags[0], 1u);
+    if (not_unit) atomicOr(&s_flags[1], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        segs[s].bx = bx;
+        segs[s].by = by;
+        segs[s].flags = (a.mode == kCompModeFeather && !s_flags[1]) ? kCompSegUnit : 0u;
+        if (s_flags[0]) atomicOr(&tiles[seg_tile[s]].flags, kCompTileGeneral);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// per frame
+// ------------------------------------------------------------------------------------------------------
+
+// cv::remap's fixed-point bilinear sum for one BGR pixel from the aligned dwords covering the two 6-byte pixel pairs,
+// then the exposure gain: (sum_y wy * (sum_x wx * v) + 512) >> 10 == (sum v * wx * wy * 32 + 2^14) >> 15 in exact
+// integers (bilinear_window_c3, kernels_common.hpp).  The vertical weights come in multiplied by 64, so that the
+// rounded byte lands in bits 16..23 and v_cvt_f32_ubyte2 picks it up without a shift; saturate_cast<uchar>(v * gain)
+// for gains below 8e6 is what v_cvt_pk_u8_f32 computes (kernels_mb.hip, blend_pixel).
+__device__ __forceinline__ uint32_t sample_window(u32x3 p0, u32x3 p1, uint32_t o0, uint32_t o1, uint32_t wx,
+                                                  uint32_t wy0s, uint32_t wy1s, float gain)
+{
+    const uint32_t lo0 = __builtin_amdgcn_alignbyte(p0.y, p0.x, o0), hi0 = __builtin_amdgcn_alignbyte(p0.z, p0.y, o0);
+    const uint32_t lo1 = __builtin_amdgcn_alignbyte(p1.y, p1.x, o1), hi1 = __builtin_amdgcn_alignbyte(p1.z, p1.y, o1);
+    const uint32_t g0 = __builtin_amdgcn_alignbyte(hi0, lo0, 1), r0 = __builtin_amdgcn_alignbyte(hi0, lo0, 2);
+    const uint32_t g1 = __builtin_amdgcn_alignbyte(hi1, lo1, 1), r1 = __builtin_amdgcn_alignbyte(hi1, lo1, 2);
+    const uint32_t hb0 = __builtin_amdgcn_udot4(lo0, wx, 0u, false), hb1 = __builtin_amdgcn_udot4(lo1, wx, 0u, false);
+    const uint32_t hg0 = __builtin_amdgcn_udot4(g0, wx, 0u, false), hg1 = __builtin_amdgcn_udot4(g1, wx, 0u, false);
+    const uint32_t hr0 = __builtin_amdgcn_udot4(r0, wx, 0u, false), hr1 = __builtin_amdgcn_udot4(r1, wx, 0u, false);
+    uint32_t b = __umul24(hb1, wy1s) + (__umul24(hb0, wy0s) + 32768u);
+    uint32_t g = __umul24(hg1, wy1s) + (__umul24(hg0, wy0s) + 32768u);
+    uint32_t r = __umul24(hr1, wy1s) + (__umul24(hr0, wy0s) + 32768u);
+    // (all 32 bits "used": when only bits 16..23 are demanded the compiler rewrites the 24-bit multiplies as plain
+    // 32-bit ones and selects the quarter-rate v_mul_lo_u32 for them)
+    asm("" : "+v"(b)); asm("" : "+v"(g)); asm("" : "+v"(r));
+    uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((b >> 16) & 0xFFu) * gain, 0u, 0u);
+    px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((g >> 16) & 0xFFu) * gain, 1u, px);
+    px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((r >> 16) & 0xFFu) * gain, 2u, px);
+    return px;
+}
+
+// per byte: b - (b != 0)   (the normalised value of a pixel one camera owns with weight exactly 1:
+// short(v / (1.0f + 1e-5f)) == v - 1 for v in 1..255, see band_quad in kernels_mb.hip)
+__device__ __forceinline__ uint32_t bytes_toward_zero(uint32_t v)
+{
+    const uint32_t nz = (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
+    return v - (nz >> 7);
+}
+
+template <int MODE>
+__device__ __forceinline__ void general_tile(const ComposeArgs& a, const FrameArgs& frames, int tx, int ty,
+                                             uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask)
+{
+    for (int i = threadIdx.x; i < kCompPx; i += 256) {
+        const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
+        if (ox >= a.out_w || oy >= a.out_h) continue;
+        int v[3], mv;
+        if (MODE == kCompModeFeather) {
+            bool m;
+            feather_pixel(a, frames, ox + a.crop_x, oy + a.crop_y, v, m);
+            mv = m ? 255 : 0;
+        } else {
+            paste_pixel(a, frames, ox + a.crop_x, oy + a.crop_y, v, mv);
+        }
+        uint8_t* o = pano + __umul24(oy, a.pano_stride) + ox * 3;
+        o[0] = static_cast<uint8_t>(v[0]); o[1] = static_cast<uint8_t>(v[1]); o[2] = static_cast<uint8_t>(v[2]);
+        if (pano_mask) pano_mask[__umul24(oy, a.mask_stride) + ox] = static_cast<uint8_t>(mv);
+    }
+}
+
+constexpr int kRowsPerLane = 4;          // 32 lanes x 4 pixels = one tile row; 8 row groups x 4 rows = the tile
+static_assert(kCompTW == 128 && kCompTH == 8 * kRowsPerLane, "thread layout of k_compose");
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
+{
+    const int pair = xcd_run_index(blockIdx.x, a.n_tiles * a.n_sets);
+    const int set = pair % a.n_sets;
+    const ComposeTile t = a.tiles[pair / a.n_sets];
+    const int tx = t.tx_ty & 0xFFFF, ty = t.tx_ty >> 16;
+    uint8_t* __restrict__ pano = a.pano[set];
+    uint8_t* __restrict__ pano_mask = a.pano_mask[set];
+    const FrameArgs& frames = fb.f[set];
+    if (t.flags & kCompTileGeneral) {
+        general_tile<MODE>(a, frames, tx, ty, pano, pano_mask);
+        return;
+    }
+    const int lane = threadIdx.x & 31, rgrp = threadIdx.x >> 5;
+    const int ox = tx * kCompTW + lane * 4;
+    const bool aligned_rows = ((static_cast<uint32_t>(reinterpret_cast<uintptr_t>(pano)) | a.pano_stride) & 3u) == 0;
+    const bool pure = MODE == kCompModeFeather && t.seg_count == 1 && (a.segs[t.seg_first].flags & kCompSegUnit);
+#pragma unroll
+    for (int it = 0; it < kRowsPerLane; ++it) {
+        const int row = rgrp * kRowsPerLane + it, oy = ty * kCompTH + row;
+        uint32_t px[4] = {0u, 0u, 0u, 0u};
+        int acc[4][3];
+        if (MODE == kCompModeFeather) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0;
+        }
+        for (uint32_t s = 0; s < t.seg_count; ++s) {
+            const ComposeSeg seg = a.segs[t.seg_first + s];
+            const uint32_t stride = frames.stride[seg.cam];
+            const uint8_t* p = frames.ptr[seg.cam] + (static_cast<size_t>(seg.by) * stride + static_cast<size_t>(seg.bx) * 3u);
+            const uint32_t adj = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p)) & 3u;
+            const uint8_t MST_GLOBAL* base = gp(p - adj);
+            const size_t idx = static_cast<size_t>(t.seg_first + s) * kCompPx + row * kCompTW + lane * 4;
+            const u32x4 e = *(const u32x4 MST_GLOBAL*)(a.table + idx);
+            const f32x4 g = *(const f32x4 MST_GLOBAL*)(a.gain + idx);
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == kCompModeFeather && !pure) w = *(const f32x4 MST_GLOBAL*)(a.weight + idx);
+            u32x3 p0[4], p1[4];
+            uint32_t o0[4], o1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // entries that are not this camera's read the segment origin's window and drop the result
+                const uint32_t dx = (e[k] >> 12) & 1023u, dy = (e[k] >> 22) & 511u;
+                o0[k] = __umul24(dy, stride) + dx * 3u + adj;
+                o1[k] = o0[k] + stride;
+                p0[k] = *(const u32x3 MST_GLOBAL*)(base + (o0[k] & ~3u));
+                p1[k] = *(const u32x3 MST_GLOBAL*)(base + (o1[k] & ~3u));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t fx = e[k] & 63u;
+                const uint32_t wx = __umul24(fx, 0xFFFFFFu) + 32u;            // (32 - fx) | fx << 24
+                const uint32_t wy1s = e[k] & 0xFC0u, wy0s = 2048u - wy1s;     // fy * 64, (32 - fy) * 64
+                const uint32_t v = sample_window(p0[k], p1[k], o0[k], o1[k], wx, wy0s, wy1s, g[k]);
+                const bool valid = (e[k] & kEntryValid) != 0;
+                if (MODE != kCompModeFeather || pure) {
+                    px[k] = valid ? v : px[k];
+                } else if (valid) {
+                    // dst += static_cast<short>(src * w): products within [0, 255], sums of at most 16 of them
+                    acc[k][0] += static_cast<int>(static_cast<float>(v & 0xFFu) * w[k]);
+                    acc[k][1] += static_cast<int>(static_cast<float>((v >> 8) & 0xFFu) * w[k]);
+                    acc[k][2] += static_cast<int>(static_cast<float>((v >> 16) & 0xFFu) * w[k]);
+                }
+            }
+        }
+        if (MODE == kCompModeFeather) {
+            if (pure) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) px[k] = bytes_toward_zero(px[k]);
+            } else {
+                const size_t widx = static_cast<size_t>(ty * a.tiles_x + tx) * kCompPx + row * kCompTW + lane * 4;
+                const f32x4 ws = *(const f32x4 MST_GLOBAL*)(a.wsum + widx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool m = ws[k] > kWeightEps;
+                    const float d = ws[k] + kWeightEps;
+                    uint32_t o = 0;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch)
+                        o |= static_cast<uint32_t>(sat_u8(trunc_s16(static_cast<float>(acc[k][ch]) / d))) << (8 * ch);
+                    px[k] = m ? o : 0u;
+                }
+            }
+        }
+        if (oy >= a.out_h || ox >= a.out_w) continue;
+        uint8_t* o = pano + __umul24(oy, a.pano_stride) + ox * 3;
+        if (ox + 3 < a.out_w) {
+            const uint32_t w0 = px[0] | px[1] << 24, w1 = px[1] >> 8 | px[2] << 16, w2 = px[2] >> 16 | px[3] << 8;
+            if (aligned_rows) *reinterpret_cast<u32x3 MST_GLOBAL*>(gp(o)) = u32x3{w0, w1, w2};
+            else *reinterpret_cast<Bytes12*>(o) = Bytes12{w0, w1, w2};
+            if (pano_mask)
+                *reinterpret_cast<u32_any*>(pano_mask + __umul24(oy, a.mask_stride) + ox) =
+                    *reinterpret_cast<const u32_any*>(a.mask_plane + static_cast<size_t>(oy) * a.out_w + ox);
+        } else {
+            for (int k = 0; k < 4 && ox + k < a.out_w; ++k) {
+                o[3 * k] = static_cast<uint8_t>(px[k]); o[3 * k + 1] = static_cast<uint8_t>(px[k] >> 8);
+                o[3 * k + 2] = static_cast<uint8_t>(px[k] >> 16);
+                if (pano_mask) pano_mask[__umul24(oy, a.mask_stride) + ox + k] = a.mask_plane[static_cast<size_t>(oy) * a.out_w + ox + k];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------
+
+void launch_compose_classify(const ComposeArgs& a, int n_canvas_tiles, uint32_t* d_out, hipStream_t s)
+{
+    if (n_canvas_tiles <= 0) return;
+    hipLaunchKernelGGL(k_compose_classify, dim3(n_canvas_tiles), dim3(256), 0, s, a, d_out);
+}
+
+void launch_compose_mask(const ComposeArgs& a, uint8_t* d_plane, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compose_mask, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(256), 0, s, a, d_plane);
+}
+
+void launch_compose_wsum(const ComposeArgs& a, int n_canvas_tiles, float* d_out, hipStream_t s)
+{
+    if (n_canvas_tiles <= 0) return;
+    hipLaunchKernelGGL(k_compose_wsum, dim3(n_canvas_tiles), dim3(256), 0, s, a, d_out);
+}
+
+void launch_compose_table(const ComposeArgs& a, int kind, int n_segs, ComposeSeg* d_segs, ComposeTile* d_tiles,
+                          const uint32_t* d_seg_tile, uint32_t* d_table, float* d_gain, float* d_weight, hipStream_t s)
+{
+    if (n_segs <= 0) return;
+#define MST_LAUNCH_CT(K) hipLaunchKernelGGL(k_compose_table<K>, dim3(n_segs), dim3(256), 0, s, a, d_segs, d_tiles, d_seg_tile, d_table, d_gain, d_weight)
+    if (kind == 0) MST_LAUNCH_CT(0); else if (kind == 1) MST_LAUNCH_CT(1); else if (kind == 2) MST_LAUNCH_CT(2); else MST_LAUNCH_CT(3);
+#undef MST_LAUNCH_CT
+}
+
+void launch_compose(const ComposeArgs& a, const FrameBatch& frames, hipStream_t s)
+{
+    if (a.n_tiles <= 0 || a.n_sets <= 0) return;
+    const dim3 grid(static_cast<unsigned>(a.n_tiles * a.n_sets));
+    if (a.mode == kCompModeFeather) hipLaunchKernelGGL(k_compose<kCompModeFeather>, grid, dim3(256), 0, s, a, frames);
+    else hipLaunchKernelGGL(k_compose<kCompModePaste>, grid, dim3(256), 0, s, a, frames);
+}
+
+}  // namespace mst
