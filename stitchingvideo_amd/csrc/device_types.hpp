@@ -94,6 +94,9 @@ struct ComposeSeg {
     int32_t cam;
     int32_t bx, by;              // smallest window coordinate over the segment's pixels (source pixels)
     uint32_t flags;              // bit 0: every contributing weight is exactly 1.0f (feather)
+    // the source window of the segment as it is staged in LDS (kernels_compose.hip): columns [wx0, wx0 + 4 * groups)
+    // with wx0 = bx rounded down to a multiple of four pixels, rows [by, by + rows)
+    int32_t wx0, groups, rows, pad;
 };
 struct ComposeTile {
     uint32_t seg_first;          // first segment (and, * kCompPx, first table entry) of the tile
@@ -101,12 +104,14 @@ struct ComposeTile {
     uint32_t flags;              // bit 0: some pixel needs the general per-pixel path (border taps, huge gains, far windows)
     uint32_t tx_ty;              // tx | ty << 16
 };
-constexpr uint32_t kCompTileGeneral = 1u;
+constexpr uint32_t kCompTileGeneral = 1u;      // some pixel needs the general per-pixel path
+constexpr uint32_t kCompTileDirect = 2u;       // some segment's source window does not fit the LDS budget: gather from memory
 constexpr uint32_t kCompSegUnit = 1u;
+constexpr int kCompLdsPx = 10240;              // staged window budget per block, in 4-byte pixels (40 KB)
 struct ComposeArgs {
     const CamDesc* cams;
     int32_t n_cams, mode;
-    const ComposeTile* tiles;    // in launch order (most segments first)
+    const ComposeTile* tiles;    // the launch's tile list, in launch order (most segments first)
     const ComposeSeg* segs;
     const uint32_t* table;       // per segment kCompPx entries: fx | fy << 6 | dx << 12 | dy << 22 | valid << 31
     const float* gain;           // per segment kCompPx floats

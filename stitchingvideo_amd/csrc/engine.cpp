@@ -691,7 +691,7 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
         t.tx_ty = static_cast<uint32_t>(ti % tiles_x) | static_cast<uint32_t>(ti / tiles_x) << 16;
         for (int c = 0; c < st.n; ++c)
             if (bits[ti] >> c & 1u) {
-                segs.push_back(ComposeSeg{c, 0, 0, 0u});
+                segs.push_back(ComposeSeg{c, 0, 0, 0u, 0, 0, 0, 0});
                 seg_tile.push_back(static_cast<uint32_t>(k));
                 ++t.seg_count;
             }
@@ -699,8 +699,9 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     const int n_segs = static_cast<int>(segs.size());
     if (static_cast<size_t>(n_segs) * kCompPx > 0xFFFFFFFFull) throw Error{MST_ERR_INVALID_ARG, "too many tile segments"};
     ComposeTile* d_tiles = st.pool.upload(tiles.data(), tiles.size(), s);
-    ComposeSeg* d_segs = st.pool.upload(segs.data(), std::max<size_t>(segs.size(), 1), s);
-    uint32_t* d_seg_tile = st.pool.upload(seg_tile.data(), std::max<size_t>(seg_tile.size(), 1), s);
+    if (segs.empty()) { segs.push_back(ComposeSeg{}); seg_tile.push_back(0u); }     // (n_segs stays 0)
+    ComposeSeg* d_segs = st.pool.upload(segs, s);
+    uint32_t* d_seg_tile = st.pool.upload(seg_tile, s);
     const size_t entries = std::max<size_t>(static_cast<size_t>(n_segs) * kCompPx, 4);
     uint32_t* d_table = st.pool.alloc<uint32_t>(entries);
     float* d_gain = st.pool.alloc<float>(entries);
@@ -719,6 +720,36 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     launch_compose_mask(ca, d_plane, s);
     ca.mask_plane = d_plane;
     check_hip(hipGetLastError(), "compose calibration kernels");
+    // Two launch lists (each in the cost order above): tiles whose segments all fit the LDS-staged form, and the rest
+    // (gather from memory; per-pixel general path where flagged).  The table kernel decided per segment.
+    check_hip(hipMemcpyAsync(tiles.data(), d_tiles, tiles.size() * sizeof(ComposeTile), hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H tiles)");
+    if (n_segs) check_hip(hipMemcpyAsync(segs.data(), d_segs, segs.size() * sizeof(ComposeSeg), hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H segments)");
+    check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(compose tables)");
+    std::vector<ComposeTile> staged, direct, general;
+    size_t lds_px = 0;
+    for (const ComposeTile& t : tiles) {
+        if (t.flags & kCompTileGeneral) { general.push_back(t); continue; }
+        if (t.flags & kCompTileDirect) { direct.push_back(t); continue; }
+        staged.push_back(t);
+        for (uint32_t k = 0; k < t.seg_count; ++k) {
+            const ComposeSeg& sg = segs[t.seg_first + k];
+            lds_px = std::max(lds_px, static_cast<size_t>(sg.groups) * 4 * sg.rows);
+        }
+    }
+    st.compose_staged = static_cast<int>(staged.size());
+    st.compose_direct = static_cast<int>(direct.size());
+    st.compose_general = static_cast<int>(general.size());
+    st.compose_lds_bytes = std::max<size_t>(lds_px * 4, 16);
+    if (staged.empty()) staged.push_back(ComposeTile{});          // (never launched: the counts above are 0)
+    if (direct.empty()) direct.push_back(ComposeTile{});
+    if (general.empty()) general.push_back(ComposeTile{});
+    st.d_compose_staged = st.pool.upload(staged, s);
+    st.d_compose_direct = st.pool.upload(direct, s);
+    st.d_compose_general = st.pool.upload(general, s);
+    if (std::getenv("MST_COMPOSE_STATS"))
+        std::fprintf(stderr, "[mst_update] compose plan: %d tiles, %d segments, %d staged in LDS (%zu bytes), %d gathered, %d general\n",
+                     n_canvas_tiles, n_segs, st.compose_staged, st.compose_lds_bytes, st.compose_direct, st.compose_general);
+    check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");     // the lists are pageable and local
     st.compose_segments = n_segs;
 }
 
@@ -850,14 +881,34 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         undistort(0, s);
         ComposeArgs ca = st->compose;
         ca.n_sets = count;
+        bool aligned = true;       // the staged form reads whole dwords: frames on a 4-byte grid (any cv::Mat of 4n columns is)
         for (int f = 0; f < count; ++f) {
             ca.pano[f] = static_cast<uint8_t*>(d_panos[f]);
             ca.pano_mask[f] = d_masks ? static_cast<uint8_t*>(d_masks[f]) : nullptr;
+            for (int i = 0; i < st->n; ++i)
+                aligned &= ((reinterpret_cast<uintptr_t>(fb.f[f].ptr[i]) | fb.f[f].stride[i]) & 3u) == 0;
         }
         ca.pano_stride = static_cast<uint32_t>(pano_stride);
         ca.mask_stride = static_cast<uint32_t>(mask_stride);
-        launch_compose(ca, fb, s);
-        mark("k_compose");
+        // (the short launches first: they run into the long one's ramp-up instead of trailing it)
+        if (st->compose_general) {
+            ca.tiles = st->d_compose_general;
+            ca.n_tiles = st->compose_general;
+            launch_compose(ca, fb, 0, true, s);
+            mark("k_compose_general");
+        }
+        if (st->compose_direct) {
+            ca.tiles = st->d_compose_direct;
+            ca.n_tiles = st->compose_direct;
+            launch_compose(ca, fb, 0, false, s);
+            mark("k_compose");
+        }
+        if (st->compose_staged) {
+            ca.tiles = st->d_compose_staged;
+            ca.n_tiles = st->compose_staged;
+            launch_compose(ca, fb, aligned ? st->compose_lds_bytes : 0, false, s);
+            mark(aligned ? "k_compose_lds" : "k_compose");
+        }
     }
     check_hip(hipGetLastError(), "compose kernels");
     set_in_flight(std::move(st));

@@ -109,6 +109,10 @@ struct CalibState {
     // single-pass composites (no blend / driver LUT / feather): tile and segment tables, see kernels_compose.hip
     ComposeArgs compose{};
     int compose_segments = 0;
+    const ComposeTile* d_compose_staged = nullptr; int compose_staged = 0;     // tiles of the LDS-staged launch
+    const ComposeTile* d_compose_direct = nullptr; int compose_direct = 0;     // tiles that gather from memory
+    const ComposeTile* d_compose_general = nullptr; int compose_general = 0;   // tiles on the per-pixel path
+    size_t compose_lds_bytes = 0;
     // output rectangle (== canvas unless the driver LUT crop is active)
     int crop_x = 0, crop_y = 0, out_w = 0, out_h = 0;
     uint64_t generation = 0;            // 1, 2, ... in mst_update order (mst_acquire_calibration)

@@ -26,7 +26,7 @@
 //
 // Tiles whose pixels cannot all take that form -- a window on the frame's last pixels that the 12-byte reads would
 // overrun, a window further than 1023 x 511 pixels from the segment origin, a gain of 8e6 and more -- run the
-// general per-pixel path (the round-1 kernels' arithmetic, kept below as device functions).
+// general per-pixel path (the round-1 kernels' arithmetic, kept below as device functions) in a launch of their own.
 #include <algorithm>
 #include <climits>
 
@@ -199,21 +199,21 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
                                                        const uint32_t* __restrict__ seg_tile, uint32_t* __restrict__ table,
                                                        float* __restrict__ gain, float* __restrict__ weight)
 {
-    __shared__ int s_min[2];
+    __shared__ int s_min[2], s_max[2];
     __shared__ uint32_t s_flags[2];      // [0]: general pixels seen, [1]: a contributing weight != 1
     const int s = blockIdx.x;
     const ComposeTile t = tiles[seg_tile[s]];
     const int cam = segs[s].cam;
     const CamDesc& c = a.cams[cam];
     const int tx = t.tx_ty & 0xFFFF, ty = t.tx_ty >> 16;
-    if (threadIdx.x == 0) { s_min[0] = INT_MAX; s_min[1] = INT_MAX; s_flags[0] = 0; s_flags[1] = 0; }
+    if (threadIdx.x == 0) { s_min[0] = INT_MAX; s_min[1] = INT_MAX; s_max[0] = INT_MIN; s_max[1] = INT_MIN; s_flags[0] = 0; s_flags[1] = 0; }
     __syncthreads();
     float kr[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) kr[i] = c.kr[i];
     constexpr int kPer = kCompPx / 256;
     // pass 1: the maps, their smallest window coordinate
-    int x_lo = INT_MAX, y_lo = INT_MAX;
+    int x_lo = INT_MAX, y_lo = INT_MAX, x_hi = INT_MIN, y_hi = INT_MIN;
     uint32_t valid_bits = 0;
     for (int j = 0; j < kPer; ++j) {
         const int i = threadIdx.x + 256 * j;
@@ -223,9 +223,9 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
         if (!contributes(a, cam, ox + a.crop_x, oy + a.crop_y, lx, ly)) continue;
         valid_bits |= 1u << j;
         const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, load_global(c.cols + lx), load_global(c.rows + ly), lx, ly);
-        if (m.fast) { x_lo = min(x_lo, m.sx); y_lo = min(y_lo, m.sy); }
+        if (m.fast) { x_lo = min(x_lo, m.sx); y_lo = min(y_lo, m.sy); x_hi = max(x_hi, m.sx + 1); y_hi = max(y_hi, m.sy + 1); }
     }
-    if (x_lo != INT_MAX) { atomicMin(&s_min[0], x_lo); atomicMin(&s_min[1], y_lo); }
+    if (x_lo != INT_MAX) { atomicMin(&s_min[0], x_lo); atomicMin(&s_min[1], y_lo); atomicMax(&s_max[0], x_hi); atomicMax(&s_max[1], y_hi); }
     __syncthreads();
     const int bx = s_min[0] == INT_MAX ? 0 : s_min[0], by = s_min[1] == INT_MAX ? 0 : s_min[1];
     // pass 2: pack
@@ -262,7 +262,16 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
         segs[s].bx = bx;
         segs[s].by = by;
         segs[s].flags = (a.mode == kCompModeFeather && !s_flags[1]) ? kCompSegUnit : 0u;
-        if (s_flags[0]) atomicOr(&tiles[seg_tile[s]].flags, kCompTileGeneral);
+        // the window as staged in LDS: whole groups of four pixels from a multiple of four (their 12 source bytes
+        // start on a dword of an aligned frame).  Too large for the budget, or a last group that would read past
+        // the end of the frame's last row: the tile gathers from memory instead.
+        const int wx0 = bx & ~3;
+        const int groups = s_max[0] == INT_MIN ? 0 : (s_max[0] - wx0 + 4) / 4, rows = s_max[1] == INT_MIN ? 0 : s_max[1] - by + 1;
+        segs[s].wx0 = wx0; segs[s].groups = groups; segs[s].rows = rows; segs[s].pad = 0;
+        const bool overrun = wx0 + 4 * groups > c.src_w && by + rows >= c.src_h;
+        uint32_t tf = s_flags[0] ? kCompTileGeneral : 0u;
+        if (groups * 4 * rows > kCompLdsPx || groups > 256 || overrun || groups == 0) tf |= kCompTileDirect;
+        if (tf) atomicOr(&tiles[seg_tile[s]].flags, tf);
     }
 }
 
@@ -305,25 +314,32 @@ __device__ __forceinline__ uint32_t bytes_toward_zero(uint32_t v)
     return v - (nz >> 7);
 }
 
+// Tiles on the general per-pixel path: 16 blocks per (tile, frame set), one pixel per thread -- these are few (frame
+// borders, degenerate sources), and a whole tile per block would leave the launch waiting for one long block.
+constexpr int kGeneralSplit = kCompPx / 256;
 template <int MODE>
-__device__ __forceinline__ void general_tile(const ComposeArgs& a, const FrameArgs& frames, int tx, int ty,
-                                             uint8_t* __restrict__ pano, uint8_t* __restrict__ pano_mask)
+__global__ __launch_bounds__(256) void k_compose_general(ComposeArgs a, FrameBatch fb)
 {
-    for (int i = threadIdx.x; i < kCompPx; i += 256) {
-        const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
-        if (ox >= a.out_w || oy >= a.out_h) continue;
-        int v[3], mv;
-        if (MODE == kCompModeFeather) {
-            bool m;
-            feather_pixel(a, frames, ox + a.crop_x, oy + a.crop_y, v, m);
-            mv = m ? 255 : 0;
-        } else {
-            paste_pixel(a, frames, ox + a.crop_x, oy + a.crop_y, v, mv);
-        }
-        uint8_t* o = pano + __umul24(oy, a.pano_stride) + ox * 3;
-        o[0] = static_cast<uint8_t>(v[0]); o[1] = static_cast<uint8_t>(v[1]); o[2] = static_cast<uint8_t>(v[2]);
-        if (pano_mask) pano_mask[__umul24(oy, a.mask_stride) + ox] = static_cast<uint8_t>(mv);
+    const int sub = blockIdx.x % kGeneralSplit, pair = blockIdx.x / kGeneralSplit;
+    const int set = pair % a.n_sets;
+    const ComposeTile t = a.tiles[pair / a.n_sets];
+    const int tx = t.tx_ty & 0xFFFF, ty = t.tx_ty >> 16;
+    uint8_t* __restrict__ pano = a.pano[set];
+    uint8_t* __restrict__ pano_mask = a.pano_mask[set];
+    const int i = sub * 256 + threadIdx.x;
+    const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
+    if (ox >= a.out_w || oy >= a.out_h) return;
+    int v[3], mv;
+    if (MODE == kCompModeFeather) {
+        bool m;
+        feather_pixel(a, fb.f[set], ox + a.crop_x, oy + a.crop_y, v, m);
+        mv = m ? 255 : 0;
+    } else {
+        paste_pixel(a, fb.f[set], ox + a.crop_x, oy + a.crop_y, v, mv);
     }
+    uint8_t* o = pano + __umul24(oy, a.pano_stride) + ox * 3;
+    o[0] = static_cast<uint8_t>(v[0]); o[1] = static_cast<uint8_t>(v[1]); o[2] = static_cast<uint8_t>(v[2]);
+    if (pano_mask) pano_mask[__umul24(oy, a.mask_stride) + ox] = static_cast<uint8_t>(mv);
 }
 
 constexpr int kRowsPerLane = 4;          // 32 lanes x 4 pixels = one tile row; 8 row groups x 4 rows = the tile
@@ -339,10 +355,6 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
     uint8_t* __restrict__ pano = a.pano[set];
     uint8_t* __restrict__ pano_mask = a.pano_mask[set];
     const FrameArgs& frames = fb.f[set];
-    if (t.flags & kCompTileGeneral) {
-        general_tile<MODE>(a, frames, tx, ty, pano, pano_mask);
-        return;
-    }
     const int lane = threadIdx.x & 31, rgrp = threadIdx.x >> 5;
     const int ox = tx * kCompTW + lane * 4;
     const bool aligned_rows = ((static_cast<uint32_t>(reinterpret_cast<uintptr_t>(pano)) | a.pano_stride) & 3u) == 0;
@@ -433,6 +445,156 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
     }
 }
 
+
+// ---- the LDS-staged form ---------------------------------------------------------------------------------------
+// Every global access of the loop above that is not 16 bytes per lane costs the texture path one slot per 32-byte
+// sector it touches; gathers touch a sector or two per LANE, and rows r and r + 1 of a tile ask for the same source
+// lines back to back (hit-on-miss stalls: half of the L1's busy cycles, rocprofv3 TCP_PENDING_STALL_CYCLES).  So the
+// segment's source window goes through the L1 exactly once, as coalesced 12-byte-per-lane loads of four pixels,
+// into LDS as 4-byte pixels (B G R x), and the bilinear taps come out of LDS with ds_read2_b32: no funnel shift, no
+// cache.  tools/ubench/sampler.hip: 366 -> 555 Gpixel/s for the same bytes in and out.
+//
+// With 4-byte pixels the weights go the other way round: vertical pass first, in the 16-bit lanes of a register
+// (8 bits x 6 bits; B and R of one pixel, or G of both), horizontal pass as v_dot2_u32_u16 over (left, right) pairs
+// with the weights times 64, which again leaves the rounded byte in bits 16..23.  Same integers:
+//   (sum_x wx * (sum_y wy * v) + 512) >> 10.
+typedef unsigned short __attribute__((ext_vector_type(2))) us2;
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
+}
+__device__ __forceinline__ uint32_t sample_lds(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1, uint32_t e, float gain)
+{
+    const uint32_t fx = e & 63u, fy = (e >> 6) & 63u;
+    const uint32_t wxp = __umul24(fx, 0x3FFFC0u) + 2048u;         // (32 - fx) * 64 | fx * 64 << 16
+    const uint32_t wy1 = fy, wy0 = 32u - fy;
+    const uint32_t lo0 = p0[0], hi0 = p0[1], lo1 = p1[0], hi1 = p1[1];
+    const uint32_t br0 = __umul24(lo0 & 0xFF00FFu, wy0) + __umul24(lo1 & 0xFF00FFu, wy1);      // VB0 | VR0 << 16
+    const uint32_t br1 = __umul24(hi0 & 0xFF00FFu, wy0) + __umul24(hi1 & 0xFF00FFu, wy1);      // VB1 | VR1 << 16
+    const uint32_t gt = __builtin_amdgcn_perm(hi0, lo0, 0x0C050C01u), gb = __builtin_amdgcn_perm(hi1, lo1, 0x0C050C01u);
+    const uint32_t gg = __umul24(gt, wy0) + __umul24(gb, wy1);                                  // VG0 | VG1 << 16
+    uint32_t b = dot2_u16(__builtin_amdgcn_perm(br1, br0, 0x05040100u), wxp, 32768u);
+    uint32_t r = dot2_u16(__builtin_amdgcn_perm(br1, br0, 0x07060302u), wxp, 32768u);
+    uint32_t g = dot2_u16(gg, wxp, 32768u);
+    asm("" : "+v"(b)); asm("" : "+v"(g)); asm("" : "+v"(r));      // (see sample_window)
+    uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((b >> 16) & 0xFFu) * gain, 0u, 0u);
+    px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((g >> 16) & 0xFFu) * gain, 1u, px);
+    px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((r >> 16) & 0xFFu) * gain, 2u, px);
+    return px;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_compose_lds(ComposeArgs a, FrameBatch fb)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_win[];
+    const int pair = xcd_run_index(blockIdx.x, a.n_tiles * a.n_sets);
+    const int set = pair % a.n_sets;
+    const ComposeTile t = a.tiles[pair / a.n_sets];
+    const int tx = t.tx_ty & 0xFFFF, ty = t.tx_ty >> 16;
+    uint8_t* __restrict__ pano = a.pano[set];
+    uint8_t* __restrict__ pano_mask = a.pano_mask[set];
+    const FrameArgs& frames = fb.f[set];
+    const int lane = threadIdx.x & 31, rgrp = threadIdx.x >> 5;
+    const int ox = tx * kCompTW + lane * 4;
+    const bool aligned_rows = ((static_cast<uint32_t>(reinterpret_cast<uintptr_t>(pano)) | a.pano_stride) & 3u) == 0;
+    const bool pure = MODE == kCompModeFeather && t.seg_count == 1 && (a.segs[t.seg_first].flags & kCompSegUnit);
+    uint32_t px[kRowsPerLane][4];
+    uint32_t acc_bg[kRowsPerLane][4], acc_r[kRowsPerLane][4];     // feather across cameras: B | G << 16, R (sums below 2^13)
+#pragma unroll
+    for (int it = 0; it < kRowsPerLane; ++it)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { px[it][k] = 0u; acc_bg[it][k] = 0u; acc_r[it][k] = 0u; }
+    for (uint32_t s = 0; s < t.seg_count; ++s) {
+        const ComposeSeg seg = a.segs[t.seg_first + s];
+        const uint32_t stride = frames.stride[seg.cam];
+        const size_t tbl = static_cast<size_t>(t.seg_first + s) * kCompPx + (rgrp * kRowsPerLane) * kCompTW + lane * 4;
+        if (s) __syncthreads();                          // the previous segment's window has been read
+        {
+            // stage: groups of four pixels = 12 source bytes (dword aligned) -> 16 LDS bytes
+            const uint8_t MST_GLOBAL* base = gp(frames.ptr[seg.cam]) + (static_cast<size_t>(seg.by) * stride + static_cast<size_t>(seg.wx0) * 3u);
+            const int n = seg.groups * seg.rows;
+            const uint32_t inv = ((1u << 20) + seg.groups - 1) / seg.groups;      // i / groups == (i * inv) >> 20 for i < 4096... checked below
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const int r = n <= 4096 ? static_cast<int>((static_cast<uint32_t>(i) * inv) >> 20) : i / seg.groups;
+                const int g = i - r * seg.groups;
+                const u32x3 d = *(const u32x3 MST_GLOBAL*)(base + __umul24(r, stride) + static_cast<uint32_t>(g) * 12u);
+                u32x4 p;
+                p.x = d.x;                                            // B0 G0 R0 (B1)
+                p.y = __builtin_amdgcn_alignbyte(d.y, d.x, 3);        // B1 G1 R1 (B2)
+                p.z = __builtin_amdgcn_alignbyte(d.z, d.y, 2);        // B2 G2 R2 (B3)
+                p.w = d.z >> 8;                                       // B3 G3 R3 0
+                *reinterpret_cast<u32x4*>(&s_win[(r * seg.groups + g) * 4]) = p;
+            }
+        }
+        __syncthreads();
+        const uint32_t pitch_b = static_cast<uint32_t>(seg.groups) * 16u;
+        const char* win = reinterpret_cast<const char*>(s_win) + (seg.bx - seg.wx0) * 4;
+#pragma unroll
+        for (int it = 0; it < kRowsPerLane; ++it) {
+            const u32x4 e = *(const u32x4 MST_GLOBAL*)(a.table + tbl + it * kCompTW);
+            const f32x4 g = *(const f32x4 MST_GLOBAL*)(a.gain + tbl + it * kCompTW);
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == kCompModeFeather && !pure) w = *(const f32x4 MST_GLOBAL*)(a.weight + tbl + it * kCompTW);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t dx = (e[k] >> 12) & 1023u, dy = (e[k] >> 22) & 511u;
+                const uint32_t addr = __umul24(dy, pitch_b) + dx * 4u;
+                const uint32_t v = sample_lds(reinterpret_cast<const uint32_t*>(win + addr),
+                                              reinterpret_cast<const uint32_t*>(win + addr + pitch_b), e[k], g[k]);
+                const bool valid = (e[k] & kEntryValid) != 0;
+                if (MODE != kCompModeFeather || pure) {
+                    px[it][k] = valid ? v : px[it][k];
+                } else if (valid) {
+                    const uint32_t tb = static_cast<uint32_t>(static_cast<int>(static_cast<float>(v & 0xFFu) * w[k]));
+                    const uint32_t tg = static_cast<uint32_t>(static_cast<int>(static_cast<float>((v >> 8) & 0xFFu) * w[k]));
+                    const uint32_t tr = static_cast<uint32_t>(static_cast<int>(static_cast<float>((v >> 16) & 0xFFu) * w[k]));
+                    acc_bg[it][k] += tb | tg << 16;
+                    acc_r[it][k] += tr;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kRowsPerLane; ++it) {
+        const int row = rgrp * kRowsPerLane + it, oy = ty * kCompTH + row;
+        if (MODE == kCompModeFeather) {
+            if (pure) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) px[it][k] = bytes_toward_zero(px[it][k]);
+            } else {
+                const size_t widx = static_cast<size_t>(ty * a.tiles_x + tx) * kCompPx + row * kCompTW + lane * 4;
+                const f32x4 ws = *(const f32x4 MST_GLOBAL*)(a.wsum + widx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool m = ws[k] > kWeightEps;
+                    const float d = ws[k] + kWeightEps;
+                    const int cb = static_cast<int>(acc_bg[it][k] & 0xFFFFu), cg = static_cast<int>(acc_bg[it][k] >> 16), cr = static_cast<int>(acc_r[it][k]);
+                    const uint32_t o = static_cast<uint32_t>(sat_u8(trunc_s16(static_cast<float>(cb) / d))) |
+                                       static_cast<uint32_t>(sat_u8(trunc_s16(static_cast<float>(cg) / d))) << 8 |
+                                       static_cast<uint32_t>(sat_u8(trunc_s16(static_cast<float>(cr) / d))) << 16;
+                    px[it][k] = m ? o : 0u;
+                }
+            }
+        }
+        if (oy >= a.out_h || ox >= a.out_w) continue;
+        uint8_t* o = pano + __umul24(oy, a.pano_stride) + ox * 3;
+        if (ox + 3 < a.out_w) {
+            const uint32_t w0 = px[it][0] | px[it][1] << 24, w1 = px[it][1] >> 8 | px[it][2] << 16, w2 = px[it][2] >> 16 | px[it][3] << 8;
+            if (aligned_rows) *reinterpret_cast<u32x3 MST_GLOBAL*>(gp(o)) = u32x3{w0, w1, w2};
+            else *reinterpret_cast<Bytes12*>(o) = Bytes12{w0, w1, w2};
+            if (pano_mask)
+                *reinterpret_cast<u32_any*>(pano_mask + __umul24(oy, a.mask_stride) + ox) =
+                    *reinterpret_cast<const u32_any*>(a.mask_plane + static_cast<size_t>(oy) * a.out_w + ox);
+        } else {
+            for (int k = 0; k < 4 && ox + k < a.out_w; ++k) {
+                o[3 * k] = static_cast<uint8_t>(px[it][k]); o[3 * k + 1] = static_cast<uint8_t>(px[it][k] >> 8);
+                o[3 * k + 2] = static_cast<uint8_t>(px[it][k] >> 16);
+                if (pano_mask) pano_mask[__umul24(oy, a.mask_stride) + ox + k] = a.mask_plane[static_cast<size_t>(oy) * a.out_w + ox + k];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------
@@ -465,10 +627,21 @@ void launch_compose_table(const ComposeArgs& a, int kind, int n_segs, ComposeSeg
 #undef MST_LAUNCH_CT
 }
 
-void launch_compose(const ComposeArgs& a, const FrameBatch& frames, hipStream_t s)
+void launch_compose(const ComposeArgs& a, const FrameBatch& frames, size_t lds_bytes, bool general, hipStream_t s)
 {
     if (a.n_tiles <= 0 || a.n_sets <= 0) return;
+    if (general) {
+        const dim3 gg(static_cast<unsigned>(a.n_tiles * a.n_sets * kGeneralSplit));
+        if (a.mode == kCompModeFeather) hipLaunchKernelGGL(k_compose_general<kCompModeFeather>, gg, dim3(256), 0, s, a, frames);
+        else hipLaunchKernelGGL(k_compose_general<kCompModePaste>, gg, dim3(256), 0, s, a, frames);
+        return;
+    }
     const dim3 grid(static_cast<unsigned>(a.n_tiles * a.n_sets));
+    if (lds_bytes) {       // every tile of the list fits the staged form
+        if (a.mode == kCompModeFeather) hipLaunchKernelGGL(k_compose_lds<kCompModeFeather>, grid, dim3(256), lds_bytes, s, a, frames);
+        else hipLaunchKernelGGL(k_compose_lds<kCompModePaste>, grid, dim3(256), lds_bytes, s, a, frames);
+        return;
+    }
     if (a.mode == kCompModeFeather) hipLaunchKernelGGL(k_compose<kCompModeFeather>, grid, dim3(256), 0, s, a, frames);
     else hipLaunchKernelGGL(k_compose<kCompModePaste>, grid, dim3(256), 0, s, a, frames);
 }

@@ -99,8 +99,17 @@ def measure(name, batch=8, min_time=0.4, latency_leg=True):
             one[i % len(one)]()
         torch.cuda.synchronize()
         ms1 = timed(one, max(20, int(0.2 * 1e3 / max(ms_seq / batch, 1e-3))))
+        # how fast the host can queue calls (no GPU wait inside the loop), and the kernels of one call by themselves
+        t0 = time.perf_counter()
+        for i in range(200):
+            one[i % len(one)]()
+        t_enq = (time.perf_counter() - t0) / 200
+        torch.cuda.synchronize()
+        ds = dev_sets[0]
+        st1 = eng.profile_stages([t.data_ptr() for t in ds], [t.stride(0) for t in ds], panos[0].data_ptr(), panos[0].stride(0), stream=stream)
         out["latency_mode"] = {"ms_per_frame": round(ms1, 5), "frames_per_s": round(1000.0 / ms1, 2),
-                               "roofline_frac": round(alg / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                               "roofline_frac": round(alg / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                               "host_enqueue_ms_per_call": round(t_enq * 1e3, 5), "kernels_ms": [(k, round(m, 5)) for k, m in st1]}
     eng.close()
     del dev_sets, panos
     torch.cuda.empty_cache()
@@ -108,9 +117,15 @@ def measure(name, batch=8, min_time=0.4, latency_leg=True):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(PATHS)
-    for nm in names:
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("names", nargs="*")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--min-time", type=float, default=0.4)
+    ap.add_argument("--no-latency-leg", action="store_true")
+    args = ap.parse_args()
+    for nm in (args.names or list(PATHS)):
         try:
-            print(json.dumps(measure(nm)), flush=True)
+            print(json.dumps(measure(nm, batch=args.batch, min_time=args.min_time, latency_leg=not args.no_latency_leg)), flush=True)
         except Exception as e:      # noqa: BLE001
             print(json.dumps({"name": nm, "error": "%s: %s" % (type(e).__name__, e)}), flush=True)

@@ -294,6 +294,76 @@ __global__ __launch_bounds__(256) void k_col_lds(Args a, const TileWin* __restri
     }
 }
 
+
+// ---- quad_lds: the LDS-staged window sampled four pixels per lane, 12-byte BGR store ---------------------------------
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_quad_lds(Args a, const TileWin* __restrict__ wins)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_src[LDS_PX];
+    const int pair = xcd_run_index(blockIdx.x, NCAM * NTILES * a.n_sets);
+    const int set = pair % a.n_sets, ctile = pair / a.n_sets, cam = ctile / NTILES, tile = ctile % NTILES;
+    const int tx = tile % TILES_X, ty = tile / TILES_X;
+    const int lane = threadIdx.x & 31, rgrp = threadIdx.x >> 5;
+    typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+    typedef float __attribute__((ext_vector_type(4))) f32x4;
+    const u32x4 GLOBAL* tab = (const u32x4 GLOBAL*)a.table + (size_t)tile * (TW / 4) * TH + lane;
+    const f32x4 GLOBAL* gt = (const f32x4 GLOBAL*)a.gain + (size_t)tile * (TW / 4) * TH + lane;
+    const TileWin w = wins[tile];
+    {
+        const uint8_t GLOBAL* base = (const uint8_t GLOBAL*)a.src[set] + cam * a.src_cam_bytes + (uint32_t)w.y0 * SSTRIDE + (uint32_t)w.x0 * 3u;
+        const int n = w.groups * w.rows;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int r = i / w.groups, g = i - r * w.groups;
+            const u32x3 d = *(const u32x3 GLOBAL*)(base + (uint32_t)r * SSTRIDE + (uint32_t)g * 12u);
+            u32x4 p;
+            p.x = d.x;
+            p.y = __builtin_amdgcn_alignbyte(d.y, d.x, 3);
+            p.z = __builtin_amdgcn_alignbyte(d.z, d.y, 2);
+            p.w = d.z >> 8;
+            *(u32x4*)&s_src[r * w.pitch + 4 * g] = p;
+        }
+    }
+    // table and gain rows of this lane do not depend on the staging: issue them before the barrier
+    u32x4 e[ROWS]; f32x4 gn[ROWS];
+#pragma unroll
+    for (int it = 0; it < ROWS; ++it) { e[it] = tab[(rgrp * ROWS + it) * (TW / 4)]; gn[it] = gt[(rgrp * ROWS + it) * (TW / 4)]; }
+    __syncthreads();
+    uint8_t GLOBAL* out = (uint8_t GLOBAL*)a.out[set] + cam * a.out_cam_px * 4 + ((size_t)(ty * TH) * DW + tx * TW + lane * 4) * 3;
+    const uint32_t pitch_b = (uint32_t)w.pitch * 4u;
+#pragma unroll
+    for (int it = 0; it < ROWS; ++it) {
+        const int row = rgrp * ROWS + it;
+        uint32_t px[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ee = e[it][k];
+            const uint32_t addr = ee & 0xFFFFu, fx = (ee >> 16) & 63u, fy = ee >> 24;
+            const uint32_t wxp = __umul24(fx, 0x3FFFC0u) + 2048u;
+            const uint32_t wy1 = fy, wy0 = 32u - fy;
+            const uint32_t* p0 = (const uint32_t*)((const char*)s_src + addr);
+            const uint32_t* p1 = (const uint32_t*)((const char*)s_src + addr + pitch_b);
+            const uint32_t lo0 = p0[0], hi0 = p0[1], lo1 = p1[0], hi1 = p1[1];
+            const uint32_t br0 = __umul24(lo0 & 0xFF00FFu, wy0) + __umul24(lo1 & 0xFF00FFu, wy1);
+            const uint32_t br1 = __umul24(hi0 & 0xFF00FFu, wy0) + __umul24(hi1 & 0xFF00FFu, wy1);
+            const uint32_t gt0 = __builtin_amdgcn_perm(hi0, lo0, 0x0C050C01u), gb0 = __builtin_amdgcn_perm(hi1, lo1, 0x0C050C01u);
+            const uint32_t gg = __umul24(gt0, wy0) + __umul24(gb0, wy1);
+            uint32_t b = dot2(__builtin_amdgcn_perm(br1, br0, 0x05040100u), wxp, 32768u);
+            uint32_t r = dot2(__builtin_amdgcn_perm(br1, br0, 0x07060302u), wxp, 32768u);
+            uint32_t g = dot2(gg, wxp, 32768u);
+            asm("" : "+v"(b)); asm("" : "+v"(g)); asm("" : "+v"(r));
+            uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((b >> 16) & 0xFFu) * gn[it][k], 0u, 0u);
+            q = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((g >> 16) & 0xFFu) * gn[it][k], 1u, q);
+            q = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((r >> 16) & 0xFFu) * gn[it][k], 2u, q);
+            px[k] = q;
+        }
+        u32x3 wv;
+        wv.x = px[0] | px[1] << 24;
+        wv.y = px[1] >> 8 | px[2] << 16;
+        wv.z = px[2] >> 16 | px[3] << 8;
+        *(u32x3 GLOBAL*)(out + (size_t)row * DW * 3) = wv;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------------------------
 static int cv_round(float v) { return (int)lrintf(v); }
 
@@ -457,6 +527,8 @@ int main()
     time_it("col_relu", [&] { hipLaunchKernelGGL(k_col_rel<true>, grid, block, 0, 0, a); }, false);
     a.table = d_lds; a.gain = d_gcol;
     time_it("col_lds", [&] { hipLaunchKernelGGL(k_col_lds<0>, grid, block, 0, 0, a, d_wins); }, false);
+    a.table = d_lds; a.gain = d_gcol;
+    time_it("quad_lds/4", [&] { hipLaunchKernelGGL(k_quad_lds<4>, grid, block, 0, 0, a, d_wins); }, true);
     a.table = d_quad; a.gain = d_gquad;
     time_it("quad_rel/4", [&] { hipLaunchKernelGGL((k_quad_rel<false, 4>), grid, block, 0, 0, a); }, true);
     time_it("quad_rel/4 late", [&] { hipLaunchKernelGGL((k_quad_rel<false, 4, true>), grid, block, 0, 0, a); }, true);
@@ -468,6 +540,8 @@ int main()
     time_it("col_relu x1", [&] { hipLaunchKernelGGL(k_col_rel<true>, grid1, block, 0, 0, a); }, false);
     a.table = d_lds; a.gain = d_gcol;
     time_it("col_lds x1", [&] { hipLaunchKernelGGL(k_col_lds<0>, grid1, block, 0, 0, a, d_wins); }, false);
+    a.table = d_lds; a.gain = d_gcol;
+    time_it("quad_lds x1", [&] { hipLaunchKernelGGL(k_quad_lds<4>, grid1, block, 0, 0, a, d_wins); }, true);
     a.table = d_quad; a.gain = d_gquad;
     time_it("quad_relu x1", [&] { hipLaunchKernelGGL((k_quad_rel<true, 4>), grid1, block, 0, 0, a); }, true);
     if (getenv("SAMPLER_ABLATE")) {
