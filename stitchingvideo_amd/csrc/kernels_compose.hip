@@ -342,13 +342,46 @@ __global__ __launch_bounds__(256) void k_compose_general(ComposeArgs a, FrameBat
     if (pano_mask) pano_mask[__umul24(oy, a.mask_stride) + ox] = static_cast<uint8_t>(mv);
 }
 
+
+// FeatherBlender's normalisation divides three sums of one pixel by the same weight sum.  IEEE division is a
+// reciprocal estimate, one Newton step on it, and two fused corrections of the quotient; the first half depends on
+// the divisor only, so it is done once per pixel.  Without the range scaling of the general sequence this is the
+// correctly rounded quotient for every divisor in [1e-5, 17] and every integer numerator in [0, 4095] -- the only
+// operands the sum of at most 16 cameras' short(pixel * weight) over (weight sum + 1e-5) can present --
+// checked exhaustively on gfx950 against the compiler's division (tools/ubench/div_exact.hip: 174 M divisors x 4096).
+struct SharedDivisor { float d, r; };
+__device__ __forceinline__ SharedDivisor shared_divisor(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return SharedDivisor{d, __builtin_fmaf(e, r0, r0)};
+}
+__device__ __forceinline__ float divide_by(float n, const SharedDivisor& s)
+{
+    const float q0 = n * s.r;
+    const float e1 = __builtin_fmaf(-s.d, q0, n);
+    const float q1 = __builtin_fmaf(e1, s.r, q0);
+    const float e2 = __builtin_fmaf(-s.d, q1, n);
+    return __builtin_fmaf(e2, s.r, q1);
+}
+// the normalised, saturated byte of one channel: quotients lie in [0, 255) (sum of v_i * w_i <= 255 * sum of w_i), so
+// short() and the 8-bit saturation of the general form never act
+__device__ __forceinline__ uint32_t feather_norm(int acc, const SharedDivisor& s)
+{
+    return static_cast<uint32_t>(static_cast<int>(divide_by(static_cast<float>(acc), s)));
+}
+
 constexpr int kRowsPerLane = 4;          // 32 lanes x 4 pixels = one tile row; 8 row groups x 4 rows = the tile
 static_assert(kCompTW == 128 && kCompTH == 8 * kRowsPerLane, "thread layout of k_compose");
 
-template <int MODE>
+// ROWS: rows per lane.  4 = one block per tile; 1 = four blocks per tile (short lists: a quarter of the dependent
+// table -> gather -> store round trips per block)
+template <int MODE, int ROWS>
 __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
 {
-    const int pair = xcd_run_index(blockIdx.x, a.n_tiles * a.n_sets);
+    constexpr int kSplit = kRowsPerLane / ROWS;
+    const int sub = blockIdx.x % kSplit;
+    const int pair = xcd_run_index(blockIdx.x / kSplit, a.n_tiles * a.n_sets);
     const int set = pair % a.n_sets;
     const ComposeTile t = a.tiles[pair / a.n_sets];
     const int tx = t.tx_ty & 0xFFFF, ty = t.tx_ty >> 16;
@@ -360,8 +393,8 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
     const bool aligned_rows = ((static_cast<uint32_t>(reinterpret_cast<uintptr_t>(pano)) | a.pano_stride) & 3u) == 0;
     const bool pure = MODE == kCompModeFeather && t.seg_count == 1 && (a.segs[t.seg_first].flags & kCompSegUnit);
 #pragma unroll
-    for (int it = 0; it < kRowsPerLane; ++it) {
-        const int row = rgrp * kRowsPerLane + it, oy = ty * kCompTH + row;
+    for (int it = 0; it < ROWS; ++it) {
+        const int row = (sub * 8 + rgrp) * ROWS + it, oy = ty * kCompTH + row;
         uint32_t px[4] = {0u, 0u, 0u, 0u};
         int acc[4][3];
         if (MODE == kCompModeFeather) {
@@ -417,11 +450,10 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const bool m = ws[k] > kWeightEps;
-                    const float d = ws[k] + kWeightEps;
+                    const SharedDivisor sd = shared_divisor(ws[k] + kWeightEps);
                     uint32_t o = 0;
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch)
-                        o |= static_cast<uint32_t>(sat_u8(trunc_s16(static_cast<float>(acc[k][ch]) / d))) << (8 * ch);
+                    for (int ch = 0; ch < 3; ++ch) o |= feather_norm(acc[k][ch], sd) << (8 * ch);
                     px[k] = m ? o : 0u;
                 }
             }
@@ -508,12 +540,23 @@ __global__ __launch_bounds__(256) void k_compose_lds(ComposeArgs a, FrameBatch f
         const ComposeSeg seg = a.segs[t.seg_first + s];
         const uint32_t stride = frames.stride[seg.cam];
         const size_t tbl = static_cast<size_t>(t.seg_first + s) * kCompPx + (rgrp * kRowsPerLane) * kCompTW + lane * 4;
+        // the lane's table, gain and weight rows do not depend on the staged window: their loads go out first, so
+        // that one round trip to memory covers them and the staging loads
+        u32x4 e_r[kRowsPerLane];
+        f32x4 g_r[kRowsPerLane], w_r[kRowsPerLane];
+#pragma unroll
+        for (int it = 0; it < kRowsPerLane; ++it) {
+            e_r[it] = *(const u32x4 MST_GLOBAL*)(a.table + tbl + it * kCompTW);
+            g_r[it] = *(const f32x4 MST_GLOBAL*)(a.gain + tbl + it * kCompTW);
+            w_r[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (MODE == kCompModeFeather && !pure) w_r[it] = *(const f32x4 MST_GLOBAL*)(a.weight + tbl + it * kCompTW);
+        }
         if (s) __syncthreads();                          // the previous segment's window has been read
         {
             // stage: groups of four pixels = 12 source bytes (dword aligned) -> 16 LDS bytes
             const uint8_t MST_GLOBAL* base = gp(frames.ptr[seg.cam]) + (static_cast<size_t>(seg.by) * stride + static_cast<size_t>(seg.wx0) * 3u);
             const int n = seg.groups * seg.rows;
-            const uint32_t inv = ((1u << 20) + seg.groups - 1) / seg.groups;      // i / groups == (i * inv) >> 20 for i < 4096... checked below
+            const uint32_t inv = ((1u << 20) + seg.groups - 1) / seg.groups;      // i / groups == (i * inv) >> 20 for i < 4096, groups <= 256
             for (int i = threadIdx.x; i < n; i += 256) {
                 const int r = n <= 4096 ? static_cast<int>((static_cast<uint32_t>(i) * inv) >> 20) : i / seg.groups;
                 const int g = i - r * seg.groups;
@@ -531,10 +574,8 @@ __global__ __launch_bounds__(256) void k_compose_lds(ComposeArgs a, FrameBatch f
         const char* win = reinterpret_cast<const char*>(s_win) + (seg.bx - seg.wx0) * 4;
 #pragma unroll
         for (int it = 0; it < kRowsPerLane; ++it) {
-            const u32x4 e = *(const u32x4 MST_GLOBAL*)(a.table + tbl + it * kCompTW);
-            const f32x4 g = *(const f32x4 MST_GLOBAL*)(a.gain + tbl + it * kCompTW);
-            f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            if (MODE == kCompModeFeather && !pure) w = *(const f32x4 MST_GLOBAL*)(a.weight + tbl + it * kCompTW);
+            const u32x4 e = e_r[it];
+            const f32x4 g = g_r[it], w = w_r[it];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t dx = (e[k] >> 12) & 1023u, dy = (e[k] >> 22) & 511u;
@@ -567,11 +608,9 @@ __global__ __launch_bounds__(256) void k_compose_lds(ComposeArgs a, FrameBatch f
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const bool m = ws[k] > kWeightEps;
-                    const float d = ws[k] + kWeightEps;
+                    const SharedDivisor sd = shared_divisor(ws[k] + kWeightEps);
                     const int cb = static_cast<int>(acc_bg[it][k] & 0xFFFFu), cg = static_cast<int>(acc_bg[it][k] >> 16), cr = static_cast<int>(acc_r[it][k]);
-                    const uint32_t o = static_cast<uint32_t>(sat_u8(trunc_s16(static_cast<float>(cb) / d))) |
-                                       static_cast<uint32_t>(sat_u8(trunc_s16(static_cast<float>(cg) / d))) << 8 |
-                                       static_cast<uint32_t>(sat_u8(trunc_s16(static_cast<float>(cr) / d))) << 16;
+                    const uint32_t o = feather_norm(cb, sd) | feather_norm(cg, sd) << 8 | feather_norm(cr, sd) << 16;
                     px[it][k] = m ? o : 0u;
                 }
             }
@@ -642,8 +681,14 @@ void launch_compose(const ComposeArgs& a, const FrameBatch& frames, size_t lds_b
         else hipLaunchKernelGGL(k_compose_lds<kCompModePaste>, grid, dim3(256), lds_bytes, s, a, frames);
         return;
     }
-    if (a.mode == kCompModeFeather) hipLaunchKernelGGL(k_compose<kCompModeFeather>, grid, dim3(256), 0, s, a, frames);
-    else hipLaunchKernelGGL(k_compose<kCompModePaste>, grid, dim3(256), 0, s, a, frames);
+    if (a.n_tiles * a.n_sets < 4096) {      // a short list: four blocks per tile
+        const dim3 g4(grid.x * 4);
+        if (a.mode == kCompModeFeather) hipLaunchKernelGGL((k_compose<kCompModeFeather, 1>), g4, dim3(256), 0, s, a, frames);
+        else hipLaunchKernelGGL((k_compose<kCompModePaste, 1>), g4, dim3(256), 0, s, a, frames);
+        return;
+    }
+    if (a.mode == kCompModeFeather) hipLaunchKernelGGL((k_compose<kCompModeFeather, 4>), grid, dim3(256), 0, s, a, frames);
+    else hipLaunchKernelGGL((k_compose<kCompModePaste, 4>), grid, dim3(256), 0, s, a, frames);
 }
 
 }  // namespace mst
