@@ -106,6 +106,7 @@ struct ComposeTile {
 };
 constexpr uint32_t kCompTileGeneral = 1u;      // some pixel needs the general per-pixel path
 constexpr uint32_t kCompTileDirect = 2u;       // some segment's source window does not fit the LDS budget: gather from memory
+constexpr uint32_t kCompTileNoGather = 4u;     // some window touches the frame's last pixels: 12-byte gathers would overrun, LDS only
 constexpr uint32_t kCompSegUnit = 1u;
 constexpr int kCompLdsPx = 10240;              // staged window budget per block, in 4-byte pixels (40 KB)
 struct ComposeArgs {

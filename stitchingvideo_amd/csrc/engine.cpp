@@ -727,15 +727,29 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(compose tables)");
     std::vector<ComposeTile> staged, direct, general;
     size_t lds_px = 0;
+    // launch order by cost: segments, those with real blend weights (feather bands: converts, products, a division per
+    // channel) counted twice -- the longest blocks start first
+    auto tile_cost = [&](const ComposeTile& t) {
+        int c = 0;
+        for (uint32_t k = 0; k < t.seg_count; ++k)
+            c += (ca.mode == kCompModeFeather && !(segs[t.seg_first + k].flags & kCompSegUnit)) ? 2 : 1;
+        return c;
+    };
+    std::stable_sort(tiles.begin(), tiles.end(), [&](const ComposeTile& x, const ComposeTile& y) { return tile_cost(x) > tile_cost(y); });
+    std::vector<ComposeTile> staged_lds_only;
     for (const ComposeTile& t : tiles) {
-        if (t.flags & kCompTileGeneral) { general.push_back(t); continue; }
+        if ((t.flags & kCompTileGeneral) || ((t.flags & kCompTileDirect) && (t.flags & kCompTileNoGather))) { general.push_back(t); continue; }
         if (t.flags & kCompTileDirect) { direct.push_back(t); continue; }
-        staged.push_back(t);
+        ((t.flags & kCompTileNoGather) ? staged_lds_only : staged).push_back(t);
         for (uint32_t k = 0; k < t.seg_count; ++k) {
             const ComposeSeg& sg = segs[t.seg_first + k];
             lds_px = std::max(lds_px, static_cast<size_t>(sg.groups) * 4 * sg.rows);
         }
     }
+    // (one list: the tiles that may also gather first, then those only the staged form can read -- with frames off the
+    // 4-byte grid the first part gathers and the second takes the general path)
+    st.compose_staged_gatherable = static_cast<int>(staged.size());
+    staged.insert(staged.end(), staged_lds_only.begin(), staged_lds_only.end());
     st.compose_staged = static_cast<int>(staged.size());
     st.compose_direct = static_cast<int>(direct.size());
     st.compose_general = static_cast<int>(general.size());
@@ -903,11 +917,19 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
             launch_compose(ca, fb, 0, false, s);
             mark("k_compose");
         }
-        if (st->compose_staged) {
+        if (st->compose_staged && aligned) {
             ca.tiles = st->d_compose_staged;
             ca.n_tiles = st->compose_staged;
-            launch_compose(ca, fb, aligned ? st->compose_lds_bytes : 0, false, s);
-            mark(aligned ? "k_compose_lds" : "k_compose");
+            launch_compose(ca, fb, st->compose_lds_bytes, false, s);
+            mark("k_compose_lds");
+        } else if (st->compose_staged) {
+            ca.tiles = st->d_compose_staged;
+            ca.n_tiles = st->compose_staged_gatherable;
+            launch_compose(ca, fb, 0, false, s);
+            ca.tiles = st->d_compose_staged + st->compose_staged_gatherable;
+            ca.n_tiles = st->compose_staged - st->compose_staged_gatherable;
+            launch_compose(ca, fb, 0, true, s);
+            mark("k_compose");
         }
     }
     check_hip(hipGetLastError(), "compose kernels");

@@ -109,7 +109,7 @@ struct CalibState {
     // single-pass composites (no blend / driver LUT / feather): tile and segment tables, see kernels_compose.hip
     ComposeArgs compose{};
     int compose_segments = 0;
-    const ComposeTile* d_compose_staged = nullptr; int compose_staged = 0;     // tiles of the LDS-staged launch
+    const ComposeTile* d_compose_staged = nullptr; int compose_staged = 0, compose_staged_gatherable = 0;     // tiles of the LDS-staged launch
     const ComposeTile* d_compose_direct = nullptr; int compose_direct = 0;     // tiles that gather from memory
     const ComposeTile* d_compose_general = nullptr; int compose_general = 0;   // tiles on the per-pixel path
     size_t compose_lds_bytes = 0;

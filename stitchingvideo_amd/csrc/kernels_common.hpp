@@ -219,6 +219,10 @@ __device__ __forceinline__ void sample_linear_reflect_c3(const uint8_t* __restri
 struct MapPx {
     int sx, sy, fx, fy;
     bool fast;
+    // the same sample as a 2x2 window INSIDE the source (BORDER_REFLECT folded in) whether or not its 12-byte reads
+    // would stay inside the frame: what a sampler that never reads past the window needs (LDS-staged windows)
+    int ix, iy, ifx, ify;
+    bool inside;
 };
 
 // KIND 3 stands for every non-separable projector: its map comes from the host-built xmap / ymap (rx, ry index it)
@@ -252,6 +256,8 @@ __device__ __forceinline__ MapPx map_px(const CamDesc& c, const float kr[9], int
         return x >= 0 && x < src_w - 1 && y >= 0 && y < src_h - 1 && (x < src_w - 3 || y < src_h - 2);
     };
     bool fast = window_ok(sx, sy);
+    MapPx m;
+    m.ix = sx; m.iy = sy; m.ifx = fx; m.ify = fy; m.inside = fast;
     if (!fast) {
         // BORDER_REFLECT folds both taps of an axis onto neighbouring (or the same) source pixels, so the
         // sample is again a 2x2 window with the two weights of the axis swapped or merged: the integer sum
@@ -264,11 +270,12 @@ __device__ __forceinline__ MapPx map_px(const CamDesc& c, const float kr[9], int
         if (ys == src_h - 1) --ys;
         const int wxl = (x0 == xs ? 32 - fx : 0) + (x1 == xs ? fx : 0);
         const int wyl = (y0 == ys ? 32 - fy : 0) + (y1 == ys ? fy : 0);
+        m.ix = xs; m.iy = ys; m.ifx = 32 - wxl; m.ify = 32 - wyl;
+        m.inside = xs >= 0 && xs < src_w - 1 && ys >= 0 && ys < src_h - 1;
         if (window_ok(xs, ys)) {
             sx = xs; sy = ys; fx = 32 - wxl; fy = 32 - wyl; fast = true;
         }
     }
-    MapPx m;
     m.sx = sx; m.sy = sy; m.fx = fx; m.fy = fy; m.fast = fast;
     return m;
 }

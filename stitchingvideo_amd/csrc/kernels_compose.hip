@@ -29,6 +29,7 @@
 // general per-pixel path (the round-1 kernels' arithmetic, kept below as device functions) in a launch of their own.
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 
 #include "kernels.hpp"
 #include "kernels_common.hpp"
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
                                                        float* __restrict__ gain, float* __restrict__ weight)
 {
     __shared__ int s_min[2], s_max[2];
-    __shared__ uint32_t s_flags[2];      // [0]: general pixels seen, [1]: a contributing weight != 1
+    __shared__ uint32_t s_flags[2];      // [0]: bit 0 general pixels seen, bit 1 windows only LDS can read; [1]: a contributing weight != 1
     const int s = blockIdx.x;
     const ComposeTile t = tiles[seg_tile[s]];
     const int cam = segs[s].cam;
@@ -223,13 +224,13 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
         if (!contributes(a, cam, ox + a.crop_x, oy + a.crop_y, lx, ly)) continue;
         valid_bits |= 1u << j;
         const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, load_global(c.cols + lx), load_global(c.rows + ly), lx, ly);
-        if (m.fast) { x_lo = min(x_lo, m.sx); y_lo = min(y_lo, m.sy); x_hi = max(x_hi, m.sx + 1); y_hi = max(y_hi, m.sy + 1); }
+        if (m.inside) { x_lo = min(x_lo, m.ix); y_lo = min(y_lo, m.iy); x_hi = max(x_hi, m.ix + 1); y_hi = max(y_hi, m.iy + 1); }
     }
     if (x_lo != INT_MAX) { atomicMin(&s_min[0], x_lo); atomicMin(&s_min[1], y_lo); atomicMax(&s_max[0], x_hi); atomicMax(&s_max[1], y_hi); }
     __syncthreads();
     const int bx = s_min[0] == INT_MAX ? 0 : s_min[0], by = s_min[1] == INT_MAX ? 0 : s_min[1];
     // pass 2: pack
-    bool general = false, not_unit = false;
+    bool general = false, not_unit = false, no_gather = false;
     for (int j = 0; j < kPer; ++j) {
         const int i = threadIdx.x + 256 * j;
         uint32_t e = 0;
@@ -239,16 +240,19 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
             int lx, ly;
             (void)contributes(a, cam, ox + a.crop_x, oy + a.crop_y, lx, ly);
             const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, load_global(c.cols + lx), load_global(c.rows + ly), lx, ly);
-            const uint32_t dx = static_cast<uint32_t>(m.sx - bx), dy = static_cast<uint32_t>(m.sy - by);
+            // (a window that folds differently for the two forms cannot happen: `fast` implies the same folded window)
+            const uint32_t dx = static_cast<uint32_t>(m.ix - bx), dy = static_cast<uint32_t>(m.iy - by);
             g = c.expos == 0 ? 1.f : gain_at(c, lx, ly);
             if (a.mode == kCompModeFeather) {
                 w = gp(c.feather_w)[static_cast<size_t>(ly) * c.roi_w + lx];
                 not_unit |= w != 1.0f;
             }
-            if (m.fast && dx < 1024u && dy < 512u && !(g >= 8.0e6f))
-                e = static_cast<uint32_t>(m.fx) | static_cast<uint32_t>(m.fy) << 6 | dx << 12 | dy << 22 | kEntryValid;
-            else
+            if (m.inside && dx < 1024u && dy < 512u && !(g >= 8.0e6f)) {
+                e = static_cast<uint32_t>(m.ifx) | static_cast<uint32_t>(m.ify) << 6 | dx << 12 | dy << 22 | kEntryValid;
+                no_gather |= !m.fast;
+            } else {
                 general = true;
+            }
         }
         const size_t o = static_cast<size_t>(s) * kCompPx + i;
         table[o] = e;
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
         if (weight) weight[o] = w;
     }
     if (general) atomicOr(&s_flags[0], 1u);
+    if (no_gather) atomicOr(&s_flags[0], 2u);
     if (not_unit) atomicOr(&s_flags[1], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
         const int groups = s_max[0] == INT_MIN ? 0 : (s_max[0] - wx0 + 4) / 4, rows = s_max[1] == INT_MIN ? 0 : s_max[1] - by + 1;
         segs[s].wx0 = wx0; segs[s].groups = groups; segs[s].rows = rows; segs[s].pad = 0;
         const bool overrun = wx0 + 4 * groups > c.src_w && by + rows >= c.src_h;
-        uint32_t tf = s_flags[0] ? kCompTileGeneral : 0u;
+        uint32_t tf = ((s_flags[0] & 1u) ? kCompTileGeneral : 0u) | ((s_flags[0] & 2u) ? kCompTileNoGather : 0u);
         if (groups * 4 * rows > kCompLdsPx || groups > 256 || overrun || groups == 0) tf |= kCompTileDirect;
         if (tf) atomicOr(&tiles[seg_tile[s]].flags, tf);
     }
@@ -515,9 +520,11 @@ __device__ __forceinline__ uint32_t sample_lds(const uint32_t* __restrict__ p0, 
     return px;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_compose_lds(ComposeArgs a, FrameBatch fb)
+// ROWS rows per lane: a block has 32 lanes x (32 / ROWS) row groups = 1024 / ROWS threads over one staged window
+template <int MODE, int ROWS>
+__global__ __launch_bounds__(1024 / ROWS) void k_compose_lds(ComposeArgs a, FrameBatch fb)
 {
+    constexpr int NT = 1024 / ROWS;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_win[];
     const int pair = xcd_run_index(blockIdx.x, a.n_tiles * a.n_sets);
     const int set = pair % a.n_sets;
@@ -530,22 +537,22 @@ __global__ __launch_bounds__(256) void k_compose_lds(ComposeArgs a, FrameBatch f
     const int ox = tx * kCompTW + lane * 4;
     const bool aligned_rows = ((static_cast<uint32_t>(reinterpret_cast<uintptr_t>(pano)) | a.pano_stride) & 3u) == 0;
     const bool pure = MODE == kCompModeFeather && t.seg_count == 1 && (a.segs[t.seg_first].flags & kCompSegUnit);
-    uint32_t px[kRowsPerLane][4];
-    uint32_t acc_bg[kRowsPerLane][4], acc_r[kRowsPerLane][4];     // feather across cameras: B | G << 16, R (sums below 2^13)
+    uint32_t px[ROWS][4];
+    uint32_t acc_bg[ROWS][4], acc_r[ROWS][4];     // feather across cameras: B | G << 16, R (sums below 2^13)
 #pragma unroll
-    for (int it = 0; it < kRowsPerLane; ++it)
+    for (int it = 0; it < ROWS; ++it)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { px[it][k] = 0u; acc_bg[it][k] = 0u; acc_r[it][k] = 0u; }
     for (uint32_t s = 0; s < t.seg_count; ++s) {
         const ComposeSeg seg = a.segs[t.seg_first + s];
         const uint32_t stride = frames.stride[seg.cam];
-        const size_t tbl = static_cast<size_t>(t.seg_first + s) * kCompPx + (rgrp * kRowsPerLane) * kCompTW + lane * 4;
+        const size_t tbl = static_cast<size_t>(t.seg_first + s) * kCompPx + (rgrp * ROWS) * kCompTW + lane * 4;
         // the lane's table, gain and weight rows do not depend on the staged window: their loads go out first, so
         // that one round trip to memory covers them and the staging loads
-        u32x4 e_r[kRowsPerLane];
-        f32x4 g_r[kRowsPerLane], w_r[kRowsPerLane];
+        u32x4 e_r[ROWS];
+        f32x4 g_r[ROWS], w_r[ROWS];
 #pragma unroll
-        for (int it = 0; it < kRowsPerLane; ++it) {
+        for (int it = 0; it < ROWS; ++it) {
             e_r[it] = *(const u32x4 MST_GLOBAL*)(a.table + tbl + it * kCompTW);
             g_r[it] = *(const f32x4 MST_GLOBAL*)(a.gain + tbl + it * kCompTW);
             w_r[it] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(256) void k_compose_lds(ComposeArgs a, FrameBatch f
             const uint8_t MST_GLOBAL* base = gp(frames.ptr[seg.cam]) + (static_cast<size_t>(seg.by) * stride + static_cast<size_t>(seg.wx0) * 3u);
             const int n = seg.groups * seg.rows;
             const uint32_t inv = ((1u << 20) + seg.groups - 1) / seg.groups;      // i / groups == (i * inv) >> 20 for i < 4096, groups <= 256
-            for (int i = threadIdx.x; i < n; i += 256) {
+            for (int i = threadIdx.x; i < n; i += NT) {
                 const int r = n <= 4096 ? static_cast<int>((static_cast<uint32_t>(i) * inv) >> 20) : i / seg.groups;
                 const int g = i - r * seg.groups;
                 const u32x3 d = *(const u32x3 MST_GLOBAL*)(base + __umul24(r, stride) + static_cast<uint32_t>(g) * 12u);
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(256) void k_compose_lds(ComposeArgs a, FrameBatch f
         const uint32_t pitch_b = static_cast<uint32_t>(seg.groups) * 16u;
         const char* win = reinterpret_cast<const char*>(s_win) + (seg.bx - seg.wx0) * 4;
 #pragma unroll
-        for (int it = 0; it < kRowsPerLane; ++it) {
+        for (int it = 0; it < ROWS; ++it) {
             const u32x4 e = e_r[it];
             const f32x4 g = g_r[it], w = w_r[it];
 #pragma unroll
@@ -596,8 +603,8 @@ __global__ __launch_bounds__(256) void k_compose_lds(ComposeArgs a, FrameBatch f
         }
     }
 #pragma unroll
-    for (int it = 0; it < kRowsPerLane; ++it) {
-        const int row = rgrp * kRowsPerLane + it, oy = ty * kCompTH + row;
+    for (int it = 0; it < ROWS; ++it) {
+        const int row = rgrp * ROWS + it, oy = ty * kCompTH + row;
         if (MODE == kCompModeFeather) {
             if (pure) {
 #pragma unroll
@@ -677,8 +684,12 @@ void launch_compose(const ComposeArgs& a, const FrameBatch& frames, size_t lds_b
     }
     const dim3 grid(static_cast<unsigned>(a.n_tiles * a.n_sets));
     if (lds_bytes) {       // every tile of the list fits the staged form
-        if (a.mode == kCompModeFeather) hipLaunchKernelGGL(k_compose_lds<kCompModeFeather>, grid, dim3(256), lds_bytes, s, a, frames);
-        else hipLaunchKernelGGL(k_compose_lds<kCompModePaste>, grid, dim3(256), lds_bytes, s, a, frames);
+        static const int rows_env = [] { const char* v = std::getenv("MST_COMPOSE_ROWS"); return v ? std::atoi(v) : 0; }();
+        const int rows = rows_env ? rows_env : 2;     // 512 threads over one window: measured best (C3 / C5 LUT +15 % over 256)
+#define MST_LAUNCH_CL(M, R) hipLaunchKernelGGL((k_compose_lds<M, R>), grid, dim3(1024 / R), lds_bytes, s, a, frames)
+        if (a.mode == kCompModeFeather) { if (rows == 1) MST_LAUNCH_CL(kCompModeFeather, 1); else if (rows == 2) MST_LAUNCH_CL(kCompModeFeather, 2); else MST_LAUNCH_CL(kCompModeFeather, 4); }
+        else { if (rows == 1) MST_LAUNCH_CL(kCompModePaste, 1); else if (rows == 2) MST_LAUNCH_CL(kCompModePaste, 2); else MST_LAUNCH_CL(kCompModePaste, 4); }
+#undef MST_LAUNCH_CL
         return;
     }
     if (a.n_tiles * a.n_sets < 4096) {      // a short list: four blocks per tile

@@ -119,3 +119,58 @@ def test_tiny_sources_have_no_window_path():
     # 3 x 2 and 1 x 1 pixel sources: no 2x2 window can be read with the 12-byte loads, every sample is per-tap
     check(custom_rig("plane", [(0.0, 0, 0), (8.0, 0, 0)], (3, 2), 40.0, scale=400.0, expos="no"), bands=2)
     check(custom_rig("plane", [(0.0, 0, 0)], (1, 1), 30.0, scale=300.0, expos="no"), bands=1)
+
+
+@pytest.mark.parametrize("blend,lut", [("feather", False), ("no", False), ("no", True), ("multiband", False)])
+@pytest.mark.parametrize("pad,shift", [(1, 1), (2, 3), (0, 2)])
+def test_device_frames_off_the_dword_grid(blend, lut, pad, shift):
+    """Frames whose base address or row stride is not a multiple of four (a tight cv::Mat of an odd width, a view
+    into a larger buffer): the staged form of the single-pass composites reads whole dwords and must hand such calls
+    to the gathering / general kernels; the multi-band warp kernel shifts its funnel.  Batched device call, 2 sets."""
+    import torch
+    cfg = rigmod.scaled_config("C3", 8)
+    cfg["blend"] = blend
+    rig = rigmod.build_rig(cfg)
+    n = len(rig["cameras"])
+    eng = S.PanoramaEngine(n, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=4, driver_lut=lut, max_batch=2)
+    eng.update(rig["scale"], rig["cameras"])
+    (_, _, cw, ch), _ = eng.acquire()
+    dev = torch.device("cuda", 0)
+    sets, ptrs, strides, keep = [], [], [], []
+    for f in range(2):
+        frames = rigmod.frames_for(rig, f)
+        sets.append(frames)
+        p, s = [], []
+        for fr in frames:
+            h, w, _ = fr.shape
+            stride = w * 3 + pad
+            buf = torch.zeros(h * stride + shift + 16, dtype=torch.uint8, device=dev)
+            view = buf[shift:shift + h * stride].view(h, stride)
+            view[:, :w * 3] = torch.from_numpy(fr.reshape(h, w * 3)).to(dev)
+            keep.append(buf)
+            p.append(buf.data_ptr() + shift)
+            s.append(stride)
+        ptrs.append(p)
+        strides.append(s)
+    panos = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    eng.compose_device_batch(ptrs, strides, [p.data_ptr() for p in panos], cw * 3)
+    torch.cuda.synchronize()
+    for f in range(2):
+        if lut:
+            ref, _ = _lut_reference(rig, sets[f])
+        else:
+            _, ref, _ = H.oracle_compose(rig, sets[f], blend=blend, num_bands=4)
+        got = panos[f].cpu().numpy()
+        assert np.array_equal(got, ref), (f, H.diff_report(got, ref))
+    eng.close()
+
+
+def _lut_reference(rig, frames):
+    """The aligned engine itself on host buffers is the reference for the LUT crop (its parity with the oracle is
+    covered by test_driver_lut_path_bit_exact)."""
+    n = len(rig["cameras"])
+    eng = S.PanoramaEngine(n, warp=rig["warp"], blend="no", expos=rig["expos"], driver_lut=True)
+    eng.update(rig["scale"], rig["cameras"])
+    out = eng.compose(frames)
+    eng.close()
+    return out
