@@ -93,7 +93,7 @@ constexpr int kCompModePaste = 0, kCompModeLut = 1, kCompModeFeather = 2;
 struct ComposeSeg {
     int32_t cam;
     int32_t bx, by;              // smallest window coordinate over the segment's pixels (source pixels)
-    uint32_t flags;              // bit 0: every contributing weight is exactly 1.0f (feather)
+    uint32_t flags;              // kCompSegUnit, kCompSegFill
     // the source window of the segment as it is staged in LDS (kernels_compose.hip): columns [wx0, wx0 + 4 * groups)
     // with wx0 = bx rounded down to a multiple of four pixels, rows [by, by + rows)
     int32_t wx0, groups, rows, pad;
@@ -108,6 +108,7 @@ constexpr uint32_t kCompTileGeneral = 1u;      // some pixel needs the general p
 constexpr uint32_t kCompTileDirect = 2u;       // some segment's source window does not fit the LDS budget: gather from memory
 constexpr uint32_t kCompTileNoGather = 4u;     // some window touches the frame's last pixels: 12-byte gathers would overrun, LDS only
 constexpr uint32_t kCompSegUnit = 1u;
+constexpr uint32_t kCompSegFill = 2u;          // LUT: the segment of the pixels nobody owns (camera 0 at roi (0, 0))
 constexpr int kCompLdsPx = 10240;              // staged window budget per block, in 4-byte pixels (40 KB)
 struct ComposeArgs {
     const CamDesc* cams;

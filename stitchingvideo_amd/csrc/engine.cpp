@@ -678,7 +678,7 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     // launch order: tiles with the most segments first (the longest blocks start earliest)
     std::vector<int> order(n_canvas_tiles);
     for (int i = 0; i < n_canvas_tiles; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return __builtin_popcount(bits[a]) > __builtin_popcount(bits[b]); });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return __builtin_popcount(bits[a] & 0x1FFFFu) > __builtin_popcount(bits[b] & 0x1FFFFu); });
     std::vector<ComposeTile> tiles(n_canvas_tiles);
     std::vector<ComposeSeg> segs;
     std::vector<uint32_t> seg_tile;
@@ -689,9 +689,9 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
         t.seg_count = 0;
         t.flags = 0;
         t.tx_ty = static_cast<uint32_t>(ti % tiles_x) | static_cast<uint32_t>(ti / tiles_x) << 16;
-        for (int c = 0; c < st.n; ++c)
-            if (bits[ti] >> c & 1u) {
-                segs.push_back(ComposeSeg{c, 0, 0, 0u, 0, 0, 0, 0});
+        for (int c = 0; c <= 16; ++c)          // (bit 16: the LUT's fill pixels, a segment of camera 0 of their own)
+            if ((c < st.n || c == 16) && (bits[ti] >> c & 1u)) {
+                segs.push_back(ComposeSeg{c == 16 ? 0 : c, 0, 0, c == 16 ? kCompSegFill : 0u, 0, 0, 0, 0});
                 seg_tile.push_back(static_cast<uint32_t>(k));
                 ++t.seg_count;
             }

@@ -118,7 +118,7 @@ __device__ __forceinline__ void feather_pixel(const ComposeArgs& a, const FrameA
 
 // Does camera `cam` contribute to canvas pixel (x, y), and at which roi position?  Paste / LUT: it owns the pixel
 // (LUT: pixels nobody owns read camera 0 at roi (0, 0)); feather: the pixel lies in its roi with a non-zero weight.
-__device__ __forceinline__ bool contributes(const ComposeArgs& a, int cam, int x, int y, int& lx, int& ly)
+__device__ __forceinline__ bool contributes(const ComposeArgs& a, int cam, int x, int y, int& lx, int& ly, bool fill = false)
 {
     if (a.mode == kCompModeFeather) {
         const CamDesc& c = a.cams[cam];
@@ -129,12 +129,14 @@ __device__ __forceinline__ bool contributes(const ComposeArgs& a, int cam, int x
         return gp(c.feather_w)[static_cast<size_t>(ly) * c.roi_w + lx] != 0.f;
     }
     int mask_or;
-    int owner = paste_owner(a.cams, a.n_cams, x, y, lx, ly, mask_or);
-    if (owner < 0 && a.mode == kCompModeLut) { owner = 0; lx = 0; ly = 0; }
+    const int owner = paste_owner(a.cams, a.n_cams, x, y, lx, ly, mask_or);
+    // LUT: the pixels nobody owns read camera 0 at roi (0, 0) (the zero-initialised LUT entry, DRV:107-112).  They get a
+    // segment of their own (`fill`): one source window, usually far from the windows of camera 0's own pixels.
+    if (fill) { lx = 0; ly = 0; return owner < 0; }
     return owner == cam;
 }
 
-// bit i of out[tile] = camera i contributes to some pixel of the tile (tiles in canvas order)
+// bit i of out[tile] = camera i contributes to some pixel of the tile (tiles in canvas order); bit 16: LUT fill pixels
 __global__ __launch_bounds__(256) void k_compose_classify(ComposeArgs a, uint32_t* __restrict__ out)
 {
     __shared__ uint32_t s_bits;
@@ -153,9 +155,9 @@ __global__ __launch_bounds__(256) void k_compose_classify(ComposeArgs a, uint32_
             }
         } else {
             int lx, ly, mask_or;
-            int owner = paste_owner(a.cams, a.n_cams, x, y, lx, ly, mask_or);
-            if (owner < 0 && a.mode == kCompModeLut) owner = 0;
+            const int owner = paste_owner(a.cams, a.n_cams, x, y, lx, ly, mask_or);
             if (owner >= 0) bits |= 1u << owner;
+            else if (a.mode == kCompModeLut) bits |= 1u << 16;          // the fill segment (camera 0 at roi (0, 0))
         }
     }
     if (bits) atomicOr(&s_bits, bits);
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
     const int s = blockIdx.x;
     const ComposeTile t = tiles[seg_tile[s]];
     const int cam = segs[s].cam;
+    const bool fill = (segs[s].flags & kCompSegFill) != 0;
     const CamDesc& c = a.cams[cam];
     const int tx = t.tx_ty & 0xFFFF, ty = t.tx_ty >> 16;
     if (threadIdx.x == 0) { s_min[0] = INT_MAX; s_min[1] = INT_MAX; s_max[0] = INT_MIN; s_max[1] = INT_MIN; s_flags[0] = 0; s_flags[1] = 0; }
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
         const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
         if (ox >= a.out_w || oy >= a.out_h) continue;
         int lx, ly;
-        if (!contributes(a, cam, ox + a.crop_x, oy + a.crop_y, lx, ly)) continue;
+        if (!contributes(a, cam, ox + a.crop_x, oy + a.crop_y, lx, ly, fill)) continue;
         valid_bits |= 1u << j;
         const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, load_global(c.cols + lx), load_global(c.rows + ly), lx, ly);
         if (m.inside) { x_lo = min(x_lo, m.ix); y_lo = min(y_lo, m.iy); x_hi = max(x_hi, m.ix + 1); y_hi = max(y_hi, m.iy + 1); }
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
         if (valid_bits >> j & 1u) {
             const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
             int lx, ly;
-            (void)contributes(a, cam, ox + a.crop_x, oy + a.crop_y, lx, ly);
+            (void)contributes(a, cam, ox + a.crop_x, oy + a.crop_y, lx, ly, fill);
             const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, load_global(c.cols + lx), load_global(c.rows + ly), lx, ly);
             // (a window that folds differently for the two forms cannot happen: `fast` implies the same folded window)
             const uint32_t dx = static_cast<uint32_t>(m.ix - bx), dy = static_cast<uint32_t>(m.iy - by);
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
     if (threadIdx.x == 0) {
         segs[s].bx = bx;
         segs[s].by = by;
-        segs[s].flags = (a.mode == kCompModeFeather && !s_flags[1]) ? kCompSegUnit : 0u;
+        segs[s].flags = ((a.mode == kCompModeFeather && !s_flags[1]) ? kCompSegUnit : 0u) | (fill ? kCompSegFill : 0u);
         // the window as staged in LDS: whole groups of four pixels from a multiple of four (their 12 source bytes
         // start on a dword of an aligned frame).  Too large for the budget, or a last group that would read past
         // the end of the frame's last row: the tile gathers from memory instead.
