@@ -49,8 +49,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
 METRIC = "stitched panorama frames/sec, 6x1080p->360deg canvas"
+printed = False          # rank 0 has printed its JSON line (camera-leg watchdog)
 KERNEL_SOURCES = ["stitchingvideo_amd/csrc/kernels_mb.hip", "stitchingvideo_amd/csrc/kernels.hip",
-                  "stitchingvideo_amd/csrc/kernels_common.hpp", "stitchingvideo_amd/csrc/device_types.hpp"]
+                  "stitchingvideo_amd/csrc/kernels_compose.hip", "stitchingvideo_amd/csrc/kernels_common.hpp",
+                  "stitchingvideo_amd/csrc/device_types.hpp"]
 
 
 def parse_args():
@@ -80,6 +82,9 @@ def parse_args():
                     help="add the driver's lens-undistort pre-pass (DRV:741) to every camera (not part of the headline)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = sized to ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = min(host cores, 32))")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` object (the other single-GPU BASELINE configurations: C2 feather, C5 multi-band, "
+                         "C3 / C5 driver LUT), e.g. under a profiler")
     return ap.parse_args()
 
 
@@ -111,24 +116,40 @@ def kernel_source_hash():
 
 
 def cpu_baseline(rig, frames, blend, budget_s=15.0, max_frames=0, threads=0):
-    """Time the oracle on the host cores.  Test infrastructure used as the reported CPU baseline only."""
+    """Time the oracle on the host cores: all cores (capped at 32: its row-parallel loops stop scaling there) and ONE
+    thread.  Test infrastructure used as the reported CPU baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = threads if threads > 0 else min(cores, 32)     # the row-parallel loops stop scaling past ~32 threads
-    t0 = time.perf_counter()
-    H.oracle_compose(rig, frames, blend=blend, threads=cores)        # warm-up + cost probe
-    one = time.perf_counter() - t0
-    n = max_frames if max_frames > 0 else max(1, min(30, int(budget_s / max(one, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        H.oracle_compose(rig, frames, blend=blend, threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames of the same workload, oracle/ (C, OpenMP over cameras and rows, %d threads)" % (n, cores)}
+    cores = threads if threads > 0 else min(cores, 32)
+
+    def sample(nthreads, budget, lo, hi):
+        t0 = time.perf_counter()
+        H.oracle_compose(rig, frames, blend=blend, threads=nthreads)        # warm-up + cost probe
+        one = time.perf_counter() - t0
+        n = max_frames if max_frames > 0 else max(lo, min(hi, int(budget / max(one, 1e-3))))
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            H.oracle_compose(rig, frames, blend=blend, threads=nthreads)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        pick = lambda q: ts[min(len(ts) - 1, int(q * len(ts)))]
+        # fps percentiles: p10 = slow tail, p90 = fast tail
+        return {"frames": n, "median_fps": round(1.0 / pick(0.5), 4), "p10_fps": round(1.0 / pick(0.9), 4),
+                "p90_fps": round(1.0 / pick(0.1), 4), "mean_fps": round(n / sum(ts), 4)}
+
+    allc = sample(cores, budget_s, 5, 30)
+    one = sample(1, budget_s, 3, 5) if cores > 1 else allc
+    return {"value": allc["mean_fps"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "median": allc["median_fps"], "p10": allc["p10_fps"], "p90": allc["p90_fps"],
+            "threads_1": {"value": one["median_fps"], "p10": one["p10_fps"], "p90": one["p90_fps"], "frames": one["frames"]},
+            "sample": "%d frames of the same workload at %d threads and %d at 1 thread, oracle/ (C, OpenMP over cameras and rows); "
+                      "median / p10 / p90 of the per-frame rates" % (allc["frames"], cores, one["frames"])}
 
 
 def main():
+    global printed
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -281,14 +302,17 @@ def main():
         seqs = args.steps * reps
         ms_per_step = wall * 1000.0 / args.steps
         dev_ms_per_seq = dev_ms / seqs
-        traffic, traffic_note = None, "profiles/traffic.json absent"
+        traffic, traffic_note, tj = None, "profiles/traffic.json absent", {}
+        wl = args.config + ("+undistort" if args.undistort else "")
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj.get("kernel_source_sha16") == kernel_source_hash():
-                traffic = tj[args.config]["bytes_per_frame"] * batch
-                traffic_note = tj.get("source", "")
+                ent = tj["entries"]["%s/%d" % (wl, batch)]
+                traffic = ent["bytes_per_frame"] * batch
+                traffic_note = ent.get("source", "")
             else:
                 traffic_note = "profiles/traffic.json predates the current kernel sources (re-run tools/profile_gpu.sh)"
+                tj = {}
         except (OSError, KeyError, ValueError):
             pass
         # one launch of a kernel processes `batch` frame sets: algorithmic bytes per launch = batch x frame.
@@ -338,7 +362,8 @@ def main():
             ms1 = e0.elapsed_time(e1) / n1
             out["latency_mode"] = {"frame_sets_per_launch": 1, "frames": n1, "ms_per_frame": round(ms1, 5),
                                    "frames_per_s": round(1000.0 / ms1, 2),
-                                   "roofline_frac": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                                   "roofline_frac": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                   "traffic": tj.get("entries", {}).get("%s/1" % wl, {}).get("bytes_per_frame")}
 
     # ---- two launch sequences in flight (MST_FLAG_OVERLAP_FRAMES): the warp + chain kernels of sequence t + 1 run
     # beside the canvas kernels of sequence t on a second stream and a second set of pyramid buffers.  Reported
@@ -372,13 +397,18 @@ def main():
         except Exception as e:          # noqa: BLE001
             out["host_buffers"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    watchdog = None
     # ---- N > 1: the north-star split measured beside the headline (C4: 8 cameras, camera i on rank i % N) ----
     if (world > 1 or args.camera_leg) and not by_camera and not args.no_camera_leg:
-        def give_up():          # every rank: a hung exchange must not take the headline (or the launcher) with it
-            if rank == 0:
-                out["camera_sharded"] = {"error": "timed out after 240 s (exchange did not complete)"}
+        # Every rank: a hung exchange must not take the headline (or the launcher) with it.  The watchdog stays armed
+        # until the process group has been torn down: when the leg fails on one rank only, its peers sit in the
+        # exchange and this rank would otherwise wait for them in the final barrier.  A run that ends through the
+        # watchdog has still printed the headline, and exits non-zero.
+        def give_up():
+            if rank == 0 and not printed:
+                out["camera_sharded"] = {"error": "timed out after 240 s (exchange or final barrier did not complete)"}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(240.0 if rank == 0 else 250.0, give_up)
         watchdog.daemon = True
         watchdog.start()
@@ -386,19 +416,38 @@ def main():
             leg = camera_sharded_leg(args, rank, world, local_rank, dev, stream)
         except Exception as e:          # noqa: BLE001  -- the headline must survive a failure of the secondary leg
             leg = {"error": "%s: %s" % (type(e).__name__, e)}
-        watchdog.cancel()
         if rank == 0:
             out["camera_sharded"] = leg
+
+    # ---- the other single-GPU BASELINE configurations, through the same entry points (tools/bench_paths.py) ----
+    if rank == 0 and world == 1 and not by_camera and not args.no_configs and args.config == "C3":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_paths
+        eng.close()
+        del dev_sets, pano_rows, panos
+        torch.cuda.empty_cache()
+        cfgs = {}
+        for nm in ("C2", "C5", "C3-LUT", "C5-LUT"):
+            try:
+                cfgs[nm] = bench_paths.measure(nm, batch=8, min_time=0.3, latency_leg=True)
+                cfgs[nm].pop("name", None)
+                cfgs[nm]["traffic"] = tj.get("entries", {}).get("%s/8" % nm, {}).get("bytes_per_frame") if rank == 0 else None
+            except Exception as e:          # noqa: BLE001
+                cfgs[nm] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["configs"] = cfgs
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not by_camera:
             out["cpu_baseline"] = cpu_baseline(rig, host_sets[0], blend, max_frames=args.cpu_frames, threads=args.cpu_threads)
         print(json.dumps(out), flush=True)
+        printed = True
 
     eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 def host_buffer_leg(eng, host_sets, cw, ch):

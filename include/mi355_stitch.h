@@ -195,6 +195,10 @@ int  mst_update(mst_engine *e, const mst_calibration *calib);
  * calibration on entry -- then size panorama buffers for the largest canvas a recalibration can produce, or do
  * not recalibrate concurrently).  Call it from the compose thread only. */
 int  mst_acquire_calibration(mst_engine *e, mst_rect *canvas, uint64_t *generation);
+/* Leave the latching mode again: from here on every call picks up the newest published calibration on entry (the
+ * behaviour of an engine that never called mst_acquire_calibration).  Before the first successful mst_update
+ * mst_acquire_calibration returns MST_ERR_NOT_CALIBRATED and does not start latching.  Compose thread only. */
+int  mst_release_calibration(mst_engine *e);
 /* resultRoi of the calibration the next compose will use (see mst_acquire_calibration); with
  * MST_FLAG_DRIVER_LUT the cropped output rect */
 int  mst_canvas(const mst_engine *e, mst_rect *canvas);

@@ -149,6 +149,13 @@ int mst_update(mst_engine* e, const mst_calibration* calib)
     });
 }
 
+int mst_release_calibration(mst_engine* e)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    e->impl.release();
+    return MST_OK;
+}
+
 int mst_acquire_calibration(mst_engine* e, mst_rect* canvas, uint64_t* generation)
 {
     if (!e) return MST_ERR_INVALID_ARG;

@@ -75,6 +75,13 @@ void* DevicePool::alloc_bytes(size_t bytes)
         total_ += bytes;
         return p;
     }
+    if (!cache_) {                   // a stage-level call: a few small buffers, one allocation each (no 64 MiB slab)
+        void* p = nullptr;
+        check_hip(hipMalloc(&p, need + kPoolAlign), "hipMalloc");
+        big_.push_back(p);
+        total_ += bytes;
+        return p;
+    }
     if (need > left_) {
         void* p = cache_ ? cache_->take() : nullptr;
         if (!p) check_hip(hipMalloc(&p, kPoolSlab + kPoolAlign), "hipMalloc");
@@ -299,9 +306,17 @@ std::shared_ptr<CalibState> Engine::state() const
 std::shared_ptr<CalibState> Engine::acquire()
 {
     std::lock_guard<std::mutex> lk(mu_);
+    if (!current_) return nullptr;        // nothing published yet: the engine does not start latching on nothing
     latched_ = current_;
     latching_ = true;
     return latched_;
+}
+
+void Engine::release()
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    latching_ = false;
+    latched_.reset();
 }
 
 void Engine::set_in_flight(std::shared_ptr<CalibState> st)

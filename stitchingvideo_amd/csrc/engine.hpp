@@ -169,6 +169,7 @@ public:
     // called acquire() -- the one it latched there (the reference's `if (Upflag) UpdateMat()`, DRV:835-836).
     std::shared_ptr<CalibState> state() const;
     std::shared_ptr<CalibState> acquire();             // latch the newest calibration for the following composes
+    void release();                                    // stop latching: every call picks up the newest calibration again
     void debug_read(int what, int camera, int level, void* buf, size_t buf_bytes, int* w, int* h);
 
     const mst_config& config() const { return cfg_; }

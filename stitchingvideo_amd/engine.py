@@ -347,7 +347,13 @@ class PanoramaEngine:
         `if (Upflag) UpdateMat();`, DRV:835-836) -> (canvas rect, generation)."""
         r, g = capi.Rect(), C.c_uint64()
         self._check(self._L.mst_acquire_calibration(self._h, C.byref(r), C.byref(g)))
+        self._latching = True
         return r.tuple(), g.value
+
+    def release(self):
+        """Stop latching: every call picks up the newest published calibration again."""
+        self._check(self._L.mst_release_calibration(self._h))
+        self._latching = False
 
     def canvas(self):
         r = capi.Rect()
@@ -379,12 +385,20 @@ class PanoramaEngine:
         ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in fr])
         strides = (C.c_size_t * n)(*[f.strides[0] for f in fr])
         # latch first, size the buffers from the latched canvas, compose against the same calibration: a concurrent
-        # update() cannot change the panorama size in between
-        (_, _, w, h), _ = self.acquire()
-        pano = np.empty((h, w, 3), np.uint8)
-        mask = np.empty((h, w), np.uint8) if want_mask else None
-        self._check(self._L.mst_compose(self._h, ptrs, strides, pano.ctypes.data, pano.strides[0],
-                                        mask.ctypes.data if want_mask else None, w))
+        # update() cannot change the panorama size in between.  An engine whose user never asked for latching goes
+        # back to "newest calibration on entry" afterwards.
+        was_latching = getattr(self, "_latching", False)
+        r, g = capi.Rect(), C.c_uint64()
+        self._check(self._L.mst_acquire_calibration(self._h, C.byref(r), C.byref(g)))
+        try:
+            _, _, w, h = r.tuple()
+            pano = np.empty((h, w, 3), np.uint8)
+            mask = np.empty((h, w), np.uint8) if want_mask else None
+            self._check(self._L.mst_compose(self._h, ptrs, strides, pano.ctypes.data, pano.strides[0],
+                                            mask.ctypes.data if want_mask else None, w))
+        finally:
+            if not was_latching:
+                self._L.mst_release_calibration(self._h)
         return pano, mask
 
     def pipeline_submit(self, frames, pano):

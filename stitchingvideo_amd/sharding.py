@@ -148,6 +148,11 @@ class ShardedStitcher:
         """Latch the newest calibration; (re)allocate the payload buffers if it changed."""
         _, gen = self.engine.acquire()
         if gen != self.generation:
+            # exchanges still in flight send from / receive into the buffers replaced below: drain them first (their
+            # frames belong to the old calibration and are dropped)
+            for works in self.pending.values():
+                for w in works or []:
+                    w.wait()
             n = self.engine.num_cameras
             # the root needs a landing buffer for every camera it does not own, an owner a send buffer for its own
             cams = [c for c in range(n) if self.owners[c] != self.root] if self.rank == self.root else self.mine

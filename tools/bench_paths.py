@@ -27,13 +27,18 @@ PATHS = {
 }
 
 
+_RIGS = {}
+
+
 def measure(name, batch=8, min_time=0.4, latency_leg=True):
     import torch
     import stitchingvideo_amd as S
     from stitchingvideo_amd import rig as rigmod
     cfg_name, blend, lut = PATHS[name]
     cfg = rigmod.CONFIGS[cfg_name]
-    rig = rigmod.build_rig(cfg)
+    if cfg_name not in _RIGS:
+        _RIGS[cfg_name] = rigmod.build_rig(cfg)
+    rig = _RIGS[cfg_name]
     n_cam = len(rig["cameras"])
     dev = torch.device("cuda", 0)
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=0,
@@ -42,7 +47,7 @@ def measure(name, batch=8, min_time=0.4, latency_leg=True):
     eng.update(rig["scale"], rig["cameras"])
     t_update = time.perf_counter() - t0
     (cx, cy, cw, ch), _ = eng.acquire()
-    n_sets = max(3, batch)
+    n_sets = max(3, batch) if rig["size"][0] <= 1920 else 3        # (4K rigs: three distinct frame sets, cycled)
     dev_sets = []
     for s in range(n_sets):
         fr = rigmod.frames_for(rig, frame_index=s)

@@ -15,5 +15,5 @@ pass sq2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_IN
 pass tcp1 TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
 pass tcc TCC_HIT_sum TCC_MISS_sum
 cd "$REPO"
-python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt"
+python3 tools/summarize_prof.py "$OUT" "$REPO/gpurun_out/traffic.json" > "$OUT/summary.txt"
 cat "$OUT/summary.txt" | grep -v "^$" | head -80

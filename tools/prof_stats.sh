@@ -2,7 +2,7 @@
 # kernel-trace only: per-dispatch durations.  Usage: tools/prof_stats.sh <tag> [bench args]
 TAG=${1:-run}; shift
 OUT=$PWD/gpurun_out/prof_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 30 --warmup 5 --no-cpu-baseline $@"
+BENCH="python3 $PWD/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-configs $@"
 cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
 python3 - "$OUT/stats/stats_kernel_trace.csv" <<'PY'
 import csv,sys,re,collections

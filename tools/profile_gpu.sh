@@ -9,7 +9,7 @@ EXTRA="$@"
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 10 --warmup 3 --min-time 0.1 --no-cpu-baseline --no-latency-leg $EXTRA"
+BENCH="python3 $PWD/bench.py --steps 10 --warmup 3 --min-time 0.1 --no-cpu-baseline --no-latency-leg --no-configs $EXTRA"
 REPO=$PWD
 echo "$BENCH" | sed "s|$PWD/||" > "$OUT/command.txt"
 cd /tmp
@@ -28,5 +28,5 @@ pass tcc TCC_HIT_sum TCC_MISS_sum
 pass grbm GRBM_GUI_ACTIVE
 fi
 cd "$REPO"
-python3 tools/summarize_prof.py "$OUT" "$OUT/traffic.json" > "$OUT/summary.txt"
+python3 tools/summarize_prof.py "$OUT" "$REPO/gpurun_out/traffic.json" > "$OUT/summary.txt"
 grep -E "^k_(blend|warp_pyr|pyr_chain)|FETCH_SIZE|WRITE_SIZE|LDS_BANK|LDS_IDX|avg_us|^k_" "$OUT/summary.txt" | head -60

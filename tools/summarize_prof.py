@@ -56,27 +56,53 @@ if counters:
 
 
 # ---- HBM-side bytes per frame set (profiles/traffic.json) ---------------------------------------------------
+# Usage: summarize_prof.py <dir> <traffic.json>: the entry "<workload>/<frame sets per launch>" of that file is
+# (re)written from this run; workload and batch come from the command line recorded in <dir>/command.txt, the per-frame
+# kernels and their launches per sequence from the run itself (every kernel launched at least as often as the least
+# launched per-frame kernel; calibration kernels run once and drop out).
 if len(sys.argv) > 2 and counters:
     import hashlib
     import json
+    import re
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
     for rel in ["stitchingvideo_amd/csrc/kernels_mb.hip", "stitchingvideo_amd/csrc/kernels.hip",
-                "stitchingvideo_amd/csrc/kernels_common.hpp", "stitchingvideo_amd/csrc/device_types.hpp"]:
+                "stitchingvideo_amd/csrc/kernels_compose.hip", "stitchingvideo_amd/csrc/kernels_common.hpp",
+                "stitchingvideo_amd/csrc/device_types.hpp"]:
         h.update(open(os.path.join(ROOT, rel), "rb").read())
-    batch = 8
-    launches = {"k_warp_pyr": 1, "k_pyr_chain": 2, "k_blend_coarse": 1, "k_blend_fine": 1}
-    per = {}
-    for k, d in counters.items():
-        base = k.split("<")[0]
-        if base in launches and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+    sha = h.hexdigest()[:16]
+    m = re.search(r"--batch\s+(\d+)", cmd)
+    batch = int(m.group(1)) if m else 8
+    m = re.search(r"--config\s+(\S+)", cmd)
+    workload = m.group(1) if m else "C3"
+    m = re.search(r"bench_paths\.py\s+(\S+)", cmd)
+    if m:
+        workload = m.group(1)
+    if "--undistort" in cmd:
+        workload += "+undistort"
+    frame_kernels = {k: d for k, d in counters.items()
+                     if k.startswith("k_") and "FETCH_SIZE" in d and "WRITE_SIZE" in d and len(d["FETCH_SIZE"]) >= 4}
+    if frame_kernels:
+        n_seq = min(len(d["FETCH_SIZE"]) for d in frame_kernels.values())
+        per = {}
+        for k, d in frame_kernels.items():
             f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]) * 2 * 1024      # gfx950: FETCH_SIZE counts half of a wide read
             w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) * 1024
-            per[base] = int((f + w) * launches[base] / batch)
-    out = {"_comment": "HBM-side bytes per frame set from rocprofv3 PMC passes of the default bench workload (8 frame sets per "
-                       "launch; FETCH_SIZE and WRITE_SIZE collected in separate runs with --kernel-trace only; FETCH_SIZE doubled "
-                       "per the gfx950 correction in MI355X_MICROARCH.md; Infinity-Cache hits are counted too), divided by 8.",
-           "kernel_source_sha16": h.hexdigest()[:16], "source": "tools/profile_gpu.sh -> tools/summarize_prof.py (%s)" % os.path.basename(root.rstrip("/")),
-           "C3": {"bytes_per_frame": sum(per.values()), "per_kernel": per}}
-    json.dump(out, open(sys.argv[2], "w"), indent=1)
-    print("\n# traffic per frame set: %.1f MB -> %s" % (sum(per.values()) / 1e6, sys.argv[2]))
+            launches = round(len(d["FETCH_SIZE"]) / n_seq)
+            per[k] = {"bytes_per_frame": int((f + w) * launches / batch), "launches_per_sequence": launches}
+        entry = {"bytes_per_frame": sum(v["bytes_per_frame"] for v in per.values()), "frame_sets_per_launch": batch,
+                 "per_kernel": per, "source": "tools/summarize_prof.py (%s)" % os.path.basename(root.rstrip("/"))}
+        try:
+            out = json.load(open(sys.argv[2]))
+            if out.get("kernel_source_sha16") != sha:
+                out = {}
+        except (OSError, ValueError):
+            out = {}
+        out.setdefault("_comment", "HBM-side bytes per frame set from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate "
+                                   "runs with --kernel-trace only; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; "
+                                   "Infinity-Cache hits are counted too), per launch sequence divided by its frame sets.  Keys: "
+                                   "<workload>/<frame sets per launch>.")
+        out["kernel_source_sha16"] = sha
+        out.setdefault("entries", {})["%s/%d" % (workload, batch)] = entry
+        json.dump(out, open(sys.argv[2], "w"), indent=1)
+        print("\n# traffic per frame set (%s, %d frame sets per launch): %.1f MB -> %s" % (workload, batch, entry["bytes_per_frame"] / 1e6, sys.argv[2]))
