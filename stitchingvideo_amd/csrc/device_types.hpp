@@ -193,6 +193,16 @@ struct TileList {
     const uint32_t* tiles;         // cam << 24 | ty << 12 | tx
     int32_t count;
     int32_t first;                 // index of tiles[0] in the calibration's full list (per-tile tables)
+    // optional: entry li of the launch is tile index[li] of the FULL list (then `tiles` is the full list and `first` is 0)
+    const uint32_t* index;
+};
+
+// The source window of one warp-kernel tile as it is staged in LDS (k_warp_pyr_lds): columns [wx0, wx0 + 4 * groups),
+// rows [by, by + rows) of the camera's frame; the tile's table entries are relative to (bx, by).
+struct WarpWin {
+    int32_t wx0, by, groups, rows, bx;
+    uint32_t flags;                // bit 0: the tile cannot take the staged form (k_warp_pyr handles it)
+    int32_t pad0, pad1;
 };
 
 }  // namespace mst

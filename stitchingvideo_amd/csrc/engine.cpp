@@ -115,6 +115,7 @@ template UndistortCam* DevicePool::upload<UndistortCam>(const UndistortCam*, siz
 template PayloadRect* DevicePool::upload<PayloadRect>(const PayloadRect*, size_t, hipStream_t);
 template ComposeTile* DevicePool::upload<ComposeTile>(const ComposeTile*, size_t, hipStream_t);
 template ComposeSeg* DevicePool::upload<ComposeSeg>(const ComposeSeg*, size_t, hipStream_t);
+template WarpWin* DevicePool::upload<WarpWin>(const WarpWin*, size_t, hipStream_t);
 template FeedImage* DevicePool::upload<FeedImage>(const FeedImage*, size_t, hipStream_t);
 template FeedPair* DevicePool::upload<FeedPair>(const FeedPair*, size_t, hipStream_t);
 
@@ -622,10 +623,56 @@ void Engine::update(const mst_calibration& calib)
         st->warp_blobs = st->pool.alloc<uint32_t>(mb_warp_blob_entries(st->warp_list.count));
         launch_warp_table(st->d_desc, cfg_.warp_kind & 0xFF, st->warp_list, st->warp_table, st->warp_blobs, s);
         check_hip(hipGetLastError(), "k_warp_table");
+        // the staged form of the warp kernel: its own map + gain tables (lane order), the tiles' source windows, and the
+        // split of every camera's tiles into those that fit it and those that stay with the gathering kernel
+        {
+            const int nt = st->warp_list.count;
+            const size_t px = mb_warp_tile_px();
+            st->warp_table_lds = st->pool.alloc<uint32_t>(std::max<size_t>(nt * px, 4));
+            st->warp_gain_lds = st->pool.alloc<float>(std::max<size_t>(nt * px, 4));
+            st->warp_wins = st->pool.alloc<WarpWin>(std::max(nt, 1));
+            static const int budget_px = [] { const char* v = std::getenv("MST_WARP_LDS_KB"); return v ? std::atoi(v) * 256 : kCompLdsPx; }();
+            launch_warp_table_lds(st->d_desc, cfg_.warp_kind & 0xFF, st->warp_list, st->warp_table_lds, st->warp_gain_lds, st->warp_wins,
+                                  budget_px, s);
+            check_hip(hipGetLastError(), "k_warp_table_lds");
+            std::vector<WarpWin> wins(std::max(nt, 1));
+            if (nt) check_hip(hipMemcpyAsync(wins.data(), st->warp_wins, nt * sizeof(WarpWin), hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H windows)");
+            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(windows)");
+            std::vector<uint32_t> staged, gathered;
+            st->warp_staged_start.assign(n + 1, 0);
+            st->warp_gathered_start.assign(n + 1, 0);
+            size_t lds_px = 0;
+            for (int i = 0; i < n; ++i) {
+                st->warp_staged_start[i] = static_cast<int>(staged.size());
+                st->warp_gathered_start[i] = static_cast<int>(gathered.size());
+                for (int k = plan.warp_cam_start[i]; k < plan.warp_cam_start[i + 1]; ++k) {
+                    if (wins[k].flags & 1u) { gathered.push_back(static_cast<uint32_t>(k)); continue; }
+                    staged.push_back(static_cast<uint32_t>(k));
+                    lds_px = std::max(lds_px, static_cast<size_t>(wins[k].groups) * 4 * wins[k].rows);
+                }
+            }
+            st->warp_staged_start[n] = static_cast<int>(staged.size());
+            st->warp_gathered_start[n] = static_cast<int>(gathered.size());
+            st->warp_lds_bytes = lds_px * 4;
+            if (staged.empty()) staged.push_back(0u);
+            if (gathered.empty()) gathered.push_back(0u);
+            st->d_warp_staged = st->pool.upload(staged, s);
+            st->d_warp_gathered = st->pool.upload(gathered, s);
+            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");      // the index lists are pageable and local
+            if (std::getenv("MST_COMPOSE_STATS")) {
+                std::fprintf(stderr, "[mst_update] warp tiles: %d, %d staged in LDS (%zu bytes), %d gathered\n", nt,
+                             st->warp_staged_start[n], st->warp_lds_bytes, st->warp_gathered_start[n]);
+                int hist[12] = {0};
+                for (int k = 0; k < nt; ++k) hist[std::min<size_t>(11, static_cast<size_t>(wins[k].groups) * 16 * wins[k].rows / 8192)]++;
+                std::fprintf(stderr, "[mst_update] warp window bytes, 8 KB bins:");
+                for (int b = 0; b < 12; ++b) std::fprintf(stderr, " %d", hist[b]);
+                std::fprintf(stderr, "\n");
+            }
+        }
         st->d_payload_rects = st->pool.upload(plan.payload_rects, s);
         st->chain_lists.clear();
         for (const MbPlanHost::ChainStep& step : plan.chain) {
-            TileList tl;
+            TileList tl{};
             tl.tiles = st->pool.upload(step.tiles, s);
             tl.count = static_cast<int32_t>(step.tiles.size());
             tl.first = 0;
@@ -664,6 +711,41 @@ void Engine::update(const mst_calibration& calib)
     old.reset();                      // if nobody else holds it: torn down here, on the calibration thread
 }
 
+
+// The warp kernel (A) over the tiles of cameras [cam0, cam1): the staged form for the tiles that fit it, the gathering
+// kernel for the rest -- and for everything when a frame of the call is off the 4-byte grid (the staged form reads whole
+// dwords) or MST_WARP_GATHER is set (A/B timing).
+void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameBatch& fb, int count, int cam0, int cam1, hipStream_t s)
+{
+    static const bool force_gather = [] { const char* v = std::getenv("MST_WARP_GATHER"); return v && v[0] == '1'; }();
+    // (one or two frame sets per launch: the gathering kernel's smaller blocks fill the chip better -- 9.5 k against 8.8 k
+    // panoramas/s one at a time on C3; from three sets on the staged form wins)
+    bool aligned = !force_gather && count > 2;
+    for (int f = 0; f < count && aligned; ++f)
+        for (int i = cam0; i < cam1; ++i)
+            if (fb.f[f].ptr[i]) aligned &= ((reinterpret_cast<uintptr_t>(fb.f[f].ptr[i]) | fb.f[f].stride[i]) & 3u) == 0;
+    const MbPlanHost& plan = st.plan;
+    if (!aligned) {
+        TileList tl{};
+        tl.tiles = st.warp_list.tiles + plan.warp_cam_start[cam0];
+        tl.count = plan.warp_cam_start[cam1] - plan.warp_cam_start[cam0];
+        tl.first = plan.warp_cam_start[cam0];
+        launch_warp_pyr(desc, st.n, cfg_.warp_kind & 0xFF, tl, fb, count, st.warp_table, st.warp_blobs, s);
+        return;
+    }
+    TileList tg{};
+    tg.tiles = st.warp_list.tiles;
+    tg.first = 0;
+    tg.index = st.d_warp_gathered + st.warp_gathered_start[cam0];
+    tg.count = st.warp_gathered_start[cam1] - st.warp_gathered_start[cam0];
+    launch_warp_pyr(desc, st.n, cfg_.warp_kind & 0xFF, tg, fb, count, st.warp_table, st.warp_blobs, s);     // (the short list first)
+    TileList ts{};
+    ts.tiles = st.warp_list.tiles;
+    ts.first = 0;
+    ts.index = st.d_warp_staged + st.warp_staged_start[cam0];
+    ts.count = st.warp_staged_start[cam1] - st.warp_staged_start[cam0];
+    launch_warp_pyr_lds(desc, st.n, ts, fb, count, st.warp_table_lds, st.warp_gain_lds, st.warp_wins, st.warp_lds_bytes, s);
+}
 
 // Per-calibration tables of the single-pass composites (kernels_compose.hip): which cameras reach each 128 x 32 output
 // tile (classified on the device, one dword per tile back to the host), one segment per (tile, camera), the
@@ -868,7 +950,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
                     canvas_pending_[k] = false;
                 }
         undistort(first_set, sf);
-        launch_warp_pyr(desc, st->n, cfg_.warp_kind & 0xFF, st->warp_list, fb, count, st->warp_table, st->warp_blobs, sf);
+        launch_warp(*st, desc, fb, count, 0, st->n, sf);
         mark("k_warp_pyr");
         // where the frame crosses from the front stream to the caller's stream: after the warp kernel (the small
         // pyramid-chain launches then fill in beside the next frame's warp) or after the chain
@@ -999,16 +1081,12 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
     const MbPlanHost& plan = st->plan;
     for (int i = 0; i < st->n; ++i) {
         if (!(camera_mask >> i & 1u)) continue;
-        TileList tl;
-        tl.tiles = st->warp_list.tiles + plan.warp_cam_start[i];
-        tl.count = plan.warp_cam_start[i + 1] - plan.warp_cam_start[i];
-        tl.first = plan.warp_cam_start[i];
-        launch_warp_pyr(set_desc, st->n, cfg_.warp_kind & 0xFF, tl, fb, 1, st->warp_table, st->warp_blobs, s);
+        launch_warp(*st, set_desc, fb, 1, i, i + 1, s);
     }
     for (size_t k = 0; k < st->chain_lists.size(); ++k)
         for (int i = 0; i < st->n; ++i) {
             if (!(camera_mask >> i & 1u)) continue;
-            TileList tl;
+            TileList tl{};
             tl.tiles = st->chain_lists[k].tiles + plan.chain[k].cam_start[i];
             tl.count = plan.chain[k].cam_start[i + 1] - plan.chain[k].cam_start[i];
             tl.first = plan.chain[k].cam_start[i];

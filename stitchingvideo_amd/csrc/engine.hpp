@@ -101,6 +101,12 @@ struct CalibState {
     std::vector<uint8_t*> undist_frames;   // num_sets x n engine-owned undistorted frames (nullptr: camera has no maps)
     uint32_t* warp_table = nullptr;     // per-tile backward-map table (frame-invariant), see kernels_mb.hip
     uint32_t* warp_blobs = nullptr;     // per tile: calibration constants of kernel A (gain rows, row weights, table origin)
+    // the staged form of kernel A (k_warp_pyr_lds): map + gain tables in its lane order, the tiles' source windows, the
+    // tile indices it takes and those left to the gathering kernel, both grouped by camera
+    uint32_t* warp_table_lds = nullptr; float* warp_gain_lds = nullptr; WarpWin* warp_wins = nullptr;
+    const uint32_t* d_warp_staged = nullptr; const uint32_t* d_warp_gathered = nullptr;
+    std::vector<int> warp_staged_start, warp_gathered_start;    // n + 1 offsets each
+    size_t warp_lds_bytes = 0;
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step
     PayloadRect* d_payload_rects = nullptr;   // camera-sharded hand-off (plan.payload_*)
     BlendArgs blend{};                  // canvas kernels (pano pointers filled per frame)
@@ -178,6 +184,7 @@ private:
     void compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
                           void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
                           hipStream_t stream, StageTimer* timer);
+    void launch_warp(const CalibState& st, const CamDesc* desc, const FrameBatch& fb, int count, int cam0, int cam1, hipStream_t s);
     void build_compose_plan(CalibState& st, hipStream_t s);     // mst_update, blend kinds NO and FEATHER
     void set_in_flight(std::shared_ptr<CalibState> st);   // keeps `st` alive; the previous one goes to retired_
     void drop_retired();                                   // calibration thread / destructor: tear old states down

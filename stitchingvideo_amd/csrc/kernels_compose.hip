@@ -498,31 +498,6 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
 // (8 bits x 6 bits; B and R of one pixel, or G of both), horizontal pass as v_dot2_u32_u16 over (left, right) pairs
 // with the weights times 64, which again leaves the rounded byte in bits 16..23.  Same integers:
 //   (sum_x wx * (sum_y wy * v) + 512) >> 10.
-typedef unsigned short __attribute__((ext_vector_type(2))) us2;
-__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
-{
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
-}
-__device__ __forceinline__ uint32_t sample_lds(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1, uint32_t e, float gain)
-{
-    const uint32_t fx = e & 63u, fy = (e >> 6) & 63u;
-    const uint32_t wxp = __umul24(fx, 0x3FFFC0u) + 2048u;         // (32 - fx) * 64 | fx * 64 << 16
-    const uint32_t wy1 = fy, wy0 = 32u - fy;
-    const uint32_t lo0 = p0[0], hi0 = p0[1], lo1 = p1[0], hi1 = p1[1];
-    const uint32_t br0 = __umul24(lo0 & 0xFF00FFu, wy0) + __umul24(lo1 & 0xFF00FFu, wy1);      // VB0 | VR0 << 16
-    const uint32_t br1 = __umul24(hi0 & 0xFF00FFu, wy0) + __umul24(hi1 & 0xFF00FFu, wy1);      // VB1 | VR1 << 16
-    const uint32_t gt = __builtin_amdgcn_perm(hi0, lo0, 0x0C050C01u), gb = __builtin_amdgcn_perm(hi1, lo1, 0x0C050C01u);
-    const uint32_t gg = __umul24(gt, wy0) + __umul24(gb, wy1);                                  // VG0 | VG1 << 16
-    uint32_t b = dot2_u16(__builtin_amdgcn_perm(br1, br0, 0x05040100u), wxp, 32768u);
-    uint32_t r = dot2_u16(__builtin_amdgcn_perm(br1, br0, 0x07060302u), wxp, 32768u);
-    uint32_t g = dot2_u16(gg, wxp, 32768u);
-    asm("" : "+v"(b)); asm("" : "+v"(g)); asm("" : "+v"(r));      // (see sample_window)
-    uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((b >> 16) & 0xFFu) * gain, 0u, 0u);
-    px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((g >> 16) & 0xFFu) * gain, 1u, px);
-    px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((r >> 16) & 0xFFu) * gain, 2u, px);
-    return px;
-}
-
 // ROWS rows per lane: a block has 32 lanes x (32 / ROWS) row groups = 1024 / ROWS threads over one staged window
 template <int MODE, int ROWS>
 __global__ __launch_bounds__(1024 / ROWS) void k_compose_lds(ComposeArgs a, FrameBatch fb)
@@ -562,23 +537,8 @@ __global__ __launch_bounds__(1024 / ROWS) void k_compose_lds(ComposeArgs a, Fram
             if (MODE == kCompModeFeather && !pure) w_r[it] = *(const f32x4 MST_GLOBAL*)(a.weight + tbl + it * kCompTW);
         }
         if (s) __syncthreads();                          // the previous segment's window has been read
-        {
-            // stage: groups of four pixels = 12 source bytes (dword aligned) -> 16 LDS bytes
-            const uint8_t MST_GLOBAL* base = gp(frames.ptr[seg.cam]) + (static_cast<size_t>(seg.by) * stride + static_cast<size_t>(seg.wx0) * 3u);
-            const int n = seg.groups * seg.rows;
-            const uint32_t inv = ((1u << 20) + seg.groups - 1) / seg.groups;      // i / groups == (i * inv) >> 20 for i < 4096, groups <= 256
-            for (int i = threadIdx.x; i < n; i += NT) {
-                const int r = n <= 4096 ? static_cast<int>((static_cast<uint32_t>(i) * inv) >> 20) : i / seg.groups;
-                const int g = i - r * seg.groups;
-                const u32x3 d = *(const u32x3 MST_GLOBAL*)(base + __umul24(r, stride) + static_cast<uint32_t>(g) * 12u);
-                u32x4 p;
-                p.x = d.x;                                            // B0 G0 R0 (B1)
-                p.y = __builtin_amdgcn_alignbyte(d.y, d.x, 3);        // B1 G1 R1 (B2)
-                p.z = __builtin_amdgcn_alignbyte(d.z, d.y, 2);        // B2 G2 R2 (B3)
-                p.w = d.z >> 8;                                       // B3 G3 R3 0
-                *reinterpret_cast<u32x4*>(&s_win[(r * seg.groups + g) * 4]) = p;
-            }
-        }
+        stage_window<NT>(s_win, gp(frames.ptr[seg.cam]) + (static_cast<size_t>(seg.by) * stride + static_cast<size_t>(seg.wx0) * 3u), stride,
+                         seg.groups, seg.rows);
         __syncthreads();
         const uint32_t pitch_b = static_cast<uint32_t>(seg.groups) * 16u;
         const char* win = reinterpret_cast<const char*>(s_win) + (seg.bx - seg.wx0) * 4;

@@ -414,9 +414,10 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     const int pair = xcd_run_index(blockIdx.x, list.count * n_sets);
     const int set = pair % n_sets;
     const int li = pair / n_sets;                               // position in the tile list
+    const int gi = list.index ? static_cast<int>(list.index[li]) : list.first + li;     // position in the calibration's full list
     // the tile's block of constants: its address needs nothing but the block index, so the loads go out first
     {
-        const uint32_t MST_GLOBAL* __restrict__ gb = gp(blobs) + static_cast<size_t>(list.first + li) * A_BLOB;
+        const uint32_t MST_GLOBAL* __restrict__ gb = gp(blobs) + static_cast<size_t>(gi) * A_BLOB;
         const uint32_t v0 = gb[tid], v1 = gb[tid + 256];
         const uint32_t v2 = tid < A_BLOB - 512 ? gb[tid + 512] : 0u;
         s_blob[tid] = v0;
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     }
     const CamDesc* __restrict__ cams = cams_all + set * n_cams;
     const FrameArgs& frames = batch.f[set];
-    const uint32_t t = list.tiles[li];
+    const uint32_t t = list.tiles[list.index ? gi : li];
     const int cam = (t >> 24) & 0x7F, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
     const int bw = c.lw[0], bh = c.lh[0], nlev = c.nlev;
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     k.src_lo2 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(k.src)) & 3u;
     k.src_al = k.src - k.src_lo2;
     // this tile's slice of the per-calibration map table: [row][col], one coalesced 4-byte load per pixel
-    const uint32_t* __restrict__ tab = table + static_cast<size_t>(list.first + li) * (A_LH * A_LW);
+    const uint32_t* __restrict__ tab = table + static_cast<size_t>(gi) * (A_LH * A_LW);
     const int col = tid & (A_LW - 1);
     const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
     __syncthreads();                                             // the tile's constants are in LDS
@@ -612,6 +613,200 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
             vg += wy * hg;
         }
         g1out[__umul24(y1 + i, lw1) + x1 + j] = pyrdown_finish(vbr, vg);
+    }
+}
+
+// ======================================================================================================
+// A, staged form: the tile's source window through LDS (see kernels_compose.hip / tools/ubench/sampler.hip)
+// ======================================================================================================
+// The gathering kernel above asks the texture path for two 12-byte windows per pixel and writes level 0 twice (LDS,
+// then a store pass); measured against the micro-benchmark's forms it sits at the rate of its memory pipeline, not of
+// its instructions.  Here the 128 x 36 tile's source window is staged once (coalesced 12-byte loads of four pixels ->
+// 4-byte pixels in LDS), a lane samples four adjacent pixels of A2_ROWS rows out of LDS (one 16-byte table load and one
+// 16-byte gain load per row: the exposure gain of every tile pixel is tabulated per calibration like the map, so the
+// gain rows / weights of the per-tile constant block are gone), stores the interior of level 0 straight from its
+// registers as 16 bytes, and only then drops the tile into LDS -- over the dead window -- for the pyrDown.
+// Lane layout of a tile row: lanes 0..30 own the interior columns 4l..4l+3 (tile columns 2 + 4l ..), lane 31 the four
+// halo columns (tile columns 0, 1, 126, 127); the tables are stored in that order.
+#ifndef MST_A2_ROWS
+#define MST_A2_ROWS 3
+#endif
+constexpr int A2_ROWS = MST_A2_ROWS, A2_RG = A_LH / A2_ROWS, A2_NT = 32 * A2_RG;      // 3 rows per lane: 12 row groups, 384 threads (2 rows / 576 threads: 230 vs 200 us per 8 frame sets)
+static_assert(A_LW == 128 && A_LH % A2_ROWS == 0 && A_TW0 == 124, "lane layout of the staged warp kernel");
+constexpr uint32_t kWinGeneral = 1u;
+
+__device__ __forceinline__ int a2_slot_of_col(int col)        // position of tile column `col` in a table row
+{
+    return col < 2 ? 124 + col : (col >= 126 ? col : col - 2);
+}
+
+// Per calibration: map, gain and window of every launched tile in the staged kernel's order.  One block per tile.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_warp_table_lds(const CamDesc* __restrict__ cams, TileList list, uint32_t* __restrict__ table,
+                                                        float* __restrict__ gain, WarpWin* __restrict__ wins, int lds_budget_px)
+{
+    __shared__ int s_min[2], s_max[2];
+    __shared__ uint32_t s_general;
+    const uint32_t t = list.tiles[blockIdx.x];
+    const int cam = (t >> 24) & 0x7F, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
+    const CamDesc& c = cams[cam];
+    const int bw = c.lw[0], bh = c.lh[0];
+    const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_min[0] = INT_MAX; s_min[1] = INT_MAX; s_max[0] = INT_MIN; s_max[1] = INT_MIN; s_general = 0; }
+    __syncthreads();
+    float kr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) kr[i] = c.kr[i];
+    const int col = tid & (A_LW - 1), half = tid >> 7;
+    // pyrDown's REFLECT_101 into the bordered image, then copyMakeBorder's REFLECT into the roi
+    const int rx = reflect<0>(reflect<1>(lx0 + col, bw) - c.left, c.roi_w);
+    const ColEntry ce = load_global(c.cols + rx);
+    int x_lo = INT_MAX, y_lo = INT_MAX, x_hi = INT_MIN, y_hi = INT_MIN;
+    bool general = false;
+    for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
+        const int row = half * A_ROWS_PER_THREAD + it;
+        const int ry = reflect<0>(reflect<1>(ly0 + row, bh) - c.top, c.roi_h);
+        const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, ce, load_global(c.rows + ry), rx, ry);
+        if (m.inside) { x_lo = min(x_lo, m.ix); y_lo = min(y_lo, m.iy); x_hi = max(x_hi, m.ix + 1); y_hi = max(y_hi, m.iy + 1); }
+        else general = true;
+    }
+    if (x_lo != INT_MAX) { atomicMin(&s_min[0], x_lo); atomicMin(&s_min[1], y_lo); atomicMax(&s_max[0], x_hi); atomicMax(&s_max[1], y_hi); }
+    __syncthreads();
+    const int bx = s_min[0] == INT_MAX ? 0 : s_min[0], by = s_min[1] == INT_MAX ? 0 : s_min[1];
+    const size_t base = static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW);
+    for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
+        const int row = half * A_ROWS_PER_THREAD + it;
+        const int ry = reflect<0>(reflect<1>(ly0 + row, bh) - c.top, c.roi_h);
+        const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, ce, load_global(c.rows + ry), rx, ry);
+        const uint32_t dx = static_cast<uint32_t>(m.ix - bx), dy = static_cast<uint32_t>(m.iy - by);
+        const float g = c.expos == 0 ? 1.f : gain_at(c, rx, ry);
+        uint32_t e = 0;
+        if (m.inside && dx < 1024u && dy < 512u && !(g >= 8.0e6f))
+            e = static_cast<uint32_t>(m.ifx) | static_cast<uint32_t>(m.ify) << 6 | dx << 12 | dy << 22 | 1u << 31;
+        else
+            general = true;
+        const size_t o = base + row * A_LW + a2_slot_of_col(col);
+        table[o] = e;
+        gain[o] = g;
+    }
+    if (general) atomicOr(&s_general, 1u);
+    __syncthreads();
+    if (tid == 0) {
+        WarpWin w;
+        w.wx0 = bx & ~3; w.by = by; w.bx = bx;
+        w.groups = s_max[0] == INT_MIN ? 0 : (s_max[0] - w.wx0 + 4) / 4;
+        w.rows = s_max[1] == INT_MIN ? 0 : s_max[1] - by + 1;
+        const bool overrun = w.wx0 + 4 * w.groups > c.src_w && by + w.rows >= c.src_h;
+        w.flags = (s_general || w.groups * 4 * w.rows > lds_budget_px || w.groups > 256 || w.groups == 0 || overrun) ? kWinGeneral : 0u;
+        w.pad0 = w.pad1 = 0;
+        wins[list.first + blockIdx.x] = w;
+    }
+}
+
+__global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restrict__ cams_all, TileList list, FrameBatch batch,
+                                                        const uint32_t* __restrict__ table, const float* __restrict__ gain,
+                                                        const WarpWin* __restrict__ wins, int n_cams, int n_sets)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];     // the staged window, later the level-0 tile [A_LH][A_LW]
+    const int tid = threadIdx.x, lane = tid & 31;
+    const int rgrp = __builtin_amdgcn_readfirstlane(tid >> 6) * 2 + ((tid >> 5) & 1);
+    const int pair = xcd_run_index(blockIdx.x, list.count * n_sets);
+    const int set = pair % n_sets, li = pair / n_sets;
+    const int gi = list.index ? static_cast<int>(list.index[li]) : list.first + li;
+    const uint32_t t = list.tiles[list.index ? gi : li];
+    const int cam = (t >> 24) & 0x7F, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
+    const CamDesc* __restrict__ cams = cams_all + set * n_cams;
+    const CamDesc& c = cams[cam];
+    const FrameArgs& frames = batch.f[set];
+    const WarpWin w = wins[gi];
+    const uint32_t stride = frames.stride[cam];
+    const int bw = c.lw[0], bh = c.lh[0], nlev = c.nlev;
+    // table and gain rows of this lane: issued before the staging loads, one round trip covers both
+    const size_t tbl = static_cast<size_t>(gi) * (A_LH * A_LW) + (rgrp * A2_ROWS) * A_LW + lane * 4;
+    u32x4_t e_r[A2_ROWS];
+    typedef float __attribute__((ext_vector_type(4))) f32x4_t;
+    f32x4_t g_r[A2_ROWS];
+#pragma unroll
+    for (int it = 0; it < A2_ROWS; ++it) {
+        e_r[it] = *(const u32x4_t MST_GLOBAL*)(table + tbl + it * A_LW);
+        g_r[it] = *(const f32x4_t MST_GLOBAL*)(gain + tbl + it * A_LW);
+    }
+    stage_window<A2_NT>(s_mem, gp(frames.ptr[cam]) + (static_cast<size_t>(w.by) * stride + static_cast<size_t>(w.wx0) * 3u), stride,
+                        w.groups, w.rows);
+    __syncthreads();
+    const uint32_t pitch_b = static_cast<uint32_t>(w.groups) * 16u;
+    const char* win = reinterpret_cast<const char*>(s_mem) + (w.bx - w.wx0) * 4;
+    uint32_t px[A2_ROWS][4];
+#pragma unroll
+    for (int it = 0; it < A2_ROWS; ++it)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = e_r[it][k];
+            const uint32_t dx = (e >> 12) & 1023u, dy = (e >> 22) & 511u;
+            const uint32_t addr = __umul24(dy, pitch_b) + dx * 4u;
+            px[it][k] = sample_lds(reinterpret_cast<const uint32_t*>(win + addr), reinterpret_cast<const uint32_t*>(win + addr + pitch_b), e, g_r[it][k]);
+        }
+    // level 0, interior of the tile, straight from the registers (lanes 0..30: 16 bytes each, 16-byte aligned when the
+    // level's width is a multiple of four: 124 * 4 bytes is)
+    const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;
+    const bool store0 = !(t >> 31);                 // (bit 31: nothing reads this tile's level 0 from memory, see mb_plan.cpp)
+    if (store0 && lane < 31) {
+        uint32_t MST_GLOBAL* __restrict__ g0out = gp(c.G[0]);
+        const int gx = lx0 + 2 + 4 * lane;
+#pragma unroll
+        for (int it = 0; it < A2_ROWS; ++it) {
+            const int row = rgrp * A2_ROWS + it, gy = ly0 + row;
+            if (row < 2 || row >= A_LH - 2 || gy >= bh || gx >= bw) continue;
+            uint32_t MST_GLOBAL* o = g0out + __umul24(gy, bw) + gx;
+            if ((bw & 3) == 0) {
+                __builtin_nontemporal_store(u32x4_t{px[it][0], px[it][1], px[it][2], px[it][3]}, reinterpret_cast<u32x4_t MST_GLOBAL*>(o));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (gx + k < bw) o[k] = px[it][k];
+            }
+        }
+    }
+    if (nlev < 2) return;
+    __syncthreads();                                // every wave is done with the window: the tile takes its place
+    uint32_t (*s_l0)[A_LW] = reinterpret_cast<uint32_t (*)[A_LW]>(s_mem);
+#pragma unroll
+    for (int it = 0; it < A2_ROWS; ++it) {
+        const int row = rgrp * A2_ROWS + it;
+        if (lane < 31) {
+            *reinterpret_cast<uint2*>(&s_l0[row][2 + 4 * lane]) = make_uint2(px[it][0], px[it][1]);
+            *reinterpret_cast<uint2*>(&s_l0[row][4 + 4 * lane]) = make_uint2(px[it][2], px[it][3]);
+        } else {
+            *reinterpret_cast<uint2*>(&s_l0[row][0]) = make_uint2(px[it][0], px[it][1]);
+            *reinterpret_cast<uint2*>(&s_l0[row][126]) = make_uint2(px[it][2], px[it][3]);
+        }
+    }
+    __syncthreads();
+    // pyrDown straight from the LDS tile (as in k_warp_pyr): a thread owns one output column and four output rows
+    uint32_t MST_GLOBAL* __restrict__ g1out = gp(c.G[1]);
+    const int lw1 = c.lw[1], lh1 = c.lh[1];
+    const int x1 = tx * A_TW1, y1 = ty * A_TH1;
+    static_assert(A_TH1 % 4 == 0, "pyrDown rows per thread");
+    constexpr int R = A_TH1 / 4;
+    if (tid < 4 * A_TW1) {
+        const int g = tid / A_TW1, j = tid - g * A_TW1;
+        uint32_t hbr[2 * R + 3], hg[2 * R + 3];
+#pragma unroll
+        for (int r = 0; r < 2 * R + 3; ++r) {
+            const uint32_t* p = &s_l0[2 * R * g + r][2 * j];
+            const uint2 p01 = *reinterpret_cast<const uint2*>(p);
+            const uint2 p23 = *reinterpret_cast<const uint2*>(p + 2);
+            tap5(p01.x, p01.y, p23.x, p23.y, p[4], hbr[r], hg[r]);
+        }
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            const int i = R * g + o;
+            if (x1 + j >= lw1 || y1 + i >= lh1) continue;
+            const uint32_t vbr = hbr[2 * o] + hbr[2 * o + 4] + 4u * (hbr[2 * o + 1] + hbr[2 * o + 3]) + 6u * hbr[2 * o + 2];
+            const uint32_t vg = hg[2 * o] + hg[2 * o + 4] + 4u * (hg[2 * o + 1] + hg[2 * o + 3]) + 6u * hg[2 * o + 2];
+            g1out[__umul24(y1 + i, lw1) + x1 + j] = pyrdown_finish(vbr, vg);
+        }
     }
 }
 
@@ -1988,6 +2183,25 @@ void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList
     hipLaunchKernelGGL((k_warp_pyr<K>), dim3(list.count * batch), dim3(256), pad, s, d_cams, list, frames, d_table, d_blobs, n_cams, batch)
     if (kind == 0) MST_LAUNCH_A(0); else if (kind == 1) MST_LAUNCH_A(1); else if (kind == 2) MST_LAUNCH_A(2); else MST_LAUNCH_A(3);
 #undef MST_LAUNCH_A
+}
+
+size_t mb_warp_tile_px() { return static_cast<size_t>(A_LH) * A_LW; }
+
+void launch_warp_table_lds(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, float* d_gain, WarpWin* d_wins,
+                           int lds_budget_px, hipStream_t s)
+{
+    if (list.count <= 0) return;
+#define MST_LAUNCH_T2(K) hipLaunchKernelGGL(k_warp_table_lds<K>, dim3(list.count), dim3(256), 0, s, d_cams, list, d_table, d_gain, d_wins, lds_budget_px)
+    if (kind == 0) MST_LAUNCH_T2(0); else if (kind == 1) MST_LAUNCH_T2(1); else if (kind == 2) MST_LAUNCH_T2(2); else MST_LAUNCH_T2(3);
+#undef MST_LAUNCH_T2
+}
+
+void launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, const TileList& list, const FrameBatch& frames, int batch,
+                         const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s)
+{
+    if (list.count <= 0 || batch <= 0) return;
+    const size_t lds = std::max(lds_bytes, mb_warp_tile_px() * sizeof(uint32_t));
+    hipLaunchKernelGGL(k_warp_pyr_lds, dim3(list.count * batch), dim3(A2_NT), lds, s, d_cams, list, frames, d_table, d_gain, d_wins, n_cams, batch);
 }
 
 void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s)
