@@ -124,6 +124,9 @@ struct ComposeArgs {
     int32_t out_w, out_h, crop_x, crop_y;      // output rectangle inside the canvas
     int32_t canvas_w, canvas_h, tiles_x;
     const float* feather_ws;     // canvas-sized weight sum (general path)
+    // lens-undistort pre-pass through the same kernel (remap with BORDER_CONSTANT): the staged window may reach outside
+    // the pad_w x pad_h frame, where it is filled with zeros; 0 = frames are only read inside (the composites)
+    int32_t pad_w, pad_h;
     uint8_t* pano[kMaxBatch]; uint32_t pano_stride;
     uint8_t* pano_mask[kMaxBatch]; uint32_t mask_stride;
 };

@@ -463,6 +463,44 @@ void Engine::update(const mst_calibration& calib)
         check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");      // the caller's maps are only borrowed
     }
     if (st->any_undistort) st->d_ucams = st->pool.upload(st->ucams, s);
+    // the pre-pass in the staged form (kernels_compose.hip): per camera one segment per 128 x 32 tile of the frame, its map
+    // recast into the composites' table form; cameras whose frames are not a multiple of four pixels wide, or with a tile
+    // whose source window does not fit, keep the gathering k_remap_fixed
+    st->undist_plans.assign(n, UndistortPlan{});
+    for (int i = 0; i < n; ++i) {
+        const UndistortCam& u = st->ucams[i];
+        if (!u.map1 || (u.w & 3) || std::getenv("MST_UNDISTORT_GATHER")) continue;
+        UndistortPlan& up = st->undist_plans[i];
+        const int tx = (u.w + kCompTW - 1) / kCompTW, ty = (u.h + kCompTH - 1) / kCompTH, nt = tx * ty;
+        ComposeSeg* d_segs = st->pool.alloc<ComposeSeg>(nt);
+        ComposeTile* d_tiles = st->pool.alloc<ComposeTile>(nt);
+        uint32_t* d_table = st->pool.alloc<uint32_t>(static_cast<size_t>(nt) * kCompPx);
+        launch_undistort_table(u, tx, ty, d_segs, d_tiles, d_table, kCompLdsPx, s);
+        check_hip(hipGetLastError(), "k_undistort_table");
+        std::vector<ComposeTile> tiles(nt);
+        std::vector<ComposeSeg> segs(nt);
+        check_hip(hipMemcpyAsync(tiles.data(), d_tiles, nt * sizeof(ComposeTile), hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H)");
+        check_hip(hipMemcpyAsync(segs.data(), d_segs, nt * sizeof(ComposeSeg), hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H)");
+        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(undistort tables)");
+        bool ok = true;
+        size_t lds_px = 4;
+        for (int k = 0; k < nt; ++k) {
+            ok &= !(tiles[k].flags & kCompTileGeneral);
+            lds_px = std::max(lds_px, static_cast<size_t>(segs[k].groups) * 4 * segs[k].rows);
+        }
+        if (!ok) continue;
+        ComposeArgs& ca = up.args;
+        ca = ComposeArgs{};
+        ca.mode = kCompModePaste;
+        ca.n_cams = 1;
+        ca.tiles = d_tiles; ca.segs = d_segs; ca.table = d_table;
+        ca.n_tiles = nt;
+        ca.out_w = u.w; ca.out_h = u.h; ca.canvas_w = u.w; ca.canvas_h = u.h; ca.tiles_x = tx;
+        ca.pad_w = u.w; ca.pad_h = u.h;
+        ca.pano_stride = static_cast<uint32_t>(u.w) * 3u;
+        up.lds_bytes = lds_px * 4;
+        up.staged = true;
+    }
 
     st->canvas = result_roi(rois);
     for (int i = 0; i < n; ++i) {
@@ -712,6 +750,34 @@ void Engine::update(const mst_calibration& calib)
 }
 
 
+// The lens-undistort pre-pass of `count` frame sets: src -> dst for every camera of `camera_mask` that has maps.  Cameras
+// with a staged plan and raw frames on the 4-byte grid take the staged kernel (one launch per camera over all sets), the
+// others the gathering k_remap_fixed (one launch for all of them).
+void Engine::launch_undistort(const CalibState& st, const FrameBatch& src, const FrameBatch& dst, int count, uint32_t camera_mask, hipStream_t s)
+{
+    FrameBatch rest = src;
+    bool any_rest = false;
+    for (int i = 0; i < st.n; ++i) {
+        if (!st.ucams[i].map1 || !(camera_mask >> i & 1u)) { for (int f = 0; f < count; ++f) rest.f[f].ptr[i] = nullptr; continue; }
+        const UndistortPlan& up = st.undist_plans[i];
+        bool staged = up.staged;
+        for (int f = 0; f < count && staged; ++f)
+            staged &= ((reinterpret_cast<uintptr_t>(src.f[f].ptr[i]) | src.f[f].stride[i]) & 3u) == 0;
+        if (!staged) { any_rest = true; continue; }
+        ComposeArgs ca = up.args;
+        ca.n_sets = count;
+        FrameBatch one{};
+        for (int f = 0; f < count; ++f) {
+            ca.pano[f] = const_cast<uint8_t*>(dst.f[f].ptr[i]);
+            one.f[f].ptr[0] = src.f[f].ptr[i];
+            one.f[f].stride[0] = src.f[f].stride[i];
+            rest.f[f].ptr[i] = nullptr;
+        }
+        launch_compose(ca, one, up.lds_bytes, false, s);
+    }
+    if (any_rest) launch_remap_fixed(st.d_ucams, st.n, st.undist_max_w, st.undist_max_h, rest, dst, count, s);
+}
+
 // The warp kernel (A) over the tiles of cameras [cam0, cam1): the staged form for the tiles that fit it, the gathering
 // kernel for the rest -- and for everything when a frame of the call is off the 4-byte grid (the staged form reads whole
 // dwords) or MST_WARP_GATHER is set (A/B timing).
@@ -927,7 +993,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
                     ub.f[f].ptr[i] = buf;
                     ub.f[f].stride[i] = static_cast<uint32_t>(st->cams[i].src_w) * 3u;
                 }
-        launch_remap_fixed(st->d_ucams, st->n, st->undist_max_w, st->undist_max_h, fb, ub, count, on);
+        launch_undistort(*st, fb, ub, count, ~0u, on);
         if (timer) timer->mark("k_remap_fixed", on);
         fb = ub;
     };
@@ -1075,7 +1141,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
                 ub.f[0].ptr[i] = buf;
                 ub.f[0].stride[i] = static_cast<uint32_t>(st->cams[i].src_w) * 3u;
             }
-        launch_remap_fixed(st->d_ucams, st->n, st->undist_max_w, st->undist_max_h, fb, ub, 1, s);
+        launch_undistort(*st, fb, ub, 1, camera_mask, s);
         fb = ub;
     }
     const MbPlanHost& plan = st->plan;

@@ -70,6 +70,13 @@ struct CameraSetup {
     int src_w = 0, src_h = 0;
 };
 
+// the lens-undistort pre-pass of one camera in the staged form (kernels_compose.hip); staged == false: k_remap_fixed
+struct UndistortPlan {
+    bool staged = false;
+    ComposeArgs args{};
+    size_t lds_bytes = 0;
+};
+
 struct CalibState {
     DevicePool pool;
     int n = 0;
@@ -91,6 +98,7 @@ struct CalibState {
     // lens-undistort pre-pass (optional per camera)
     std::vector<UndistortCam> ucams;    // host copy (device map pointers)
     UndistortCam* d_ucams = nullptr;
+    std::vector<UndistortPlan> undist_plans;
     bool any_undistort = false;
     int undist_max_w = 0, undist_max_h = 0;
     struct CoarseDev { const uint32_t* cams = nullptr; const uint32_t* pure = nullptr; const uint32_t* order = nullptr; };
@@ -184,6 +192,7 @@ private:
     void compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
                           void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
                           hipStream_t stream, StageTimer* timer);
+    void launch_undistort(const CalibState& st, const FrameBatch& src, const FrameBatch& dst, int count, uint32_t camera_mask, hipStream_t s);
     void launch_warp(const CalibState& st, const CamDesc* desc, const FrameBatch& fb, int count, int cam0, int cam1, hipStream_t s);
     void build_compose_plan(CalibState& st, hipStream_t s);     // mst_update, blend kinds NO and FEATHER
     void set_in_flight(std::shared_ptr<CalibState> st);   // keeps `st` alive; the previous one goes to retired_

@@ -83,6 +83,10 @@ void launch_compose_wsum(const ComposeArgs& a, int n_canvas_tiles, float* d_out,
 // calibration: per segment the map / gain / weight tables, window origin and flags; sets the tiles' general-path flag
 void launch_compose_table(const ComposeArgs& a, int kind, int n_segs, ComposeSeg* d_segs, ComposeTile* d_tiles,
                           const uint32_t* d_seg_tile, uint32_t* d_table, float* d_gain, float* d_weight, hipStream_t s);
+// lens-undistort pre-pass in the composites' table form: one tile + segment + 4096 entries per 128 x 32 tile of the frame
+// (tile flag kCompTileGeneral: the camera keeps the gathering k_remap_fixed)
+void launch_undistort_table(const UndistortCam& u, int tiles_x, int tiles_y, ComposeSeg* d_segs, ComposeTile* d_tiles, uint32_t* d_table,
+                            int lds_budget_px, hipStream_t s);
 // per frame: a.n_sets frame sets in one launch (a.pano[f], frames.f[f]) over the tile list a.tiles.  general: the
 // per-pixel path; else lds_bytes != 0: the LDS-staged form (every segment of the list must fit), 0: gathers from memory
 void launch_compose(const ComposeArgs& a, const FrameBatch& frames, size_t lds_bytes, bool general, hipStream_t s);

@@ -317,16 +317,20 @@ __device__ __forceinline__ void warped_pixel(const CamDesc& c, const uint8_t* __
 typedef uint32_t __attribute__((ext_vector_type(3))) u32x3_t;
 typedef uint32_t __attribute__((ext_vector_type(4))) u32x4_t;
 // `groups` x `rows` groups of four pixels (12 source bytes on a dword boundary -> 16 LDS bytes, B G R x), by NT threads
-template <int NT>
+// PAD: the window may reach outside the fw x fh frame (origin (wx0, wy0) in frame pixels, wx0 and fw multiples of four, so
+// a group lies inside or outside as a whole); groups outside are zeros -- cv::remap's BORDER_CONSTANT
+template <int NT, bool PAD = false>
 __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const uint8_t MST_GLOBAL* __restrict__ base, uint32_t stride,
-                                             int groups, int rows)
+                                             int groups, int rows, int wx0 = 0, int wy0 = 0, int fw = 0, int fh = 0)
 {
     const int n = groups * rows;
     const uint32_t inv = ((1u << 20) + groups - 1) / groups;      // i / groups == (i * inv) >> 20 for i < 4096, groups <= 256
     for (int i = threadIdx.x; i < n; i += NT) {
         const int r = n <= 4096 ? static_cast<int>((static_cast<uint32_t>(i) * inv) >> 20) : i / groups;
         const int g = i - r * groups;
-        const u32x3_t d = *(const u32x3_t MST_GLOBAL*)(base + __umul24(r, stride) + static_cast<uint32_t>(g) * 12u);
+        u32x3_t d = {0u, 0u, 0u};
+        if (!PAD || (static_cast<unsigned>(wy0 + r) < static_cast<unsigned>(fh) && static_cast<unsigned>(wx0 + 4 * g) < static_cast<unsigned>(fw)))
+            d = *(const u32x3_t MST_GLOBAL*)(base + static_cast<ptrdiff_t>(r) * static_cast<ptrdiff_t>(stride) + static_cast<ptrdiff_t>(g) * 12);
         u32x4_t p;
         p.x = d.x;                                            // B0 G0 R0 (B1)
         p.y = __builtin_amdgcn_alignbyte(d.y, d.x, 3);        // B1 G1 R1 (B2)

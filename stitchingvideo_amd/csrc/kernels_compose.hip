@@ -283,6 +283,68 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
     }
 }
 
+// ---- lens-undistort pre-pass (DRV:232,741) through the staged kernel ------------------------------------------------
+// cv::remap(frame, undistorted, map1 CV_16SC2, map2 CV_16UC1, INTER_LINEAR, BORDER_CONSTANT 0): the integer tap and the
+// 5-bit fractions come ready-made from initUndistortRectifyMap.  Per calibration they are recast into the composites'
+// table form (one segment per 128 x 32 tile of the frame, the frame being its own "panorama"); taps outside the frame
+// are zeros, which the staged window provides by itself (stage_window<PAD>), so a window only has to start at -1.
+// A pixel all of whose taps lie outside is simply 0 (entry invalid).
+__global__ __launch_bounds__(256) void k_undistort_table(UndistortCam u, int tiles_x, ComposeSeg* __restrict__ segs, ComposeTile* __restrict__ tiles,
+                                                         uint32_t* __restrict__ table, int lds_budget_px)
+{
+    __shared__ int s_min[2], s_max[2];
+    const int s = blockIdx.x, tx = s % tiles_x, ty = s / tiles_x;
+    if (threadIdx.x == 0) { s_min[0] = INT_MAX; s_min[1] = INT_MAX; s_max[0] = INT_MIN; s_max[1] = INT_MIN; }
+    __syncthreads();
+    constexpr int kPer = kCompPx / 256;
+    int x_lo = INT_MAX, y_lo = INT_MAX, x_hi = INT_MIN, y_hi = INT_MIN;
+    uint32_t valid_bits = 0;
+    for (int j = 0; j < kPer; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
+        if (ox >= u.w || oy >= u.h) continue;
+        const size_t mi = static_cast<size_t>(oy) * u.w + ox;
+        const int sx = gp(u.map1)[2 * mi], sy = gp(u.map1)[2 * mi + 1];
+        if (sx < -1 || sx >= u.w || sy < -1 || sy >= u.h) continue;       // every tap outside: 0
+        valid_bits |= 1u << j;
+        x_lo = min(x_lo, sx); y_lo = min(y_lo, sy); x_hi = max(x_hi, sx + 1); y_hi = max(y_hi, sy + 1);
+    }
+    if (x_lo != INT_MAX) { atomicMin(&s_min[0], x_lo); atomicMin(&s_min[1], y_lo); atomicMax(&s_max[0], x_hi); atomicMax(&s_max[1], y_hi); }
+    __syncthreads();
+    const int bx = s_min[0] == INT_MAX ? 0 : s_min[0], by = s_min[1] == INT_MAX ? 0 : s_min[1];
+    bool far = false;
+    for (int j = 0; j < kPer; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        uint32_t e = 0;
+        if (valid_bits >> j & 1u) {
+            const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
+            const size_t mi = static_cast<size_t>(oy) * u.w + ox;
+            const int sx = gp(u.map1)[2 * mi], sy = gp(u.map1)[2 * mi + 1];
+            const uint32_t fr = gp(u.map2)[mi];
+            const uint32_t dx = static_cast<uint32_t>(sx - bx), dy = static_cast<uint32_t>(sy - by);
+            if (dx < 1024u && dy < 512u) e = (fr & 31u) | ((fr >> 5) & 31u) << 6 | dx << 12 | dy << 22 | kEntryValid;
+            else far = true;
+        }
+        table[static_cast<size_t>(s) * kCompPx + i] = e;
+    }
+    const int any_far = __syncthreads_or(far);
+    if (threadIdx.x == 0) {
+        ComposeSeg sg{};
+        sg.cam = 0; sg.bx = bx; sg.by = by; sg.flags = 0;
+        // floor to a multiple of four that may be negative (column -1 lives in the all-zero group [-4, -1])
+        sg.wx0 = bx >= 0 ? (bx & ~3) : -4;
+        sg.groups = s_max[0] == INT_MIN ? 0 : (s_max[0] - sg.wx0 + 4) / 4;
+        sg.rows = s_max[1] == INT_MIN ? 0 : s_max[1] - by + 1;
+        segs[s] = sg;
+        ComposeTile t{};
+        t.seg_first = static_cast<uint32_t>(s);
+        t.seg_count = sg.groups ? 1u : 0u;
+        t.flags = (any_far || sg.groups * 4 * sg.rows > lds_budget_px || sg.groups > 256) ? kCompTileGeneral : 0u;
+        t.tx_ty = static_cast<uint32_t>(tx) | static_cast<uint32_t>(ty) << 16;
+        tiles[s] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // per frame
 // ------------------------------------------------------------------------------------------------------
@@ -532,13 +594,17 @@ __global__ __launch_bounds__(1024 / ROWS) void k_compose_lds(ComposeArgs a, Fram
 #pragma unroll
         for (int it = 0; it < ROWS; ++it) {
             e_r[it] = *(const u32x4 MST_GLOBAL*)(a.table + tbl + it * kCompTW);
-            g_r[it] = *(const f32x4 MST_GLOBAL*)(a.gain + tbl + it * kCompTW);
+            g_r[it] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (a.gain) g_r[it] = *(const f32x4 MST_GLOBAL*)(a.gain + tbl + it * kCompTW);
             w_r[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (MODE == kCompModeFeather && !pure) w_r[it] = *(const f32x4 MST_GLOBAL*)(a.weight + tbl + it * kCompTW);
         }
         if (s) __syncthreads();                          // the previous segment's window has been read
-        stage_window<NT>(s_win, gp(frames.ptr[seg.cam]) + (static_cast<size_t>(seg.by) * stride + static_cast<size_t>(seg.wx0) * 3u), stride,
-                         seg.groups, seg.rows);
+        {
+            const uint8_t MST_GLOBAL* wbase = gp(frames.ptr[seg.cam]) + (static_cast<ptrdiff_t>(seg.by) * static_cast<ptrdiff_t>(stride) + static_cast<ptrdiff_t>(seg.wx0) * 3);
+            if (MODE == kCompModePaste && a.pad_w) stage_window<NT, true>(s_win, wbase, stride, seg.groups, seg.rows, seg.wx0, seg.by, a.pad_w, a.pad_h);
+            else stage_window<NT>(s_win, wbase, stride, seg.groups, seg.rows);
+        }
         __syncthreads();
         const uint32_t pitch_b = static_cast<uint32_t>(seg.groups) * 16u;
         const char* win = reinterpret_cast<const char*>(s_win) + (seg.bx - seg.wx0) * 4;
@@ -634,6 +700,12 @@ void launch_compose_table(const ComposeArgs& a, int kind, int n_segs, ComposeSeg
 #define MST_LAUNCH_CT(K) hipLaunchKernelGGL(k_compose_table<K>, dim3(n_segs), dim3(256), 0, s, a, d_segs, d_tiles, d_seg_tile, d_table, d_gain, d_weight)
     if (kind == 0) MST_LAUNCH_CT(0); else if (kind == 1) MST_LAUNCH_CT(1); else if (kind == 2) MST_LAUNCH_CT(2); else MST_LAUNCH_CT(3);
 #undef MST_LAUNCH_CT
+}
+
+void launch_undistort_table(const UndistortCam& u, int tiles_x, int tiles_y, ComposeSeg* d_segs, ComposeTile* d_tiles, uint32_t* d_table,
+                            int lds_budget_px, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_undistort_table, dim3(tiles_x * tiles_y), dim3(256), 0, s, u, tiles_x, d_segs, d_tiles, d_table, lds_budget_px);
 }
 
 void launch_compose(const ComposeArgs& a, const FrameBatch& frames, size_t lds_bytes, bool general, hipStream_t s)
