@@ -70,6 +70,7 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--batch", type=int, default=8,
                     help="frame sets per launch sequence (mst_compose_device_batch); 1 = one frame set per sequence")
+    ap.add_argument("--strip-leg", action="store_true", help="run the strip-sharded measurement at N = 1 too (one strip = the whole canvas)")
     ap.add_argument("--shard", default="frames", choices=["frames", "cameras"],
                     help="N > 1 headline: frames = every rank stitches its own frame sets (default, no collective); "
                          "cameras = camera i on rank i %% N, payload sent to rank 0 over RCCL, rank 0 blends (SURVEY 8e)")
@@ -418,6 +419,14 @@ def main():
             leg = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
             out["camera_sharded"] = leg
+    # ---- N > 1: the canvas cut into N column strips, rank r composes strip r, strips concatenated on rank 0 ----
+    if (world > 1 or args.strip_leg) and not by_camera and not args.no_camera_leg:
+        try:
+            leg = strip_sharded_leg(args, rank, world, local_rank, dev, stream)
+        except Exception as e:          # noqa: BLE001
+            leg = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            out["strip_sharded"] = leg
 
     # ---- the other single-GPU BASELINE configurations, through the same entry points (tools/bench_paths.py) ----
     if rank == 0 and world == 1 and not by_camera and not args.no_configs and args.config == "C3":
@@ -550,6 +559,79 @@ def camera_sharded_leg(args_ns, rank, world, local_rank, dev, stream):
             "scaling": "strong", "frames": n, "frames_per_s": round(n / wall, 2), "ms_per_frame": round(wall * 1e3 / n, 4),
             "payload_bytes_per_frame_to_root": payload,
             "roofline_frac": round(alg * n / wall / 1e9 / HBM_PEAK_GBS, 5)}
+
+
+def strip_sharded_leg(args_ns, rank, world, local_rank, dev, stream):
+    """The canvas split over the GPUs (second form) on the headline workload C3: rank r's engine composes
+    column strip r of `world` (mst_config.strip_index / strip_count: every kernel restricted to what the strip depends on,
+    pixels identical to the whole-canvas run), 8 frame sets per launch sequence, and the strips of every panorama are
+    concatenated on rank 0 by one grouped point-to-point step per launch sequence.  Every rank holds the frames of all
+    cameras (a capture side would deliver each stream to the one or two GPUs whose strips it reaches).  Strong scaling."""
+    import torch
+    import torch.distributed as dist
+    import stitchingvideo_amd as S
+    from stitchingvideo_amd import rig as rigmod
+    from stitchingvideo_amd import sharding
+    cfg = rigmod.CONFIGS["C3"]
+    rig = rigmod.build_rig(cfg)
+    n_cam = len(rig["cameras"])
+    batch = 8
+    eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend="multiband", expos=rig["expos"], num_bands=5, device=local_rank,
+                           max_batch=batch, strip=(rank, world))
+    eng.update(rig["scale"], rig["cameras"])
+    (cx, cy, cw, ch), _ = eng.acquire()
+    sx, _, sw, _ = eng.strip()
+    x0 = sx - cx
+    sets = [[torch.from_numpy(f).to(dev) for f in rigmod.frames_for(rig, frame_index=s)] for s in range(batch)]
+    strips = [torch.empty((ch, max(sw, 1), 3), dtype=torch.uint8, device=dev) for _ in range(batch)]
+    panos = [torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(batch)] if rank == 0 else [None] * batch
+    mine = torch.tensor([x0, sw], dtype=torch.int64, device=dev)
+    if world > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rects = [(int(t[0]), int(t[1])) for t in allr]
+    else:
+        rects = [(x0, sw)]
+    call = eng.make_device_batch_call([[t.data_ptr() for t in ds] for ds in sets], [[t.stride(0) for t in ds] for ds in sets],
+                                      [b.data_ptr() - x0 * 3 for b in strips], strips[0].stride(0), stream=stream)
+
+    def run(n, gather):
+        for _ in range(n):
+            if sw > 0:
+                call()
+            if gather and world > 1:
+                for k in range(batch):
+                    sharding.gather_strips_to_root(strips[k], rects, 0, rank, panos[k])
+            elif gather:
+                for k in range(batch):
+                    panos[k][:, x0:x0 + sw] = strips[k]
+
+    def timed(n, gather):
+        run(3, gather)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(n, gather)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return sharding.max_over_ranks([time.perf_counter() - t0], device=dev)[0]
+
+    n = max(10, args_ns.camera_leg_steps)
+    t_compose = timed(n, False)
+    t_total = timed(n, True)
+    eng.close()
+    alg = rigmod.algorithmic_bytes(rig, (cw, ch))
+    return {"workload": "C3: %dx%dx%d BGR8 streams, spherical warp, gain_blocks, multiband blend (5 bands), canvas %dx%d"
+                        % (n_cam, rig["size"][0], rig["size"][1], cw, ch),
+            "parallelism": "canvas cut into %d column strips, rank r composes strip r (restricted work lists), %d frame sets per launch, "
+                           "strips concatenated on rank 0 (one grouped point-to-point step per launch sequence)" % (world, batch),
+            "scaling": "strong", "strip_columns": rects,
+            "frames_per_s": round(n * batch / t_total, 2), "frames_per_s_strips_left_in_place": round(n * batch / t_compose, 2),
+            "roofline_frac": round(alg * n * batch / t_total / 1e9 / HBM_PEAK_GBS, 5)}
 
 
 if __name__ == "__main__":

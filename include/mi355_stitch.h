@@ -134,6 +134,13 @@ typedef struct mst_config {
     int32_t  weight_type;        /* MST_WEIGHT_*: MultiBandBlender's weight_type (blenders.hpp:101), default CV_32F */
     float    warp_a, warp_b;     /* A, B of CompressedRectilinear* / Panini* warpers when warp_kind carries
                                   * MST_WARP_AB_CUSTOM (detail/warpers.hpp:232-305) */
+    /* Canvas split over GPUs (second form): this engine composes column strip `strip_index` of
+     * `strip_count` equal strips of the canvas (boundaries on multiples of 256 panorama columns; mst_strip tells which).
+     * Every kernel of the path runs only on the tiles that strip can depend on -- for the multi-band blend the strip
+     * widened by the pyrUp reach of every level -- so its pixels are exactly those of the whole panorama.  The panorama
+     * buffer keeps the whole canvas's geometry (pointer = canvas column 0; only the strip's columns are written and the
+     * row stride only has to cover the strip's last column).  strip_count 0 or 1: the whole canvas. */
+    int32_t  strip_index, strip_count;
 } mst_config;
 
 typedef struct mst_camera {
@@ -202,6 +209,8 @@ int  mst_release_calibration(mst_engine *e);
 /* resultRoi of the calibration the next compose will use (see mst_acquire_calibration); with
  * MST_FLAG_DRIVER_LUT the cropped output rect */
 int  mst_canvas(const mst_engine *e, mst_rect *canvas);
+/* the columns this engine writes (mst_config.strip_index / strip_count), as a rectangle inside mst_canvas's */
+int  mst_strip(const mst_engine *e, mst_rect *strip);
 /* corners[i] / sizes[i] */
 int  mst_camera_roi(const mst_engine *e, int camera, mst_rect *roi);
 /* final mask_warped of a camera as the engine holds it (warpRoi-sized CV_8U, `stride` bytes per row): the caller's

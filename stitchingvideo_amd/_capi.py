@@ -40,7 +40,7 @@ DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, 
     1, 2, 3, 4, 5, 6
 
 EXPORTS = [
-    "mst_warp_kind_from_name", "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_acquire_calibration", "mst_release_calibration", "mst_canvas", "mst_camera_roi", "mst_camera_mask",
+    "mst_warp_kind_from_name", "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_acquire_calibration", "mst_release_calibration", "mst_canvas", "mst_strip", "mst_camera_roi", "mst_camera_mask",
     "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_device_batch", "mst_compose_profile",
     "mst_compose_profile_batch", "mst_synchronize", "mst_warp_roi",
     "mst_host_alloc", "mst_host_free", "mst_pipeline_submit", "mst_pipeline_wait", "mst_pipeline_pending",
@@ -58,7 +58,7 @@ class Config(C.Structure):
                 ("expos_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("upblack", C.c_float), ("downblack", C.c_float), ("leftblack", C.c_float),
                 ("rightblack", C.c_float), ("max_batch", C.c_int32), ("weight_type", C.c_int32),
-                ("warp_a", C.c_float), ("warp_b", C.c_float)]
+                ("warp_a", C.c_float), ("warp_b", C.c_float), ("strip_index", C.c_int32), ("strip_count", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -124,6 +124,8 @@ def load():
     L.mst_update.argtypes = [vp, C.POINTER(Calibration)]
     L.mst_acquire_calibration.restype = C.c_int
     L.mst_acquire_calibration.argtypes = [vp, C.POINTER(Rect), C.POINTER(C.c_uint64)]
+    L.mst_strip.restype = C.c_int
+    L.mst_strip.argtypes = [vp, C.POINTER(Rect)]
     L.mst_release_calibration.restype = C.c_int
     L.mst_release_calibration.argtypes = [vp]
     L.mst_canvas.restype = C.c_int

@@ -3,6 +3,8 @@
 #include <cstring>
 #include <new>
 
+#include <algorithm>
+
 #include "engine.hpp"
 #include "kernels.hpp"
 
@@ -102,6 +104,8 @@ int mst_create(const mst_config* cfg, mst_engine** out)
     int rc = guarded(nullptr, [&] {
         require(cfg && out, "null config or output pointer");
         require(cfg->struct_size == static_cast<int32_t>(sizeof(mst_config)), "mst_config.struct_size mismatch");
+        require(cfg->strip_count >= 0 && cfg->strip_count <= 64 && cfg->strip_index >= 0 &&
+                (cfg->strip_count <= 1 ? cfg->strip_index == 0 : cfg->strip_index < cfg->strip_count), "bad strip_index / strip_count");
         require(cfg->num_cameras >= 1 && cfg->num_cameras <= MST_MAX_CAMERAS, "num_cameras out of range");
         require(valid_warp(cfg->warp_kind), "unknown warp kind");
         require((cfg->warp_kind & MST_WARP_AB_CUSTOM) != MST_WARP_AB_CUSTOM || (cfg->warp_a > 0.f && cfg->warp_b > 0.f),
@@ -180,6 +184,19 @@ int mst_canvas(const mst_engine* e, mst_rect* canvas)
     canvas->y = st->canvas.y + st->crop_y;
     canvas->width = st->out_w;
     canvas->height = st->out_h;
+    return MST_OK;
+}
+
+int mst_strip(const mst_engine* e, mst_rect* strip)
+{
+    if (!e || !strip) return MST_ERR_INVALID_ARG;
+    auto st = e->impl.state();
+    if (!st) return MST_ERR_NOT_CALIBRATED;
+    const int x0 = std::min(st->strip_x0, st->out_w), x1 = std::min(st->strip_x1, st->out_w);
+    strip->x = st->canvas.x + st->crop_x + x0;
+    strip->y = st->canvas.y + st->crop_y;
+    strip->width = x1 - x0;
+    strip->height = st->out_h;
     return MST_OK;
 }
 

@@ -206,7 +206,7 @@ BlendArgs CalibState::blend_for(int frame_sets, int* n_coarse, size_t* lds_bytes
     ba.coarse_order = coarse_dev[v].order;
     ba.coarse_tiles_x = ct.tiles_x;
     for (int l = 0; l < kMaxLevels; ++l) ba.lds_off[l] = ct.lds_off[l];
-    *n_coarse = ct.tiles_x * ct.tiles_y;
+    *n_coarse = static_cast<int>(ct.order.size());
     *lds_bytes = ct.lds_bytes;
     return ba;
 }
@@ -632,7 +632,8 @@ void Engine::update(const mst_calibration& calib)
         ba.final_w = cv.final_w; ba.final_h = cv.final_h;
         ba.alpha = static_cast<float>(1. / 255.);
         ba.weights_16s = cfg_.weight_type == MST_WEIGHT_16S ? 1 : 0;
-        build_mb_plan(st->desc, wh, ba, (cfg_.flags & MST_FLAG_DEBUG) != 0, st->plan);
+        strip_columns(cv.cw[0], &st->strip_x0, &st->strip_x1);
+        build_mb_plan(st->desc, wh, ba, (cfg_.flags & MST_FLAG_DEBUG) != 0, st->plan, st->strip_x0, st->strip_x1);
         clk.mark("work-list plan (host)");
         const MbPlanHost& plan = st->plan;
         ba.tiles_x = plan.blend_tiles_x;
@@ -750,6 +751,22 @@ void Engine::update(const mst_calibration& calib)
 }
 
 
+// Column strip [x0, x1) of this engine inside a canvas `width` columns wide (mst_config.strip_index / strip_count):
+// equal shares, boundaries on multiples of 256 columns (a level-1 canvas tile), the last strip takes the rest.
+void Engine::strip_columns(int width, int* x0, int* x1) const
+{
+    *x0 = 0; *x1 = width;
+    const int g = cfg_.strip_count, k = cfg_.strip_index;
+    if (g <= 1) return;
+    auto bound = [&](int i) {
+        if (i >= g) return width;
+        const long b = (static_cast<long>(i) * width / g + 255) / 256 * 256;
+        return static_cast<int>(std::min<long>(b, width));
+    };
+    *x0 = bound(k);
+    *x1 = std::max(*x0, bound(k + 1));
+}
+
 // The lens-undistort pre-pass of `count` frame sets: src -> dst for every camera of `camera_mask` that has maps.  Cameras
 // with a staged plan and raw frames on the 4-byte grid take the staged kernel (one launch per camera over all sets), the
 // others the gathering k_remap_fixed (one launch for all of them).
@@ -832,6 +849,7 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     if (tiles_x > 0xFFFF || tiles_y > 0xFFFF) throw Error{MST_ERR_INVALID_ARG, "output too large for the tile tables"};
     ca.tiles_x = tiles_x;
     const int n_canvas_tiles = tiles_x * tiles_y;
+    strip_columns(st.out_w, &st.strip_x0, &st.strip_x1);
     uint32_t* d_bits = st.pool.alloc<uint32_t>(n_canvas_tiles);
     launch_compose_classify(ca, n_canvas_tiles, d_bits, s);
     check_hip(hipGetLastError(), "k_compose_classify");
@@ -839,13 +857,17 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     check_hip(hipMemcpyAsync(bits.data(), d_bits, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H tile cameras)");
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(tile cameras)");
     // launch order: tiles with the most segments first (the longest blocks start earliest)
-    std::vector<int> order(n_canvas_tiles);
-    for (int i = 0; i < n_canvas_tiles; ++i) order[i] = i;
+    std::vector<int> order;
+    for (int i = 0; i < n_canvas_tiles; ++i) {          // (canvas split over GPUs: the tiles of this engine's strip)
+        const int x = (i % tiles_x) * kCompTW;
+        if (x < st.strip_x1 && x + kCompTW > st.strip_x0) order.push_back(i);
+    }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return __builtin_popcount(bits[a] & 0x1FFFFu) > __builtin_popcount(bits[b] & 0x1FFFFu); });
-    std::vector<ComposeTile> tiles(n_canvas_tiles);
+    const int n_tiles = static_cast<int>(order.size());
+    std::vector<ComposeTile> tiles(n_tiles);
     std::vector<ComposeSeg> segs;
     std::vector<uint32_t> seg_tile;
-    for (int k = 0; k < n_canvas_tiles; ++k) {
+    for (int k = 0; k < n_tiles; ++k) {
         const int ti = order[k];
         ComposeTile& t = tiles[k];
         t.seg_first = static_cast<uint32_t>(segs.size());
@@ -870,7 +892,7 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     float* d_gain = st.pool.alloc<float>(entries);
     float* d_weight = ca.mode == kCompModeFeather ? st.pool.alloc<float>(entries) : nullptr;
     ca.tiles = d_tiles; ca.segs = d_segs; ca.table = d_table; ca.gain = d_gain; ca.weight = d_weight;
-    ca.n_tiles = n_canvas_tiles;
+    ca.n_tiles = n_tiles;
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");     // tiles / segs / seg_tile are pageable and local
     launch_compose_table(ca, cfg_.warp_kind & 0xFF, n_segs, d_segs, d_tiles, d_seg_tile, d_table, d_gain, d_weight, s);
     check_hip(hipGetLastError(), "k_compose_table");
@@ -971,7 +993,9 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
             fb.f[f].ptr[i] = static_cast<const uint8_t*>(p);
             fb.f[f].stride[i] = static_cast<uint32_t>(stride);
         }
-    if (pano_stride < static_cast<size_t>(st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
+    // (an engine that composes one column strip only needs rows that reach from the strip's first to its last column)
+    const int strip_w = std::min(st->strip_x1, st->out_w) - std::min(st->strip_x0, st->out_w);
+    if (pano_stride < static_cast<size_t>(cfg_.strip_count > 1 ? strip_w : st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
     if (pano_stride >= (size_t{1} << 24) || mask_stride >= (size_t{1} << 24))
         throw Error{MST_ERR_INVALID_ARG, "panorama and mask strides must be below 16 MiB"};
     if (d_masks && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
@@ -1043,7 +1067,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         ba.mask_stride = static_cast<uint32_t>(mask_stride);
         if (!st->c1.empty())
             for (int f = 0; f < count; ++f) ba.c1[f] = st->c1[first_set + f];
-        const int n_fine = st->plan.blend_tiles_x * st->plan.blend_tiles_y;
+        const int n_fine = static_cast<int>(st->plan.block_order.size());
         if (ba.nlev > 1) {
             launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 1);
             mark("k_blend_coarse");
@@ -1182,7 +1206,7 @@ void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t
     ba.pano_mask[0] = static_cast<uint8_t*>(d_mask); ba.mask_stride = static_cast<uint32_t>(mask_stride);
     if (stage_set_ >= st->num_sets) throw Error{MST_ERR_INVALID_ARG, "stage set beyond mst_config.max_batch"};
     if (!st->c1.empty()) ba.c1[0] = st->c1[stage_set_];
-    launch_blend(st->d_desc + static_cast<size_t>(stage_set_) * st->n, ba, st->plan.blend_tiles_x * st->plan.blend_tiles_y,
+    launch_blend(st->d_desc + static_cast<size_t>(stage_set_) * st->n, ba, static_cast<int>(st->plan.block_order.size()),
                  n_coarse, 1, lds_bytes, s);
     check_hip(hipGetLastError(), "canvas stage kernel");
     set_in_flight(std::move(st));

@@ -129,6 +129,7 @@ struct CalibState {
     size_t compose_lds_bytes = 0;
     // output rectangle (== canvas unless the driver LUT crop is active)
     int crop_x = 0, crop_y = 0, out_w = 0, out_h = 0;
+    int strip_x0 = 0, strip_x1 = 0;     // the output columns this engine writes (canvas split over GPUs), output coordinates
     uint64_t generation = 0;            // 1, 2, ... in mst_update order (mst_acquire_calibration)
     ~CalibState();
 };
@@ -192,6 +193,7 @@ private:
     void compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
                           void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
                           hipStream_t stream, StageTimer* timer);
+    void strip_columns(int width, int* x0, int* x1) const;
     void launch_undistort(const CalibState& st, const FrameBatch& src, const FrameBatch& dst, int count, uint32_t camera_mask, hipStream_t s);
     void launch_warp(const CalibState& st, const CamDesc* desc, const FrameBatch& fb, int count, int cam0, int cam1, hipStream_t s);
     void build_compose_plan(CalibState& st, hipStream_t s);     // mst_update, blend kinds NO and FEATHER

@@ -209,7 +209,7 @@ void mark_footprint(const std::vector<uint8_t>& coarse, int cw, int ch, std::vec
 
 
 void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<uint8_t>>>& weight_class,
-                   const BlendArgs& blend, bool keep_level0, MbPlanHost& plan)
+                   const BlendArgs& blend, bool keep_level0, MbPlanHost& plan, int strip_x0, int strip_x1)
 {
     const int n = static_cast<int>(desc.size());
     const int nlev = blend.nlev, nb = nlev - 1;
@@ -226,6 +226,19 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
     };
     plan = MbPlanHost{};
     plan.cams.resize(n);
+    // Canvas split over GPUs: the canvas columns of every level that the strip's panorama columns can depend on --
+    // level l + 1 from level l by the pyrUp reach the canvas kernels use for their tiles (blend_region).  Weights
+    // outside count as zero below; nothing else changes: the lists then hold exactly the work the strip needs, and
+    // inside these ranges every value is the one the whole-canvas run computes.
+    strip_x0 = std::max(0, strip_x0);
+    strip_x1 = std::min(blend.cw[0], strip_x1);
+    const bool striped = strip_x0 > 0 || strip_x1 < blend.cw[0];
+    std::vector<int> sx0(nlev, 0), sx1(nlev, 0);
+    sx0[0] = strip_x0; sx1[0] = strip_x1;
+    for (int l = 1; l < nlev; ++l) {
+        sx0[l] = std::max(0, ((sx0[l - 1] >> 1) - 1) & ~1);
+        sx1[l] = std::min(blend.cw[l], (((sx1[l - 1] - 1) >> 1) + 3) & ~1);
+    }
     parallel_for(n, 16, [&](int c) {
         const CamDesc& d = desc[c];
         MbCameraNeed& cn = plan.cams[c];
@@ -241,6 +254,14 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                 const size_t i0 = static_cast<size_t>(k) << 18, i1 = std::min(px, i0 + (size_t{1} << 18));
                 for (size_t i = i0; i < i1; ++i) o[i] = w[i] & 1u;
             });
+            if (striped) {
+                const int lo = std::max(0, std::min(d.lw[l], sx0[l] - d.ox[l])), hi = std::max(lo, std::min(d.lw[l], sx1[l] - d.ox[l]));
+                for (int y = 0; y < d.lh[l]; ++y) {
+                    uint8_t* row = o + static_cast<size_t>(y) * d.lw[l];
+                    std::memset(row, 0, lo);
+                    std::memset(row + hi, 0, d.lw[l] - hi);
+                }
+            }
         }
         for (int l = nb; l >= 0; --l) {
             cn.need[l] = cn.nz[l];
@@ -448,6 +469,14 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
         const int nc = __builtin_popcount(e & 0x3FFFFFFFu);
         return (e >> 30) ? 4 + 2 * nc : 10 + 2 * nc;
     });
+    if (striped) {            // only the strip's panorama tiles are written
+        std::vector<uint32_t> kept;
+        for (uint32_t tile : plan.block_order) {
+            const int x = static_cast<int>(tile % plan.blend_tiles_x) * c_tw;
+            if (x < strip_x1 && x + c_tw > strip_x0) kept.push_back(tile);
+        }
+        plan.block_order.swap(kept);
+    }
     // Level-1 tiles, once per tile height the launcher may pick (MbPlanHost::coarse).  Levels on which the tile's region
     // (tile + pyrUp halo) is owned by ONE camera with a weight of exactly 1.0f everywhere and no other camera has a
     // non-zero weight there go down the integer path as well; a tile whose levels are all owned by the same camera
@@ -501,6 +530,14 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
             const bool l1_owned = ct.pure[tile] & 2u;               // float bands on some coarser levels only
             return (l1_owned ? 6 : 10) + 2 * __builtin_popcount(e);
         });
+        if (striped) {        // only the level-1 tiles the strip's panorama tiles read
+            std::vector<uint32_t> kept;
+            for (uint32_t tile : ct.order) {
+                const int x = static_cast<int>(tile % ct.tiles_x) * cc_tw;
+                if (x < sx1[1] && x + cc_tw > sx0[1]) kept.push_back(tile);
+            }
+            ct.order.swap(kept);
+        }
         int off = 0;
         for (int l = 2; l < nlev; ++l) {
             ct.lds_off[l] = off;

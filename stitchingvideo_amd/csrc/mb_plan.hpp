@@ -59,7 +59,9 @@ struct MbPlanHost {
 // device (k_weight_class), so that the plan never needs the float pyramids on the host.  `blend` must have
 // nlev/cw/ch/final_w/final_h filled in.  keep_level0 (MST_FLAG_DEBUG): store the warped level 0 of every launched tile,
 // also of those no panorama pixel reads it from (mst_debug_read then shows all of it).
+// strip_x0 / strip_x1: the columns [x0, x1) of the (padded) canvas this engine composes (canvas split over GPUs); every
+// list is restricted to what those panorama columns can depend on.  0 / cw[0]: everything.
 void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<uint8_t>>>& weight_class,
-                   const BlendArgs& blend, bool keep_level0, MbPlanHost& plan);
+                   const BlendArgs& blend, bool keep_level0, MbPlanHost& plan, int strip_x0 = 0, int strip_x1 = 1 << 30);
 
 }  // namespace mst

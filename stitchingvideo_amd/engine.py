@@ -265,7 +265,7 @@ class PanoramaEngine:
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
                  feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False,
-                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None):
+                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -285,6 +285,8 @@ class PanoramaEngine:
         if warp_ab is not None:          # CompressedRectilinear* / Panini* with arbitrary (A, B)
             cfg.warp_kind = (cfg.warp_kind & 0xFF) | capi.WARP_AB_CUSTOM
             cfg.warp_a, cfg.warp_b = float(warp_ab[0]), float(warp_ab[1])
+        if strip is not None:            # (index, count): this engine composes one column strip of the canvas (canvas split over GPUs)
+            cfg.strip_index, cfg.strip_count = int(strip[0]), int(strip[1])
         self.num_cameras = num_cameras
         self.device = device
         capi.check(self._L.mst_create(C.byref(cfg), C.byref(self._h)))
@@ -358,6 +360,12 @@ class PanoramaEngine:
     def canvas(self):
         r = capi.Rect()
         self._check(self._L.mst_canvas(self._h, C.byref(r)))
+        return r.tuple()
+
+    def strip(self):
+        """The columns this engine writes, as a rectangle inside canvas() (the whole canvas without strip=...)."""
+        r = capi.Rect()
+        self._check(self._L.mst_strip(self._h, C.byref(r)))
         return r.tuple()
 
     def camera_roi(self, i):

@@ -8,7 +8,11 @@ The per-frame path shards over independent units with no data-path collective:
   streams -- camera i belongs to rank i % world; used by the camera-sharded mode,
              where the owner of the canvas gathers the other ranks' contributions once per frame.
 
-Only timing/bookkeeping values cross ranks here (a MAX all-reduce of the elapsed time).
+  strips  -- the CANVAS is cut into `world` column strips (second form): rank r composes strip r from
+             the cameras that reach it (every kernel of the path restricted to what the strip depends on, bit-exact),
+             and the strips are concatenated -- on the root by one grouped point-to-point step, or left where they are.
+
+Only timing/bookkeeping values cross ranks here (a MAX all-reduce of the elapsed time) besides those exchanges.
 """
 import torch
 import torch.distributed as dist
@@ -221,3 +225,103 @@ def copy_payload(src_engine, dst_engine, cameras, device, stream=None):
         dst_engine.payload_unpack(c, buf.data_ptr(), stream=stream)
         moved += nbytes
     return moved
+
+
+# ---- canvas split into column strips (mst_config.strip_index / strip_count) -------------------------------------
+
+def strip_columns(width, index, count):
+    """Columns [x0, x1) of strip `index` of `count` in a canvas `width` columns wide: the host-side mirror of
+    Engine::strip_columns (equal shares, boundaries on multiples of 256 columns, the last strip takes the rest).
+    For the multi-band blend `width` is the PADDED canvas width (a multiple of 2^bands); the written columns are
+    the intersection with the final canvas (mst_strip / PanoramaEngine.strip())."""
+    if count <= 1:
+        return 0, width
+
+    def bound(i):
+        if i >= count:
+            return width
+        return min(width, (i * width // count + 255) // 256 * 256)
+    x0 = bound(index)
+    return x0, max(x0, bound(index + 1))
+
+
+def gather_strips_to_root(strip, rects, root, rank, pano=None):
+    """One exchange step of the strip-sharded mode: every rank != root sends its strip (a CONTIGUOUS (H, w_r, 3) uint8
+    tensor) to the root, which drops all strips into `pano` ((H, W, 3), its own strip included).  rects[r] = (x, w) of
+    rank r's strip inside the panorama -- static per calibration and known to every rank (strip_columns), so no sizes
+    travel.  All transfers go out as ONE batch_isend_irecv (ncclGroupStart/End on RCCL: every peer uses its own xGMI
+    link to the root).  Returns `pano` on the root, None elsewhere."""
+    world = len(rects)
+    if rank != root:
+        if rects[rank][1] > 0:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, strip, root, tag=100 + rank)]):
+                w.wait()
+        return None
+    ops, bufs = [], {}
+    for r in range(world):
+        x, w = rects[r]
+        if r == root or w <= 0:
+            continue
+        bufs[r] = torch.empty((pano.shape[0], w, 3), dtype=torch.uint8, device=pano.device)
+        ops.append(dist.P2POp(dist.irecv, bufs[r], r, tag=100 + r))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    x, w = rects[root]
+    if w > 0:
+        pano[:, x:x + w] = strip
+    for wk in works:
+        wk.wait()
+    for r, b in bufs.items():
+        x, w = rects[r]
+        pano[:, x:x + w] = b
+    return pano
+
+
+class StripStitcher:
+    """Canvas strips sharded one-per-rank.  Every rank creates its PanoramaEngine with strip=(rank, world), publishes
+    the same calibration and holds the frames of the cameras that reach its strip (here: all of them -- the capture
+    side delivers a camera's stream to the one or two GPUs whose strips it touches).  compose() runs this rank's
+    launch sequence into a strip-sized buffer; gather() concatenates the strips on the root."""
+
+    def __init__(self, engine, rank, world, root=0, device=None):
+        self.engine, self.rank, self.world, self.root, self.device = engine, rank, world, root, device
+        self.generation = None
+
+    def refresh(self):
+        (cx, cy, cw, ch), gen = self.engine.acquire()
+        if gen != self.generation:
+            sx, sy, sw, sh = self.engine.strip()
+            self.canvas = (cw, ch)
+            self.x0, self.w = sx - cx, sw
+            # rank r's strip, from the same arithmetic every rank runs: (x, w) inside the final canvas
+            self.rects = None
+            self.strip_buf = torch.empty((ch, max(sw, 1), 3), dtype=torch.uint8, device=self.device)
+            self.generation = gen
+        return gen
+
+    def set_rects(self, rects):
+        """rects[r] = (x, w) of every rank's strip (each rank can compute them from the padded canvas width; the
+        multi-band engine reports its own through strip(), so the simplest is one all-gather per calibration)."""
+        self.rects = list(rects)
+
+    def exchange_rects(self):
+        mine = torch.tensor([self.x0, self.w], dtype=torch.int64, device=self.device if dist.get_backend() == "nccl" else None)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine)
+        self.rects = [(int(t[0]), int(t[1])) for t in out]
+
+    def compose(self, frame_ptrs, frame_strides, stream=None):
+        """This rank's strip of one panorama into self.strip_buf ((H, w, 3), contiguous)."""
+        if self.generation is None:
+            self.refresh()
+        if self.w <= 0:
+            return self.strip_buf
+        # the engine addresses the panorama from canvas column 0: hand it the strip buffer shifted left by the strip's origin
+        self.engine.compose_device(frame_ptrs, frame_strides, self.strip_buf.data_ptr() - self.x0 * 3, self.strip_buf.stride(0),
+                                   stream=stream)
+        return self.strip_buf
+
+    def gather(self, pano=None):
+        if self.rects is None:
+            self.exchange_rects()
+        return gather_strips_to_root(self.strip_buf[:, :max(self.w, 0)].contiguous() if self.w != self.strip_buf.shape[1] else self.strip_buf,
+                                     self.rects, self.root, self.rank, pano)

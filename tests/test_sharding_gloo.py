@@ -137,3 +137,68 @@ def test_gloo_world2_ragged_payload_blends_to_the_oracle_panorama():
         p.join(timeout=60)
     assert all(ok is True for _, ok in res), res
     assert all(p.exitcode == 0 for p in procs)
+
+
+# ---- canvas strips: ragged column strips of the oracle's panorama, concatenated on the root --------------------
+def test_strip_columns_partition_the_canvas():
+    for width in (256, 1000, 3259, 7872, 11328, 15712):
+        for count in (1, 2, 3, 4, 8):
+            xs = [sh.strip_columns(width, k, count) for k in range(count)]
+            assert xs[0][0] == 0 and xs[-1][1] == width
+            assert all(a[1] == b[0] for a, b in zip(xs, xs[1:]))                    # no gap, no overlap
+            assert all(x0 % 256 == 0 or x0 == width for x0, _ in xs)          # (x0 == width: an empty strip of a narrow canvas)
+            assert all(x1 >= x0 for x0, x1 in xs)
+
+
+def _strip_worker(rank, world, port, q):
+    """Every rank holds its column strip of the panorama (here cut from the oracle's; on the GPU box a
+    PanoramaEngine(strip=(rank, world)) composes exactly these columns -- tests/test_gpu_strips.py), the strips go to
+    rank 0 through the same gather_strips_to_root() the GPU path uses, and rank 0 must hold the whole panorama."""
+    import sys
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import helpers as H
+        from stitchingvideo_amd import rig as rigmod
+        rig = rigmod.build_rig(rigmod.scaled_config("C3", 6))
+        frames = rigmod.frames_for(rig, 1)
+        rect, opano, _ = H.oracle_compose(rig, frames, num_bands=3)
+        cw, ch = rect[2], rect[3]
+        padded = (cw + 7) // 8 * 8                                    # 3 bands: the canvas padded to a multiple of 8
+        rects = []
+        for r in range(world):
+            x0, x1 = sh.strip_columns(padded, r, world)
+            rects.append((min(x0, cw), min(x1, cw) - min(x0, cw)))
+        x, w = rects[rank]
+        mine = torch.from_numpy(np.ascontiguousarray(opano[:, x:x + w]))
+        pano = torch.zeros((ch, cw, 3), dtype=torch.uint8) if rank == 0 else None
+        out = sh.gather_strips_to_root(mine, rects, 0, rank, pano)
+        ok = True
+        if rank == 0:
+            ok = bool(np.array_equal(out.numpy(), opano)) and len({w for _, w in rects}) > 1      # ragged strips
+        else:
+            ok = out is None
+        dist.barrier()
+        q.put((rank, ok))
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, "%s: %s" % (type(e).__name__, e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_strips_concatenate_to_the_oracle_panorama():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok is True for _, ok in res), res
+    assert all(p.exitcode == 0 for p in procs)
