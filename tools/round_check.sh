@@ -1,23 +1,30 @@
-# Round-end check on the GPU box (via gpurun): the -m gpu suite, the rocprofv3 passes behind profiles/
-# (tools/profile_gpu.sh; its traffic.json is put in place first so that the bench lines of the same box carry it),
-# bench.py (default, --batch 1, --undistort) and mst_update timing.  Outputs under gpurun_out/round and gpurun_out/prof_r02;
-# copy what should be judged into profiles/.
+# Round-end run on the GPU box (via gpurun): the -m gpu suite, the rocprofv3 passes behind profiles/ for every
+# single-GPU workload (C3 at 8 and at 1 frame set per launch through bench.py; C2, C5, C3-LUT, C5-LUT through
+# tools/bench_paths.py), their merged traffic.json (put in place before the bench lines of the same box are taken, so
+# that those carry it), bench.py (default, --batch 1, --undistort) and mst_update timing.  Outputs under
+# gpurun_out/round and gpurun_out/prof_<tag>; copy what should be judged into profiles/ (tools/collect_profiles.sh).
 cd $GRAFT_REPO_ROOT
+TAG=${1:-r03}
 mkdir -p gpurun_out/round
 (time python -m pytest tests -m gpu -x -q) > gpurun_out/round/pytest.log 2>&1
 tail -3 gpurun_out/round/pytest.log
-bash tools/profile_gpu.sh r02 > gpurun_out/round/profile.log 2>&1
-tail -3 gpurun_out/round/profile.log
-bash tools/profile_gpu.sh r02b1 quick --batch 1 > gpurun_out/round/profile_b1.log 2>&1
-cp gpurun_out/prof_r02/traffic.json profiles/traffic.json
+rm -f gpurun_out/traffic.json
+bash tools/profile_gpu.sh ${TAG}_c3 > gpurun_out/round/profile_c3.log 2>&1
+bash tools/profile_gpu.sh ${TAG}_c3_b1 quick --batch 1 > gpurun_out/round/profile_c3_b1.log 2>&1
+for p in C2 C5 C3-LUT C5-LUT; do
+  bash tools/prof_paths.sh ${TAG}_$p $p > gpurun_out/round/profile_$p.log 2>&1
+done
+cp gpurun_out/traffic.json profiles/traffic.json
 python bench.py > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err
 python -c "
 import json; d=json.load(open('gpurun_out/round/bench.json'))
-print(d['value'], d['roofline']['frac'], d['roofline']['traffic'], [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']], d.get('latency_mode'), d.get('overlapped'), d.get('host_buffers'), d.get('cpu_baseline'))"
-python bench.py --batch 1 --no-cpu-baseline > gpurun_out/round/bench_batch1.json 2>/dev/null
-python bench.py --undistort --no-cpu-baseline --no-latency-leg > gpurun_out/round/bench_undistort.json 2>/dev/null
+print(d['value'], d['roofline']['frac'], d['roofline']['traffic'], [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']], d.get('latency_mode'), d.get('overlapped'), d.get('host_buffers'), d.get('cpu_baseline'))
+for k,v in d.get('configs',{}).items(): print(k, v.get('frames_per_s'), v.get('roofline_frac'), v.get('traffic'), v.get('latency_mode',{}).get('roofline_frac'))"
+python bench.py --batch 1 --no-cpu-baseline --no-configs > gpurun_out/round/bench_batch1.json 2>/dev/null
+python bench.py --undistort --no-cpu-baseline --no-configs --no-latency-leg > gpurun_out/round/bench_undistort.json 2>/dev/null
 python -c "
 import json
 for f in ('bench_batch1','bench_undistort'):
     d=json.load(open('gpurun_out/round/%s.json'%f)); print(f, d['value'], [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']])"
+python tools/strip_model.py > gpurun_out/round/strip_model.jsonl 2>/dev/null
 python tools/time_update.py 2>&1 | tail -4
