@@ -329,9 +329,23 @@ int  mst_exposure_apply(int device, int expos_kind, uint8_t *image, int width, i
 /* VoronoiSeamFinder::find (--seam voronoi, CLI:106; seam_finders.cpp:74-85,108-160) on the device: for every
  * overlapping pair i < j, in order, the overlap pixels go to the image whose un-contested region is nearer in the L1
  * metric.  masks[i]: CV_8U of sizes_wh[2i] x sizes_wh[2i+1] at corner corners_xy[2i..] (host memory), updated in
- * place.  (The graph-cut and dynamic-programming seam finders stay on the host: out of scope) */
+ * place.  (The graph-cut seam finder stays on the host: out of scope) */
 int  mst_seam_voronoi(int device, int num_images, const int32_t *corners_xy, const int32_t *sizes_wh,
                       uint8_t *const *masks, const size_t *mask_strides);
+/* DpSeamFinder::find (--seam dp_color / dp_colorgrad, CLI:627-630; seam_finders.cpp:163-1045): every pair of images,
+ * farthest centres first; per pair the connected components of "first only / second only / both", the conflicts between
+ * neighbouring components resolved by a minimum-cost seam (dynamic programming over the colour difference, optionally
+ * divided by the gradient magnitude) between the two most distant contact points.  images[i]: CV_8UC3 or CV_32FC3 (the
+ * sample feeds CV_32F, CLI:488-489) of sizes_wh[2i] x sizes_wh[2i+1] at corners_xy[2i..]; masks[i]: CV_8U, updated in
+ * place.  The per-pixel passes (contour masks, gradients, cost maps, the DP recurrence, the mask update) run on the device;
+ * the component bookkeeping, whose order is the result, on the host. */
+#define MST_IMAGE_8UC3   0
+#define MST_IMAGE_32FC3  1
+#define MST_SEAM_DP_COLOR       0
+#define MST_SEAM_DP_COLOR_GRAD  1
+int  mst_seam_dp(int device, int num_images, const int32_t *corners_xy, const int32_t *sizes_wh, const void *const *images,
+                 const size_t *image_strides, int image_type, uint8_t *const *masks, const size_t *mask_strides,
+                 int cost_function);
 /* ExposureCompensator::feed -- the calibration-side half (exposure_compensate.cpp:63-147, 165-222; the driver's
  * BlockFeed, DRV:251-306): gains from the overlaps of the seam-scale warped images.  images[i]: CV_8UC3 of
  * sizes_wh[2i] x sizes_wh[2i+1] at canvas corner corners_xy[2i..]; masks[i]: CV_8U, 255 = valid.

@@ -154,6 +154,10 @@ void mo_mask_fixup(const uint8_t *seam_mask, int sw, int sh, const uint8_t *mask
 
 /* ---- VoronoiSeamFinder (seam_finders.cpp:74-85, 108-160): masks tightly packed, updated in place ---- */
 void mo_voronoi_seams(int n, const int *corners_xy, const int *sizes_wh, uint8_t *const *masks);
+/* ---- DpSeamFinder (seam_finders.cpp:163-1045): images CV_32FC3 (is_float) or CV_8UC3, BGR, tight; cost_func 0 = COLOR,
+ * 1 = COLOR_GRAD; masks tightly packed, updated in place ---- */
+void mo_dp_seams(int n, const int *corners_xy, const int *sizes_wh, const void *const *images, int is_float, int cost_func,
+                 uint8_t *const *masks);
 
 /* ---- util (a10) -------------------------------------------------------------- */
 mo_rect mo_result_roi(const int *corners_xy, const int *sizes_wh, int n);

@@ -5,7 +5,7 @@ include/mi355_stitch.h); this package is the thin host-side mirror of the refere
 warper / exposure-compensator / frame-loop interfaces plus the synthetic-rig input producers.
 """
 from . import _capi as capi  # noqa: F401
-from .engine import (PinnedArray, VoronoiSeamFinder, BlocksGainCompensator, CylindricalWarper, GainCompensator, PanoramaEngine,  # noqa: F401
+from .engine import (PinnedArray, VoronoiSeamFinder, DpSeamFinder, BlocksGainCompensator, CylindricalWarper, GainCompensator, PanoramaEngine,  # noqa: F401
                      PlaneWarper, RotationWarper, SphericalWarper, init_undistort_rectify_map, multiband_geometry,
                      remap_fixed, synth_frame)
 

@@ -48,7 +48,7 @@ EXPORTS = [
     "mst_payload_bytes", "mst_payload_pack", "mst_payload_unpack", "mst_stage_select_set",
     "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
     "mst_init_undistort_rectify_map", "mst_remap_fixed",
-    "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame", "mst_gain_map_size", "mst_exposure_feed", "mst_seam_voronoi",
+    "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame", "mst_gain_map_size", "mst_exposure_feed", "mst_seam_voronoi", "mst_seam_dp",
 ]
 
 
@@ -192,6 +192,9 @@ def load():
     L.mst_exposure_apply.restype = C.c_int
     L.mst_exposure_apply.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_int,
                                      C.c_int, C.c_float]
+    L.mst_seam_dp.restype = C.c_int
+    L.mst_seam_dp.argtypes = [C.c_int, C.c_int, ip, ip, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int, C.POINTER(vp),
+                              C.POINTER(C.c_size_t), C.c_int]
     L.mst_seam_voronoi.restype = C.c_int
     L.mst_seam_voronoi.argtypes = [C.c_int, C.c_int, ip, ip, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.mst_gain_map_size.restype = C.c_int

@@ -543,6 +543,19 @@ int mst_seam_voronoi(int device, int num_images, const int32_t* corners_xy, cons
     });
 }
 
+int mst_seam_dp(int device, int num_images, const int32_t* corners_xy, const int32_t* sizes_wh, const void* const* images,
+                const size_t* image_strides, int image_type, uint8_t* const* masks, const size_t* mask_strides, int cost_function)
+{
+    return guarded(nullptr, [&] {
+        require(num_images >= 1 && num_images <= MST_MAX_CAMERAS, "num_images out of range");
+        require(corners_xy && sizes_wh && images && image_strides && masks && mask_strides, "null argument");
+        require(image_type == MST_IMAGE_8UC3 || image_type == MST_IMAGE_32FC3, "images must be CV_8UC3 or CV_32FC3 (seam_finders.cpp:709-720)");
+        require(cost_function == MST_SEAM_DP_COLOR || cost_function == MST_SEAM_DP_COLOR_GRAD, "unknown cost function");
+        mst::dp_seams(device, num_images, corners_xy, sizes_wh, images, image_strides, image_type == MST_IMAGE_32FC3 ? 1 : 0, masks,
+                      mask_strides, cost_function);
+    });
+}
+
 int mst_gain_map_size(int image_width, int image_height, int block_width, int block_height, int* gain_w, int* gain_h)
 {
     return guarded(nullptr, [&] {

@@ -257,6 +257,10 @@ void exposure_feed(int device, int expos_kind, int n, const int32_t* corners_xy,
 void voronoi_seams(int device, int n, const int32_t* corners_xy, const int32_t* sizes_wh, uint8_t* const* masks,
                    const size_t* mask_strides);
 
+// DpSeamFinder::find (dp_seam.hip): images CV_8UC3 or CV_32FC3 (host), masks (host, CV_8U) updated in place; cost_func 0 COLOR, 1 COLOR_GRAD
+void dp_seams(int device, int n, const int32_t* corners_xy, const int32_t* sizes_wh, const void* const* images, const size_t* image_strides,
+              int image_is_f32, uint8_t* const* masks, const size_t* mask_strides, int cost_func);
+
 void check_hip(hipError_t e, const char* what);
 void select_device(int device);
 

@@ -123,6 +123,31 @@ class VoronoiSeamFinder:
         capi.check(capi.load().mst_seam_voronoi(self.device, n, cxy, swh, mp, mstr))
 
 
+class DpSeamFinder:
+    """cv::detail::DpSeamFinder (seam_finders.hpp:95-178): find(src, corners, masks) updates the masks in place.
+    cost: "color" (DpSeamFinder::COLOR, --seam dp_color) or "color_grad" (--seam dp_colorgrad).  src: CV_8UC3 or CV_32FC3."""
+
+    def __init__(self, cost="color", device=0):
+        self.cost = {"color": 0, "color_grad": 1}[cost]
+        self.device = device
+
+    def find(self, src, corners, masks):
+        n = len(masks)
+        is_f32 = src[0].dtype != np.uint8
+        imgs = [np.ascontiguousarray(im, np.float32 if is_f32 else np.uint8) for im in src]
+        for im, m in zip(imgs, masks):
+            if im.ndim != 3 or im.shape[2] != 3 or m.dtype != np.uint8 or m.shape != im.shape[:2] or not m.flags.c_contiguous or \
+                    not m.flags.writeable:
+                raise capi.StitchError(capi.ERR_INVALID_ARG, "src must be CV_8UC3 / CV_32FC3, masks writable C-contiguous CV_8U of the same sizes")
+        cxy = (C.c_int * (2 * n))(*[int(v) for p in corners for v in p])
+        swh = (C.c_int * (2 * n))(*[v for im in imgs for v in (im.shape[1], im.shape[0])])
+        ip = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        istr = (C.c_size_t * n)(*[im.strides[0] for im in imgs])
+        mp = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
+        mstr = (C.c_size_t * n)(*[m.strides[0] for m in masks])
+        capi.check(capi.load().mst_seam_dp(self.device, n, cxy, swh, ip, istr, 1 if is_f32 else 0, mp, mstr, self.cost))
+
+
 def _feed(device, kind, corners, images, masks, block=(32, 32)):
     """ExposureCompensator::feed (exposure_compensate.cpp:63-147,165-222) -> gains (list) or gain maps (list of arrays)."""
     n = len(images)

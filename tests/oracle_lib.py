@@ -333,6 +333,20 @@ def voronoi_seams(corners, masks):
     return out
 
 
+def dp_seams(corners, images, masks, cost="color"):
+    """DpSeamFinder(COLOR | COLOR_GRAD)::find -> new list of masks.  images: CV_32FC3 or CV_8UC3 (h, w, 3) arrays."""
+    n = len(masks)
+    out = [np.ascontiguousarray(m, np.uint8).copy() for m in masks]
+    is_float = images[0].dtype != np.uint8
+    imgs = [np.ascontiguousarray(im, np.float32 if is_float else np.uint8) for im in images]
+    cxy = (C.c_int * (2 * n))(*[int(v) for p in corners for v in p])
+    swh = (C.c_int * (2 * n))(*[v for m in out for v in (m.shape[1], m.shape[0])])
+    ip = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+    mp = (C.c_void_p * n)(*[m.ctypes.data for m in out])
+    lib().mo_dp_seams(n, cxy, swh, ip, 1 if is_float else 0, {"color": 0, "color_grad": 1}[cost], mp)
+    return out
+
+
 def dilate3x3(mask):
     mask = np.ascontiguousarray(mask, np.uint8)
     dst = np.empty_like(mask)

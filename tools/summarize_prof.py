@@ -80,10 +80,16 @@ if len(sys.argv) > 2 and counters:
         workload = m.group(1)
     if "--undistort" in cmd:
         workload += "+undistort"
+    # per-frame kernels of every path (calibration kernels -- tables, weight pyramids -- run per mst_update and drop out);
+    # launches per sequence come from the run itself
+    per_frame = {"k_warp_pyr", "k_warp_pyr_lds", "k_pyr_chain", "k_blend_coarse", "k_blend_fine", "k_compose", "k_compose_lds",
+                 "k_compose_general", "k_remap_fixed"}
     frame_kernels = {k: d for k, d in counters.items()
-                     if k.startswith("k_") and "FETCH_SIZE" in d and "WRITE_SIZE" in d and len(d["FETCH_SIZE"]) >= 4}
+                     if k.split("<")[0] in per_frame and "FETCH_SIZE" in d and "WRITE_SIZE" in d}
     if frame_kernels:
-        n_seq = min(len(d["FETCH_SIZE"]) for d in frame_kernels.values())
+        # a sequence launches most kernels once; short side lists (gathered / general tiles) ride along at the same count
+        counts = sorted(len(d["FETCH_SIZE"]) for d in frame_kernels.values())
+        n_seq = counts[0]
         per = {}
         for k, d in frame_kernels.items():
             f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]) * 2 * 1024      # gfx950: FETCH_SIZE counts half of a wide read
