@@ -282,3 +282,41 @@ def test_voronoi_seams_two_restatements_agree():
         open_rig, cut_rig = rigmod.build_rig(cfg, seams=False), rigmod.build_rig(cfg, seams=True)
         got = O.voronoi_seams(open_rig["corners"], [c["mask"] for c in open_rig["cameras"]])
         assert all(np.array_equal(a, c["mask"]) for a, c in zip(got, cut_rig["cameras"]))
+
+
+def test_dp_seam_finder_properties_and_two_rectangle_case():
+    """DpSeamFinder restatement (oracle/dpseam.c).  No reference-held vector exists for it (parity unpinned); what is
+    pinned here: it resolves every overlap (no pixel kept by two cameras, none dropped that a camera covered), it is
+    deterministic, its two cost functions differ, and the hand-traced case of two side-by-side rectangles: the seam
+    between the intersection and the FIRST-only component starts and ends where the two image contours cross (the
+    intersection's left corners), hugs that side, and the intersection then goes to the second image as a whole
+    (states INTERS -> INTERS_SECOND, seam_finders.cpp:443)."""
+    rig = rigmod.build_rig(rigmod.scaled_config("C3", 8), seams=False)
+    frames = rigmod.frames_for(rig, 0)
+    import helpers as H
+    imgs, masks = [], []
+    for c, f in zip(rig["cameras"], frames):
+        _, w = O.warp(H.WARP_O[rig["warp"]], rig["scale"], c["K"], c["R"], f, O.INTER_LINEAR, O.BORDER_REFLECT)
+        imgs.append(w.astype(np.float32))
+        masks.append(c["mask"].copy())
+    a = O.dp_seams(rig["corners"], imgs, masks, "color")
+    b = O.dp_seams(rig["corners"], imgs, masks, "color")
+    g = O.dp_seams(rig["corners"], imgs, masks, "color_grad")
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert any(not np.array_equal(x, y) for x, y in zip(a, g))
+    cx, cy = min(c[0] for c in rig["corners"]), min(c[1] for c in rig["corners"])
+    W = max(c[0] + m.shape[1] for c, m in zip(rig["corners"], a)) - cx
+    Hh = max(c[1] + m.shape[0] for c, m in zip(rig["corners"], a)) - cy
+    for out in (a, g):
+        cover, cover0 = np.zeros((Hh, W), np.int32), np.zeros((Hh, W), np.int32)
+        for (x, y), m, m0 in zip(rig["corners"], out, masks):
+            cover[y - cy:y - cy + m.shape[0], x - cx:x - cx + m.shape[1]] += (m != 0)
+            cover0[y - cy:y - cy + m.shape[0], x - cx:x - cx + m.shape[1]] += (m0 != 0)
+        assert cover0.max() == 2 and cover.max() == 1
+        assert not ((cover == 0) & (cover0 > 0)).any()
+    # two rectangles, 12 columns of overlap
+    h, w, ov = 20, 30, 12
+    im1, im2 = np.full((h, w, 3), 100, np.float32), np.full((h, w, 3), 200, np.float32)
+    m1, m2 = np.full((h, w), 255, np.uint8), np.full((h, w), 255, np.uint8)
+    o1, o2 = O.dp_seams([(0, 0), (w - ov, 0)], [im1, im2], [m1, m2], "color")
+    assert (o1[:, :w - ov] == 255).all() and (o1[:, w - ov:] == 0).all() and (o2 == 255).all()
