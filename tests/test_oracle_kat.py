@@ -291,9 +291,10 @@ def test_dp_seam_finder_properties_and_two_rectangle_case():
     between the intersection and the FIRST-only component starts and ends where the two image contours cross (the
     intersection's left corners), hugs that side, and the intersection then goes to the second image as a whole
     (states INTERS -> INTERS_SECOND, seam_finders.cpp:443)."""
+    from stitchingvideo_amd import rig as rigmod
+    import helpers as H
     rig = rigmod.build_rig(rigmod.scaled_config("C3", 8), seams=False)
     frames = rigmod.frames_for(rig, 0)
-    import helpers as H
     imgs, masks = [], []
     for c, f in zip(rig["cameras"], frames):
         _, w = O.warp(H.WARP_O[rig["warp"]], rig["scale"], c["K"], c["R"], f, O.INTER_LINEAR, O.BORDER_REFLECT)
