@@ -670,37 +670,53 @@ void Engine::update(const mst_calibration& calib)
             st->warp_table_lds = st->pool.alloc<uint32_t>(std::max<size_t>(nt * px, 4));
             st->warp_gain_lds = st->pool.alloc<float>(std::max<size_t>(nt * px, 4));
             st->warp_wins = st->pool.alloc<WarpWin>(std::max(nt, 1));
-            static const int budget_px = [] { const char* v = std::getenv("MST_WARP_LDS_KB"); return v ? std::atoi(v) * 256 : kCompLdsPx; }();
+            // window size classes of the staged launches, in KB of LDS (one launch per class: a launch's LDS size is uniform, and
+            // the blocks per CU follow from it); tiles past the last class stay with the gathering kernel
+            static const std::vector<int> classes_kb = [] {
+                std::vector<int> v;
+                const char* e = std::getenv("MST_WARP_LDS_CLASSES");
+                for (const char* p = e ? e : "40"; *p;) { v.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+                return v;
+            }();
+            const int budget_px = classes_kb.back() * 256;
             launch_warp_table_lds(st->d_desc, cfg_.warp_kind & 0xFF, st->warp_list, st->warp_table_lds, st->warp_gain_lds, st->warp_wins,
                                   budget_px, s);
             check_hip(hipGetLastError(), "k_warp_table_lds");
             std::vector<WarpWin> wins(std::max(nt, 1));
             if (nt) check_hip(hipMemcpyAsync(wins.data(), st->warp_wins, nt * sizeof(WarpWin), hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H windows)");
             check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(windows)");
-            std::vector<uint32_t> staged, gathered;
-            st->warp_staged_start.assign(n + 1, 0);
+            const int ncls = static_cast<int>(classes_kb.size());
+            std::vector<std::vector<uint32_t>> staged(ncls);
+            std::vector<uint32_t> gathered;
+            st->warp_classes.assign(ncls, CalibState::WarpClass{});
+            for (int c = 0; c < ncls; ++c) st->warp_classes[c].start.assign(n + 1, 0);
             st->warp_gathered_start.assign(n + 1, 0);
-            size_t lds_px = 0;
             for (int i = 0; i < n; ++i) {
-                st->warp_staged_start[i] = static_cast<int>(staged.size());
+                for (int c = 0; c < ncls; ++c) st->warp_classes[c].start[i] = static_cast<int>(staged[c].size());
                 st->warp_gathered_start[i] = static_cast<int>(gathered.size());
                 for (int k = plan.warp_cam_start[i]; k < plan.warp_cam_start[i + 1]; ++k) {
                     if (wins[k].flags & 1u) { gathered.push_back(static_cast<uint32_t>(k)); continue; }
-                    staged.push_back(static_cast<uint32_t>(k));
-                    lds_px = std::max(lds_px, static_cast<size_t>(wins[k].groups) * 4 * wins[k].rows);
+                    const size_t bytes = static_cast<size_t>(wins[k].groups) * 16 * wins[k].rows;
+                    int c = 0;
+                    while (c + 1 < ncls && bytes > static_cast<size_t>(classes_kb[c]) * 1024) ++c;
+                    staged[c].push_back(static_cast<uint32_t>(k));
+                    st->warp_classes[c].lds_bytes = std::max(st->warp_classes[c].lds_bytes, bytes);
                 }
             }
-            st->warp_staged_start[n] = static_cast<int>(staged.size());
             st->warp_gathered_start[n] = static_cast<int>(gathered.size());
-            st->warp_lds_bytes = lds_px * 4;
-            if (staged.empty()) staged.push_back(0u);
+            int n_staged = 0;
+            for (int c = 0; c < ncls; ++c) {
+                st->warp_classes[c].start[n] = static_cast<int>(staged[c].size());
+                n_staged += static_cast<int>(staged[c].size());
+                if (staged[c].empty()) staged[c].push_back(0u);
+                st->warp_classes[c].d_index = st->pool.upload(staged[c], s);
+            }
             if (gathered.empty()) gathered.push_back(0u);
-            st->d_warp_staged = st->pool.upload(staged, s);
             st->d_warp_gathered = st->pool.upload(gathered, s);
             check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");      // the index lists are pageable and local
             if (std::getenv("MST_COMPOSE_STATS")) {
-                std::fprintf(stderr, "[mst_update] warp tiles: %d, %d staged in LDS (%zu bytes), %d gathered\n", nt,
-                             st->warp_staged_start[n], st->warp_lds_bytes, st->warp_gathered_start[n]);
+                std::fprintf(stderr, "[mst_update] warp tiles: %d, %d staged in LDS (%d size classes), %d gathered\n", nt, n_staged, ncls,
+                             st->warp_gathered_start[n]);
                 int hist[12] = {0};
                 for (int k = 0; k < nt; ++k) hist[std::min<size_t>(11, static_cast<size_t>(wins[k].groups) * 16 * wins[k].rows / 8192)]++;
                 std::fprintf(stderr, "[mst_update] warp window bytes, 8 KB bins:");
@@ -822,12 +838,15 @@ void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameB
     tg.index = st.d_warp_gathered + st.warp_gathered_start[cam0];
     tg.count = st.warp_gathered_start[cam1] - st.warp_gathered_start[cam0];
     launch_warp_pyr(desc, st.n, cfg_.warp_kind & 0xFF, tg, fb, count, st.warp_table, st.warp_blobs, s);     // (the short list first)
-    TileList ts{};
-    ts.tiles = st.warp_list.tiles;
-    ts.first = 0;
-    ts.index = st.d_warp_staged + st.warp_staged_start[cam0];
-    ts.count = st.warp_staged_start[cam1] - st.warp_staged_start[cam0];
-    launch_warp_pyr_lds(desc, st.n, ts, fb, count, st.warp_table_lds, st.warp_gain_lds, st.warp_wins, st.warp_lds_bytes, s);
+    for (int c = static_cast<int>(st.warp_classes.size()) - 1; c >= 0; --c) {       // (the large-window classes first: fewer, longer blocks)
+        const CalibState::WarpClass& wc = st.warp_classes[c];
+        TileList ts{};
+        ts.tiles = st.warp_list.tiles;
+        ts.first = 0;
+        ts.index = wc.d_index + wc.start[cam0];
+        ts.count = wc.start[cam1] - wc.start[cam0];
+        launch_warp_pyr_lds(desc, st.n, ts, fb, count, st.warp_table_lds, st.warp_gain_lds, st.warp_wins, wc.lds_bytes, s);
+    }
 }
 
 // Per-calibration tables of the single-pass composites (kernels_compose.hip): which cameras reach each 128 x 32 output

@@ -112,9 +112,10 @@ struct CalibState {
     // the staged form of kernel A (k_warp_pyr_lds): map + gain tables in its lane order, the tiles' source windows, the
     // tile indices it takes and those left to the gathering kernel, both grouped by camera
     uint32_t* warp_table_lds = nullptr; float* warp_gain_lds = nullptr; WarpWin* warp_wins = nullptr;
-    const uint32_t* d_warp_staged = nullptr; const uint32_t* d_warp_gathered = nullptr;
-    std::vector<int> warp_staged_start, warp_gathered_start;    // n + 1 offsets each
-    size_t warp_lds_bytes = 0;
+    struct WarpClass { const uint32_t* d_index = nullptr; std::vector<int> start; size_t lds_bytes = 0; };    // one staged launch
+    std::vector<WarpClass> warp_classes;                        // by window size; start: n + 1 offsets into d_index
+    const uint32_t* d_warp_gathered = nullptr;
+    std::vector<int> warp_gathered_start;                       // n + 1 offsets
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step
     PayloadRect* d_payload_rects = nullptr;   // camera-sharded hand-off (plan.payload_*)
     BlendArgs blend{};                  // canvas kernels (pano pointers filled per frame)
