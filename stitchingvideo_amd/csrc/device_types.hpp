@@ -118,7 +118,6 @@ struct ComposeArgs {
     const uint32_t* table;       // per segment kCompPx entries: fx | fy << 6 | dx << 12 | dy << 22 | valid << 31
     const float* gain;           // per segment kCompPx floats
     const float* weight;         // feather: per segment kCompPx floats
-    const float* wsum;           // feather: per tile (canvas order) kCompPx floats: dst_weight_map_
     const uint8_t* mask_plane;   // out_h x out_w: the blender's dst_mask (static per calibration)
     int32_t n_tiles, n_sets;
     int32_t out_w, out_h, crop_x, crop_y;      // output rectangle inside the canvas

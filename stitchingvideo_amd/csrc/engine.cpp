@@ -915,11 +915,6 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");     // tiles / segs / seg_tile are pageable and local
     launch_compose_table(ca, cfg_.warp_kind & 0xFF, n_segs, d_segs, d_tiles, d_seg_tile, d_table, d_gain, d_weight, s);
     check_hip(hipGetLastError(), "k_compose_table");
-    if (ca.mode == kCompModeFeather) {
-        float* d_wsum = st.pool.alloc<float>(static_cast<size_t>(n_canvas_tiles) * kCompPx);
-        launch_compose_wsum(ca, n_canvas_tiles, d_wsum, s);
-        ca.wsum = d_wsum;
-    }
     uint8_t* d_plane = st.pool.alloc<uint8_t>(static_cast<size_t>(st.out_w) * st.out_h + 16);
     launch_compose_mask(ca, d_plane, s);
     ca.mask_plane = d_plane;
@@ -940,8 +935,34 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
         return c;
     };
     std::stable_sort(tiles.begin(), tiles.end(), [&](const ComposeTile& x, const ComposeTile& y) { return tile_cost(x) > tile_cost(y); });
+    // ... but not back to back: the weighted tiles of a feather blend are long dependent chains (a CU full of them
+    // idles between their memory round trips), the unit-weight tiles are short and dense.  Spread the former evenly
+    // over the leading part of the list so that every CU runs a mix.
+    static const int spread_env = [] { const char* v = std::getenv("MST_COMPOSE_SPREAD"); return v ? std::atoi(v) : 100; }();
+    if (ca.mode == kCompModeFeather && spread_env > 0) {
+        size_t n_heavy = 0;
+        while (n_heavy < tiles.size() && tile_cost(tiles[n_heavy]) > 1) ++n_heavy;
+        const size_t n_light = tiles.size() - n_heavy;
+        if (n_heavy && n_light) {
+            std::vector<ComposeTile> mixed;
+            mixed.reserve(tiles.size());
+            const size_t span = std::max<size_t>(n_heavy, tiles.size() * static_cast<size_t>(std::min(spread_env, 100)) / 100);
+            size_t h = 0, l = 0;
+            for (size_t pos = 0; pos < tiles.size(); ++pos) {
+                // heavy tile k sits at position k * span / n_heavy
+                const bool want_heavy = h < n_heavy && (pos >= h * span / n_heavy || l >= n_light);
+                mixed.push_back(want_heavy ? tiles[h++] : tiles[n_heavy + l++]);
+            }
+            tiles.swap(mixed);
+        }
+    }
     std::vector<ComposeTile> staged_lds_only;
+    static const int only_env = [] { const char* v = std::getenv("MST_COMPOSE_ONLY"); return v ? std::atoi(v) : 0; }();   // diagnostic
     for (const ComposeTile& t : tiles) {
+        if (only_env && t.seg_count) {
+            const bool pure = t.seg_count == 1 && (segs[t.seg_first].flags & kCompSegUnit);
+            if ((only_env == 1) != pure) continue;
+        }
         if ((t.flags & kCompTileGeneral) || ((t.flags & kCompTileDirect) && (t.flags & kCompTileNoGather))) { general.push_back(t); continue; }
         if (t.flags & kCompTileDirect) { direct.push_back(t); continue; }
         ((t.flags & kCompTileNoGather) ? staged_lds_only : staged).push_back(t);
@@ -967,6 +988,19 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     if (std::getenv("MST_COMPOSE_STATS"))
         std::fprintf(stderr, "[mst_update] compose plan: %d tiles, %d segments, %d staged in LDS (%zu bytes), %d gathered, %d general\n",
                      n_canvas_tiles, n_segs, st.compose_staged, st.compose_lds_bytes, st.compose_direct, st.compose_general);
+    if (std::getenv("MST_COMPOSE_STATS")) {
+        int one_unit = 0, one_w = 0, multi = 0, multi_unit_segs = 0, multi_segs = 0;
+        size_t win_px = 0;
+        for (const ComposeTile& t : tiles) {
+            if (!t.seg_count) continue;
+            const bool unit0 = segs[t.seg_first].flags & kCompSegUnit;
+            if (t.seg_count == 1) (unit0 ? one_unit : one_w)++;
+            else { ++multi; for (uint32_t k = 0; k < t.seg_count; ++k) { ++multi_segs; multi_unit_segs += (segs[t.seg_first + k].flags & kCompSegUnit) ? 1 : 0; } }
+            for (uint32_t k = 0; k < t.seg_count; ++k) win_px += static_cast<size_t>(segs[t.seg_first + k].groups) * 4 * segs[t.seg_first + k].rows;
+        }
+        std::fprintf(stderr, "[mst_update] compose tiles: %d one unit segment, %d one weighted segment, %d with several (%d segments, %d of them unit); "
+                             "mean window %zu px\n", one_unit, one_w, multi, multi_segs, multi_unit_segs, n_segs ? win_px / n_segs : 0);
+    }
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");     // the lists are pageable and local
     st.compose_segments = n_segs;
 }

@@ -79,7 +79,6 @@ void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int
 // calibration: bit i of d_out[canvas tile] = camera i contributes to the tile
 void launch_compose_classify(const ComposeArgs& a, int n_canvas_tiles, uint32_t* d_out, hipStream_t s);
 void launch_compose_mask(const ComposeArgs& a, uint8_t* d_plane, hipStream_t s);            // the blender's dst_mask
-void launch_compose_wsum(const ComposeArgs& a, int n_canvas_tiles, float* d_out, hipStream_t s);   // feather: tiled dst_weight_map_
 // calibration: per segment the map / gain / weight tables, window origin and flags; sets the tiles' general-path flag
 void launch_compose_table(const ComposeArgs& a, int kind, int n_segs, ComposeSeg* d_segs, ComposeTile* d_tiles,
                           const uint32_t* d_seg_tile, uint32_t* d_table, float* d_gain, float* d_weight, hipStream_t s);

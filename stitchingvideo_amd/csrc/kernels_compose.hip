@@ -182,18 +182,6 @@ __global__ __launch_bounds__(256) void k_compose_mask(ComposeArgs a, uint8_t* __
     plane[static_cast<size_t>(oy) * a.out_w + ox] = static_cast<uint8_t>(m);
 }
 
-// dst_weight_map_ in tile order (feather): [canvas tile][row][column]
-__global__ __launch_bounds__(256) void k_compose_wsum(ComposeArgs a, float* __restrict__ out)
-{
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-    for (int i = threadIdx.x; i < kCompPx; i += 256) {
-        const int ox = tx * kCompTW + (i % kCompTW), oy = ty * kCompTH + (i / kCompTW);
-        float w = 0.f;
-        if (ox < a.out_w && oy < a.out_h) w = gp(a.feather_ws)[static_cast<size_t>(oy + a.crop_y) * a.canvas_w + ox + a.crop_x];
-        out[static_cast<size_t>(blockIdx.x) * kCompPx + i] = w;
-    }
-}
-
 // One block per segment: the table, gain and weight entries of its 128 x 32 pixels, the segment's window origin and
 // flags, and the owning tile's "general path" flag.  seg_tile[s]: index of the segment's tile in `tiles`.
 constexpr uint32_t kEntryValid = 1u << 31;
@@ -467,6 +455,7 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
         const int row = (sub * 8 + rgrp) * ROWS + it, oy = ty * kCompTH + row;
         uint32_t px[4] = {0u, 0u, 0u, 0u};
         int acc[4][3];
+        f32x4 ws = {0.f, 0.f, 0.f, 0.f};       // dst_weight_map_: the cameras' weights summed in feed order (entries of other cameras hold 0)
         if (MODE == kCompModeFeather) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0;
@@ -481,7 +470,7 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
             const u32x4 e = *(const u32x4 MST_GLOBAL*)(a.table + idx);
             const f32x4 g = *(const f32x4 MST_GLOBAL*)(a.gain + idx);
             f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            if (MODE == kCompModeFeather && !pure) w = *(const f32x4 MST_GLOBAL*)(a.weight + idx);
+            if (MODE == kCompModeFeather && !pure) { w = *(const f32x4 MST_GLOBAL*)(a.weight + idx); ws += w; }
             u32x3 p0[4], p1[4];
             uint32_t o0[4], o1[4];
 #pragma unroll
@@ -515,8 +504,6 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) px[k] = bytes_toward_zero(px[k]);
             } else {
-                const size_t widx = static_cast<size_t>(ty * a.tiles_x + tx) * kCompPx + row * kCompTW + lane * 4;
-                const f32x4 ws = *(const f32x4 MST_GLOBAL*)(a.wsum + widx);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const bool m = ws[k] > kWeightEps;
@@ -583,6 +570,9 @@ __global__ __launch_bounds__(1024 / ROWS) void k_compose_lds(ComposeArgs a, Fram
     for (int it = 0; it < ROWS; ++it)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { px[it][k] = 0u; acc_bg[it][k] = 0u; acc_r[it][k] = 0u; }
+    f32x4 ws[ROWS];                               // dst_weight_map_, summed in feed order as the segments go by
+#pragma unroll
+    for (int it = 0; it < ROWS; ++it) ws[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (uint32_t s = 0; s < t.seg_count; ++s) {
         const ComposeSeg seg = a.segs[t.seg_first + s];
         const uint32_t stride = frames.stride[seg.cam];
@@ -612,6 +602,7 @@ __global__ __launch_bounds__(1024 / ROWS) void k_compose_lds(ComposeArgs a, Fram
         for (int it = 0; it < ROWS; ++it) {
             const u32x4 e = e_r[it];
             const f32x4 g = g_r[it], w = w_r[it];
+            if (MODE == kCompModeFeather) ws[it] += w;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t dx = (e[k] >> 12) & 1023u, dy = (e[k] >> 22) & 511u;
@@ -639,12 +630,10 @@ __global__ __launch_bounds__(1024 / ROWS) void k_compose_lds(ComposeArgs a, Fram
 #pragma unroll
                 for (int k = 0; k < 4; ++k) px[it][k] = bytes_toward_zero(px[it][k]);
             } else {
-                const size_t widx = static_cast<size_t>(ty * a.tiles_x + tx) * kCompPx + row * kCompTW + lane * 4;
-                const f32x4 ws = *(const f32x4 MST_GLOBAL*)(a.wsum + widx);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const bool m = ws[k] > kWeightEps;
-                    const SharedDivisor sd = shared_divisor(ws[k] + kWeightEps);
+                    const bool m = ws[it][k] > kWeightEps;
+                    const SharedDivisor sd = shared_divisor(ws[it][k] + kWeightEps);
                     const int cb = static_cast<int>(acc_bg[it][k] & 0xFFFFu), cg = static_cast<int>(acc_bg[it][k] >> 16), cr = static_cast<int>(acc_r[it][k]);
                     const uint32_t o = feather_norm(cb, sd) | feather_norm(cg, sd) << 8 | feather_norm(cr, sd) << 16;
                     px[it][k] = m ? o : 0u;
@@ -685,12 +674,6 @@ void launch_compose_classify(const ComposeArgs& a, int n_canvas_tiles, uint32_t*
 void launch_compose_mask(const ComposeArgs& a, uint8_t* d_plane, hipStream_t s)
 {
     hipLaunchKernelGGL(k_compose_mask, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(256), 0, s, a, d_plane);
-}
-
-void launch_compose_wsum(const ComposeArgs& a, int n_canvas_tiles, float* d_out, hipStream_t s)
-{
-    if (n_canvas_tiles <= 0) return;
-    hipLaunchKernelGGL(k_compose_wsum, dim3(n_canvas_tiles), dim3(256), 0, s, a, d_out);
 }
 
 void launch_compose_table(const ComposeArgs& a, int kind, int n_segs, ComposeSeg* d_segs, ComposeTile* d_tiles,
