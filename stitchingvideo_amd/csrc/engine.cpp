@@ -927,7 +927,7 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     std::vector<ComposeTile> staged, direct, general;
     size_t lds_px = 0;
     // launch order by cost: segments, those with real blend weights (feather bands: converts, products, a division per
-    // channel) counted twice -- the longest blocks start first
+    // channel) counted twice
     auto tile_cost = [&](const ComposeTile& t) {
         int c = 0;
         for (uint32_t k = 0; k < t.seg_count; ++k)
@@ -935,25 +935,37 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
         return c;
     };
     std::stable_sort(tiles.begin(), tiles.end(), [&](const ComposeTile& x, const ComposeTile& y) { return tile_cost(x) > tile_cost(y); });
-    // ... but not back to back: the weighted tiles of a feather blend are long dependent chains (a CU full of them
-    // idles between their memory round trips), the unit-weight tiles are short and dense.  Spread the former evenly
-    // over the leading part of the list so that every CU runs a mix.
-    static const int spread_env = [] { const char* v = std::getenv("MST_COMPOSE_SPREAD"); return v ? std::atoi(v) : 100; }();
-    if (ca.mode == kCompModeFeather && spread_env > 0) {
+    // MST_COMPOSE_ORDER: 0 cost order as sorted above, 1 heavy tiles spread evenly over it, 2 raster order,
+    // 3 raster order with the heavy tiles of its last eighth moved to the front (no long block in the launch's tail)
+    // Measured (C2 / C3 feather, C3 / C5 LUT, frac): cost order 0.26 / 0.24 / 0.37 / 0.45, spread 0.31 / 0.28 / 0.45 / 0.50,
+    // raster 0.34 / 0.31 / 0.44 / 0.50, raster + tail fix 0.35 / 0.31 / 0.43 / 0.49.  The long tiles (several segments,
+    // real feather weights) are chains of memory round trips: a CU full of them idles, so they must not lead the list.
+    static const int order_env = [] { const char* v = std::getenv("MST_COMPOSE_ORDER"); return v ? std::atoi(v) : -1; }();
+    const int order_kind = order_env >= 0 ? order_env : (ca.mode == kCompModeFeather ? 3 : 1);
+    auto raster_key = [](const ComposeTile& t) { return t.tx_ty; };           // ty << 16 | tx
+    if (order_kind == 1) {
         size_t n_heavy = 0;
         while (n_heavy < tiles.size() && tile_cost(tiles[n_heavy]) > 1) ++n_heavy;
         const size_t n_light = tiles.size() - n_heavy;
         if (n_heavy && n_light) {
             std::vector<ComposeTile> mixed;
             mixed.reserve(tiles.size());
-            const size_t span = std::max<size_t>(n_heavy, tiles.size() * static_cast<size_t>(std::min(spread_env, 100)) / 100);
             size_t h = 0, l = 0;
             for (size_t pos = 0; pos < tiles.size(); ++pos) {
-                // heavy tile k sits at position k * span / n_heavy
-                const bool want_heavy = h < n_heavy && (pos >= h * span / n_heavy || l >= n_light);
+                // heavy tile k sits at position k * size / n_heavy
+                const bool want_heavy = h < n_heavy && (pos >= h * tiles.size() / n_heavy || l >= n_light);
                 mixed.push_back(want_heavy ? tiles[h++] : tiles[n_heavy + l++]);
             }
             tiles.swap(mixed);
+        }
+    } else if (order_kind >= 2) {
+        std::stable_sort(tiles.begin(), tiles.end(), [&](const ComposeTile& x, const ComposeTile& y) { return raster_key(x) < raster_key(y); });
+        if (order_kind == 3) {
+            const size_t tail = tiles.size() - tiles.size() / 8;
+            std::vector<ComposeTile> front, rest;
+            for (size_t i = 0; i < tiles.size(); ++i) ((i >= tail && tile_cost(tiles[i]) > 1) ? front : rest).push_back(tiles[i]);
+            front.insert(front.end(), rest.begin(), rest.end());
+            tiles.swap(front);
         }
     }
     std::vector<ComposeTile> staged_lds_only;
