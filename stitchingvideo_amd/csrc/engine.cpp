@@ -1234,17 +1234,20 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
         fb = ub;
     }
     const MbPlanHost& plan = st->plan;
+    // one launch per run of consecutive cameras in the mask (the tile lists are in camera order)
+    std::vector<std::pair<int, int>> runs;
     for (int i = 0; i < st->n; ++i) {
         if (!(camera_mask >> i & 1u)) continue;
-        launch_warp(*st, set_desc, fb, 1, i, i + 1, s);
+        if (!runs.empty() && runs.back().second == i) runs.back().second = i + 1;
+        else runs.emplace_back(i, i + 1);
     }
+    for (const auto& r : runs) launch_warp(*st, set_desc, fb, 1, r.first, r.second, s);
     for (size_t k = 0; k < st->chain_lists.size(); ++k)
-        for (int i = 0; i < st->n; ++i) {
-            if (!(camera_mask >> i & 1u)) continue;
+        for (const auto& r : runs) {
             TileList tl{};
-            tl.tiles = st->chain_lists[k].tiles + plan.chain[k].cam_start[i];
-            tl.count = plan.chain[k].cam_start[i + 1] - plan.chain[k].cam_start[i];
-            tl.first = plan.chain[k].cam_start[i];
+            tl.tiles = st->chain_lists[k].tiles + plan.chain[k].cam_start[r.first];
+            tl.count = plan.chain[k].cam_start[r.second] - plan.chain[k].cam_start[r.first];
+            tl.first = plan.chain[k].cam_start[r.first];
             launch_pyr_chain(set_desc, st->n, tl, plan.chain[k].base, plan.chain[k].k, 1, s);
         }
     check_hip(hipGetLastError(), "camera stage kernels");
