@@ -908,7 +908,7 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     uint32_t* d_seg_tile = st.pool.upload(seg_tile, s);
     const size_t entries = std::max<size_t>(static_cast<size_t>(n_segs) * kCompPx, 4);
     uint32_t* d_table = st.pool.alloc<uint32_t>(entries);
-    float* d_gain = st.pool.alloc<float>(entries);
+    float* d_gain = cfg_.expos_kind == MST_EXPOS_NO ? nullptr : st.pool.alloc<float>(entries);      // (no compensation: every gain is 1)
     float* d_weight = ca.mode == kCompModeFeather ? st.pool.alloc<float>(entries) : nullptr;
     ca.tiles = d_tiles; ca.segs = d_segs; ca.table = d_table; ca.gain = d_gain; ca.weight = d_weight;
     ca.n_tiles = n_tiles;

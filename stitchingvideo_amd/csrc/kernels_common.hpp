@@ -319,24 +319,86 @@ typedef uint32_t __attribute__((ext_vector_type(4))) u32x4_t;
 // `groups` x `rows` groups of four pixels (12 source bytes on a dword boundary -> 16 LDS bytes, B G R x), by NT threads
 // PAD: the window may reach outside the fw x fh frame (origin (wx0, wy0) in frame pixels, wx0 and fw multiples of four, so
 // a group lies inside or outside as a whole); groups outside are zeros -- cv::remap's BORDER_CONSTANT
-template <int NT, bool PAD = false>
+#ifndef MST_STAGE_U_PASTE
+#define MST_STAGE_U_PASTE 3         // 512 threads: 6 K pixels per pass, 63 VGPRs (four blocks per CU)
+#endif
+#ifndef MST_STAGE_U_FEATHER
+#define MST_STAGE_U_FEATHER 1       // batching costs the feather kernel its third block per CU (72 -> 84 VGPRs): -3 .. -7 %
+#endif
+#ifndef MST_STAGE_U_WARP
+#define MST_STAGE_U_WARP 4          // 384 threads: 6 K pixels per pass
+#endif
+// U: loads a thread keeps in flight.  One load per trip of a plain loop means one memory round trip per trip (the LDS
+// write needs the data): a 6 K pixel window over 512 threads is three round trips in a row -- with the staging loads
+// ablated the LUT composite ran 42 % faster.  The trips are therefore taken U at a time: U loads issued back to back,
+// then U LDS writes.  Same box, same run: kernel A 31.1 -> 29.1 us per frame set, C3 / C5 LUT 0.459 / 0.529 -> 0.474 / 0.551.
+template <int NT, bool PAD = false, int U = 4>
 __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const uint8_t MST_GLOBAL* __restrict__ base, uint32_t stride,
                                              int groups, int rows, int wx0 = 0, int wy0 = 0, int fw = 0, int fh = 0)
 {
     const int n = groups * rows;
+    if constexpr (U == 1) {      // one load per trip, scheduled by the compiler (fewest registers: the feather blend's choice)
+        for (int i = threadIdx.x; i < n; i += NT) {
+            const int r = i / groups, g = i - r * groups;
+            u32x3_t d = {0u, 0u, 0u};
+            if (!PAD || (static_cast<unsigned>(wy0 + r) < static_cast<unsigned>(fh) && static_cast<unsigned>(wx0 + 4 * g) < static_cast<unsigned>(fw)))
+                d = *(const u32x3_t MST_GLOBAL*)(base + static_cast<ptrdiff_t>(r) * static_cast<ptrdiff_t>(stride) + static_cast<ptrdiff_t>(g) * 12);
+            u32x4_t p;
+            p.x = d.x; p.y = __builtin_amdgcn_alignbyte(d.y, d.x, 3); p.z = __builtin_amdgcn_alignbyte(d.z, d.y, 2); p.w = d.z >> 8;
+            *reinterpret_cast<u32x4_t*>(&s_win[i * 4]) = p;
+        }
+        return;
+    } else {
+    // the window's base is block-uniform: as a scalar pair for the loads' saddr operand
+    const uint64_t vb = reinterpret_cast<uint64_t>(base);
+    const uint64_t sbase = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(vb >> 32)))) << 32 |
+                           static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(vb)));      // (the builtin returns int)
+    // (row, group) of trip k of this thread: i = threadIdx.x + k * NT, walked without a division per trip
     const uint32_t inv = ((1u << 20) + groups - 1) / groups;      // i / groups == (i * inv) >> 20 for i < 4096, groups <= 256
-    for (int i = threadIdx.x; i < n; i += NT) {
-        const int r = n <= 4096 ? static_cast<int>((static_cast<uint32_t>(i) * inv) >> 20) : i / groups;
-        const int g = i - r * groups;
-        u32x3_t d = {0u, 0u, 0u};
-        if (!PAD || (static_cast<unsigned>(wy0 + r) < static_cast<unsigned>(fh) && static_cast<unsigned>(wx0 + 4 * g) < static_cast<unsigned>(fw)))
-            d = *(const u32x3_t MST_GLOBAL*)(base + static_cast<ptrdiff_t>(r) * static_cast<ptrdiff_t>(stride) + static_cast<ptrdiff_t>(g) * 12);
-        u32x4_t p;
-        p.x = d.x;                                            // B0 G0 R0 (B1)
-        p.y = __builtin_amdgcn_alignbyte(d.y, d.x, 3);        // B1 G1 R1 (B2)
-        p.z = __builtin_amdgcn_alignbyte(d.z, d.y, 2);        // B2 G2 R2 (B3)
-        p.w = d.z >> 8;                                       // B3 G3 R3 0
-        *reinterpret_cast<u32x4_t*>(&s_win[(r * groups + g) * 4]) = p;
+    const int step_r = static_cast<int>((static_cast<uint32_t>(NT) * inv) >> 20), step_g = NT - step_r * groups;
+    int r = static_cast<int>((static_cast<uint32_t>(threadIdx.x) * inv) >> 20), g = static_cast<int>(threadIdx.x) - r * groups;
+    for (int i0 = threadIdx.x; i0 < n; i0 += NT * U) {
+        u32x3_t d[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // trips past the end re-read the window's last row, groups outside the frame (PAD) the nearest one inside:
+            // a load that is always legal needs no branch around it.  The loads are written as asm so that all U are
+            // issued back to back: left to the compiler, the last ones sink below the first LDS writes (register
+            // shuffling for ds_write_b128) and every trip waits for its own round trip again.
+            int rr = min(r, rows - 1), gg = g;
+            ok[u] = true;
+            if (PAD) {
+                ok[u] = static_cast<unsigned>(wy0 + rr) < static_cast<unsigned>(fh) && static_cast<unsigned>(wx0 + 4 * gg) < static_cast<unsigned>(fw);
+                rr = min(max(wy0 + rr, 0), fh - 1) - wy0;
+                gg = (min(max(wx0 + 4 * gg, 0), fw - 4) - wx0) >> 2;
+            }
+            // (32-bit offset from the block-uniform base: frames are below 4 GiB, mst_compose* checks)
+            const uint32_t off = static_cast<uint32_t>(rr) * stride + static_cast<uint32_t>(gg) * 12u;
+            asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(d[u]) : "v"(off), "s"(sbase) : "memory");
+            r += step_r; g += step_g;
+            if (g >= groups) { g -= groups; ++r; }
+        }
+        // every d[u] is an operand of the wait: nothing may read (or copy) one before it
+        if constexpr (U == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]) : : "memory");
+        else if constexpr (U == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : : "memory");
+        else if constexpr (U == 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]) : : "memory");
+        else if constexpr (U == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]) : : "memory");
+        else static_assert(U >= 3 && U <= 6, "stage_window: 1 or 3 to 6 loads in flight");
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * NT;
+            if (i < n) {
+                if (PAD && !ok[u]) d[u] = u32x3_t{0u, 0u, 0u};
+                u32x4_t p;
+                p.x = d[u].x;                                            // B0 G0 R0 (B1)
+                p.y = __builtin_amdgcn_alignbyte(d[u].y, d[u].x, 3);     // B1 G1 R1 (B2)
+                p.z = __builtin_amdgcn_alignbyte(d[u].z, d[u].y, 2);     // B2 G2 R2 (B3)
+                p.w = d[u].z >> 8;                                       // B3 G3 R3 0
+                *reinterpret_cast<u32x4_t*>(&s_win[i * 4]) = p;          // (row r, group g) sits at r * groups + g == i
+            }
+        }
+    }
     }
 }
 

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
         }
         const size_t o = static_cast<size_t>(s) * kCompPx + i;
         table[o] = e;
-        gain[o] = g;
+        if (gain) gain[o] = g;
         if (weight) weight[o] = w;
     }
     if (general) atomicOr(&s_flags[0], 1u);
@@ -468,7 +468,8 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
             const uint8_t MST_GLOBAL* base = gp(p - adj);
             const size_t idx = static_cast<size_t>(t.seg_first + s) * kCompPx + row * kCompTW + lane * 4;
             const u32x4 e = *(const u32x4 MST_GLOBAL*)(a.table + idx);
-            const f32x4 g = *(const f32x4 MST_GLOBAL*)(a.gain + idx);
+            f32x4 g = {1.f, 1.f, 1.f, 1.f};
+            if (a.gain) g = *(const f32x4 MST_GLOBAL*)(a.gain + idx);
             f32x4 w = {0.f, 0.f, 0.f, 0.f};
             if (MODE == kCompModeFeather && !pure) { w = *(const f32x4 MST_GLOBAL*)(a.weight + idx); ws += w; }
             u32x3 p0[4], p1[4];
@@ -548,8 +549,15 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a, FrameBatch fb)
 // with the weights times 64, which again leaves the rounded byte in bits 16..23.  Same integers:
 //   (sum_x wx * (sum_y wy * v) + 512) >> 10.
 // ROWS rows per lane: a block has 32 lanes x (32 / ROWS) row groups = 1024 / ROWS threads over one staged window
+#ifndef MST_COMPOSE_WAVES_PASTE
+#define MST_COMPOSE_WAVES_PASTE 8
+#endif
+#ifndef MST_COMPOSE_WAVES_FEATHER
+#define MST_COMPOSE_WAVES_FEATHER 6
+#endif
 template <int MODE, int ROWS>
-__global__ __launch_bounds__(1024 / ROWS) void k_compose_lds(ComposeArgs a, FrameBatch fb)
+__global__ __launch_bounds__(1024 / ROWS) __attribute__((amdgpu_waves_per_eu(ROWS == 2 ? (MODE == kCompModeFeather ? MST_COMPOSE_WAVES_FEATHER : MST_COMPOSE_WAVES_PASTE) : 2)))
+void k_compose_lds(ComposeArgs a, FrameBatch fb)
 {
     constexpr int NT = 1024 / ROWS;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_win[];
@@ -592,8 +600,8 @@ __global__ __launch_bounds__(1024 / ROWS) void k_compose_lds(ComposeArgs a, Fram
         if (s) __syncthreads();                          // the previous segment's window has been read
         {
             const uint8_t MST_GLOBAL* wbase = gp(frames.ptr[seg.cam]) + (static_cast<ptrdiff_t>(seg.by) * static_cast<ptrdiff_t>(stride) + static_cast<ptrdiff_t>(seg.wx0) * 3);
-            if (MODE == kCompModePaste && a.pad_w) stage_window<NT, true>(s_win, wbase, stride, seg.groups, seg.rows, seg.wx0, seg.by, a.pad_w, a.pad_h);
-            else stage_window<NT>(s_win, wbase, stride, seg.groups, seg.rows);
+            if (MODE == kCompModePaste && a.pad_w) stage_window<NT, true, MST_STAGE_U_PASTE>(s_win, wbase, stride, seg.groups, seg.rows, seg.wx0, seg.by, a.pad_w, a.pad_h);
+            else stage_window<NT, false, (MODE == kCompModeFeather ? MST_STAGE_U_FEATHER : MST_STAGE_U_PASTE)>(s_win, wbase, stride, seg.groups, seg.rows);
         }
         __syncthreads();
         const uint32_t pitch_b = static_cast<uint32_t>(seg.groups) * 16u;

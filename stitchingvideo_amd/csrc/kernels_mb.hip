@@ -732,7 +732,7 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
         e_r[it] = *(const u32x4_t MST_GLOBAL*)(table + tbl + it * A_LW);
         g_r[it] = *(const f32x4_t MST_GLOBAL*)(gain + tbl + it * A_LW);
     }
-    stage_window<A2_NT>(s_mem, gp(frames.ptr[cam]) + (static_cast<size_t>(w.by) * stride + static_cast<size_t>(w.wx0) * 3u), stride,
+    stage_window<A2_NT, false, MST_STAGE_U_WARP>(s_mem, gp(frames.ptr[cam]) + (static_cast<size_t>(w.by) * stride + static_cast<size_t>(w.wx0) * 3u), stride,
                         w.groups, w.rows);
     __syncthreads();
     const uint32_t pitch_b = static_cast<uint32_t>(w.groups) * 16u;

@@ -30,7 +30,7 @@ PATHS = {
 _RIGS = {}
 
 
-def measure(name, batch=8, min_time=0.4, latency_leg=True):
+def measure(name, batch=8, min_time=0.4, latency_leg=True, expos=None):
     import torch
     import stitchingvideo_amd as S
     from stitchingvideo_amd import rig as rigmod
@@ -41,7 +41,7 @@ def measure(name, batch=8, min_time=0.4, latency_leg=True):
     rig = _RIGS[cfg_name]
     n_cam = len(rig["cameras"])
     dev = torch.device("cuda", 0)
-    eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=0,
+    eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=expos or rig["expos"], num_bands=5, device=0,
                            driver_lut=lut, max_batch=batch)
     t0 = time.perf_counter()
     eng.update(rig["scale"], rig["cameras"])
@@ -128,9 +128,10 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--min-time", type=float, default=0.4)
     ap.add_argument("--no-latency-leg", action="store_true")
+    ap.add_argument("--expos", default=None, help="override the rig's exposure compensation (no | gain | gain_blocks): ablation runs")
     args = ap.parse_args()
     for nm in (args.names or list(PATHS)):
         try:
-            print(json.dumps(measure(nm, batch=args.batch, min_time=args.min_time, latency_leg=not args.no_latency_leg)), flush=True)
+            print(json.dumps(measure(nm, batch=args.batch, min_time=args.min_time, latency_leg=not args.no_latency_leg, expos=args.expos)), flush=True)
         except Exception as e:      # noqa: BLE001
             print(json.dumps({"name": nm, "error": "%s: %s" % (type(e).__name__, e)}), flush=True)
