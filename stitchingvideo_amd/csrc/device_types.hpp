@@ -204,7 +204,9 @@ struct TileList {
 struct WarpWin {
     int32_t wx0, by, groups, rows, bx;
     uint32_t flags;                // bit 0: the tile cannot take the staged form (k_warp_pyr handles it)
-    int32_t pad0, pad1;
+    // filled in for the launch-ordered copies the staged kernel reads (one scalar load gives the block everything):
+    uint32_t tile;                 // cam << 24 | ty << 12 | tx (| bit 31), the tile-list word
+    int32_t index;                 // the tile's index in the calibration's full list (table / gain rows)
 };
 
 }  // namespace mst

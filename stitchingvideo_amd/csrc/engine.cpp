@@ -686,7 +686,7 @@ void Engine::update(const mst_calibration& calib)
             if (nt) check_hip(hipMemcpyAsync(wins.data(), st->warp_wins, nt * sizeof(WarpWin), hipMemcpyDeviceToHost, s), "hipMemcpyAsync(D2H windows)");
             check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(windows)");
             const int ncls = static_cast<int>(classes_kb.size());
-            std::vector<std::vector<uint32_t>> staged(ncls);
+            std::vector<std::vector<WarpWin>> staged(ncls);      // per class, in launch order: window + tile word + index
             std::vector<uint32_t> gathered;
             st->warp_classes.assign(ncls, CalibState::WarpClass{});
             for (int c = 0; c < ncls; ++c) st->warp_classes[c].start.assign(n + 1, 0);
@@ -699,7 +699,10 @@ void Engine::update(const mst_calibration& calib)
                     const size_t bytes = static_cast<size_t>(wins[k].groups) * 16 * wins[k].rows;
                     int c = 0;
                     while (c + 1 < ncls && bytes > static_cast<size_t>(classes_kb[c]) * 1024) ++c;
-                    staged[c].push_back(static_cast<uint32_t>(k));
+                    WarpWin ww = wins[k];
+                    ww.tile = plan.warp_tiles[k];
+                    ww.index = k;
+                    staged[c].push_back(ww);
                     st->warp_classes[c].lds_bytes = std::max(st->warp_classes[c].lds_bytes, bytes);
                 }
             }
@@ -708,8 +711,8 @@ void Engine::update(const mst_calibration& calib)
             for (int c = 0; c < ncls; ++c) {
                 st->warp_classes[c].start[n] = static_cast<int>(staged[c].size());
                 n_staged += static_cast<int>(staged[c].size());
-                if (staged[c].empty()) staged[c].push_back(0u);
-                st->warp_classes[c].d_index = st->pool.upload(staged[c], s);
+                if (staged[c].empty()) staged[c].push_back(WarpWin{});
+                st->warp_classes[c].d_wins = st->pool.upload(staged[c], s);
             }
             if (gathered.empty()) gathered.push_back(0u);
             st->d_warp_gathered = st->pool.upload(gathered, s);
@@ -840,12 +843,8 @@ void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameB
     launch_warp_pyr(desc, st.n, cfg_.warp_kind & 0xFF, tg, fb, count, st.warp_table, st.warp_blobs, s);     // (the short list first)
     for (int c = static_cast<int>(st.warp_classes.size()) - 1; c >= 0; --c) {       // (the large-window classes first: fewer, longer blocks)
         const CalibState::WarpClass& wc = st.warp_classes[c];
-        TileList ts{};
-        ts.tiles = st.warp_list.tiles;
-        ts.first = 0;
-        ts.index = wc.d_index + wc.start[cam0];
-        ts.count = wc.start[cam1] - wc.start[cam0];
-        launch_warp_pyr_lds(desc, st.n, ts, fb, count, st.warp_table_lds, st.warp_gain_lds, st.warp_wins, wc.lds_bytes, s);
+        launch_warp_pyr_lds(desc, st.n, wc.start[cam1] - wc.start[cam0], fb, count, st.warp_table_lds, st.warp_gain_lds,
+                            wc.d_wins + wc.start[cam0], wc.lds_bytes, s);
     }
 }
 

@@ -112,8 +112,8 @@ struct CalibState {
     // the staged form of kernel A (k_warp_pyr_lds): map + gain tables in its lane order, the tiles' source windows, the
     // tile indices it takes and those left to the gathering kernel, both grouped by camera
     uint32_t* warp_table_lds = nullptr; float* warp_gain_lds = nullptr; WarpWin* warp_wins = nullptr;
-    struct WarpClass { const uint32_t* d_index = nullptr; std::vector<int> start; size_t lds_bytes = 0; };    // one staged launch
-    std::vector<WarpClass> warp_classes;                        // by window size; start: n + 1 offsets into d_index
+    struct WarpClass { const WarpWin* d_wins = nullptr; std::vector<int> start; size_t lds_bytes = 0; };    // one staged launch
+    std::vector<WarpClass> warp_classes;                        // by window size; start: n + 1 offsets into d_wins (launch order)
     const uint32_t* d_warp_gathered = nullptr;
     std::vector<int> warp_gathered_start;                       // n + 1 offsets
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step

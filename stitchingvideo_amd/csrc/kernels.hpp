@@ -68,7 +68,7 @@ void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList
 size_t mb_warp_tile_px();
 void launch_warp_table_lds(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, float* d_gain, WarpWin* d_wins,
                            int lds_budget_px, hipStream_t s);
-void launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, const TileList& list, const FrameBatch& frames, int batch,
+void launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, int n_tiles, const FrameBatch& frames, int batch,
                          const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s);
 void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s);
 // which: bit 0 = k_blend_coarse (levels 1 .. top -> collapsed level-1 canvas), bit 1 = k_blend_fine (level 0 -> panorama)

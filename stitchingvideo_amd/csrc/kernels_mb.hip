@@ -699,27 +699,27 @@ __global__ __launch_bounds__(256) void k_warp_table_lds(const CamDesc* __restric
         w.rows = s_max[1] == INT_MIN ? 0 : s_max[1] - by + 1;
         const bool overrun = w.wx0 + 4 * w.groups > c.src_w && by + w.rows >= c.src_h;
         w.flags = (s_general || w.groups * 4 * w.rows > lds_budget_px || w.groups > 256 || w.groups == 0 || overrun) ? kWinGeneral : 0u;
-        w.pad0 = w.pad1 = 0;
+        w.tile = 0; w.index = 0;
         wins[list.first + blockIdx.x] = w;
     }
 }
 
-__global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restrict__ cams_all, TileList list, FrameBatch batch,
+__global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restrict__ cams_all, int n_tiles, FrameBatch batch,
                                                         const uint32_t* __restrict__ table, const float* __restrict__ gain,
                                                         const WarpWin* __restrict__ wins, int n_cams, int n_sets)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];     // the staged window, later the level-0 tile [A_LH][A_LW]
     const int tid = threadIdx.x, lane = tid & 31;
     const int rgrp = __builtin_amdgcn_readfirstlane(tid >> 6) * 2 + ((tid >> 5) & 1);
-    const int pair = xcd_run_index(blockIdx.x, list.count * n_sets);
+    const int pair = xcd_run_index(blockIdx.x, n_tiles * n_sets);
     const int set = pair % n_sets, li = pair / n_sets;
-    const int gi = list.index ? static_cast<int>(list.index[li]) : list.first + li;
-    const uint32_t t = list.tiles[list.index ? gi : li];
+    const WarpWin w = wins[li];                     // (launch order: window, tile word and table index in one load)
+    const int gi = w.index;
+    const uint32_t t = w.tile;
     const int cam = (t >> 24) & 0x7F, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc* __restrict__ cams = cams_all + set * n_cams;
     const CamDesc& c = cams[cam];
     const FrameArgs& frames = batch.f[set];
-    const WarpWin w = wins[gi];
     const uint32_t stride = frames.stride[cam];
     const int bw = c.lw[0], bh = c.lh[0], nlev = c.nlev;
     // table and gain rows of this lane: issued before the staging loads, one round trip covers both
@@ -2196,12 +2196,12 @@ void launch_warp_table_lds(const CamDesc* d_cams, int kind, const TileList& list
 #undef MST_LAUNCH_T2
 }
 
-void launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, const TileList& list, const FrameBatch& frames, int batch,
+void launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, int n_tiles, const FrameBatch& frames, int batch,
                          const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s)
 {
-    if (list.count <= 0 || batch <= 0) return;
+    if (n_tiles <= 0 || batch <= 0) return;
     const size_t lds = std::max(lds_bytes, mb_warp_tile_px() * sizeof(uint32_t));
-    hipLaunchKernelGGL(k_warp_pyr_lds, dim3(list.count * batch), dim3(A2_NT), lds, s, d_cams, list, frames, d_table, d_gain, d_wins, n_cams, batch);
+    hipLaunchKernelGGL(k_warp_pyr_lds, dim3(n_tiles * batch), dim3(A2_NT), lds, s, d_cams, n_tiles, frames, d_table, d_gain, d_wins, n_cams, batch);
 }
 
 void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s)
