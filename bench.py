@@ -81,6 +81,9 @@ def parse_args():
     ap.add_argument("--camera-leg-steps", type=int, default=100)
     ap.add_argument("--undistort", action="store_true",
                     help="add the driver's lens-undistort pre-pass (DRV:741) to every camera (not part of the headline)")
+    ap.add_argument("--lens-composed", action="store_true",
+                    help="with --undistort: compose the lens maps into the warp's map instead (MST_FLAG_LENS_COMPOSED: one "
+                         "resampling, no pre-pass; the fused variant's own pixels, not the reference's)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = sized to ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (0 = min(host cores, 32))")
     ap.add_argument("--no-configs", action="store_true",
@@ -179,7 +182,7 @@ def main():
     batch = 1 if by_camera else max(1, min(args.batch, 8))
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
                            overlap_frames=args.overlap and not args.no_overlap and blend == "multiband" and not by_camera,
-                           max_batch=batch)
+                           max_batch=batch, lens_composed=args.undistort and args.lens_composed)
     if args.undistort:
         # the reference's fisheye intrinsics (DRV:209-216, quoted for 1280x720) scaled to the frame size
         fw, fh = rig["size"]
@@ -304,7 +307,7 @@ def main():
         ms_per_step = wall * 1000.0 / args.steps
         dev_ms_per_seq = dev_ms / seqs
         traffic, traffic_note, tj = None, "profiles/traffic.json absent", {}
-        wl = args.config + ("+undistort" if args.undistort else "")
+        wl = args.config + (("+lens-composed" if args.lens_composed else "+undistort") if args.undistort else "")
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj.get("kernel_source_sha16") == kernel_source_hash():
@@ -334,7 +337,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "frames_resident_in_hbm": True, "frame_sets_per_step": batch * reps,
                        "launch_sequences_per_step": reps, "frame_sets_per_launch": batch,
-                       "lens_undistort": bool(args.undistort), "timed_region_s": round(wall, 4),
+                       "lens_undistort": ("composed into the warp map" if args.lens_composed else "pre-pass") if args.undistort else False,
+                       "timed_region_s": round(wall, 4),
                        "parallelism": "frames sharded over %d rank(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,

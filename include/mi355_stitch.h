@@ -99,6 +99,11 @@ int mst_warp_kind_from_name(const char *name);
                                       (feedSizeRemap, DRV:150-177); requires MST_BLEND_NO */
 
 #define MST_FLAG_DEBUG        2u   /* keep a copy of the collapsed canvas levels for mst_debug_read */
+#define MST_FLAG_LENS_COMPOSED 8u  /* SURVEY 8 f1 as written: cameras that carry undistort maps get them COMPOSED into the warp's
+                                      backward map at mst_update (mst_compose_lens_maps) and every frame is resampled ONCE, from the
+                                      raw frame -- no pre-pass, the plain rate.  Not the reference's pixels (it resamples twice,
+                                      DRV:741 then DRV:752): one interpolation blur less; parity is against the oracle's
+                                      statement of the same composition. */
 #define MST_FLAG_OVERLAP_FRAMES 4u /* throughput mode for mst_compose_device(_batch): the per-camera kernels of call t+1
                                       run on an engine-owned stream while the canvas kernel of call t is still
                                       running on the caller's stream (two runs of pyramid sets alternate).  Results and
@@ -311,6 +316,11 @@ int  mst_build_maps_host(int warp_kind, float scale, const float K[9], const flo
 /* cv::initUndistortRectifyMap(K, dist, R, newK, Size(width, height), CV_16SC2, map1, map2) as RunTestEyeFishMap calls
  * it (DRV:201-238); host only.  K, newK: 3x3 row-major doubles; R: 3x3 or NULL (identity); dist: 0, 4, 5 or 8
  * coefficients (k1 k2 p1 p2 [k3 [k4 k5 k6]]).  map1: height x width x 2 shorts, map2: height x width ushorts. */
+/* The map composition of MST_FLAG_LENS_COMPOSED, host only: (xmap, ymap)[k] <- the lens maps (map1 + map2's fractions / 32)
+ * interpolated bilinearly at (xmap, ymap)[k] clamped to the width x height frame, in float32:
+ * x0 = min((int)u, width - 2), ax = u - x0; r0 = m00 * (1 - ax) + m10 * ax; r1 = m01 * (1 - ax) + m11 * ax;
+ * L = r0 * (1 - ay) + r1 * ay.  n map entries, updated in place. */
+int  mst_compose_lens_maps(float *xmap, float *ymap, size_t n, const int16_t *map1, const uint16_t *map2, int width, int height);
 int  mst_init_undistort_rectify_map(const double K[9], const double *dist, int num_dist, const double R[9],
                                     const double newK[9], int width, int height, int16_t *map1, uint16_t *map2);
 /* remap(src, dst, map1, map2, INTER_LINEAR) for a CV_8UC3 host image with such maps (default constant border,

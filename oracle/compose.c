@@ -36,6 +36,15 @@ mo_rect mo_compose_panorama(const mo_compose_config *cfg, const mo_compose_camer
         int w = sizes[2 * i], h = sizes[2 * i + 1];
         uint8_t *img_warped = (uint8_t *)malloc((size_t)w * h * 3);
         /* :275 w->warp(img, K, R, INTER_LINEAR, BORDER_REFLECT, img_warped) */
+        if (cams[i].lens_map1 && cams[i].lens_map2) {
+            /* the fused lens variant (mst_oracle.h: mo_compose_lens_maps): buildMaps, compose, one remap of the raw frame */
+            float *xm = (float *)malloc(sizeof(float) * (size_t)w * h), *ym = (float *)malloc(sizeof(float) * (size_t)w * h);
+            mo_build_maps(cfg->warp_kind, cfg->scale, cams[i].K, cams[i].R, cams[i].T, cams[i].src_w, cams[i].src_h, xm, ym);
+            mo_compose_lens_maps(xm, ym, (size_t)w * h, cams[i].lens_map1, cams[i].lens_map2, cams[i].src_w, cams[i].src_h);
+            mo_remap_8u(cams[i].frame, cams[i].src_w, cams[i].src_h, cams[i].src_stride, 3, img_warped, w, h, (size_t)w * 3,
+                        xm, ym, (size_t)w, MO_INTER_LINEAR, MO_BORDER_REFLECT);
+            free(xm); free(ym);
+        } else
         mo_warp_8u(cfg->warp_kind, cfg->scale, cams[i].K, cams[i].R, cams[i].T,
                    cams[i].frame, cams[i].src_w, cams[i].src_h, cams[i].src_stride, 3,
                    MO_INTER_LINEAR, MO_BORDER_REFLECT, img_warped);

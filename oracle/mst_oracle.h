@@ -113,6 +113,17 @@ void mo_remap_8u_fixed(const uint8_t *src, int sw, int sh, size_t sstride, int c
                        uint8_t *dst, int dw, int dh, size_t dstride,
                        const int16_t *map1, const uint16_t *map2);
 
+/* SURVEY 8 f1 as written: "composing the distortion model into the warp's backward map" -- ONE resampling of the raw
+ * frame.  This is NOT what the reference computes (it resamples twice, DRV:741 then DRV:752); it is this project's
+ * definition of the fused variant and is its own parity target:
+ *   (u, v)  = the warp's backward map at the ROI pixel (float, as buildMaps stores it), clamped to the frame;
+ *   L(u, v) = the lens maps (map1 + fractions of map2 / 32, as floats) interpolated bilinearly at (u, v):
+ *             x0 = min((int)u, w - 2), ax = u - x0;  r0 = m00 * (1 - ax) + m10 * ax;  r1 = m01 * (1 - ax) + m11 * ax;
+ *             L = r0 * (1 - ay) + r1 * ay      (float32, no contraction);
+ *   the composed maps (Lx, Ly) then go through the warp's own remap(INTER_LINEAR, BORDER_REFLECT) of the RAW frame.
+ * xmap / ymap: n floats each, updated in place.  Frames of one pixel in a dimension use that row / column alone. */
+void mo_compose_lens_maps(float *xmap, float *ymap, size_t n, const int16_t *map1, const uint16_t *map2, int w, int h);
+
 /* ---- exposure (a7) ---------------------------------------------------------- */
 void mo_resize_linear_32f(const float *src, int sw, int sh, float *dst, int dw, int dh);
 void mo_blocks_gain_apply(uint8_t *img, int w, int h, size_t stride,
@@ -211,6 +222,8 @@ typedef struct {
     const float *gain_map; int gain_w, gain_h;   /* GAIN_BLOCKS */
     double gain;                                 /* GAIN */
     const uint8_t *mask;         /* final mask_warped (stitcher.cpp:294), warpRoi sized, tight */
+    /* optional: the camera's lens maps (src_w x src_h), composed into the warp's map (mo_compose_lens_maps); the frame is RAW */
+    const int16_t *lens_map1; const uint16_t *lens_map2;
 } mo_compose_camera;
 
 /* pano (CV_8UC3) and pano_mask (CV_8U) malloc'd; free with mo_free.  Returns canvas rect. */

@@ -113,3 +113,41 @@ void mo_remap_8u_fixed(const uint8_t *src, int sw, int sh, size_t sstride, int c
         }
     }
 }
+
+
+/* ---- the fused (single-resampling) variant: see mst_oracle.h ------------------------------------------------------- */
+static void lens_at(const int16_t *map1, const uint16_t *map2, int w, int x, int y, float *mx, float *my)
+{
+    size_t i = (size_t)y * w + x;
+    *mx = (float)map1[2 * i] + (float)(map2[i] & 31) * (1.0f / 32.0f);
+    *my = (float)map1[2 * i + 1] + (float)((map2[i] >> 5) & 31) * (1.0f / 32.0f);
+}
+
+void mo_compose_lens_maps(float *xmap, float *ymap, size_t n, const int16_t *map1, const uint16_t *map2, int w, int h)
+{
+    for (size_t k = 0; k < n; ++k) {
+        float u = xmap[k], v = ymap[k];
+        /* NaN compares false: it ends up at 0 like the clamp of a negative coordinate */
+        if (!(u > 0.0f)) u = 0.0f;
+        if (!(v > 0.0f)) v = 0.0f;
+        if (u > (float)(w - 1)) u = (float)(w - 1);
+        if (v > (float)(h - 1)) v = (float)(h - 1);
+        int x0 = (int)u, y0 = (int)v;
+        if (x0 > w - 2) x0 = w - 2;
+        if (y0 > h - 2) y0 = h - 2;
+        if (x0 < 0) x0 = 0;
+        if (y0 < 0) y0 = 0;
+        int x1 = x0 + 1 < w ? x0 + 1 : x0, y1 = y0 + 1 < h ? y0 + 1 : y0;
+        float ax = u - (float)x0, ay = v - (float)y0;
+        float ax0 = 1.0f - ax, ay0 = 1.0f - ay;
+        float m00x, m00y, m10x, m10y, m01x, m01y, m11x, m11y;
+        lens_at(map1, map2, w, x0, y0, &m00x, &m00y);
+        lens_at(map1, map2, w, x1, y0, &m10x, &m10y);
+        lens_at(map1, map2, w, x0, y1, &m01x, &m01y);
+        lens_at(map1, map2, w, x1, y1, &m11x, &m11y);
+        float r0x = m00x * ax0 + m10x * ax, r1x = m01x * ax0 + m11x * ax;
+        float r0y = m00y * ax0 + m10y * ax, r1y = m01y * ax0 + m11y * ax;
+        xmap[k] = r0x * ay0 + r1x * ay;
+        ymap[k] = r0y * ay0 + r1y * ay;
+    }
+}

@@ -463,6 +463,15 @@ int mst_warp(int device, int warp_kind, float scale, const float K[9], const flo
     });
 }
 
+int mst_compose_lens_maps(float* xmap, float* ymap, size_t n, const int16_t* map1, const uint16_t* map2, int width, int height)
+{
+    return guarded(nullptr, [&] {
+        require(xmap && ymap && map1 && map2, "null map pointer");
+        require(width > 0 && height > 0, "bad lens map size");
+        mst::compose_lens_maps(xmap, ymap, n, map1, map2, width, height);
+    });
+}
+
 int mst_init_undistort_rectify_map(const double K[9], const double* dist, int num_dist, const double R[9],
                                    const double newK[9], int width, int height, int16_t* map1, uint16_t* map2)
 {

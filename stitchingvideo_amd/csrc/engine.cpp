@@ -393,6 +393,19 @@ void Engine::update(const mst_calibration& calib)
         CamDesc& d = st->desc[i];
         fill_camera_desc(st->pool, s, cs.proj, cs.roi, c.src_width, c.src_height, cfg_.expos_kind, c.gain_map,
                          c.gain_w, c.gain_h, c.gain, d);
+        if (cfg_.flags & MST_FLAG_LENS_COMPOSED) {
+            // every camera reads its backward map from memory (one kernel instantiation per launch); cameras with lens maps
+            // get them composed in: a single resampling of the raw frame, no pre-pass (mst_compose_lens_maps)
+            if ((c.undistort_map1 == nullptr) != (c.undistort_map2 == nullptr)) throw Error{MST_ERR_INVALID_ARG, "undistort maps come in pairs"};
+            const size_t px = static_cast<size_t>(cs.roi.width) * cs.roi.height;
+            std::vector<float> xm(px), ym(px);
+            backward_map_host(cs.proj, cs.roi, build_map_tables(cs.proj, cs.roi), xm.data(), ym.data());
+            if (c.undistort_map1) compose_lens_maps(xm.data(), ym.data(), px, c.undistort_map1, c.undistort_map2, c.src_width, c.src_height);
+            d.xmap = st->pool.upload(xm, s);
+            d.ymap = st->pool.upload(ym, s);
+            d.kind = std::max(d.kind, 3);          // (>= 3: the kernels take xmap / ymap, kernels_common.hpp backward_map)
+            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");      // xm / ym are local
+        }
         const size_t mask_px = static_cast<size_t>(cs.roi.width) * cs.roi.height;
         uint8_t* d_mask = st->pool.alloc<uint8_t>(mask_px);
         d.mask = d_mask;
@@ -448,7 +461,7 @@ void Engine::update(const mst_calibration& calib)
     st->undist_frames.assign(static_cast<size_t>(st->num_sets) * n, nullptr);
     for (int i = 0; i < n; ++i) {
         const mst_camera& c = calib.cameras[i];
-        if (!c.undistort_map1 && !c.undistort_map2) continue;
+        if ((!c.undistort_map1 && !c.undistort_map2) || (cfg_.flags & MST_FLAG_LENS_COMPOSED)) continue;
         if (!c.undistort_map1 || !c.undistort_map2) throw Error{MST_ERR_INVALID_ARG, "undistort maps come in pairs"};
         const size_t px = static_cast<size_t>(c.src_width) * c.src_height;
         UndistortCam& u = st->ucams[i];
@@ -660,7 +673,7 @@ void Engine::update(const mst_calibration& calib)
         // frame-invariant backward map of every launched tile, in the order kernel A consumes it
         st->warp_table = st->pool.alloc<uint32_t>(mb_warp_table_entries(st->warp_list.count));
         st->warp_blobs = st->pool.alloc<uint32_t>(mb_warp_blob_entries(st->warp_list.count));
-        launch_warp_table(st->d_desc, cfg_.warp_kind & 0xFF, st->warp_list, st->warp_table, st->warp_blobs, s);
+        launch_warp_table(st->d_desc, map_kind(), st->warp_list, st->warp_table, st->warp_blobs, s);
         check_hip(hipGetLastError(), "k_warp_table");
         // the staged form of the warp kernel: its own map + gain tables (lane order), the tiles' source windows, and the
         // split of every camera's tiles into those that fit it and those that stay with the gathering kernel
@@ -679,7 +692,7 @@ void Engine::update(const mst_calibration& calib)
                 return v;
             }();
             const int budget_px = classes_kb.back() * 256;
-            launch_warp_table_lds(st->d_desc, cfg_.warp_kind & 0xFF, st->warp_list, st->warp_table_lds, st->warp_gain_lds, st->warp_wins,
+            launch_warp_table_lds(st->d_desc, map_kind(), st->warp_list, st->warp_table_lds, st->warp_gain_lds, st->warp_wins,
                                   budget_px, s);
             check_hip(hipGetLastError(), "k_warp_table_lds");
             std::vector<WarpWin> wins(std::max(nt, 1));
@@ -832,7 +845,7 @@ void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameB
         tl.tiles = st.warp_list.tiles + plan.warp_cam_start[cam0];
         tl.count = plan.warp_cam_start[cam1] - plan.warp_cam_start[cam0];
         tl.first = plan.warp_cam_start[cam0];
-        launch_warp_pyr(desc, st.n, cfg_.warp_kind & 0xFF, tl, fb, count, st.warp_table, st.warp_blobs, s);
+        launch_warp_pyr(desc, st.n, map_kind(), tl, fb, count, st.warp_table, st.warp_blobs, s);
         return;
     }
     TileList tg{};
@@ -840,7 +853,7 @@ void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameB
     tg.first = 0;
     tg.index = st.d_warp_gathered + st.warp_gathered_start[cam0];
     tg.count = st.warp_gathered_start[cam1] - st.warp_gathered_start[cam0];
-    launch_warp_pyr(desc, st.n, cfg_.warp_kind & 0xFF, tg, fb, count, st.warp_table, st.warp_blobs, s);     // (the short list first)
+    launch_warp_pyr(desc, st.n, map_kind(), tg, fb, count, st.warp_table, st.warp_blobs, s);     // (the short list first)
     for (int c = static_cast<int>(st.warp_classes.size()) - 1; c >= 0; --c) {       // (the large-window classes first: fewer, longer blocks)
         const CalibState::WarpClass& wc = st.warp_classes[c];
         launch_warp_pyr_lds(desc, st.n, wc.start[cam1] - wc.start[cam0], fb, count, st.warp_table_lds, st.warp_gain_lds,
@@ -912,7 +925,7 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     ca.tiles = d_tiles; ca.segs = d_segs; ca.table = d_table; ca.gain = d_gain; ca.weight = d_weight;
     ca.n_tiles = n_tiles;
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");     // tiles / segs / seg_tile are pageable and local
-    launch_compose_table(ca, cfg_.warp_kind & 0xFF, n_segs, d_segs, d_tiles, d_seg_tile, d_table, d_gain, d_weight, s);
+    launch_compose_table(ca, map_kind(), n_segs, d_segs, d_tiles, d_seg_tile, d_table, d_gain, d_weight, s);
     check_hip(hipGetLastError(), "k_compose_table");
     uint8_t* d_plane = st.pool.alloc<uint8_t>(static_cast<size_t>(st.out_w) * st.out_h + 16);
     launch_compose_mask(ca, d_plane, s);

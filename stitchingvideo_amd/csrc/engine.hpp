@@ -196,6 +196,9 @@ private:
                           hipStream_t stream, StageTimer* timer);
     void strip_columns(int width, int* x0, int* x1) const;
     void launch_undistort(const CalibState& st, const FrameBatch& src, const FrameBatch& dst, int count, uint32_t camera_mask, hipStream_t s);
+    // which map_px<KIND> the table kernels and the gathering warp kernel are launched with: the projection's own
+    // per-axis form, or "read the map" (3) for the non-separable projectors and for MST_FLAG_LENS_COMPOSED
+    int map_kind() const { return (cfg_.flags & MST_FLAG_LENS_COMPOSED) ? 3 : (cfg_.warp_kind & 0xFF); }
     void launch_warp(const CalibState& st, const CamDesc* desc, const FrameBatch& fb, int count, int cam0, int cam1, hipStream_t s);
     void build_compose_plan(CalibState& st, hipStream_t s);     // mst_update, blend kinds NO and FEATHER
     void set_in_flight(std::shared_ptr<CalibState> st);   // keeps `st` alive; the previous one goes to retired_

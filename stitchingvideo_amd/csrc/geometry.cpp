@@ -636,6 +636,33 @@ int cv_round64(double v)
 }
 }  // namespace
 
+void compose_lens_maps(float* xmap, float* ymap, size_t n, const int16_t* map1, const uint16_t* map2, int w, int h)
+{
+    auto lens = [&](int x, int y, float& mx, float& my) {
+        const size_t i = static_cast<size_t>(y) * w + x;
+        mx = static_cast<float>(map1[2 * i]) + static_cast<float>(map2[i] & 31) * (1.0f / 32.0f);
+        my = static_cast<float>(map1[2 * i + 1]) + static_cast<float>((map2[i] >> 5) & 31) * (1.0f / 32.0f);
+    };
+    const float xmax = static_cast<float>(w - 1), ymax = static_cast<float>(h - 1);
+    for (size_t k = 0; k < n; ++k) {
+        float u = xmap[k], v = ymap[k];
+        if (!(u > 0.0f)) u = 0.0f;             // (NaN lands on 0 too)
+        if (!(v > 0.0f)) v = 0.0f;
+        if (u > xmax) u = xmax;
+        if (v > ymax) v = ymax;
+        const int x0 = std::max(0, std::min(static_cast<int>(u), w - 2)), y0 = std::max(0, std::min(static_cast<int>(v), h - 2));
+        const int x1 = std::min(x0 + 1, w - 1), y1 = std::min(y0 + 1, h - 1);
+        const float ax = u - static_cast<float>(x0), ay = v - static_cast<float>(y0);
+        const float ax0 = 1.0f - ax, ay0 = 1.0f - ay;
+        float ax_[4], ay_[4];
+        lens(x0, y0, ax_[0], ay_[0]); lens(x1, y0, ax_[1], ay_[1]); lens(x0, y1, ax_[2], ay_[2]); lens(x1, y1, ax_[3], ay_[3]);
+        const float r0x = ax_[0] * ax0 + ax_[1] * ax, r1x = ax_[2] * ax0 + ax_[3] * ax;
+        const float r0y = ay_[0] * ax0 + ay_[1] * ax, r1y = ay_[2] * ax0 + ay_[3] * ax;
+        xmap[k] = r0x * ay0 + r1x * ay;
+        ymap[k] = r0y * ay0 + r1y * ay;
+    }
+}
+
 bool init_undistort_rectify_map(const double K[9], const double* dist, int ndist, const double* R, const double newK[9],
                                 int width, int height, int16_t* map1, uint16_t* map2)
 {

@@ -108,6 +108,8 @@ struct BandGeometry {
 // doubles; dist: 0, 4, 5 or 8 coefficients k1 k2 p1 p2 [k3 [k4 k5 k6]].  map1: h x w x 2 shorts (integer source
 // coordinate), map2: h x w ushorts ((fy << 5) | fx, the row of cv::remap's bilinear weight table).  False if
 // the coefficient count is not one OpenCV accepts.
+// MST_FLAG_LENS_COMPOSED: the lens maps interpolated at the warp's backward map (mi355_stitch.h: mst_compose_lens_maps)
+void compose_lens_maps(float* xmap, float* ymap, size_t n, const int16_t* map1, const uint16_t* map2, int w, int h);
 bool init_undistort_rectify_map(const double K[9], const double* dist, int ndist, const double* R, const double newK[9],
                                 int width, int height, int16_t* map1, uint16_t* map2);
 

@@ -242,6 +242,20 @@ def init_undistort_rectify_map(K, dist, size, R=None, newK=None):
     return m1, m2
 
 
+def compose_lens_maps(xmap, ymap, map1, map2):
+    """The map composition of PanoramaEngine(lens_composed=True) (mst_compose_lens_maps): the lens maps interpolated at the
+    warp's backward map; returns new (xmap, ymap).  Host only."""
+    x = np.ascontiguousarray(xmap, np.float32).copy()
+    y = np.ascontiguousarray(ymap, np.float32).copy()
+    m1 = np.ascontiguousarray(map1, np.int16)
+    m2 = np.ascontiguousarray(map2, np.uint16)
+    h, w = m2.shape
+    if m1.shape != (h, w, 2):
+        raise ValueError("map1 must be (h, w, 2) int16 and map2 (h, w) uint16")
+    capi.check(capi.load().mst_compose_lens_maps(x.ctypes.data, y.ctypes.data, x.size, m1.ctypes.data, m2.ctypes.data, w, h))
+    return x, y
+
+
 def remap_fixed(image, map1, map2, device=0):
     """cv::remap(image, dst, map1, map2, INTER_LINEAR) with CV_16SC2 / CV_16UC1 maps on a CV_8UC3 image (DRV:741)."""
     image = np.ascontiguousarray(image, np.uint8)
@@ -290,7 +304,7 @@ class PanoramaEngine:
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
                  feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False,
-                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None):
+                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None, lens_composed=False):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -303,7 +317,7 @@ class PanoramaEngine:
         cfg.feather_sharpness = feather_sharpness
         cfg.device = device
         cfg.flags = (capi.FLAG_DRIVER_LUT if driver_lut else 0) | (capi.FLAG_DEBUG if debug else 0) | \
-            (capi.FLAG_OVERLAP_FRAMES if overlap_frames else 0)
+            (capi.FLAG_OVERLAP_FRAMES if overlap_frames else 0) | (capi.FLAG_LENS_COMPOSED if lens_composed else 0)
         cfg.upblack, cfg.downblack, cfg.leftblack, cfg.rightblack = crop
         cfg.max_batch = max_batch
         cfg.weight_type = {"32f": 0, "16s": 1}[weight_type] if isinstance(weight_type, str) else int(weight_type)

@@ -46,7 +46,8 @@ class ComposeCamera(C.Structure):
                 ("frame", C.c_void_p), ("src_w", C.c_int), ("src_h", C.c_int),
                 ("src_stride", C.c_size_t),
                 ("gain_map", C.c_void_p), ("gain_w", C.c_int), ("gain_h", C.c_int),
-                ("gain", C.c_double), ("mask", C.c_void_p)]
+                ("gain", C.c_double), ("mask", C.c_void_p),
+                ("lens_map1", C.c_void_p), ("lens_map2", C.c_void_p)]
 
 
 _lib = None
@@ -81,6 +82,8 @@ def lib():
     L.mo_warp_8u.restype = Rect
     L.mo_warp_8u.argtypes = [C.c_int, C.c_float, fp, fp, fp, vp, C.c_int, C.c_int, C.c_size_t,
                              C.c_int, C.c_int, C.c_int, vp]
+    L.mo_compose_lens_maps.restype = None
+    L.mo_compose_lens_maps.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_int, C.c_int]
     L.mo_init_undistort_rectify_map.restype = C.c_int
     L.mo_init_undistort_rectify_map.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
     L.mo_remap_8u_fixed.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, C.c_int, C.c_int,
@@ -183,6 +186,17 @@ def init_undistort_rectify_map(K, dist, size, R=None, newK=None):
     if rc != 0:
         raise ValueError("bad distortion coefficient count")
     return m1, m2
+
+
+def compose_lens_maps(xmap, ymap, map1, map2):
+    """The fused lens variant's map composition (mst_oracle.h); returns new (xmap, ymap)."""
+    x = np.ascontiguousarray(xmap, np.float32).copy()
+    y = np.ascontiguousarray(ymap, np.float32).copy()
+    m1 = np.ascontiguousarray(map1, np.int16)
+    m2 = np.ascontiguousarray(map2, np.uint16)
+    h, w = m2.shape
+    lib().mo_compose_lens_maps(_ptr(x), _ptr(y), C.c_size_t(x.size), _ptr(m1), _ptr(m2), w, h)
+    return x, y
 
 
 def remap_fixed(src, map1, map2):
@@ -453,6 +467,11 @@ def compose_panorama(warp_kind, scale, blend_kind, expos_kind, cams, num_bands=5
             arr[i].gain_map = g.ctypes.data; arr[i].gain_w = g.shape[1]; arr[i].gain_h = g.shape[0]
         arr[i].gain = float(c.get("gain", 1.0))
         arr[i].mask = mask.ctypes.data
+        if c.get("lens_maps") is not None:          # the fused single-resampling variant: frame is the RAW frame
+            m1 = np.ascontiguousarray(c["lens_maps"][0], np.int16)
+            m2 = np.ascontiguousarray(c["lens_maps"][1], np.uint16)
+            keep += [m1, m2]
+            arr[i].lens_map1 = m1.ctypes.data; arr[i].lens_map2 = m2.ctypes.data
     p, m = C.c_void_p(), C.c_void_p()
     r = L.mo_compose_panorama(C.byref(cfg), arr, len(cams), C.byref(p), C.byref(m))
     pano = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (r.height, r.width, 3)).copy()

@@ -52,6 +52,31 @@ def test_map_builder_properties():
         S.init_undistort_rectify_map(K, [0.1, 0.2, 0.3], (8, 8))          # 3 coefficients: not a shape OpenCV takes
 
 
+def test_lens_map_composition_matches_oracle_and_identity():
+    """MST_FLAG_LENS_COMPOSED (SURVEY 8 f1 as written): the host composition agrees with the oracle bit for bit; undistorted
+    lens maps (the identity) leave the warp's map unchanged inside the frame."""
+    rng = np.random.default_rng(11)
+    w, h = 333, 211
+    K = np.array([[w * 0.6, 0, w * 0.47], [0, w * 0.62, h * 0.55], [0, 0, 1]])
+    m1, m2 = S.init_undistort_rectify_map(K, [0.1, -0.05, 0.001, 0.002, 0.03], (w, h))
+    x = rng.uniform(-20, w + 20, 5000).astype(np.float32)
+    y = rng.uniform(-20, h + 20, 5000).astype(np.float32)
+    x[:7] = [np.nan, -1.0, 0.0, w - 1, w - 1.0001, np.inf, -np.inf]
+    y[:7] = [3.0, -1.0, 0.0, h - 1, h - 1.0001, 5.0, 5.0]
+    a = S.compose_lens_maps(x, y, m1, m2)
+    b = O.compose_lens_maps(x, y, m1, m2)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    i1, i2 = S.init_undistort_rectify_map(K, [0, 0, 0, 0], (w, h))
+    inside = (x >= 0) & (x <= w - 1) & (y >= 0) & (y <= h - 1)
+    cx, cy = S.compose_lens_maps(x, y, i1, i2)
+    assert np.abs(cx[inside] - x[inside]).max() < 1e-4 and np.abs(cy[inside] - y[inside]).max() < 1e-4
+    # a one-row lens map: the row alone is used
+    r1, r2 = S.init_undistort_rectify_map(np.array([[50.0, 0, 20], [0, 50, 0], [0, 0, 1]]), [0.05, 0, 0, 0], (40, 1))
+    a = S.compose_lens_maps(x[:200], y[:200], r1, r2)
+    b = O.compose_lens_maps(x[:200], y[:200], r1, r2)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
 def _frame(w, h, seed):
     return np.random.default_rng(seed).integers(0, 256, (h, w, 3)).astype(np.uint8)
 
@@ -114,4 +139,52 @@ def test_compose_with_undistort_prepass(blend):
     eng.synchronize()
     for i in range(3):
         assert np.array_equal(panos[i].cpu().numpy(), expect[i][1]), "pipelined frame %d" % i
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blend,warp", [("multiband", "spherical"), ("feather", "plane"), ("no", "cylindrical"), ("multiband", "fisheye")])
+def test_compose_with_lens_maps_composed_into_the_warp(blend, warp):
+    """SURVEY 8 f1 as written (MST_FLAG_LENS_COMPOSED): one resampling of the RAW frames through the composed map, no
+    pre-pass; parity against the oracle's statement of the same composition, single frames and a batch."""
+    import torch
+    cfg = rigmod.scaled_config("C3" if warp != "plane" else "C2", 8)
+    cfg["blend"] = blend
+    cfg["warp"] = warp
+    rig = rigmod.build_rig(cfg)
+    w, h = rig["size"]
+    K = np.array([[w * 0.52, 0, w * 0.49], [0, w * 0.52, h * 0.51], [0, 0, 1]])
+    maps = []
+    for i, c in enumerate(rig["cameras"]):
+        if i == 1:
+            maps.append(None)                       # a camera without lens maps: the plain map, read from memory
+            continue
+        maps.append(S.init_undistort_rectify_map(K, [-0.35 + 0.02 * i, 0.15, 0.001 * i, -0.002], (w, h)))
+        c["undistort"] = maps[-1]
+    eng = H.make_engine(rig, max_batch=3, lens_composed=True)
+    _, _, cw, ch = eng.canvas()
+    host = [rigmod.frames_for(rig, i) for i in range(3)]
+
+    def expect(frames):
+        cams = []
+        for c, f, m in zip(rig["cameras"], frames, maps):
+            cams.append(dict(K=c["K"], R=c["R"], frame=f, mask=c["mask"], gain_map=c.get("gain_map"), gain=c.get("gain", 1.0),
+                             lens_maps=m))
+        return O.compose_panorama(H.WARP_O[rig["warp"]], rig["scale"], H.BLEND_O[blend], H.EXPOS_O[rig["expos"]], cams)
+
+    exp = [expect(fr) for fr in host]
+    pano, mask = eng.compose(host[0])
+    assert np.array_equal(pano, exp[0][1]), H.diff_report(pano, exp[0][1])
+    assert np.array_equal(mask, exp[0][2])
+    # (and it is NOT the two-stage result: the pre-pass variant differs wherever the lens bends)
+    two = H.oracle_compose(rig, [f if m is None else O.remap_fixed(f, m[0], m[1]) for f, m in zip(host[0], maps)])
+    assert not np.array_equal(two[1], exp[0][1])
+    dev = torch.device("cuda", 0)
+    dfr = [[torch.from_numpy(f).to(dev) for f in fr] for fr in host]
+    panos = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(3)]
+    eng.compose_device_batch([[t.data_ptr() for t in fr] for fr in dfr], [[t.stride(0) for t in fr] for fr in dfr],
+                             [p.data_ptr() for p in panos], panos[0].stride(0))
+    eng.synchronize()
+    for i in range(3):
+        assert np.array_equal(panos[i].cpu().numpy(), exp[i][1]), "frame set %d" % i
     eng.close()
