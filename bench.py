@@ -401,6 +401,20 @@ def main():
             out["host_buffers"] = host_buffer_leg(eng, host_sets, cw, ch)
         except Exception as e:          # noqa: BLE001
             out["host_buffers"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the same pipeline fed NV12 frames (MST_FLAG_FRAMES_NV12: half the bytes over PCIe, converted on the device)
+        try:
+            import numpy as np
+            eng_nv = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank, frames_nv12=True)
+            eng_nv.update(rig["scale"], rig["cameras"])
+            fw, fh = rig["size"]
+            rng = np.random.default_rng(7)
+            nv_sets = [[rng.integers(16, 236, (fh * 3 // 2, fw)).astype(np.uint8) for _ in range(n_cam)] for _ in range(2)]
+            hb = host_buffer_leg(eng_nv, nv_sets, cw, ch, serial=False)
+            out["host_buffers"]["nv12_pipeline_fps"] = hb["pipeline_fps"]
+            out["host_buffers"]["nv12_mb_in_per_frame"] = hb["mb_in_per_frame"]
+            eng_nv.close()
+        except Exception as e:          # noqa: BLE001
+            out["host_buffers"]["nv12_error"] = "%s: %s" % (type(e).__name__, e)
 
     watchdog = None
     # ---- N > 1: the north-star split measured beside the headline (C4: 8 cameras, camera i on rank i % N) ----
@@ -463,13 +477,13 @@ def main():
         watchdog.cancel()
 
 
-def host_buffer_leg(eng, host_sets, cw, ch):
+def host_buffer_leg(eng, host_sets, cw, ch, serial=True):
     """Frames in host memory, panorama back to host memory (what the VC++ host hands over: cv::Mat data).
     serial: mst_compose per frame, pageable numpy buffers (H2D -> kernels -> D2H in series).
     pipeline: mst_pipeline_submit / wait, page-locked buffers, H2D(t+1) || kernels(t) || D2H(t-1)."""
     import numpy as np
     import stitchingvideo_amd as S
-    n_ser = 30
+    n_ser = 30 if serial else 2
     t0 = time.perf_counter()
     for i in range(n_ser):
         eng.compose(host_sets[i % len(host_sets)], want_mask=False)

@@ -99,6 +99,13 @@ int mst_warp_kind_from_name(const char *name);
                                       (feedSizeRemap, DRV:150-177); requires MST_BLEND_NO */
 
 #define MST_FLAG_DEBUG        2u   /* keep a copy of the collapsed canvas levels for mst_debug_read */
+#define MST_FLAG_FRAMES_NV12 16u   /* the frames of every compose call (host, device, batch, pipeline) are NV12 as decoders deliver
+                                      them: one plane pointer per camera, src_height rows of Y then src_height / 2 rows of
+                                      interleaved U V, all `stride` bytes apart (a CV_8UC1 Mat of height * 3 / 2 rows, what
+                                      cvtColor(COLOR_YUV2BGR_NV12) takes); stride >= src_width; width and height even.  The engine
+                                      converts on the device first (OpenCV 2.4.11's fixed-point BT.601, bit for bit) -- half the
+                                      bytes over PCIe for host frames.  The reference itself is BGR-only
+                                      (stitching_sharemem.cpp:112-115); SURVEY 8 f3.  Not for the mst_stage_* calls. */
 #define MST_FLAG_LENS_COMPOSED 8u  /* SURVEY 8 f1 as written: cameras that carry undistort maps get them COMPOSED into the warp's
                                       backward map at mst_update (mst_compose_lens_maps) and every frame is resampled ONCE, from the
                                       raw frame -- no pre-pass, the plain rate.  Not the reference's pixels (it resamples twice,
@@ -316,6 +323,9 @@ int  mst_build_maps_host(int warp_kind, float scale, const float K[9], const flo
 /* cv::initUndistortRectifyMap(K, dist, R, newK, Size(width, height), CV_16SC2, map1, map2) as RunTestEyeFishMap calls
  * it (DRV:201-238); host only.  K, newK: 3x3 row-major doubles; R: 3x3 or NULL (identity); dist: 0, 4, 5 or 8
  * coefficients (k1 k2 p1 p2 [k3 [k4 k5 k6]]).  map1: height x width x 2 shorts, map2: height x width ushorts. */
+/* cv::cvtColor(yuv, bgr, COLOR_YUV2BGR_NV12) on the device (the conversion behind MST_FLAG_FRAMES_NV12), host buffers:
+ * yuv = (height * 3 / 2) rows of yuv_stride bytes, bgr = height rows of bgr_stride bytes; width and height even. */
+int  mst_cvt_nv12_bgr(int device, const uint8_t *yuv, int width, int height, size_t yuv_stride, uint8_t *bgr, size_t bgr_stride);
 /* The map composition of MST_FLAG_LENS_COMPOSED, host only: (xmap, ymap)[k] <- the lens maps (map1 + map2's fractions / 32)
  * interpolated bilinearly at (xmap, ymap)[k] clamped to the width x height frame, in float32:
  * x0 = min((int)u, width - 2), ax = u - x0; r0 = m00 * (1 - ax) + m10 * ax; r1 = m01 * (1 - ax) + m11 * ax;

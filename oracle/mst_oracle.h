@@ -124,6 +124,12 @@ void mo_remap_8u_fixed(const uint8_t *src, int sw, int sh, size_t sstride, int c
  * xmap / ymap: n floats each, updated in place.  Frames of one pixel in a dimension use that row / column alone. */
 void mo_compose_lens_maps(float *xmap, float *ymap, size_t n, const int16_t *map1, const uint16_t *map2, int w, int h);
 
+/* ---- NV12 ingest (optional): cv::cvtColor(yuv, bgr, COLOR_YUV2BGR_NV12) of OpenCV 2.4.11
+ * (imgproc/src/color.cpp, YUV420sp2RGB888Invoker<bIdx = 0, uIdx = 0>): BT.601 limited range in 20-bit fixed point.
+ * The reference itself is BGR-only (stitching_sharemem.cpp:112-115); NV12 is what hardware decoders deliver.
+ * yuv: (h * 3 / 2) rows of `stride` bytes -- h rows of Y, then h / 2 rows of interleaved U V; w and h even. */
+void mo_cvt_nv12_bgr(const uint8_t *yuv, int w, int h, size_t stride, uint8_t *bgr, size_t bgr_stride);
+
 /* ---- exposure (a7) ---------------------------------------------------------- */
 void mo_resize_linear_32f(const float *src, int sw, int sh, float *dst, int dw, int dh);
 void mo_blocks_gain_apply(uint8_t *img, int w, int h, size_t stride,

@@ -151,3 +151,34 @@ void mo_compose_lens_maps(float *xmap, float *ymap, size_t n, const int16_t *map
         ymap[k] = r0y * ay0 + r1y * ay;
     }
 }
+
+
+/* ---- NV12 -> BGR (mst_oracle.h) ------------------------------------------------------------------------------------ */
+static uint8_t sat_u8_i(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+void mo_cvt_nv12_bgr(const uint8_t *yuv, int w, int h, size_t stride, uint8_t *bgr, size_t bgr_stride)
+{
+    /* color.cpp: ITUR_BT_601_CY / CUB / CUG / CVG / CVR, ITUR_BT_601_SHIFT = 20 */
+    const int CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527, SHIFT = 20;
+    const uint8_t *uvp = yuv + stride * (size_t)h;
+    for (int j = 0; j < h; j += 2) {
+        const uint8_t *y1 = yuv + stride * (size_t)j, *y2 = y1 + stride, *uv = uvp + stride * (size_t)(j / 2);
+        uint8_t *row1 = bgr + bgr_stride * (size_t)j, *row2 = row1 + bgr_stride;
+        for (int i = 0; i < w; i += 2) {
+            int u = (int)uv[i] - 128, v = (int)uv[i + 1] - 128;
+            int ruv = (1 << (SHIFT - 1)) + CVR * v;
+            int guv = (1 << (SHIFT - 1)) + CVG * v + CUG * u;
+            int buv = (1 << (SHIFT - 1)) + CUB * u;
+            const uint8_t *ys[4] = {y1 + i, y1 + i + 1, y2 + i, y2 + i + 1};
+            uint8_t *os[4] = {row1 + 3 * i, row1 + 3 * i + 3, row2 + 3 * i, row2 + 3 * i + 3};
+            for (int k = 0; k < 4; ++k) {
+                int yy = (int)*ys[k] - 16;
+                if (yy < 0) yy = 0;
+                yy *= CY;
+                os[k][2] = sat_u8_i((yy + ruv) >> SHIFT);      /* R */
+                os[k][1] = sat_u8_i((yy + guv) >> SHIFT);      /* G */
+                os[k][0] = sat_u8_i((yy + buv) >> SHIFT);      /* B */
+            }
+        }
+    }
+}

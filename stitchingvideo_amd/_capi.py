@@ -36,6 +36,7 @@ FLAG_DRIVER_LUT = 1
 FLAG_DEBUG = 2
 FLAG_OVERLAP_FRAMES = 4
 FLAG_LENS_COMPOSED = 8
+FLAG_FRAMES_NV12 = 16
 MAX_CAMERAS, MAX_BANDS = 16, 10
 DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, DBG_CANVAS_S16, DBG_CAM_NEED_U8 = \
     1, 2, 3, 4, 5, 6
@@ -48,7 +49,7 @@ EXPORTS = [
     "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
     "mst_payload_bytes", "mst_payload_pack", "mst_payload_unpack", "mst_stage_select_set",
     "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
-    "mst_init_undistort_rectify_map", "mst_compose_lens_maps", "mst_remap_fixed",
+    "mst_init_undistort_rectify_map", "mst_compose_lens_maps", "mst_cvt_nv12_bgr", "mst_remap_fixed",
     "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame", "mst_gain_map_size", "mst_exposure_feed", "mst_seam_voronoi", "mst_seam_dp",
 ]
 
@@ -148,6 +149,8 @@ def load():
     L.mst_compose_profile_batch.restype = C.c_int
     L.mst_compose_profile_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                             C.c_size_t, vp, C.c_int, vp, fp, ip]
+    L.mst_cvt_nv12_bgr.restype = C.c_int
+    L.mst_cvt_nv12_bgr.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
     L.mst_compose_lens_maps.restype = C.c_int
     L.mst_compose_lens_maps.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_int, C.c_int]
     L.mst_init_undistort_rectify_map.restype = C.c_int

@@ -463,6 +463,31 @@ int mst_warp(int device, int warp_kind, float scale, const float K[9], const flo
     });
 }
 
+int mst_cvt_nv12_bgr(int device, const uint8_t* yuv, int width, int height, size_t yuv_stride, uint8_t* bgr, size_t bgr_stride)
+{
+    return guarded(nullptr, [&] {
+        require(yuv && bgr, "null image pointer");
+        require(width > 0 && height > 0 && width % 2 == 0 && height % 2 == 0, "NV12 frames have even sizes");
+        const size_t row = static_cast<size_t>(width) * 3, rows_in = static_cast<size_t>(height) * 3 / 2;
+        require(yuv_stride >= static_cast<size_t>(width) && bgr_stride >= row && row < (size_t{1} << 24), "bad stride");
+        mst::select_device(device);
+        StageCtx ctx;
+        mst::check_hip(hipStreamCreate(&ctx.s), "hipStreamCreate");
+        uint8_t* d_src = ctx.pool.alloc<uint8_t>(static_cast<size_t>(width) * rows_in + 16);
+        uint8_t* d_dst = ctx.pool.alloc<uint8_t>(row * height + 16);
+        mst::check_hip(hipMemcpy2DAsync(d_src, width, yuv, yuv_stride, width, rows_in, hipMemcpyHostToDevice, ctx.s), "hipMemcpy2DAsync");
+        const int2 size = make_int2(width, height);
+        const int2* d_size = ctx.pool.upload(&size, 1, ctx.s);
+        mst::FrameBatch fs{}, fd{};
+        fs.f[0].ptr[0] = d_src; fs.f[0].stride[0] = static_cast<uint32_t>(width);
+        fd.f[0].ptr[0] = d_dst; fd.f[0].stride[0] = static_cast<uint32_t>(row);
+        mst::launch_nv12_to_bgr(fs, fd, d_size, 1, width, height, 1, ctx.s);
+        mst::check_hip(hipGetLastError(), "k_nv12_to_bgr");
+        mst::check_hip(hipMemcpy2DAsync(bgr, bgr_stride, d_dst, row, row, height, hipMemcpyDeviceToHost, ctx.s), "hipMemcpy2DAsync");
+        mst::check_hip(hipStreamSynchronize(ctx.s), "hipStreamSynchronize");
+    });
+}
+
 int mst_compose_lens_maps(float* xmap, float* ymap, size_t n, const int16_t* map1, const uint16_t* map2, int width, int height)
 {
     return guarded(nullptr, [&] {

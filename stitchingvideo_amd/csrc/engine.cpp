@@ -116,6 +116,7 @@ template PayloadRect* DevicePool::upload<PayloadRect>(const PayloadRect*, size_t
 template ComposeTile* DevicePool::upload<ComposeTile>(const ComposeTile*, size_t, hipStream_t);
 template ComposeSeg* DevicePool::upload<ComposeSeg>(const ComposeSeg*, size_t, hipStream_t);
 template WarpWin* DevicePool::upload<WarpWin>(const WarpWin*, size_t, hipStream_t);
+template int2* DevicePool::upload<int2>(const int2*, size_t, hipStream_t);
 template FeedImage* DevicePool::upload<FeedImage>(const FeedImage*, size_t, hipStream_t);
 template FeedPair* DevicePool::upload<FeedPair>(const FeedPair*, size_t, hipStream_t);
 
@@ -456,6 +457,21 @@ void Engine::update(const mst_calibration& calib)
     st->num_sets = st->sets_per_slot;
     if ((cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && cfg_.blend_kind == MST_BLEND_MULTI_BAND) st->num_sets = 2 * st->sets_per_slot;
 
+    if (cfg_.flags & MST_FLAG_FRAMES_NV12) {        // the BGR frames the callers' NV12 frames are converted into
+        std::vector<int2> sizes(n);
+        st->nv12_frames.assign(static_cast<size_t>(st->num_sets) * n, nullptr);
+        for (int i = 0; i < n; ++i) {
+            const mst_camera& c = calib.cameras[i];
+            if ((c.src_width | c.src_height) & 1) throw Error{MST_ERR_INVALID_ARG, "NV12 frames have even sizes"};
+            sizes[i] = make_int2(c.src_width, c.src_height);
+            st->frame_max_w = std::max(st->frame_max_w, c.src_width);
+            st->frame_max_h = std::max(st->frame_max_h, c.src_height);
+            for (int k = 0; k < st->num_sets; ++k)
+                st->nv12_frames[static_cast<size_t>(k) * n + i] = st->pool.alloc<uint8_t>(static_cast<size_t>(c.src_width) * c.src_height * 3 + 16);
+        }
+        st->d_frame_sizes = st->pool.upload(sizes, s);
+        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+    }
     // optional lens-undistort maps (DRV:232): uploaded once, applied to every frame before the warp
     st->ucams.assign(n, UndistortCam{nullptr, nullptr, 0, 0});
     st->undist_frames.assign(static_cast<size_t>(st->num_sets) * n, nullptr);
@@ -1054,7 +1070,8 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
     if (!d_frames || !strides || !d_panos) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama table"};
     if (count < 1 || count > kMaxBatch) throw Error{MST_ERR_INVALID_ARG, "batch size out of range"};
-    if ((st->blend_kind == MST_BLEND_MULTI_BAND || st->any_undistort) && count > 1 && count > st->sets_per_slot)
+    const bool nv12 = !st->nv12_frames.empty();
+    if ((st->blend_kind == MST_BLEND_MULTI_BAND || st->any_undistort || nv12) && count > 1 && count > st->sets_per_slot)
         throw Error{MST_ERR_INVALID_ARG, "batch larger than mst_config.max_batch"};
     hipStream_t s = stream ? stream : stream_;
     FrameBatch fb{};
@@ -1063,9 +1080,9 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
             const void* p = d_frames[f * st->n + i];
             const size_t stride = strides[f * st->n + i];
             if (!p) throw Error{MST_ERR_INVALID_ARG, "null frame pointer"};
-            if (stride < static_cast<size_t>(st->cams[i].src_w) * 3) throw Error{MST_ERR_INVALID_ARG, "frame stride too small"};
+            if (stride < static_cast<size_t>(st->cams[i].src_w) * (nv12 ? 1 : 3)) throw Error{MST_ERR_INVALID_ARG, "frame stride too small"};
             if (stride >= (size_t{1} << 24)) throw Error{MST_ERR_INVALID_ARG, "frame stride must be below 16 MiB"};
-            if (stride * static_cast<size_t>(st->cams[i].src_h) > 0xFFFFFFFFull)
+            if (stride * static_cast<size_t>(st->cams[i].src_h) * (nv12 ? 3 : 2) / 2 > 0xFFFFFFFFull)
                 throw Error{MST_ERR_INVALID_ARG, "frames of 4 GiB and more are not supported (32-bit byte offsets)"};
             fb.f[f].ptr[i] = static_cast<const uint8_t*>(p);
             fb.f[f].stride[i] = static_cast<uint32_t>(stride);
@@ -1086,6 +1103,17 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
     // lens-undistort pre-pass: remap the caller's frames into the engine's buffers of frame sets first_set.. and
     // point the frame table at them (cameras without maps keep the caller's frames)
     auto undistort = [&](int first_set, hipStream_t on) {
+        if (nv12) {              // NV12 ingest: the callers' frames into the engine's BGR frames of these sets, first of all
+            FrameBatch cb{};
+            for (int f = 0; f < count; ++f)
+                for (int i = 0; i < st->n; ++i) {
+                    cb.f[f].ptr[i] = st->nv12_frames[static_cast<size_t>(first_set + f) * st->n + i];
+                    cb.f[f].stride[i] = static_cast<uint32_t>(st->cams[i].src_w) * 3u;
+                }
+            launch_nv12_to_bgr(fb, cb, st->d_frame_sizes, st->n, st->frame_max_w, st->frame_max_h, count, on);
+            if (timer) timer->mark("k_nv12_to_bgr", on);
+            fb = cb;
+        }
         if (!st->any_undistort) return;
         FrameBatch ub = fb;
         for (int f = 0; f < count; ++f)
@@ -1221,6 +1249,7 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
     std::shared_ptr<CalibState> st = state();
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_stage_cameras before a successful mst_update"};
     if (st->blend_kind != MST_BLEND_MULTI_BAND) throw Error{MST_ERR_INVALID_ARG, "stage calls exist for multi-band only"};
+    if (!st->nv12_frames.empty()) throw Error{MST_ERR_INVALID_ARG, "stage calls take BGR frames (MST_FLAG_FRAMES_NV12 is for the compose calls)"};
     if (!d_frames || !strides) throw Error{MST_ERR_INVALID_ARG, "null frame table"};
     hipStream_t s = stream ? stream : stream_;
     FrameBatch fb{};
@@ -1357,15 +1386,16 @@ void Engine::compose_host(const uint8_t* const* frames, const size_t* strides, u
     std::vector<size_t> dstride(n);
     for (int i = 0; i < n; ++i) {
         const int w = st->cams[i].src_w, h = st->cams[i].src_h;
-        if (!frames[i] || strides[i] < static_cast<size_t>(w) * 3) throw Error{MST_ERR_INVALID_ARG, "bad frame"};
-        const size_t row = static_cast<size_t>(w) * 3, bytes = row * h;
+        const bool nv12 = (cfg_.flags & MST_FLAG_FRAMES_NV12) != 0;      // (h * 3 / 2 rows of w bytes instead of h rows of 3 w)
+        if (!frames[i] || strides[i] < static_cast<size_t>(w) * (nv12 ? 1 : 3)) throw Error{MST_ERR_INVALID_ARG, "bad frame"};
+        const size_t row = static_cast<size_t>(w) * (nv12 ? 1 : 3), rows = nv12 ? static_cast<size_t>(h) * 3 / 2 : h, bytes = row * rows;
         if (d_frame_bytes_[i] < bytes) {
             if (d_frames_[i]) (void)hipFree(d_frames_[i]);
             d_frames_[i] = nullptr;
             check_hip(hipMalloc(reinterpret_cast<void**>(&d_frames_[i]), bytes), "hipMalloc(frame)");
             d_frame_bytes_[i] = bytes;
         }
-        copy_rows(d_frames_[i], row, frames[i], strides[i], row, h, hipMemcpyHostToDevice, stream_);
+        copy_rows(d_frames_[i], row, frames[i], strides[i], row, rows, hipMemcpyHostToDevice, stream_);
         dptr[i] = d_frames_[i];
         dstride[i] = row;
     }
@@ -1425,15 +1455,16 @@ void Engine::pipeline_submit(const uint8_t* const* frames, const size_t* strides
     // wait() has already observed (d2h_done follows compute_done), so the copies may start right away
     for (int i = 0; i < n; ++i) {
         const int w = st->cams[i].src_w, h = st->cams[i].src_h;
-        if (!frames[i] || strides[i] < static_cast<size_t>(w) * 3) throw Error{MST_ERR_INVALID_ARG, "bad frame"};
-        const size_t row = static_cast<size_t>(w) * 3, bytes = row * h;
+        const bool nv12 = (cfg_.flags & MST_FLAG_FRAMES_NV12) != 0;
+        if (!frames[i] || strides[i] < static_cast<size_t>(w) * (nv12 ? 1 : 3)) throw Error{MST_ERR_INVALID_ARG, "bad frame"};
+        const size_t row = static_cast<size_t>(w) * (nv12 ? 1 : 3), rows = nv12 ? static_cast<size_t>(h) * 3 / 2 : h, bytes = row * rows;
         if (ps.d_frame_bytes[i] < bytes) {
             if (ps.d_frames[i]) (void)hipFree(ps.d_frames[i]);
             ps.d_frames[i] = nullptr;
             check_hip(hipMalloc(reinterpret_cast<void**>(&ps.d_frames[i]), bytes + 16), "hipMalloc(frame)");
             ps.d_frame_bytes[i] = bytes;
         }
-        copy_rows(ps.d_frames[i], row, frames[i], strides[i], row, h, hipMemcpyHostToDevice, pipe_in_);
+        copy_rows(ps.d_frames[i], row, frames[i], strides[i], row, rows, hipMemcpyHostToDevice, pipe_in_);
         dptr[i] = ps.d_frames[i];
         dstride[i] = row;
     }

@@ -106,6 +106,10 @@ struct CalibState {
     // `blend` completed for a launch of `frame_sets` frame sets: the tile tables / LDS layout of its launch variant
     BlendArgs blend_for(int frame_sets, int* n_coarse, size_t* lds_bytes) const;
     std::vector<uint64_t*> c1;               // per buffer set: collapsed level-1 canvas (k_blend_coarse -> k_blend_fine)
+    // MST_FLAG_FRAMES_NV12: num_sets x n engine-owned BGR frames the callers' NV12 frames are converted into, (w, h) per camera
+    std::vector<uint8_t*> nv12_frames;
+    const int2* d_frame_sizes = nullptr;
+    int frame_max_w = 0, frame_max_h = 0;
     std::vector<uint8_t*> undist_frames;   // num_sets x n engine-owned undistorted frames (nullptr: camera has no maps)
     uint32_t* warp_table = nullptr;     // per-tile backward-map table (frame-invariant), see kernels_mb.hip
     uint32_t* warp_blobs = nullptr;     // per tile: calibration constants of kernel A (gain rows, row weights, table origin)

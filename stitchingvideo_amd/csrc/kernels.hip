@@ -529,6 +529,72 @@ void launch_warp_u8(const CamDesc* d_cam, const uint8_t* d_src, size_t src_strid
 #undef MST_LAUNCH_WARP
 }
 
+// ---- NV12 ingest (mi355_stitch.h: MST_FLAG_FRAMES_NV12) ---------------------------------------------------------
+// cv::cvtColor(COLOR_YUV2BGR_NV12) of OpenCV 2.4.11 (color.cpp, YUV420sp2RGB888Invoker<0, 0>): BT.601 limited range,
+// 20-bit fixed point.  A thread converts 4 x 2 pixels (two chroma pairs): one dword of each luma row, one dword of
+// chroma in, 12 bytes per row out.  HBM-bound (1.5 bytes in, 3 out per pixel).
+namespace {
+__device__ __forceinline__ uint32_t nv12_px(int y, int ruv, int guv, int buv)
+{
+    const int yy = max(0, y - 16) * 1220542;
+    const int r = min(max((yy + ruv) >> 20, 0), 255), g = min(max((yy + guv) >> 20, 0), 255), b = min(max((yy + buv) >> 20, 0), 255);
+    return static_cast<uint32_t>(b) | static_cast<uint32_t>(g) << 8 | static_cast<uint32_t>(r) << 16;
+}
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+struct __attribute__((packed, aligned(1))) Px4 { uint32_t x, y, z; };
+
+__global__ __launch_bounds__(256) void k_nv12_to_bgr(FrameBatch src, FrameBatch dst, const int2* __restrict__ sizes, int n_cams, int gx, int gy)
+{
+    const int per = gx * gy;
+    const int which = blockIdx.x / per, rem = blockIdx.x - which * per;
+    const int set = which / n_cams, cam = which - set * n_cams;
+    const int w = sizes[cam].x, h = sizes[cam].y;
+    const uint8_t* __restrict__ yuv = src.f[set].ptr[cam];
+    uint8_t* __restrict__ out = const_cast<uint8_t*>(dst.f[set].ptr[cam]);
+    if (!yuv || !out) return;
+    const uint32_t ss = src.f[set].stride[cam], ds = dst.f[set].stride[cam];
+    const int x = ((rem % gx) * 64 + (threadIdx.x & 63)) * 4, y = ((rem / gx) * 4 + (threadIdx.x >> 6)) * 2;
+    if (x >= w || y >= h) return;
+    const uint8_t* y1 = yuv + static_cast<size_t>(y) * ss + x;
+    const uint8_t* uv = yuv + static_cast<size_t>(h) * ss + static_cast<size_t>(y >> 1) * ss + x;
+    uint32_t l1, l2, c;
+    if (x + 4 <= w) {
+        l1 = *reinterpret_cast<const u32_unaligned*>(y1);
+        l2 = *reinterpret_cast<const u32_unaligned*>(y1 + ss);
+        c = *reinterpret_cast<const u32_unaligned*>(uv);
+    } else {                      // (w == 2 mod 4: the last thread of a row has one chroma pair)
+        l1 = y1[0] | y1[1] << 8; l2 = y1[ss] | y1[ss + 1] << 8; c = uv[0] | uv[1] << 8;
+    }
+    uint32_t p[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = static_cast<int>((c >> (16 * k)) & 0xFFu) - 128, v = static_cast<int>((c >> (16 * k + 8)) & 0xFFu) - 128;
+        const int ruv = (1 << 19) + 1673527 * v, guv = (1 << 19) - 852492 * v - 409993 * u, buv = (1 << 19) + 2116026 * u;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            p[0][2 * k + q] = nv12_px(static_cast<int>((l1 >> (16 * k + 8 * q)) & 0xFFu), ruv, guv, buv);
+            p[1][2 * k + q] = nv12_px(static_cast<int>((l2 >> (16 * k + 8 * q)) & 0xFFu), ruv, guv, buv);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        uint8_t* o = out + static_cast<size_t>(y + r) * ds + static_cast<size_t>(x) * 3;
+        if (x + 4 <= w) {
+            *reinterpret_cast<Px4*>(o) = Px4{p[r][0] | p[r][1] << 24, p[r][1] >> 8 | p[r][2] << 16, p[r][2] >> 16 | p[r][3] << 8};
+        } else {
+            for (int k = 0; k < 2; ++k) { o[3 * k] = static_cast<uint8_t>(p[r][k]); o[3 * k + 1] = static_cast<uint8_t>(p[r][k] >> 8); o[3 * k + 2] = static_cast<uint8_t>(p[r][k] >> 16); }
+        }
+    }
+}
+}  // namespace
+
+void launch_nv12_to_bgr(const FrameBatch& src, const FrameBatch& dst, const int2* d_sizes, int n_cams, int max_w, int max_h, int batch, hipStream_t s)
+{
+    if (n_cams <= 0 || batch <= 0 || max_w <= 0 || max_h <= 0) return;
+    const int gx = (max_w + 255) / 256, gy = (max_h + 7) / 8;         // a block: 64 x 4 threads of 4 x 2 pixels
+    hipLaunchKernelGGL(k_nv12_to_bgr, dim3(static_cast<unsigned>(gx * gy * n_cams * batch)), dim3(256), 0, s, src, dst, d_sizes, n_cams, gx, gy);
+}
+
 void launch_remap_fixed(const UndistortCam* d_ucams, int n_cams, int max_w, int max_h, const FrameBatch& src,
                         const FrameBatch& dst, int batch, hipStream_t s)
 {

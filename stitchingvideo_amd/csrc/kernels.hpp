@@ -13,6 +13,8 @@ void launch_warp_u8(const CamDesc* d_cam, const uint8_t* d_src, size_t src_strid
                     int interp, int border, uint8_t* d_dst, size_t dst_stride, int w, int h, hipStream_t s);
 void launch_exposure_apply(const CamDesc* d_cam, uint8_t* d_img, size_t stride, int w, int h, hipStream_t s);
 // lens-undistort pre-pass: dst.f[set].ptr[cam] <- remap(src.f[set].ptr[cam]) for every camera that has maps
+// NV12 frames ((h * 3 / 2) rows of stride bytes) -> BGR frames, every camera of every frame set in one launch; sizes[cam] = (w, h)
+void launch_nv12_to_bgr(const FrameBatch& src, const FrameBatch& dst, const int2* d_sizes, int n_cams, int max_w, int max_h, int batch, hipStream_t s);
 void launch_remap_fixed(const UndistortCam* d_ucams, int n_cams, int max_w, int max_h, const FrameBatch& src,
                         const FrameBatch& dst, int batch, hipStream_t s);
 

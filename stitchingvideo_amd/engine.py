@@ -242,6 +242,17 @@ def init_undistort_rectify_map(K, dist, size, R=None, newK=None):
     return m1, m2
 
 
+def cvt_nv12_bgr(yuv, device=0):
+    """cv::cvtColor(yuv, COLOR_YUV2BGR_NV12) on the device: (H * 3 / 2, W) uint8 -> (H, W, 3) BGR."""
+    yuv = np.ascontiguousarray(yuv, np.uint8)
+    if yuv.ndim != 2 or yuv.shape[0] % 3:
+        raise ValueError("NV12 frames are (H * 3 / 2, W) uint8")
+    h, w = yuv.shape[0] * 2 // 3, yuv.shape[1]
+    out = np.empty((h, w, 3), np.uint8)
+    capi.check(capi.load().mst_cvt_nv12_bgr(device, yuv.ctypes.data, w, h, yuv.strides[0], out.ctypes.data, out.strides[0]))
+    return out
+
+
 def compose_lens_maps(xmap, ymap, map1, map2):
     """The map composition of PanoramaEngine(lens_composed=True) (mst_compose_lens_maps): the lens maps interpolated at the
     warp's backward map; returns new (xmap, ymap).  Host only."""
@@ -304,7 +315,7 @@ class PanoramaEngine:
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
                  feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False,
-                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None, lens_composed=False):
+                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None, lens_composed=False, frames_nv12=False):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -317,7 +328,8 @@ class PanoramaEngine:
         cfg.feather_sharpness = feather_sharpness
         cfg.device = device
         cfg.flags = (capi.FLAG_DRIVER_LUT if driver_lut else 0) | (capi.FLAG_DEBUG if debug else 0) | \
-            (capi.FLAG_OVERLAP_FRAMES if overlap_frames else 0) | (capi.FLAG_LENS_COMPOSED if lens_composed else 0)
+            (capi.FLAG_OVERLAP_FRAMES if overlap_frames else 0) | (capi.FLAG_LENS_COMPOSED if lens_composed else 0) | (capi.FLAG_FRAMES_NV12 if frames_nv12 else 0)
+        self._frames_nv12 = bool(frames_nv12)
         cfg.upblack, cfg.downblack, cfg.leftblack, cfg.rightblack = crop
         cfg.max_batch = max_batch
         cfg.weight_type = {"32f": 0, "16s": 1}[weight_type] if isinstance(weight_type, str) else int(weight_type)
@@ -427,8 +439,11 @@ class PanoramaEngine:
     def compose(self, frames, want_mask=True):
         """frames: list of (H, W, 3) uint8 host arrays -> (pano uint8 (H, W, 3), mask uint8 or None)."""
         n = len(frames)
-        fr = [f if (f.dtype == np.uint8 and f.strides[2] == 1 and f.strides[1] == 3) else np.ascontiguousarray(f, np.uint8)
-              for f in frames]
+        if getattr(self, "_frames_nv12", False):      # (H * 3 / 2, W) uint8: Y rows, then interleaved U V rows
+            fr = [f if (f.dtype == np.uint8 and f.ndim == 2 and f.strides[1] == 1) else np.ascontiguousarray(f, np.uint8) for f in frames]
+        else:
+            fr = [f if (f.dtype == np.uint8 and f.strides[2] == 1 and f.strides[1] == 3) else np.ascontiguousarray(f, np.uint8)
+                  for f in frames]
         ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in fr])
         strides = (C.c_size_t * n)(*[f.strides[0] for f in fr])
         # latch first, size the buffers from the latched canvas, compose against the same calibration: a concurrent

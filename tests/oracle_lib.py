@@ -82,6 +82,8 @@ def lib():
     L.mo_warp_8u.restype = Rect
     L.mo_warp_8u.argtypes = [C.c_int, C.c_float, fp, fp, fp, vp, C.c_int, C.c_int, C.c_size_t,
                              C.c_int, C.c_int, C.c_int, vp]
+    L.mo_cvt_nv12_bgr.restype = None
+    L.mo_cvt_nv12_bgr.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
     L.mo_compose_lens_maps.restype = None
     L.mo_compose_lens_maps.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_int, C.c_int]
     L.mo_init_undistort_rectify_map.restype = C.c_int
@@ -197,6 +199,15 @@ def compose_lens_maps(xmap, ymap, map1, map2):
     h, w = m2.shape
     lib().mo_compose_lens_maps(_ptr(x), _ptr(y), C.c_size_t(x.size), _ptr(m1), _ptr(m2), w, h)
     return x, y
+
+
+def cvt_nv12_bgr(yuv):
+    """cvtColor(COLOR_YUV2BGR_NV12): yuv (h * 3 / 2, w) uint8 -> (h, w, 3) BGR."""
+    yuv = np.ascontiguousarray(yuv, np.uint8)
+    h, w = yuv.shape[0] * 2 // 3, yuv.shape[1]
+    out = np.empty((h, w, 3), np.uint8)
+    lib().mo_cvt_nv12_bgr(_ptr(yuv), w, h, yuv.strides[0], _ptr(out), out.strides[0])
+    return out
 
 
 def remap_fixed(src, map1, map2):
