@@ -192,6 +192,18 @@ typedef struct mst_calibration {
 
 typedef struct mst_rect { int32_t x, y, width, height; } mst_rect;
 
+/* ---- a calibration as one binary (host only) --------------------------------------------------
+ * Everything mst_update takes -- K, R, T, scale, gain maps, masks, lens maps, seam masks -- in a self-contained,
+ * checksummed blob: a calibration that GetPreStruct() (DRV:348-694) produced once can be replayed (benchmarks and parity
+ * runs on the same inputs; a restart without re-registration).  The reference has no such thing.
+ * mst_calibration_blob_size: bytes needed, 0 for an invalid calibration.  mst_calibration_save: `written` = bytes used.
+ * mst_calibration_load: fills `out` and `cameras` (room for max_cameras); their array pointers point INTO the blob, which
+ * must stay alive and unchanged while the calibration is in use (mst_update copies what it needs).  Masks come back
+ * tightly packed.  A blob that is truncated, altered or of another version is MST_ERR_INVALID_ARG. */
+size_t mst_calibration_blob_size(const mst_calibration *calib);
+int    mst_calibration_save(const mst_calibration *calib, void *blob, size_t capacity, size_t *written);
+int    mst_calibration_load(const void *blob, size_t bytes, mst_calibration *out, mst_camera *cameras, int max_cameras);
+
 /* ---- engine lifetime ------------------------------------------------------------------- */
 int  mst_create(const mst_config *cfg, mst_engine **out);
 void mst_destroy(mst_engine *e);

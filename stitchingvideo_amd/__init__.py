@@ -6,9 +6,9 @@ warper / exposure-compensator / frame-loop interfaces plus the synthetic-rig inp
 """
 from . import _capi as capi  # noqa: F401
 from .engine import (PinnedArray, VoronoiSeamFinder, DpSeamFinder, BlocksGainCompensator, CylindricalWarper, GainCompensator, PanoramaEngine,  # noqa: F401
-                     PlaneWarper, RotationWarper, SphericalWarper, compose_lens_maps, cvt_nv12_bgr, init_undistort_rectify_map, multiband_geometry,
+                     PlaneWarper, RotationWarper, SphericalWarper, compose_lens_maps, cvt_nv12_bgr, init_undistort_rectify_map, load_calibration, save_calibration, multiband_geometry,
                      remap_fixed, synth_frame)
 
 __all__ = ["capi", "PanoramaEngine", "RotationWarper", "PlaneWarper", "SphericalWarper", "CylindricalWarper",
            "GainCompensator", "BlocksGainCompensator", "multiband_geometry", "synth_frame",
-           "init_undistort_rectify_map", "compose_lens_maps", "cvt_nv12_bgr", "remap_fixed"]
+           "init_undistort_rectify_map", "compose_lens_maps", "cvt_nv12_bgr", "remap_fixed", "save_calibration", "load_calibration"]

@@ -50,6 +50,7 @@ EXPORTS = [
     "mst_payload_bytes", "mst_payload_pack", "mst_payload_unpack", "mst_stage_select_set",
     "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
     "mst_init_undistort_rectify_map", "mst_compose_lens_maps", "mst_cvt_nv12_bgr", "mst_remap_fixed",
+    "mst_calibration_blob_size", "mst_calibration_save", "mst_calibration_load",
     "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame", "mst_gain_map_size", "mst_exposure_feed", "mst_seam_voronoi", "mst_seam_dp",
 ]
 
@@ -149,6 +150,12 @@ def load():
     L.mst_compose_profile_batch.restype = C.c_int
     L.mst_compose_profile_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                             C.c_size_t, vp, C.c_int, vp, fp, ip]
+    L.mst_calibration_blob_size.restype = C.c_size_t
+    L.mst_calibration_blob_size.argtypes = [C.POINTER(Calibration)]
+    L.mst_calibration_save.restype = C.c_int
+    L.mst_calibration_save.argtypes = [C.POINTER(Calibration), vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mst_calibration_load.restype = C.c_int
+    L.mst_calibration_load.argtypes = [vp, C.c_size_t, C.POINTER(Calibration), C.POINTER(Camera), C.c_int]
     L.mst_cvt_nv12_bgr.restype = C.c_int
     L.mst_cvt_nv12_bgr.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]
     L.mst_compose_lens_maps.restype = C.c_int

@@ -305,6 +305,96 @@ def synth_frame(camera, frame_index, width, height):
     return out
 
 
+def calibration_struct(scale, cameras):
+    """(scale, list of camera dicts) -> (capi.Calibration, the arrays it points into: keep them alive while it is used).
+    Camera dict keys: size (w, h), K, R, [T], [gain_map | gain], mask | seam_mask, [undistort = (map1, map2)]."""
+    n = len(cameras)
+    arr = (capi.Camera * n)()
+    keep = []
+    for i, c in enumerate(cameras):
+        arr[i].src_width, arr[i].src_height = int(c["size"][0]), int(c["size"][1])
+        arr[i].K = _f9(c["K"])
+        arr[i].R = _f9(c["R"])
+        arr[i].T = _f3(c.get("T"))
+        g = c.get("gain_map")
+        if g is not None:
+            g = np.ascontiguousarray(g, np.float32)
+            keep.append(g)
+            arr[i].gain_map, arr[i].gain_w, arr[i].gain_h = g.ctypes.data, g.shape[1], g.shape[0]
+        arr[i].gain = float(c.get("gain", 1.0))
+        sm = c.get("seam_mask")                # seam-scale mask: the engine does the fix-up (stitcher.cpp:291-294)
+        if sm is not None:
+            sm = np.ascontiguousarray(sm, np.uint8)
+            keep.append(sm)
+            arr[i].seam_mask, arr[i].seam_mask_width, arr[i].seam_mask_height = sm.ctypes.data, sm.shape[1], sm.shape[0]
+            arr[i].seam_mask_stride = sm.strides[0]
+        if c.get("mask") is not None:
+            m = np.ascontiguousarray(c["mask"], np.uint8)
+            keep.append(m)
+            arr[i].mask, arr[i].mask_width, arr[i].mask_height = m.ctypes.data, m.shape[1], m.shape[0]
+            arr[i].mask_stride = m.strides[0]
+        und = c.get("undistort")               # (map1 int16 (h, w, 2), map2 uint16 (h, w)) or None
+        if und is not None:
+            m1 = np.ascontiguousarray(und[0], np.int16)
+            m2 = np.ascontiguousarray(und[1], np.uint16)
+            if m1.shape != (arr[i].src_height, arr[i].src_width, 2) or m2.shape != m1.shape[:2]:
+                raise ValueError("undistort maps must be frame-sized (h, w, 2) int16 and (h, w) uint16")
+            keep += [m1, m2]
+            arr[i].undistort_map1, arr[i].undistort_map2 = m1.ctypes.data, m2.ctypes.data
+    cal = capi.Calibration(C.sizeof(capi.Calibration), n, float(scale), arr)
+    keep.append(arr)
+    return cal, keep
+
+
+def save_calibration(scale, cameras):
+    """The calibration as one self-contained binary (mst_calibration_save) -> bytes."""
+    cal, keep = calibration_struct(scale, cameras)
+    L = capi.load()
+    size = L.mst_calibration_blob_size(C.byref(cal))
+    if not size:
+        raise ValueError("not a valid calibration")
+    buf = (C.c_uint8 * size)()
+    written = C.c_size_t()
+    capi.check(L.mst_calibration_save(C.byref(cal), buf, size, C.byref(written)))
+    return bytes(buf[:written.value])
+
+
+def load_calibration(blob):
+    """bytes from save_calibration -> (scale, list of camera dicts as PanoramaEngine.update takes them)."""
+    L = capi.load()
+    raw = np.frombuffer(bytes(blob), np.uint8).copy()
+    cams = (capi.Camera * capi.MAX_CAMERAS)()
+    cal = capi.Calibration()
+    capi.check(L.mst_calibration_load(raw.ctypes.data, raw.size, C.byref(cal), cams, capi.MAX_CAMERAS))
+
+    def arr(ptr, shape, dtype):
+        if not ptr:
+            return None
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        off = ptr - raw.ctypes.data
+        return raw[off:off + n].view(dtype).reshape(shape).copy()
+
+    out = []
+    for i in range(cal.num_cameras):
+        c = cams[i]
+        d = dict(size=(c.src_width, c.src_height), K=np.array(c.K[:], np.float32).reshape(3, 3),
+                 R=np.array(c.R[:], np.float32).reshape(3, 3), T=np.array(c.T[:], np.float32), gain=float(c.gain))
+        g = arr(c.gain_map, (c.gain_h, c.gain_w), np.float32)
+        if g is not None:
+            d["gain_map"] = g
+        m = arr(c.mask, (c.mask_height, c.mask_width), np.uint8)
+        if m is not None:
+            d["mask"] = m
+        sm = arr(c.seam_mask, (c.seam_mask_height, c.seam_mask_width), np.uint8)
+        if sm is not None:
+            d["seam_mask"] = sm
+        if c.undistort_map1:
+            d["undistort"] = (arr(c.undistort_map1, (c.src_height, c.src_width, 2), np.int16),
+                              arr(c.undistort_map2, (c.src_height, c.src_width), np.uint16))
+        out.append(d)
+    return float(cal.warped_image_scale), out
+
+
 class PanoramaEngine:
     """N frames in, one panorama out, every frame (the reference's StitchingAll loop).
 
@@ -359,40 +449,7 @@ class PanoramaEngine:
         capi.check(rc, self._h)
 
     def update(self, scale, cameras):
-        n = len(cameras)
-        arr = (capi.Camera * n)()
-        keep = []
-        for i, c in enumerate(cameras):
-            arr[i].src_width, arr[i].src_height = int(c["size"][0]), int(c["size"][1])
-            arr[i].K = _f9(c["K"])
-            arr[i].R = _f9(c["R"])
-            arr[i].T = _f3(c.get("T"))
-            g = c.get("gain_map")
-            if g is not None:
-                g = np.ascontiguousarray(g, np.float32)
-                keep.append(g)
-                arr[i].gain_map, arr[i].gain_w, arr[i].gain_h = g.ctypes.data, g.shape[1], g.shape[0]
-            arr[i].gain = float(c.get("gain", 1.0))
-            sm = c.get("seam_mask")                # seam-scale mask: the engine does the fix-up (stitcher.cpp:291-294)
-            if sm is not None:
-                sm = np.ascontiguousarray(sm, np.uint8)
-                keep.append(sm)
-                arr[i].seam_mask, arr[i].seam_mask_width, arr[i].seam_mask_height = sm.ctypes.data, sm.shape[1], sm.shape[0]
-                arr[i].seam_mask_stride = sm.strides[0]
-            if c.get("mask") is not None:
-                m = np.ascontiguousarray(c["mask"], np.uint8)
-                keep.append(m)
-                arr[i].mask, arr[i].mask_width, arr[i].mask_height = m.ctypes.data, m.shape[1], m.shape[0]
-                arr[i].mask_stride = m.strides[0]
-            und = c.get("undistort")               # (map1 int16 (h, w, 2), map2 uint16 (h, w)) or None
-            if und is not None:
-                m1 = np.ascontiguousarray(und[0], np.int16)
-                m2 = np.ascontiguousarray(und[1], np.uint16)
-                if m1.shape != (arr[i].src_height, arr[i].src_width, 2) or m2.shape != m1.shape[:2]:
-                    raise ValueError("undistort maps must be frame-sized (h, w, 2) int16 and (h, w) uint16")
-                keep += [m1, m2]
-                arr[i].undistort_map1, arr[i].undistort_map2 = m1.ctypes.data, m2.ctypes.data
-        cal = capi.Calibration(C.sizeof(capi.Calibration), n, float(scale), arr)
+        cal, keep = calibration_struct(scale, cameras)
         self._check(self._L.mst_update(self._h, C.byref(cal)))
 
     def acquire(self):
