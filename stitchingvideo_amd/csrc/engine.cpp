@@ -700,11 +700,13 @@ void Engine::update(const mst_calibration& calib)
             st->warp_gain_lds = st->pool.alloc<float>(std::max<size_t>(nt * px, 4));
             st->warp_wins = st->pool.alloc<WarpWin>(std::max(nt, 1));
             // window size classes of the staged launches, in KB of LDS (one launch per class: a launch's LDS size is uniform, and
-            // the blocks per CU follow from it); tiles past the last class stay with the gathering kernel
+            // the blocks per CU follow from it); tiles past the last class stay with the gathering kernel.  C3: 2085 tiles up
+            // to 40 KB, 443 (bounding boxes of slanted tiles near the frame corners) up to 72 KB.  With one load per staging
+            // trip the 72 KB class was no faster than gathering; with the loads in batches it is: 28.7-29.3 -> 27.5 us.
             static const std::vector<int> classes_kb = [] {
                 std::vector<int> v;
                 const char* e = std::getenv("MST_WARP_LDS_CLASSES");
-                for (const char* p = e ? e : "40"; *p;) { v.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+                for (const char* p = e ? e : "40,72"; *p;) { v.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
                 return v;
             }();
             const int budget_px = classes_kb.back() * 256;
