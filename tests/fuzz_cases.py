@@ -49,8 +49,10 @@ def one_case(rng, idx):
                 rig["cameras"][i]["undistort"] = maps[i]
     count = int(rng.integers(1, 4))
     wt = "16s" if (blend == "multiband" and rng.integers(0, 3) == 0) else "32f"
+    # lens maps either as the reference's pre-pass (two resamplings) or composed into the warp map (one)
+    composed = any(m is not None for m in maps) and bool(rng.integers(0, 2))
     eng = H.make_engine(rig, blend=blend, num_bands=bands, max_batch=count, weight_type=wt,
-                        overlap_frames=bool(rng.integers(0, 2)) and blend == "multiband")
+                        overlap_frames=bool(rng.integers(0, 2)) and blend == "multiband", lens_composed=composed)
     _, _, cw, ch = eng.canvas()
     dev = torch.device("cuda", 0)
     host = [rigmod.frames_for(rig, int(rng.integers(0, 1000))) for _ in range(count)]
@@ -65,10 +67,13 @@ def one_case(rng, idx):
     eng.synchronize()
     ok = True
     for f in range(count):
-        und = [fr if m is None else O.remap_fixed(fr, m[0], m[1]) for fr, m in zip(host[f], maps)]
-        rect, opano, omask = H.oracle_compose(rig, und, blend=blend, num_bands=bands, weight_type=wt)
+        if composed:
+            rect, opano, omask = H.oracle_compose(rig, host[f], blend=blend, num_bands=bands, weight_type=wt, lens_maps=maps)
+        else:
+            und = [fr if m is None else O.remap_fixed(fr, m[0], m[1]) for fr, m in zip(host[f], maps)]
+            rect, opano, omask = H.oracle_compose(rig, und, blend=blend, num_bands=bands, weight_type=wt)
         ok &= eng.canvas() == rect and np.array_equal(panos[f].cpu().numpy(), opano) and np.array_equal(masks[f].cpu().numpy(), omask)
     eng.close()
-    desc = "%s n=%d %dx%d f=%.0f s=%.0f %s %s/%s b=%d seams=%d batch=%d lens=%d canvas=%dx%d" % (
-        warp, n, w, h, focal, scale, expos, blend, wt, bands, seams, count, sum(m is not None for m in maps), cw, ch)
+    desc = "%s n=%d %dx%d f=%.0f s=%.0f %s %s/%s b=%d seams=%d batch=%d lens=%d%s canvas=%dx%d" % (
+        warp, n, w, h, focal, scale, expos, blend, wt, bands, seams, count, sum(m is not None for m in maps), "c" if composed else "", cw, ch)
     return ("ok   " if ok else "FAIL ") + desc

@@ -10,11 +10,12 @@ BLEND_O = {"no": O.BLEND_NO, "feather": O.BLEND_FEATHER, "multiband": O.BLEND_MU
 EXPOS_O = {"no": O.EXPOS_NO, "gain": O.EXPOS_GAIN, "gain_blocks": O.EXPOS_GAIN_BLOCKS}
 
 
-def oracle_compose(rig, frames, blend=None, num_bands=5, sharpness=0.02, threads=1, weight_type=None):
+def oracle_compose(rig, frames, blend=None, num_bands=5, sharpness=0.02, threads=1, weight_type=None, lens_maps=None):
+    """lens_maps: per camera (map1, map2) or None -- the composed single-resampling variant (frames are then RAW)."""
     cams = []
-    for c, f in zip(rig["cameras"], frames):
+    for i, (c, f) in enumerate(zip(rig["cameras"], frames)):
         cams.append(dict(K=c["K"], R=c["R"], frame=f, mask=c["mask"], gain_map=c.get("gain_map"),
-                         gain=c.get("gain", 1.0)))
+                         gain=c.get("gain", 1.0), lens_maps=None if lens_maps is None else lens_maps[i]))
     return O.compose_panorama(WARP_O[rig["warp"]], rig["scale"], BLEND_O[blend or rig["blend"]],
                               EXPOS_O[rig["expos"]], cams, num_bands=num_bands, sharpness=sharpness,
                               weight_type=O.WEIGHT_16S if weight_type == "16s" else O.WEIGHT_32F, num_threads=threads)
