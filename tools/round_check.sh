@@ -15,7 +15,7 @@ for p in C2 C5 C3-LUT C5-LUT; do
   bash tools/prof_paths.sh ${TAG}_$p $p > gpurun_out/round/profile_$p.log 2>&1
 done
 cp gpurun_out/traffic.json profiles/traffic.json
-python bench.py > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err
+( time python bench.py > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err ) 2>&1 | grep real
 python -c "
 import json; d=json.load(open('gpurun_out/round/bench.json'))
 print(d['value'], d['roofline']['frac'], d['roofline']['traffic'], [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']], d.get('latency_mode'), d.get('overlapped'), d.get('host_buffers'), d.get('cpu_baseline'))
