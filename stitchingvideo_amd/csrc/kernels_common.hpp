@@ -375,7 +375,11 @@ __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const
             }
             // (32-bit offset from the block-uniform base: frames are below 4 GiB, mst_compose* checks)
             const uint32_t off = static_cast<uint32_t>(rr) * stride + static_cast<uint32_t>(gg) * 12u;
+#ifdef MST_ABLATE_STAGE          // (timing experiment, tools/variants.sh: what the source stream costs; the pixels are wrong)
+            d[u] = u32x3_t{off, off, off};
+#else
             asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(d[u]) : "v"(off), "s"(sbase) : "memory");
+#endif
             r += step_r; g += step_g;
             if (g >= groups) { g -= groups; ++r; }
         }
