@@ -5,7 +5,7 @@
 // blender set-up rule :729-749, compositing loop :656-756) and the driver's frame loop
 // (R64/stitching_detailed.cpp:724-770: per frame N Mats in, one Mat out, "Stitching, time: ... sec").
 // Registration (features / matching / bundle adjustment / seams) is out of scope: cameras come from
-// --yaw / --focal (a ring rig, R = R_y(yaw)), seams are `--seam no` (all-255 warped masks).
+// --yaw / --focal (a ring rig, R = R_y(yaw)); seams: `--seam no` (all-255 warped masks), voronoi or the two DP finders.
 //
 //   stitching_detailed_mi355 --synthetic 6 1920x1080 --focal 1250 --warp spherical --blend multiband
 //                            --expos_comp gain_blocks --frames 100 --output result.ppm
@@ -75,6 +75,10 @@ void usage()
         "  --expos_comp (no|gain_blocks)                     default gain_blocks (synthetic block gains)\n"
         "  --blend (no|feather|multiband)                    default multiband\n"
         "  --blend_strength <float>   [0,100], default 5 (same rule as the sample: width = sqrt(area)*s/100)\n"
+        "  --seam (no|voronoi|dp_color|dp_colorgrad)          seam finder on the full-resolution warped images (CLI:106 has\n"
+        "                             the graph-cut finders too: those stay on the host side of the real application); default no\n"
+        "  --save_calibration <file>  write the calibration (K, R, scale, gains, final masks) as one binary (mst_calibration_save)\n"
+        "  --load_calibration <file>  compose from such a file instead of --yaw / --focal / --seam\n"
         "  --lut                      the driver's hard-seam LUT composite with its crop margins\n"
         "  --frames <K>               frame-loop iterations (default 1)\n"
         "  --output <result.ppm>      default result.ppm\n");
@@ -102,6 +106,7 @@ int main(int argc, char** argv)
     int synthetic_n = 0, W = 0, H = 0, frames = 1;
     double focal = 1250.0, blend_strength = 5.0;
     std::string warp_type = "spherical", expos = "gain_blocks", blend = "multiband", result_name = "result.ppm";
+    std::string seam = "no", save_calib, load_calib;
     bool lut = false;
     mst_engine* engine = nullptr;
 
@@ -120,6 +125,9 @@ int main(int argc, char** argv)
         else if (a == "--frames") frames = std::atoi(next());
         else if (a == "--output" || a == "--result") result_name = next();
         else if (a == "--lut") lut = true;
+        else if (a == "--seam") seam = next();
+        else if (a == "--save_calibration") save_calib = next();
+        else if (a == "--load_calibration") load_calib = next();
         else if (a.rfind("--", 0) == 0) { std::printf("Bad flag: %s\n", a.c_str()); return -1; }
         else img_names.push_back(a);
     }
@@ -178,6 +186,58 @@ int main(int argc, char** argv)
         brx = std::max(brx, roi.x + roi.width); bry = std::max(bry, roi.y + roi.height);
     }
 
+    if (seam != "no" && seam != "voronoi" && seam != "dp_color" && seam != "dp_colorgrad") { std::printf("Bad seam finding method\n"); return 1; }   // CLI:631-635
+    if (seam != "no" && load_calib.empty()) {
+        // the sample finds seams on warped images at seam scale and resizes the masks (CLI:477-640, 714-722); this tool works at
+        // full resolution throughout: warp every first frame, hand images + masks to the finder, use its masks as the final ones
+        std::vector<int32_t> xy(2 * num_images), wh(2 * num_images);
+        std::vector<std::vector<uint8_t>> warped(num_images);
+        std::vector<const void*> iptr(num_images);
+        std::vector<size_t> istr(num_images), mstr(num_images);
+        std::vector<uint8_t*> mptr(num_images);
+        std::vector<uint8_t> first(static_cast<size_t>(W) * H * 3);
+        for (int i = 0; i < num_images; ++i) {
+            mst_rect roi;
+            CHECK(mst_warp_roi(warp_kind, scale, cams[i].K, cams[i].R, cams[i].T, W, H, &roi));
+            xy[2 * i] = roi.x; xy[2 * i + 1] = roi.y; wh[2 * i] = roi.width; wh[2 * i + 1] = roi.height;
+            if (synthetic_n) CHECK(mst_synth_frame(i, 0, W, H, first.data(), static_cast<size_t>(W) * 3));
+            const uint8_t* src = synthetic_n ? first.data() : stills[i].bgr.data();
+            warped[i].resize(static_cast<size_t>(roi.width) * roi.height * 3);
+            CHECK(mst_warp(0, warp_kind, scale, cams[i].K, cams[i].R, cams[i].T, src, W, H, static_cast<size_t>(W) * 3, 3, MST_INTER_LINEAR,
+                           MST_BORDER_REFLECT, warped[i].data(), static_cast<size_t>(roi.width) * 3));
+            iptr[i] = warped[i].data(); istr[i] = static_cast<size_t>(roi.width) * 3;
+            mptr[i] = masks[i].data(); mstr[i] = roi.width;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        if (seam == "voronoi") CHECK(mst_seam_voronoi(0, num_images, xy.data(), wh.data(), mptr.data(), mstr.data()));
+        else CHECK(mst_seam_dp(0, num_images, xy.data(), wh.data(), iptr.data(), istr.data(), MST_IMAGE_8UC3, mptr.data(), mstr.data(),
+                               seam == "dp_color" ? MST_SEAM_DP_COLOR : MST_SEAM_DP_COLOR_GRAD));
+        std::printf("Finding seams, time: %g sec\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());   // CLI:639
+    }
+    mst_calibration cal = {static_cast<int32_t>(sizeof(mst_calibration)), num_images, scale, cams.data()};
+    std::vector<uint8_t> blob;
+    std::vector<mst_camera> loaded(MST_MAX_CAMERAS);
+    if (!load_calib.empty()) {
+        FILE* f = std::fopen(load_calib.c_str(), "rb");
+        if (!f) { std::printf("Can't open %s\n", load_calib.c_str()); return -1; }
+        std::fseek(f, 0, SEEK_END); blob.resize(static_cast<size_t>(std::ftell(f))); std::fseek(f, 0, SEEK_SET);
+        const bool ok = std::fread(blob.data(), 1, blob.size(), f) == blob.size();
+        std::fclose(f);
+        if (!ok || mst_calibration_load(blob.data(), blob.size(), &cal, loaded.data(), MST_MAX_CAMERAS) != MST_OK || cal.num_cameras != num_images) {
+            std::printf("%s is not a calibration of %d cameras\n", load_calib.c_str(), num_images); return -1;
+        }
+        std::printf("Calibration of %d cameras from %s\n", cal.num_cameras, load_calib.c_str());
+    }
+    if (!save_calib.empty()) {
+        std::vector<uint8_t> out(mst_calibration_blob_size(&cal));
+        size_t n = 0;
+        if (out.empty() || mst_calibration_save(&cal, out.data(), out.size(), &n) != MST_OK) { std::printf("Can't serialise the calibration\n"); return -1; }
+        FILE* f = std::fopen(save_calib.c_str(), "wb");
+        if (!f || std::fwrite(out.data(), 1, n, f) != n) { std::printf("Can't write %s\n", save_calib.c_str()); return -1; }
+        std::fclose(f);
+        std::printf("Calibration written to %s (%zu bytes)\n", save_calib.c_str(), n);
+    }
+
     // blender set-up rule of the sample (CLI:729-749)
     mst_config cfg;
     std::memset(&cfg, 0, sizeof(cfg));
@@ -201,7 +261,6 @@ int main(int argc, char** argv)
         cfg.upblack = cfg.downblack = 0.1f; cfg.leftblack = cfg.rightblack = 10.f;   // DRV:47
     }
     CHECK(mst_create(&cfg, &engine));
-    mst_calibration cal = {static_cast<int32_t>(sizeof(mst_calibration)), num_images, scale, cams.data()};
     CHECK(mst_update(engine, &cal));
     mst_rect canvas;
     CHECK(mst_canvas(engine, &canvas));
