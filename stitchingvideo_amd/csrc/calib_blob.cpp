@@ -138,12 +138,13 @@ int mst_calibration_load(const void* blob, size_t bytes, mst_calibration* out, m
     if (arrays_at > h.total_bytes) return MST_ERR_INVALID_ARG;
     if (fnv1a(base + sizeof(BlobHeader), h.total_bytes - sizeof(BlobHeader)) != h.checksum) return MST_ERR_INVALID_ARG;
     const CameraRecord* recs = reinterpret_cast<const CameraRecord*>(base + recs_at);
-    auto inside = [&](uint64_t off, size_t len) { return off >= arrays_at && off % 8 == 0 && off + len <= h.total_bytes; };
+    // (no sum of file-supplied values: a crafted offset must not wrap)
+    auto inside = [&](uint64_t off, size_t len) { return off >= arrays_at && off % 8 == 0 && off <= h.total_bytes && len <= h.total_bytes - off; };
     for (uint32_t i = 0; i < h.num_cameras; ++i) {
         const CameraRecord& r = recs[i];
         mst_camera& c = cameras[i];
         std::memset(&c, 0, sizeof(c));
-        if (r.src_width <= 0 || r.src_height <= 0) return MST_ERR_INVALID_ARG;
+        if (r.src_width <= 0 || r.src_height <= 0 || r.src_width > 65536 || r.src_height > 65536) return MST_ERR_INVALID_ARG;
         c.src_width = r.src_width; c.src_height = r.src_height;
         std::memcpy(c.K, r.K, sizeof(c.K)); std::memcpy(c.R, r.R, sizeof(c.R)); std::memcpy(c.T, r.T, sizeof(c.T));
         c.gain = r.gain;

@@ -77,3 +77,49 @@ def test_engine_from_a_reloaded_blob():
     pano2, mask2 = eng2.compose(frames)
     assert np.array_equal(pano, pano2) and np.array_equal(mask, mask2)
     eng.close(); eng2.close()
+
+
+def _fnv1a(b):
+    h = 0xcbf29ce484222325
+    for x in b:
+        h = ((h ^ x) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_loader_survives_crafted_blobs():
+    """Random damage WITH the checksum repaired (so that the field validators are what stands between the file and the
+    pointers): the loader must answer OK or INVALID_ARG, and every pointer it hands out must lie inside the blob."""
+    import struct
+    rig = rigmod.build_rig(rigmod.scaled_config("C2", 16))
+    blob = bytearray(S.save_calibration(rig["scale"], rig["cameras"]))
+    L = capi.load()
+    rng = np.random.default_rng(5)
+    header = 32                      # magic, version, cameras, scale, total_bytes, checksum
+    records_end = header + 2 * 168   # two camera records (see csrc/calib_blob.cpp)
+    accepted = 0
+    for trial in range(400):
+        b = bytearray(blob)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(8, records_end))                 # header fields after the magic, and the records
+            if header - 8 <= pos < header:
+                continue                                            # (the checksum itself is rewritten below)
+            b[pos] = int(rng.integers(0, 256))
+        if trial % 5 == 0:                                          # a huge offset that would wrap a naive bound check
+            struct.pack_into("<Q", b, records_end - 8 * int(rng.integers(1, 6)), 0xFFFFFFFFFFFFFFF8)
+        struct.pack_into("<Q", b, 24, _fnv1a(bytes(b[header:])))
+        raw = np.frombuffer(bytes(b), np.uint8).copy()
+        cams = (capi.Camera * capi.MAX_CAMERAS)()
+        cal = capi.Calibration()
+        rc = L.mst_calibration_load(raw.ctypes.data, raw.size, C.byref(cal), cams, capi.MAX_CAMERAS)
+        assert rc in (0, capi.ERR_INVALID_ARG)
+        if rc == 0:
+            accepted += 1
+            lo, hi = raw.ctypes.data, raw.ctypes.data + raw.size
+            for i in range(cal.num_cameras):
+                c = cams[i]
+                for ptr, n in ((c.gain_map, 4 * c.gain_w * c.gain_h), (c.mask, c.mask_width * c.mask_height),
+                               (c.undistort_map1, 4 * c.src_width * c.src_height), (c.undistort_map2, 2 * c.src_width * c.src_height),
+                               (c.seam_mask, c.seam_mask_width * c.seam_mask_height)):
+                    if ptr:
+                        assert lo <= ptr and ptr + n <= hi
+    assert accepted > 0            # (some damage only touches values, not structure: K, R, gains)
