@@ -411,6 +411,46 @@ def main():
                                                       "roofline_frac": round(alg_bytes * n3 / w3 / 1e9 / HBM_PEAK_GBS, 5)}
         eng2.close()
 
+    # ---- the one-frame-set call replayed as a hipGraph (MST_FLAG_GRAPH_REPLAY): same kernels, one hipGraphLaunch per call ----
+    if rank == 0 and world == 1 and not by_camera and "latency_mode" in out:
+        try:
+            eng3 = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
+                                    graph_replay=True, max_batch=batch)
+            eng3.update(rig["scale"], rig["cameras"])
+            eng3.acquire()
+            ring = [(ds, panos[k % len(panos)]) for k, ds in enumerate(dev_sets)]
+
+            def enqueue_rate(engine, n):
+                for i in range(3 * len(ring)):                       # (first turn: capture)
+                    ds, pn = ring[i % len(ring)]
+                    engine.compose_device([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pn.data_ptr(), pn.stride(0), stream=stream)
+                torch.cuda.synchronize()
+                calls = [engine.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pn.data_ptr(), pn.stride(0), stream=stream)
+                         for ds, pn in ring]
+                t_host = 0.0
+                for rep in range(10):                                # the host's share: a dozen calls into an empty queue
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(12):
+                        calls[i % len(calls)]()
+                    t_host += (time.perf_counter() - t0) / 12
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    calls[i % len(calls)]()
+                torch.cuda.synchronize()
+                return t_host / 10, (time.perf_counter() - t0) / n
+            n4 = max(50, int(0.3 / max(t_seq / batch, 1e-6)))
+            h_plain, w_plain = enqueue_rate(eng, n4)
+            h_graph, w_graph = enqueue_rate(eng3, n4)
+            out["latency_mode"]["graph_replay"] = {"frames": n4, "frames_per_s": round(1.0 / w_graph, 2),
+                                                   "host_enqueue_us_per_call": round(h_graph * 1e6, 2),
+                                                   "host_enqueue_us_per_call_kernel_by_kernel": round(h_plain * 1e6, 2),
+                                                   "frames_per_s_kernel_by_kernel": round(1.0 / w_plain, 2)}
+            eng3.close()
+        except Exception as e:          # noqa: BLE001
+            out["latency_mode"]["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- host buffers: the PCIe-inclusive rate (never `value`): serial mst_compose vs the three-stage pipeline ----
     if rank == 0 and world == 1 and not by_camera and not args.no_latency_leg and blend == "multiband":
         try:

@@ -99,6 +99,12 @@ int mst_warp_kind_from_name(const char *name);
                                       (feedSizeRemap, DRV:150-177); requires MST_BLEND_NO */
 
 #define MST_FLAG_DEBUG        2u   /* keep a copy of the collapsed canvas levels for mst_debug_read */
+#define MST_FLAG_GRAPH_REPLAY 32u   /* mst_compose_device(_batch): the launch sequence of a call (5-6 kernels for the multi-band blend)
+                                      is captured into a hipGraph the first time a given set of buffers (frames, panoramas, masks,
+                                      strides, count) is seen under a calibration, and replayed with one hipGraphLaunch from then
+                                      on -- a frame loop over a ring of buffers pays the kernel-by-kernel enqueue once per ring
+                                      slot.  Same kernels, same results; not with MST_FLAG_OVERLAP_FRAMES (whose calls depend on
+                                      each other).  Up to 32 sequences are kept per engine. */
 #define MST_FLAG_FRAMES_NV12 16u   /* the frames of every compose call (host, device, batch, pipeline) are NV12 as decoders deliver
                                       them: one plane pointer per camera, src_height rows of Y then src_height / 2 rows of
                                       interleaved U V, all `stride` bytes apart (a CV_8UC1 Mat of height * 3 / 2 rows, what

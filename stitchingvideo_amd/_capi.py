@@ -37,6 +37,7 @@ FLAG_DEBUG = 2
 FLAG_OVERLAP_FRAMES = 4
 FLAG_LENS_COMPOSED = 8
 FLAG_FRAMES_NV12 = 16
+FLAG_GRAPH_REPLAY = 32
 MAX_CAMERAS, MAX_BANDS = 16, 10
 DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, DBG_CANVAS_S16, DBG_CAM_NEED_U8 = \
     1, 2, 3, 4, 5, 6

@@ -273,6 +273,7 @@ Engine::~Engine()
 {
     (void)hipSetDevice(cfg_.device);
     (void)hipDeviceSynchronize();
+    drop_graphs();
     current_.reset();
     latched_.reset();
     in_flight_.reset();
@@ -1055,11 +1056,64 @@ void Engine::compose_device(const void* const* d_frames, const size_t* strides, 
     compose_batch(1, d_frames, strides, panos, pano_stride, d_mask ? masks : nullptr, mask_stride, stream, timer);
 }
 
+void Engine::drop_graphs()
+{
+    for (GraphEntry& g : graphs_)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    graphs_.clear();
+}
+
 void Engine::compose_batch(int count, const void* const* d_frames, const size_t* strides, void* const* d_panos,
                            size_t pano_stride, void* const* d_masks, size_t mask_stride, hipStream_t stream,
                            StageTimer* timer)
 {
-    compose_batch_on(state(), count, d_frames, strides, d_panos, pano_stride, d_masks, mask_stride, stream, timer);
+    std::shared_ptr<CalibState> st = state();
+    const bool replay = (cfg_.flags & MST_FLAG_GRAPH_REPLAY) && !(cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && !timer && st &&
+                        d_frames && strides && d_panos && count >= 1 && count <= kMaxBatch;
+    if (!replay) {
+        compose_batch_on(std::move(st), count, d_frames, strides, d_panos, pano_stride, d_masks, mask_stride, stream, timer);
+        return;
+    }
+    // the launch sequence depends on the calibration and on every pointer / stride of the call: that is the key
+    select_device(cfg_.device);
+    hipStream_t s = stream ? stream : stream_;
+    std::vector<uint64_t> key;
+    key.reserve(6 + 3 * static_cast<size_t>(count) * (st->n + 1));
+    key.push_back(st->generation); key.push_back(static_cast<uint64_t>(count));
+    key.push_back(pano_stride); key.push_back(mask_stride); key.push_back(d_masks != nullptr);
+    for (int i = 0; i < count * st->n; ++i) { key.push_back(reinterpret_cast<uint64_t>(d_frames[i])); key.push_back(strides[i]); }
+    for (int f = 0; f < count; ++f) {
+        key.push_back(reinterpret_cast<uint64_t>(d_panos[f]));
+        key.push_back(d_masks ? reinterpret_cast<uint64_t>(d_masks[f]) : 0);
+    }
+    for (GraphEntry& g : graphs_)
+        if (g.key == key) {
+            check_hip(hipGraphLaunch(g.exec, s), "hipGraphLaunch");
+            set_in_flight(std::move(st));
+            return;
+        }
+    // sequences of older calibrations can never be asked for again
+    for (size_t i = 0; i < graphs_.size();)
+        if (graphs_[i].key[0] != st->generation) { (void)hipGraphExecDestroy(graphs_[i].exec); graphs_.erase(graphs_.begin() + i); }
+        else ++i;
+    if (graphs_.size() >= 32) { (void)hipGraphExecDestroy(graphs_.front().exec); graphs_.erase(graphs_.begin()); }
+    hipGraph_t graph = nullptr;
+    check_hip(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+    try {
+        compose_batch_on(st, count, d_frames, strides, d_panos, pano_stride, d_masks, mask_stride, s, nullptr);
+    } catch (...) {
+        (void)hipStreamEndCapture(s, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+    }
+    check_hip(hipStreamEndCapture(s, &graph), "hipStreamEndCapture");
+    GraphEntry e;
+    e.key = std::move(key);
+    const hipError_t ie = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    check_hip(ie, "hipGraphInstantiate");
+    check_hip(hipGraphLaunch(e.exec, s), "hipGraphLaunch");
+    graphs_.push_back(std::move(e));
 }
 
 // One calibration state for the whole call: callers that size buffers first (compose_host) pass the snapshot they

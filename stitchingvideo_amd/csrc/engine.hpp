@@ -207,6 +207,10 @@ private:
     void build_compose_plan(CalibState& st, hipStream_t s);     // mst_update, blend kinds NO and FEATHER
     void set_in_flight(std::shared_ptr<CalibState> st);   // keeps `st` alive; the previous one goes to retired_
     void drop_retired();                                   // calibration thread / destructor: tear old states down
+    // MST_FLAG_GRAPH_REPLAY: launch sequences captured per (calibration generation, buffers) and replayed
+    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; };
+    std::vector<GraphEntry> graphs_;
+    void drop_graphs();
     mst_config cfg_;
     hipStream_t stream_ = nullptr;        // compose stream
     hipStream_t calib_stream_ = nullptr;  // mst_update builds the next state here

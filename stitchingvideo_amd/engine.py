@@ -405,7 +405,7 @@ class PanoramaEngine:
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
                  feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False,
-                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None, lens_composed=False, frames_nv12=False):
+                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None, lens_composed=False, frames_nv12=False, graph_replay=False):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -418,7 +418,8 @@ class PanoramaEngine:
         cfg.feather_sharpness = feather_sharpness
         cfg.device = device
         cfg.flags = (capi.FLAG_DRIVER_LUT if driver_lut else 0) | (capi.FLAG_DEBUG if debug else 0) | \
-            (capi.FLAG_OVERLAP_FRAMES if overlap_frames else 0) | (capi.FLAG_LENS_COMPOSED if lens_composed else 0) | (capi.FLAG_FRAMES_NV12 if frames_nv12 else 0)
+            (capi.FLAG_OVERLAP_FRAMES if overlap_frames else 0) | (capi.FLAG_LENS_COMPOSED if lens_composed else 0) | (capi.FLAG_FRAMES_NV12 if frames_nv12 else 0) | \
+            (capi.FLAG_GRAPH_REPLAY if graph_replay else 0)
         self._frames_nv12 = bool(frames_nv12)
         cfg.upblack, cfg.downblack, cfg.leftblack, cfg.rightblack = crop
         cfg.max_batch = max_batch

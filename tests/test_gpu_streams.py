@@ -431,3 +431,57 @@ def test_unaligned_panorama_and_mask_buffers(base_off, row_pad, mask_off, mask_p
     assert np.array_equal(mrows[:, :cw], omask)
     assert (mrows[:, cw:] == 0x5A).all() and (gm[:mask_off] == 0x5A).all() and (gm[mask_off + ch * mstride:] == 0x5A).all()
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blend", ["multiband", "feather", "no"])
+def test_graph_replay_of_the_launch_sequence(blend):
+    """MST_FLAG_GRAPH_REPLAY: the launch sequence of a call is captured once per set of buffers and replayed; a ring of
+    two frame sets and two panoramas over several turns, a batch call, then a recalibration (new generation: new graphs)."""
+    import torch
+    cfg = rigmod.scaled_config("C3", 8)
+    cfg["blend"] = blend
+    rig = rigmod.build_rig(cfg)
+    eng = H.make_engine(rig, max_batch=2, graph_replay=True)
+    _, _, cw, ch = eng.canvas()
+    dev = torch.device("cuda", 0)
+    host = [rigmod.frames_for(rig, i) for i in range(2)]
+    exp = [H.oracle_compose(rig, fr) for fr in host]
+    stream = torch.cuda.Stream(device=dev)
+    dfr = [[torch.from_numpy(f).to(dev) for f in fr] for fr in host]
+    panos = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    masks = [torch.zeros((ch, cw), dtype=torch.uint8, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for turn in range(4):                                  # turn 0 captures two graphs, the others replay them
+        for k in range(2):
+            panos[k].zero_(); masks[k].zero_()
+            torch.cuda.synchronize()
+            eng.compose_device([t.data_ptr() for t in dfr[k]], [t.stride(0) for t in dfr[k]], panos[k].data_ptr(), panos[k].stride(0),
+                               masks[k].data_ptr(), masks[k].stride(0), stream=stream.cuda_stream)
+            stream.synchronize()
+            assert np.array_equal(panos[k].cpu().numpy(), exp[k][1]), "turn %d slot %d" % (turn, k)
+            assert np.array_equal(masks[k].cpu().numpy(), exp[k][2])
+    for rep in range(2):                                   # a batch of both frame sets: its own graph
+        for p in panos:
+            p.zero_()
+        torch.cuda.synchronize()
+        eng.compose_device_batch([[t.data_ptr() for t in fr] for fr in dfr], [[t.stride(0) for t in fr] for fr in dfr],
+                                 [p.data_ptr() for p in panos], panos[0].stride(0), stream=stream.cuda_stream)
+        stream.synchronize()
+        for k in range(2):
+            assert np.array_equal(panos[k].cpu().numpy(), exp[k][1])
+    # recalibration: the same buffers under a new calibration must not replay the old sequence
+    rig2 = rigmod.build_rig(cfg)
+    for c in rig2["cameras"]:
+        if c.get("gain_map") is not None:
+            c["gain_map"] = (np.asarray(c["gain_map"], np.float32) * np.float32(1.07)).astype(np.float32)
+    eng.update(rig2["scale"], rig2["cameras"])
+    exp2 = H.oracle_compose(rig2, host[0])
+    for rep in range(2):
+        panos[0].zero_()
+        torch.cuda.synchronize()
+        eng.compose_device([t.data_ptr() for t in dfr[0]], [t.stride(0) for t in dfr[0]], panos[0].data_ptr(), panos[0].stride(0),
+                           stream=stream.cuda_stream)
+        stream.synchronize()
+        assert np.array_equal(panos[0].cpu().numpy(), exp2[1])
+    eng.close()
