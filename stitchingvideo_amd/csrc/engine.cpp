@@ -761,13 +761,24 @@ void Engine::update(const mst_calibration& calib)
         }
         st->d_payload_rects = st->pool.upload(plan.payload_rects, s);
         st->chain_lists.clear();
+        st->chain_units.clear();
+        static const bool chain_only = [] { const char* v = std::getenv("MST_PYR_CHAIN"); return v && v[0] == '1'; }();   // A/B timing
         for (const MbPlanHost::ChainStep& step : plan.chain) {
             TileList tl{};
             tl.tiles = st->pool.upload(step.tiles, s);
             tl.count = static_cast<int32_t>(step.tiles.size());
             tl.first = 0;
             st->chain_lists.push_back(tl);
+            CalibState::StreamUnits su;
+            if (!chain_only && !step.unit_cam_start[0].empty())
+                for (int j = 0; j < step.k; ++j) {
+                    std::vector<uint32_t> u = step.units[j];
+                    if (u.empty()) u.push_back(0u);
+                    su.d[j] = st->pool.upload(u, s);
+                }
+            st->chain_units.push_back(su);
         }
+        check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");      // (the padded unit lists are local)
     } else {
         st->d_desc = st->pool.upload(st->desc, s);
         if (cfg_.blend_kind == MST_BLEND_FEATHER) {
@@ -1213,7 +1224,13 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         if (overlap && split_after_warp) cross();
         hipStream_t sc = (overlap && !split_after_warp) ? sf : s;
         for (size_t i = 0; i < st->chain_lists.size(); ++i) {
-            launch_pyr_chain(desc, st->n, st->chain_lists[i], st->plan.chain[i].base, st->plan.chain[i].k, count, sc);
+            const MbPlanHost::ChainStep& step = st->plan.chain[i];
+            if (st->chain_units[i].d[0]) {
+                for (int j = 0; j < step.k; ++j)
+                    launch_pyrdown_stream(desc, st->n, st->chain_units[i].d[j], static_cast<int>(step.units[j].size()), step.base + j, count, sc);
+            } else {
+                launch_pyr_chain(desc, st->n, st->chain_lists[i], step.base, step.k, count, sc);
+            }
             mark("k_pyr_chain");
         }
         if (overlap && !split_after_warp) cross();
@@ -1341,6 +1358,13 @@ void Engine::stage_cameras(uint32_t camera_mask, const void* const* d_frames, co
     for (const auto& r : runs) launch_warp(*st, set_desc, fb, 1, r.first, r.second, s);
     for (size_t k = 0; k < st->chain_lists.size(); ++k)
         for (const auto& r : runs) {
+            if (st->chain_units[k].d[0]) {
+                const MbPlanHost::ChainStep& step = plan.chain[k];
+                for (int j = 0; j < step.k; ++j)
+                    launch_pyrdown_stream(set_desc, st->n, st->chain_units[k].d[j] + step.unit_cam_start[j][r.first],
+                                          step.unit_cam_start[j][r.second] - step.unit_cam_start[j][r.first], step.base + j, 1, s);
+                continue;
+            }
             TileList tl{};
             tl.tiles = st->chain_lists[k].tiles + plan.chain[k].cam_start[r.first];
             tl.count = plan.chain[k].cam_start[r.second] - plan.chain[k].cam_start[r.first];

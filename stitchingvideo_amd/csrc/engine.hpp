@@ -121,6 +121,8 @@ struct CalibState {
     const uint32_t* d_warp_gathered = nullptr;
     std::vector<int> warp_gathered_start;                       // n + 1 offsets
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step
+    struct StreamUnits { const uint32_t* d[2] = {nullptr, nullptr}; };
+    std::vector<StreamUnits> chain_units;   // per plan.chain step: the streaming kernel's unit lists (null: k_pyr_chain runs the step)
     PayloadRect* d_payload_rects = nullptr;   // camera-sharded hand-off (plan.payload_*)
     BlendArgs blend{};                  // canvas kernels (pano pointers filled per frame)
     // feather

@@ -73,6 +73,11 @@ void launch_warp_table_lds(const CamDesc* d_cams, int kind, const TileList& list
 void launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, int n_tiles, const FrameBatch& frames, int batch,
                          const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s);
 void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s);
+// the streaming form of one pyrDown level (level -> level + 1): units of mb_stream_unit_cols() output columns x mb_stream_unit_rows() output
+// rows (cam << 24 | uy << 12 | ux), one wave each; source levels of even size only
+int  mb_stream_unit_rows();
+int  mb_stream_unit_cols();
+void launch_pyrdown_stream(const CamDesc* d_cams, int n_cams, const uint32_t* d_units, int n_units, int level, int batch, hipStream_t s);
 // which: bit 0 = k_blend_coarse (levels 1 .. top -> collapsed level-1 canvas), bit 1 = k_blend_fine (level 0 -> panorama)
 void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
                   hipStream_t s, int which = 3);

@@ -411,12 +411,12 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
 {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
 }
-__device__ __forceinline__ uint32_t sample_lds(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1, uint32_t e, float gain)
+// The staged sampler on the four taps' dwords (top row lo0 hi0, bottom row lo1 hi1: B G R x each) with the fractions
+// already unpacked.
+__device__ __forceinline__ uint32_t sample_taps(uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1, uint32_t fx, uint32_t fy, float gain)
 {
-    const uint32_t fx = e & 63u, fy = (e >> 6) & 63u;
     const uint32_t wxp = __umul24(fx, 0x3FFFC0u) + 2048u;         // (32 - fx) * 64 | fx * 64 << 16
     const uint32_t wy1 = fy, wy0 = 32u - fy;
-    const uint32_t lo0 = p0[0], hi0 = p0[1], lo1 = p1[0], hi1 = p1[1];
     const uint32_t br0 = __umul24(lo0 & 0xFF00FFu, wy0) + __umul24(lo1 & 0xFF00FFu, wy1);      // VB0 | VR0 << 16
     const uint32_t br1 = __umul24(hi0 & 0xFF00FFu, wy0) + __umul24(hi1 & 0xFF00FFu, wy1);      // VB1 | VR1 << 16
     const uint32_t gt = __builtin_amdgcn_perm(hi0, lo0, 0x0C050C01u), gb = __builtin_amdgcn_perm(hi1, lo1, 0x0C050C01u);
@@ -429,6 +429,10 @@ __device__ __forceinline__ uint32_t sample_lds(const uint32_t* __restrict__ p0, 
     px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((g >> 16) & 0xFFu) * gain, 1u, px);
     px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((r >> 16) & 0xFFu) * gain, 2u, px);
     return px;
+}
+__device__ __forceinline__ uint32_t sample_lds(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1, uint32_t e, float gain)
+{
+    return sample_taps(p0[0], p0[1], p1[0], p1[1], e & 63u, (e >> 6) & 63u, gain);
 }
 
 

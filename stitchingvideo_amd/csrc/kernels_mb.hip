@@ -65,6 +65,9 @@ __device__ __forceinline__ unsigned long long stamp_now()
 namespace {
 
 // ---- packed-pixel helpers --------------------------------------------------------------------------
+// two dwords in global memory: a pixel pair of a Gaussian level, or a pixel of the collapsed level-1 canvas (HIP's uint2
+// class cannot be used through address-space pointers)
+typedef uint32_t __attribute__((ext_vector_type(2))) GPix;
 __device__ __forceinline__ uint32_t lanes_br(uint32_t p) { return p & 0x00FF00FFu; }
 __device__ __forceinline__ uint32_t lane_g(uint32_t p) { return (p >> 8) & 0xFFu; }
 
@@ -622,22 +625,37 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
 // The gathering kernel above asks the texture path for two 12-byte windows per pixel and writes level 0 twice (LDS,
 // then a store pass); measured against the micro-benchmark's forms it sits at the rate of its memory pipeline, not of
 // its instructions.  Here the 128 x 36 tile's source window is staged once (coalesced 12-byte loads of four pixels ->
-// 4-byte pixels in LDS), a lane samples four adjacent pixels of A2_ROWS rows out of LDS (one 16-byte table load and one
+// 4-byte pixels in LDS) and a lane samples four pixels of A2_ROWS rows out of LDS (one 16-byte table load and one
 // 16-byte gain load per row: the exposure gain of every tile pixel is tabulated per calibration like the map, so the
-// gain rows / weights of the per-tile constant block are gone), stores the interior of level 0 straight from its
-// registers as 16 bytes, and only then drops the tile into LDS -- over the dead window -- for the pyrDown.
-// Lane layout of a tile row: lanes 0..30 own the interior columns 4l..4l+3 (tile columns 2 + 4l ..), lane 31 the four
-// halo columns (tile columns 0, 1, 126, 127); the tables are stored in that order.
+// gain rows / weights of the per-tile constant block are gone).
+//
+// Lane layout of a tile row (round 4): lane l of a 32-lane row group owns the tile columns l, l + 32, l + 64, l + 96.
+// The taps of one sampling step are then 32 neighbouring source pixels -- consecutive LDS dwords, one per bank --
+// where round 3's "four adjacent pixels per lane" put the 32 lanes of a ds_read at a stride of four dwords: eight
+// banks, four lanes each (SQ_LDS_BANK_CONFLICT was 51 % of the kernel's LDS-active cycles).  The tables are stored in
+// lane order (slot = lane * 4 + k).  Level 0 no longer leaves from the registers -- a lane's four pixels are 32 columns
+// apart -- but from the LDS tile the pyrDown needs anyway: the tile is dropped over the dead window (one ds_write_b32
+// per pixel, conflict-free), and after the barrier a pass of 16-byte LDS reads / 16-byte non-temporal stores writes
+// the interior while the other waves start on the pyrDown.
+// Table entry: byte offset of the 2 x 2 window's first pixel inside the staged window | fx << 17 | fy << 23 | 1 << 31
+// (the window's row pitch is a per-tile constant, so the offset is final at calibration time: one v_and per pixel
+// where round 3 unpacked dx, dy and multiplied).
 #ifndef MST_A2_ROWS
 #define MST_A2_ROWS 3
 #endif
 constexpr int A2_ROWS = MST_A2_ROWS, A2_RG = A_LH / A2_ROWS, A2_NT = 32 * A2_RG;      // 3 rows per lane: 12 row groups, 384 threads (2 rows / 576 threads: 230 vs 200 us per 8 frame sets)
 static_assert(A_LW == 128 && A_LH % A2_ROWS == 0 && A_TW0 == 124, "lane layout of the staged warp kernel");
 constexpr uint32_t kWinGeneral = 1u;
+// LDS image of the level-0 tile: tile column c of row r at dword r * A2_TPITCH + 2 + c, so that the interior's groups of
+// four (columns 2 + 4 g ..) are 16-byte aligned for the store pass and the pyrDown's pixel pairs (columns 2 j, 2 j + 1)
+// 8-byte aligned
+constexpr int A2_TPITCH = 132, A2_TOFF = 2;
+constexpr size_t A2_TILE_LDS = static_cast<size_t>(A_LH) * A2_TPITCH * sizeof(uint32_t);
+constexpr uint32_t kA2MaxWindowBytes = 1u << 17;     // the entry's offset field
 
 __device__ __forceinline__ int a2_slot_of_col(int col)        // position of tile column `col` in a table row
 {
-    return col < 2 ? 124 + col : (col >= 126 ? col : col - 2);
+    return (col & 31) * 4 + (col >> 5);
 }
 
 // Per calibration: map, gain and window of every launched tile in the staged kernel's order.  One block per tile.
@@ -674,18 +692,24 @@ __global__ __launch_bounds__(256) void k_warp_table_lds(const CamDesc* __restric
     if (x_lo != INT_MAX) { atomicMin(&s_min[0], x_lo); atomicMin(&s_min[1], y_lo); atomicMax(&s_max[0], x_hi); atomicMax(&s_max[1], y_hi); }
     __syncthreads();
     const int bx = s_min[0] == INT_MAX ? 0 : s_min[0], by = s_min[1] == INT_MAX ? 0 : s_min[1];
+    const int wx0 = bx & ~3;
+    const int groups = s_max[0] == INT_MIN ? 0 : (s_max[0] - wx0 + 4) / 4;
+    const int rows = s_max[1] == INT_MIN ? 0 : s_max[1] - by + 1;
+    const uint32_t pitch_b = static_cast<uint32_t>(groups) * 16u;
+    const bool addressable = static_cast<uint64_t>(pitch_b) * static_cast<uint32_t>(rows) <= kA2MaxWindowBytes;
     const size_t base = static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW);
     for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
         const int row = half * A_ROWS_PER_THREAD + it;
         const int ry = reflect<0>(reflect<1>(ly0 + row, bh) - c.top, c.roi_h);
         const MapPx m = map_px<KIND>(c, kr, c.src_w, c.src_h, ce, load_global(c.rows + ry), rx, ry);
-        const uint32_t dx = static_cast<uint32_t>(m.ix - bx), dy = static_cast<uint32_t>(m.iy - by);
         const float g = c.expos == 0 ? 1.f : gain_at(c, rx, ry);
         uint32_t e = 0;
-        if (m.inside && dx < 1024u && dy < 512u && !(g >= 8.0e6f))
-            e = static_cast<uint32_t>(m.ifx) | static_cast<uint32_t>(m.ify) << 6 | dx << 12 | dy << 22 | 1u << 31;
-        else
+        if (m.inside && addressable && !(g >= 8.0e6f)) {
+            const uint32_t off = static_cast<uint32_t>(m.iy - by) * pitch_b + static_cast<uint32_t>(m.ix - wx0) * 4u;
+            e = off | static_cast<uint32_t>(m.ifx) << 17 | static_cast<uint32_t>(m.ify) << 23 | 1u << 31;
+        } else {
             general = true;
+        }
         const size_t o = base + row * A_LW + a2_slot_of_col(col);
         table[o] = e;
         gain[o] = g;
@@ -694,9 +718,9 @@ __global__ __launch_bounds__(256) void k_warp_table_lds(const CamDesc* __restric
     __syncthreads();
     if (tid == 0) {
         WarpWin w;
-        w.wx0 = bx & ~3; w.by = by; w.bx = bx;
-        w.groups = s_max[0] == INT_MIN ? 0 : (s_max[0] - w.wx0 + 4) / 4;
-        w.rows = s_max[1] == INT_MIN ? 0 : s_max[1] - by + 1;
+        w.wx0 = wx0; w.by = by; w.bx = bx;
+        w.groups = groups;
+        w.rows = rows;
         const bool overrun = w.wx0 + 4 * w.groups > c.src_w && by + w.rows >= c.src_h;
         w.flags = (s_general || w.groups * 4 * w.rows > lds_budget_px || w.groups > 256 || w.groups == 0 || overrun) ? kWinGeneral : 0u;
         w.tile = 0; w.index = 0;
@@ -708,7 +732,8 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
                                                         const uint32_t* __restrict__ table, const float* __restrict__ gain,
                                                         const WarpWin* __restrict__ wins, int n_cams, int n_sets)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];     // the staged window, later the level-0 tile [A_LH][A_LW]
+    MST_STAMP(0, 0);
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];     // the staged window, later the level-0 tile [A_LH][A2_TPITCH]
     const int tid = threadIdx.x, lane = tid & 31;
     const int rgrp = __builtin_amdgcn_readfirstlane(tid >> 6) * 2 + ((tid >> 5) & 1);
     const int pair = xcd_run_index(blockIdx.x, n_tiles * n_sets);
@@ -734,55 +759,60 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
     }
     stage_window<A2_NT, false, MST_STAGE_U_WARP>(s_mem, gp(frames.ptr[cam]) + (static_cast<size_t>(w.by) * stride + static_cast<size_t>(w.wx0) * 3u), stride,
                         w.groups, w.rows);
+    MST_STAMP(0, 1);
     __syncthreads();
+    MST_STAMP(0, 2);
     const uint32_t pitch_b = static_cast<uint32_t>(w.groups) * 16u;
-    const char* win = reinterpret_cast<const char*>(s_mem) + (w.bx - w.wx0) * 4;
+    const char* win = reinterpret_cast<const char*>(s_mem);
     uint32_t px[A2_ROWS][4];
 #pragma unroll
     for (int it = 0; it < A2_ROWS; ++it)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t e = e_r[it][k];
-            const uint32_t dx = (e >> 12) & 1023u, dy = (e >> 22) & 511u;
-            const uint32_t addr = __umul24(dy, pitch_b) + dx * 4u;
-            px[it][k] = sample_lds(reinterpret_cast<const uint32_t*>(win + addr), reinterpret_cast<const uint32_t*>(win + addr + pitch_b), e, g_r[it][k]);
+            const uint32_t addr = e & (kA2MaxWindowBytes - 1u);
+            const uint32_t* p0 = reinterpret_cast<const uint32_t*>(win + addr);
+            const uint32_t* p1 = reinterpret_cast<const uint32_t*>(win + addr + pitch_b);
+            px[it][k] = sample_taps(p0[0], p0[1], p1[0], p1[1], (e >> 17) & 63u, (e >> 23) & 63u, g_r[it][k]);
         }
-    // level 0, interior of the tile, straight from the registers (lanes 0..30: 16 bytes each, 16-byte aligned when the
-    // level's width is a multiple of four: 124 * 4 bytes is)
+    MST_STAMP(0, 3);
+    __syncthreads();                                // every wave is done with the window: the tile takes its place
+#pragma unroll
+    for (int it = 0; it < A2_ROWS; ++it) {
+        uint32_t* trow = s_mem + (rgrp * A2_ROWS + it) * A2_TPITCH + A2_TOFF + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) trow[32 * k] = px[it][k];
+    }
+    __syncthreads();
+    MST_STAMP(0, 4);
+    // level 0, interior of the tile: 31 groups of four pixels per row, 16 bytes each way (16-byte aligned in global memory
+    // when the level's width is a multiple of four: 124 * 4 bytes is)
     const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;
     const bool store0 = !(t >> 31);                 // (bit 31: nothing reads this tile's level 0 from memory, see mb_plan.cpp)
-    if (store0 && lane < 31) {
+    if (store0) {
         uint32_t MST_GLOBAL* __restrict__ g0out = gp(c.G[0]);
-        const int gx = lx0 + 2 + 4 * lane;
+        constexpr int kGroups = A_TW0 / 4;
+        const bool wide = (bw & 3) == 0;
 #pragma unroll
-        for (int it = 0; it < A2_ROWS; ++it) {
-            const int row = rgrp * A2_ROWS + it, gy = ly0 + row;
-            if (row < 2 || row >= A_LH - 2 || gy >= bh || gx >= bw) continue;
+        for (int i0 = 0; i0 < A_TH0 * kGroups; i0 += A2_NT) {
+            const int i = i0 + tid;
+            const int r = static_cast<int>((static_cast<uint32_t>(i) * 2115u) >> 16);       // i / 31 for i < 1984
+            const int g = i - r * kGroups;
+            const int gy = ly0 + 2 + r, gx = lx0 + 2 + 4 * g;
+            if (i >= A_TH0 * kGroups || gy >= bh || gx >= bw) continue;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(s_mem + (2 + r) * A2_TPITCH + A2_TOFF + 2 + 4 * g);
             uint32_t MST_GLOBAL* o = g0out + __umul24(gy, bw) + gx;
-            if ((bw & 3) == 0) {
-                __builtin_nontemporal_store(u32x4_t{px[it][0], px[it][1], px[it][2], px[it][3]}, reinterpret_cast<u32x4_t MST_GLOBAL*>(o));
+            if (wide) {
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t MST_GLOBAL*>(o));
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (gx + k < bw) o[k] = px[it][k];
+                    if (gx + k < bw) o[k] = v[k];
             }
         }
     }
     if (nlev < 2) return;
-    __syncthreads();                                // every wave is done with the window: the tile takes its place
-    uint32_t (*s_l0)[A_LW] = reinterpret_cast<uint32_t (*)[A_LW]>(s_mem);
-#pragma unroll
-    for (int it = 0; it < A2_ROWS; ++it) {
-        const int row = rgrp * A2_ROWS + it;
-        if (lane < 31) {
-            *reinterpret_cast<uint2*>(&s_l0[row][2 + 4 * lane]) = make_uint2(px[it][0], px[it][1]);
-            *reinterpret_cast<uint2*>(&s_l0[row][4 + 4 * lane]) = make_uint2(px[it][2], px[it][3]);
-        } else {
-            *reinterpret_cast<uint2*>(&s_l0[row][0]) = make_uint2(px[it][0], px[it][1]);
-            *reinterpret_cast<uint2*>(&s_l0[row][126]) = make_uint2(px[it][2], px[it][3]);
-        }
-    }
-    __syncthreads();
+    MST_STAMP(0, 5);
     // pyrDown straight from the LDS tile (as in k_warp_pyr): a thread owns one output column and four output rows
     uint32_t MST_GLOBAL* __restrict__ g1out = gp(c.G[1]);
     const int lw1 = c.lw[1], lh1 = c.lh[1];
@@ -794,7 +824,7 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
         uint32_t hbr[2 * R + 3], hg[2 * R + 3];
 #pragma unroll
         for (int r = 0; r < 2 * R + 3; ++r) {
-            const uint32_t* p = &s_l0[2 * R * g + r][2 * j];
+            const uint32_t* p = s_mem + (2 * R * g + r) * A2_TPITCH + A2_TOFF + 2 * j;
             const uint2 p01 = *reinterpret_cast<const uint2*>(p);
             const uint2 p23 = *reinterpret_cast<const uint2*>(p + 2);
             tap5(p01.x, p01.y, p23.x, p23.y, p[4], hbr[r], hg[r]);
@@ -808,6 +838,8 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
             g1out[__umul24(y1 + i, lw1) + x1 + j] = pyrdown_finish(vbr, vg);
         }
     }
+    MST_STAMP(0, 6);
+    MST_STAMP_VAL(0, 8, static_cast<unsigned long long>(w.groups) * 16u * w.rows);
 }
 
 // ======================================================================================================
@@ -958,6 +990,83 @@ __global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restri
 }
 
 // ======================================================================================================
+// B, streaming form: one cv::pyrDown level l -> l + 1 without LDS (round 4)
+// ======================================================================================================
+// k_pyr_chain spends 264 VALU lane-instructions per output pixel (index arithmetic of its LDS regions, the halo every
+// chained level recomputes, per-element divisions) and three barrier-separated phases per block; on the two large
+// levels (1 -> 2 -> 3: 58 of the 67 us the chain launches take per 8 frame sets on C3) that is the whole cost.  Here a
+// wave owns PS_W = 62 output columns x PS_R output rows: lane i holds the pixel pair (columns 2 ox, 2 ox + 1: 8 bytes,
+// the wave 512 contiguous bytes per source row) of output column ox = 62 ux + i - 1, so lanes 1..62 produce outputs and
+// lanes 0 and 63 only carry the pairs beside them; the pair on a lane's left and the pixel on its right come over
+// wave-wide DPP shifts (wave_shr:1 / wave_shl:1).  All 2 R + 3 source rows of the unit are requested before the first is
+// used (one basic block, no branch: the compiler counts vmcnt down row by row), every row is filtered horizontally
+// once and the last five filtered rows are kept in registers.  Source levels have even sizes (the bordered level 0 is a
+// multiple of 2^bands), so REFLECT_101 only ever folds column / row -2, -1 and `size` back inside.
+constexpr int PS_R = 8, PS_W = 62;
+__device__ __forceinline__ uint32_t wave_from_below(uint32_t v)      // lane i <- lane i - 1 (lane 0 keeps its own)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint32_t wave_from_above(uint32_t v)      // lane i <- lane i + 1 (lane 63 keeps its own)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x130, 0xF, 0xF, false));
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_pyrdown_stream(const CamDesc* __restrict__ cams_all, const uint32_t* __restrict__ units,
+                                                        int n_units, int l, int n_cams)
+{
+    const CamDesc* __restrict__ cams = cams_all + blockIdx.y * n_cams;
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int ui = xcd_run_index(blockIdx.x, (n_units + 3) >> 2) * 4 + wave;
+    if (ui >= n_units) return;                                   // (wave-uniform)
+    const uint32_t u = units[ui];
+    const int cam = (u >> 24) & 0x7F, uy = (u >> 12) & 0xFFF, ux = u & 0xFFF;
+    const CamDesc& c = cams[cam];
+    const int sw = c.lw[l], sh = c.lh[l], dw = c.lw[l + 1], dh = c.lh[l + 1];
+    uint32_t MST_GLOBAL* __restrict__ dst = gp(c.G[l + 1]);
+    const int ox = ux * PS_W + lane - 1, oy0 = uy * R;
+    const int pc = min(max(ox, 0), dw - 1);                      // this lane's pixel pair (lanes outside the level: the nearest one)
+    const bool left_border = ox <= 0, right_border = ox >= dw - 1;
+    const uint32_t MST_GLOBAL* __restrict__ col = gp(c.G[l]) + 2 * pc;
+    struct Row { uint32_t hbr, hg; };
+    auto row_of = [&](int iy) {                                  // REFLECT_101, -2 <= iy <= sh (scalar)
+        const int a = iy < 0 ? -iy : iy;
+        return a >= sh ? 2 * sh - 2 - a : a;
+    };
+    // (the DPP shifts first, on every lane: see from_lane_below)
+    auto filter = [&](const uint2& p, Row& h) {
+        const uint32_t bx = wave_from_below(p.x), by = wave_from_below(p.y), ax = wave_from_above(p.x);
+        const uint32_t lx = left_border ? ax : bx, ly = left_border ? p.y : by;      // columns -2, -1 -> 2, 1
+        const uint32_t rx = right_border ? p.x : ax;                                 // column sw -> sw - 2
+        tap5(lx, ly, p.x, p.y, rx, h.hbr, h.hg);
+    };
+    constexpr int kRows = 2 * R + 3;
+    uint2 raw[kRows];
+#pragma unroll
+    for (int t = 0; t < kRows; ++t) {
+        const GPix v = *(const GPix MST_GLOBAL*)(col + __umul24(static_cast<uint32_t>(row_of(min(2 * oy0 + t - 2, sh))), static_cast<uint32_t>(sw)));
+        raw[t] = make_uint2(v.x, v.y);
+    }
+    Row h[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) filter(raw[t], h[t]);
+    const bool col_ok = lane >= 1 && lane <= PS_W && ox < dw;
+    uint32_t MST_GLOBAL* o = dst + __umul24(oy0, dw) + max(ox, 0);
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const uint32_t vbr = h[0].hbr + h[4].hbr + 4u * (h[1].hbr + h[3].hbr) + 6u * h[2].hbr;
+        const uint32_t vg = h[0].hg + h[4].hg + 4u * (h[1].hg + h[3].hg) + 6u * h[2].hg;
+        if (col_ok && oy0 + t < dh) *o = pyrdown_finish(vbr, vg);
+        o += dw;
+        if (t + 1 < R) {
+            h[0] = h[2]; h[1] = h[3]; h[2] = h[4];
+            filter(raw[2 * t + 5], h[3]); filter(raw[2 * t + 6], h[4]);
+        }
+    }
+}
+
+// ======================================================================================================
 // C: the canvas -- k_blend_coarse (levels 1 .. top of a level-1 tile in one block) and k_blend_fine (level 0)
 // ======================================================================================================
 // Tile heights, C3 on MI355X, canvas stage per frame set (8 sets per launch) / one-set-at-a-time panoramas per s:
@@ -1082,8 +1191,7 @@ __device__ __forceinline__ void pyrup_quad_s16(const uint2 v[3][3], int out[4][3
     }
 }
 
-// a pixel of the collapsed level-1 canvas in global memory (HIP's uint2 class cannot be used through address-space pointers)
-typedef uint32_t __attribute__((ext_vector_type(2))) GPix;
+// (GPix: a pixel of the collapsed level-1 canvas in global memory, see the packed-pixel helpers)
 typedef const GPix MST_GLOBAL* C1Ptr;
 template <typename T> __device__ __forceinline__ uint2 as_u2(const T& t) { return make_uint2(t.x, t.y); }
 
@@ -2200,7 +2308,7 @@ void launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, int n_tiles, const F
                          const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s)
 {
     if (n_tiles <= 0 || batch <= 0) return;
-    const size_t lds = std::max(lds_bytes, mb_warp_tile_px() * sizeof(uint32_t));
+    const size_t lds = std::max(lds_bytes, A2_TILE_LDS);
     hipLaunchKernelGGL(k_warp_pyr_lds, dim3(n_tiles * batch), dim3(A2_NT), lds, s, d_cams, n_tiles, frames, d_table, d_gain, d_wins, n_cams, batch);
 }
 
@@ -2209,6 +2317,15 @@ void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, i
     if (list.count <= 0 || k <= 0 || batch <= 0) return;
     if (k == 1) hipLaunchKernelGGL(k_pyr_chain<1>, dim3(list.count, batch), dim3(B_THREADS), 0, s, d_cams, list, base, n_cams);
     else hipLaunchKernelGGL(k_pyr_chain<2>, dim3(list.count, batch), dim3(B_THREADS), 0, s, d_cams, list, base, n_cams);
+}
+
+int mb_stream_unit_rows() { return PS_R; }
+int mb_stream_unit_cols() { return PS_W; }
+
+void launch_pyrdown_stream(const CamDesc* d_cams, int n_cams, const uint32_t* d_units, int n_units, int level, int batch, hipStream_t s)
+{
+    if (n_units <= 0 || batch <= 0) return;
+    hipLaunchKernelGGL(k_pyrdown_stream<PS_R>, dim3((n_units + 3) / 4, batch), dim3(256), 0, s, d_cams, d_units, n_units, level, n_cams);
 }
 
 void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, int num_coarse, int batch, size_t lds_bytes,

@@ -344,6 +344,37 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                         step.tiles.push_back(static_cast<uint32_t>(c) << 24 | static_cast<uint32_t>(ty) << 12 | tx);
         }
         step.cam_start.push_back(static_cast<int>(step.tiles.size()));
+        // the streaming form for the large levels (every source level of the step must have even sizes)
+        bool stream = base <= 2;
+        for (int c = 0; c < n && stream; ++c)
+            for (int j = 0; j < k; ++j) stream = stream && (desc[c].lw[base + j] % 2 == 0) && (desc[c].lh[base + j] % 2 == 0);
+        if (stream) {
+            const int ur = mb_stream_unit_rows(), uc = mb_stream_unit_cols();
+            for (int j = 0; j < k; ++j) {
+                const int l = base + 1 + j;
+                for (int c = 0; c < n; ++c) {
+                    step.unit_cam_start[j].push_back(static_cast<int>(step.units[j].size()));
+                    const CamDesc& d = desc[c];
+                    const int ux_n = (d.lw[l] + uc - 1) / uc, uy_n = (d.lh[l] + ur - 1) / ur;
+                    std::vector<uint8_t> used(static_cast<size_t>(ux_n) * uy_n, 0);
+                    const std::vector<uint8_t>& need = plan.cams[c].need[l];
+                    for (int y = 0; y < d.lh[l]; ++y) {
+                        const uint8_t* row = need.data() + static_cast<size_t>(y) * d.lw[l];
+                        uint8_t* urow = used.data() + static_cast<size_t>(y / ur) * ux_n;
+                        for (int x = next_set(row, 0, d.lw[l]); x < d.lw[l];) {
+                            const int t = x / uc;
+                            urow[t] = 1;
+                            x = next_set(row, std::min(d.lw[l], (t + 1) * uc), d.lw[l]);
+                        }
+                    }
+                    for (int uy = 0; uy < uy_n; ++uy)
+                        for (int ux = 0; ux < ux_n; ++ux)
+                            if (used[static_cast<size_t>(uy) * ux_n + ux])
+                                step.units[j].push_back(static_cast<uint32_t>(c) << 24 | static_cast<uint32_t>(uy) << 12 | ux);
+                }
+                step.unit_cam_start[j].push_back(static_cast<int>(step.units[j].size()));
+            }
+        }
         plan.chain.push_back(std::move(step));
         base += k;
     }

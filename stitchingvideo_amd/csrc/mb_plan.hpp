@@ -31,7 +31,15 @@ struct MbPlanHost {
     std::vector<uint32_t> warp_tiles;                         // kernel A, grouped by camera: cam << 24 | ty << 12 | tx, bit 31 =
                                                               // level 0 of the tile is not stored (no level-0 weight under it)
     std::vector<int> warp_cam_start;                          // n+1 offsets into warp_tiles
-    struct ChainStep { int base, k; std::vector<uint32_t> tiles; std::vector<int> cam_start; };
+    // A step that starts on a large level (base <= 2) is run by the streaming kernel instead, one launch per level:
+    // units[j] = the mb_stream_unit_cols() x mb_stream_unit_rows() output units of level base + 1 + j that hold a needed pixel
+    // (cam << 24 | uy << 12 | ux, grouped by camera: unit_cam_start[j]); empty when the step stays with k_pyr_chain.
+    // `tiles` always describes what the step computes (the camera-sharded payload is cut from it).
+    struct ChainStep {
+        int base, k;
+        std::vector<uint32_t> tiles; std::vector<int> cam_start;
+        std::vector<uint32_t> units[2]; std::vector<int> unit_cam_start[2];
+    };
     std::vector<ChainStep> chain;                             // kernel B launches
     std::vector<uint32_t> block_cams;                         // k_blend_fine, one entry per panorama tile (BlendArgs)
     std::vector<uint32_t> block_order;                        // k_blend_fine, tile index launched as block i

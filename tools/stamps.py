@@ -27,7 +27,7 @@ for rep in range(3):
 L = capi.load()
 L.mst_debug_stamps.restype = C.c_int
 L.mst_debug_stamps.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
-for which, name, labels in ((0, "A k_warp_pyr", ["prologue", "pixel loop", "barrier+drain", "pyrDown"]),
+for which, name, labels in ((0, "A k_warp_pyr_lds", ["tables+staging", "barrier", "sampling", "bar+tile+bar", "L0 store pass", "pyrDown"]),
                             (1, "C k_blend_coarse", ["phase1 bands", "barrier", "collapse", "level 1"]),
                             (2, "C k_blend_fine", ["level 0"])):
     buf = np.zeros(1 << 17, np.uint64)
@@ -37,7 +37,7 @@ for which, name, labels in ((0, "A k_warp_pyr", ["prologue", "pixel loop", "barr
     st = buf.reshape(-1, 16).astype(np.int64)
     live = st[:, 0] != 0
     st = st[live]
-    last = 1 if which == 2 else 4
+    last = 1 if which == 2 else (6 if which == 0 else 4)
     d = np.diff(st[:, :last + 1], axis=1)
     total = st[:, last] - st[:, 0]
     print("%s: %d blocks stamped, mean lifetime %.0f cycles (p10 %.0f, p90 %.0f)" % (name, len(st), total.mean(), np.percentile(total, 10), np.percentile(total, 90)))
@@ -55,7 +55,8 @@ for which, name, labels in ((0, "A k_warp_pyr", ["prologue", "pixel loop", "barr
         ncam = np.array([bin(int(e) & 0x7FFFFFFF).count("1") for e in entry])
         classes = [("pure", pure == 1), ("1 cam, not pure", (pure == 0) & (ncam == 1)), ("2 cams", ncam == 2), (">=3 cams", ncam >= 3), ("no camera", ncam == 0)]
     else:
-        classes = [("all", np.ones(len(st), bool))]
+        wb = st[:, 8]
+        classes = [("all", np.ones(len(st), bool)), ("window < 24 KB", wb < 24576), ("24-40 KB", (wb >= 24576) & (wb <= 40960)), ("> 40 KB", wb > 40960)]
     for cname, m in classes:
         if not m.any():
             continue
