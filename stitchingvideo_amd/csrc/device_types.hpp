@@ -156,6 +156,12 @@ struct BlendArgs {
     uint8_t* pano[kMaxBatch]; uint32_t pano_stride;          // one panorama (and optional mask) per frame set
     uint8_t* pano_mask[kMaxBatch]; uint32_t mask_stride;
     uint64_t* c1[kMaxBatch];                   // collapsed level-1 canvas of each frame set: ch[1] x cw[1], 8 bytes a pixel
+    // Round 4: with three and more levels k_blend_coarse stops at level 2 and hands its tile's interior of the collapsed
+    // level-2 canvas (ch[2] x cw[2], 8 bytes a pixel) to k_blend_mid, which forms level 1 the way k_blend_fine forms level 0
+    uint64_t* c2[kMaxBatch];
+    int32_t split;                             // 1: k_blend_coarse -> c2, k_blend_mid -> c1; 0: k_blend_coarse -> c1 (two levels)
+    const uint32_t* coarse_order2;             // k_blend_coarse's own launch order when split (a strip engine also needs the
+    int32_t n_coarse2;                         // tiles whose level-2 interiors its level-1 tiles read as pyrUp halo)
     // k_blend_fine, per panorama tile: bit i = camera i has a non-zero level-0 weight under the tile; bit 31 = the
     // tile's level 0 is owned by ONE camera with weight exactly 1 (integer band path) -- then only that camera's bit;
     // bit 30 = one or two cameras with 0/1 weights, never both non-zero on a pixel (integer path with masks)

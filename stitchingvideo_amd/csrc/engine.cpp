@@ -205,6 +205,8 @@ BlendArgs CalibState::blend_for(int frame_sets, int* n_coarse, size_t* lds_bytes
     ba.coarse_cams = coarse_dev[v].cams;
     ba.coarse_pure = coarse_dev[v].pure;
     ba.coarse_order = coarse_dev[v].order;
+    ba.coarse_order2 = coarse_dev[v].order2;
+    ba.n_coarse2 = static_cast<int>(ct.order2.size());
     ba.coarse_tiles_x = ct.tiles_x;
     for (int l = 0; l < kMaxLevels; ++l) ba.lds_off[l] = ct.lds_off[l];
     *n_coarse = static_cast<int>(ct.order.size());
@@ -676,6 +678,7 @@ void Engine::update(const mst_calibration& calib)
                 st->coarse_dev[v].cams = st->pool.upload(ct.cams, s);
                 st->coarse_dev[v].pure = st->pool.upload(ct.pure, s);
                 st->coarse_dev[v].order = st->pool.upload(ct.order, s);
+                st->coarse_dev[v].order2 = ct.order2.empty() ? nullptr : st->pool.upload(ct.order2, s);
             }
         }
         if (nb >= 1) {
@@ -683,6 +686,18 @@ void Engine::update(const mst_calibration& calib)
             st->c1.assign(st->num_sets, nullptr);
             for (int k = 0; k < st->num_sets; ++k)
                 st->c1[k] = st->pool.alloc<uint64_t>(static_cast<size_t>(cv.cw[1]) * cv.ch[1]);
+            // ... and, opt-in (MST_SPLIT=1), the collapsed level-2 canvas between k_blend_coarse and k_blend_mid.  Measured on
+            // C3 (profiles/r04_experiments.md): k_blend_coarse alone 83 us per 8 frame sets; split 49 + 59: the level-1 pass is
+            // no faster in k_blend_fine's shape (most of its tiles carry fractional weights and take the float path either
+            // way), and the levels above it cost more than the ablation of round 3 suggested.  Off by default.
+            const char* split_env = std::getenv("MST_SPLIT");       // (read per calibration: the parity test switches it)
+            const bool split = split_env && split_env[0] == '1';
+            st->c2.clear();
+            if (nb >= 2 && split) {
+                st->c2.assign(st->num_sets, nullptr);
+                for (int k = 0; k < st->num_sets; ++k)
+                    st->c2[k] = st->pool.alloc<uint64_t>(static_cast<size_t>(cv.cw[2]) * cv.ch[2]);
+            }
         }
         st->warp_list.tiles = st->pool.upload(plan.warp_tiles, s);
         st->warp_list.count = static_cast<int32_t>(plan.warp_tiles.size());
@@ -1245,6 +1260,8 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         ba.mask_stride = static_cast<uint32_t>(mask_stride);
         if (!st->c1.empty())
             for (int f = 0; f < count; ++f) ba.c1[f] = st->c1[first_set + f];
+        if (!st->c2.empty())
+            for (int f = 0; f < count; ++f) ba.c2[f] = st->c2[first_set + f];
         const int n_fine = static_cast<int>(st->plan.block_order.size());
         if (ba.nlev > 1) {
             launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 1);
@@ -1395,6 +1412,7 @@ void Engine::stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t
     ba.pano_mask[0] = static_cast<uint8_t*>(d_mask); ba.mask_stride = static_cast<uint32_t>(mask_stride);
     if (stage_set_ >= st->num_sets) throw Error{MST_ERR_INVALID_ARG, "stage set beyond mst_config.max_batch"};
     if (!st->c1.empty()) ba.c1[0] = st->c1[stage_set_];
+    if (!st->c2.empty()) ba.c2[0] = st->c2[stage_set_];
     launch_blend(st->d_desc + static_cast<size_t>(stage_set_) * st->n, ba, static_cast<int>(st->plan.block_order.size()),
                  n_coarse, 1, lds_bytes, s);
     check_hip(hipGetLastError(), "canvas stage kernel");

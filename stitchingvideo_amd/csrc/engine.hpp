@@ -101,11 +101,12 @@ struct CalibState {
     std::vector<UndistortPlan> undist_plans;
     bool any_undistort = false;
     int undist_max_w = 0, undist_max_h = 0;
-    struct CoarseDev { const uint32_t* cams = nullptr; const uint32_t* pure = nullptr; const uint32_t* order = nullptr; };
+    struct CoarseDev { const uint32_t* cams = nullptr; const uint32_t* pure = nullptr; const uint32_t* order = nullptr; const uint32_t* order2 = nullptr; };
     CoarseDev coarse_dev[2];               // k_blend_coarse tile tables of plan.coarse[v] on the device
     // `blend` completed for a launch of `frame_sets` frame sets: the tile tables / LDS layout of its launch variant
     BlendArgs blend_for(int frame_sets, int* n_coarse, size_t* lds_bytes) const;
-    std::vector<uint64_t*> c1;               // per buffer set: collapsed level-1 canvas (k_blend_coarse -> k_blend_fine)
+    std::vector<uint64_t*> c1;               // per buffer set: collapsed level-1 canvas (k_blend_coarse / k_blend_mid -> k_blend_fine)
+    std::vector<uint64_t*> c2;               // per buffer set: collapsed level-2 canvas (k_blend_coarse -> k_blend_mid), three and more levels
     // MST_FLAG_FRAMES_NV12: num_sets x n engine-owned BGR frames the callers' NV12 frames are converted into, (w, h) per camera
     std::vector<uint8_t*> nv12_frames;
     const int2* d_frame_sizes = nullptr;

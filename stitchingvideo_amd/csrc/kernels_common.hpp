@@ -417,13 +417,15 @@ __device__ __forceinline__ uint32_t sample_taps(uint32_t lo0, uint32_t hi0, uint
 {
     const uint32_t wxp = __umul24(fx, 0x3FFFC0u) + 2048u;         // (32 - fx) * 64 | fx * 64 << 16
     const uint32_t wy1 = fy, wy0 = 32u - fy;
-    const uint32_t br0 = __umul24(lo0 & 0xFF00FFu, wy0) + __umul24(lo1 & 0xFF00FFu, wy1);      // VB0 | VR0 << 16
-    const uint32_t br1 = __umul24(hi0 & 0xFF00FFu, wy0) + __umul24(hi1 & 0xFF00FFu, wy1);      // VB1 | VR1 << 16
+    // one byte of both pixels of a row per register (X0 | X1 << 16): three perms per row, vertical lerp on both pixels
+    // at once (24-bit multiplies, no carry between the halves: 255 * 32 < 2^16), then the horizontal pass is one v_dot2
+    // per channel with no shuffle in front of it
+    const uint32_t bt = __builtin_amdgcn_perm(hi0, lo0, 0x0C040C00u), bb = __builtin_amdgcn_perm(hi1, lo1, 0x0C040C00u);
     const uint32_t gt = __builtin_amdgcn_perm(hi0, lo0, 0x0C050C01u), gb = __builtin_amdgcn_perm(hi1, lo1, 0x0C050C01u);
-    const uint32_t gg = __umul24(gt, wy0) + __umul24(gb, wy1);                                  // VG0 | VG1 << 16
-    uint32_t b = dot2_u16(__builtin_amdgcn_perm(br1, br0, 0x05040100u), wxp, 32768u);
-    uint32_t r = dot2_u16(__builtin_amdgcn_perm(br1, br0, 0x07060302u), wxp, 32768u);
-    uint32_t g = dot2_u16(gg, wxp, 32768u);
+    const uint32_t rt = __builtin_amdgcn_perm(hi0, lo0, 0x0C060C02u), rb = __builtin_amdgcn_perm(hi1, lo1, 0x0C060C02u);
+    uint32_t b = dot2_u16(__umul24(bt, wy0) + __umul24(bb, wy1), wxp, 32768u);
+    uint32_t g = dot2_u16(__umul24(gt, wy0) + __umul24(gb, wy1), wxp, 32768u);
+    uint32_t r = dot2_u16(__umul24(rt, wy0) + __umul24(rb, wy1), wxp, 32768u);
     asm("" : "+v"(b)); asm("" : "+v"(g)); asm("" : "+v"(r));      // (see sample_window)
     uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((b >> 16) & 0xFFu) * gain, 0u, 0u);
     px = __builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>((g >> 16) & 0xFFu) * gain, 1u, px);

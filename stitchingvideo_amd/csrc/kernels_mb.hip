@@ -1182,12 +1182,14 @@ __device__ __forceinline__ void pyrup_quad_s16(const uint2 v[3][3], int out[4][3
             ho[r][ch] = 4 * (bv[ch] + cv[ch]);
         }
     }
+    // (cv::pyrUp's saturate_cast<short> cannot trigger: every output is (sum of w_i * v_i + 32) >> 6 with non-negative
+    // weights summing to 64 over CV_16S inputs, i.e. it lies between the smallest and the largest input)
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        out[0][ch] = sat_s16((he[0][ch] + 6 * he[1][ch] + he[2][ch] + 32) >> 6);
-        out[1][ch] = sat_s16((ho[0][ch] + 6 * ho[1][ch] + ho[2][ch] + 32) >> 6);
-        out[2][ch] = sat_s16((4 * (he[1][ch] + he[2][ch]) + 32) >> 6);
-        out[3][ch] = sat_s16((4 * (ho[1][ch] + ho[2][ch]) + 32) >> 6);
+        out[0][ch] = (he[0][ch] + 6 * he[1][ch] + he[2][ch] + 32) >> 6;
+        out[1][ch] = (ho[0][ch] + 6 * ho[1][ch] + ho[2][ch] + 32) >> 6;
+        out[2][ch] = (4 * (he[1][ch] + he[2][ch]) + 32) >> 6;
+        out[3][ch] = (4 * (ho[1][ch] + ho[2][ch]) + 32) >> 6;
     }
 }
 
@@ -1855,10 +1857,10 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
         int upv[4][3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            upv[0][ch] = sat_s16((rc[0].he[ch] + 6 * rc[1].he[ch] + rc[2].he[ch] + 32) >> 6);
-            upv[1][ch] = sat_s16((rc[0].ho[ch] + 6 * rc[1].ho[ch] + rc[2].ho[ch] + 32) >> 6);
-            upv[2][ch] = sat_s16((4 * (rc[1].he[ch] + rc[2].he[ch]) + 32) >> 6);
-            upv[3][ch] = sat_s16((4 * (rc[1].ho[ch] + rc[2].ho[ch]) + 32) >> 6);
+            upv[0][ch] = (rc[0].he[ch] + 6 * rc[1].he[ch] + rc[2].he[ch] + 32) >> 6;      // (no saturation needed: see pyrup_quad_s16)
+            upv[1][ch] = (rc[0].ho[ch] + 6 * rc[1].ho[ch] + rc[2].ho[ch] + 32) >> 6;
+            upv[2][ch] = (4 * (rc[1].he[ch] + rc[2].he[ch]) + 32) >> 6;
+            upv[3][ch] = (4 * (rc[1].ho[ch] + rc[2].ho[ch]) + 32) >> 6;
         }
         int band[4][3];              // normalised band of level L
         uint32_t many = 0;           // MASKED: a byte per quad pixel, non-zero under a camera
@@ -1888,11 +1890,11 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
                 }
             }
         }
-        int v[4][3];                 // collapsed level L; cv::add saturates
+        int v[4][3];                 // collapsed level L; cv::add saturates (level 0: convertTo(8U)'s clamp to [0, 255] absorbs it)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) v[q][ch] = sat_s16(upv[q][ch] + band[q][ch]);
+            for (int ch = 0; ch < 3; ++ch) v[q][ch] = L == 0 ? upv[q][ch] + band[q][ch] : sat_s16(upv[q][ch] + band[q][ch]);
         if (L == 0) {
             uint32_t o8[4][3];
 #pragma unroll
@@ -1988,7 +1990,7 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
             m[k] = ws[k] > kWeightEps;                                           // dst_mask_ = weights > eps
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const int v = TOP ? n[k][ch] : sat_s16(up[k][ch] + n[k][ch]);
+                const int v = TOP ? n[k][ch] : up[k][ch] + n[k][ch];       // (cv::add's saturation is absorbed by the clamp to [0, 255])
                 o8[k][ch] = m[k] ? static_cast<uint32_t>(sat_u8(v)) : 0u;
             }
         }
@@ -1996,21 +1998,15 @@ __device__ __forceinline__ void final_level(const CamDesc* __restrict__ cams, co
     }
 }
 
-// The base level of k_blend_coarse (level 1): its band is formed like any other, the collapsed level above comes out
-// of LDS, and the sum -- the collapsed level-1 canvas -- goes to global memory for k_blend_fine (8 bytes a pixel).
-template <int NT, bool TOP, bool PURE, bool W16 = false>
-__device__ __forceinline__ void coarse_base_level(const CamDesc* __restrict__ cams, const BlendArgs& a, uint32_t cam_bits,
-                                                  const uint2* __restrict__ lds, const int* __restrict__ s_reg,
-                                                  uint2* __restrict__ c1)
+// The base level of the coarse canvas stage (level 1): its band is formed like any other, the collapsed level above comes
+// out of LDS (k_blend_coarse, two-level pyramids) or out of the collapsed level-2 canvas in global memory (k_blend_mid), and
+// the sum -- the collapsed level-1 canvas -- goes to global memory for k_blend_fine (8 bytes a pixel).
+template <int NT, bool TOP, bool PURE, bool W16, typename Ptr>
+__device__ __forceinline__ void base_level_from(const CamDesc* __restrict__ cams, const BlendArgs& a, uint32_t cam_bits,
+                                                const QuadIter& it, Ptr s_up, int ux0, int uy0, int upitch,
+                                                uint2* __restrict__ c1)
 {
     constexpr int l = 1;
-    const QuadIter it(s_reg, l);
-    Region ur = it.r;
-    const uint2* s_up = nullptr;
-    if (!TOP) {
-        ur = table_region(s_reg, l + 1);
-        s_up = lds + a.lds_off[l + 1];
-    }
     const int cw = a.cw[l];
     const bool wide = (cw & 1) == 0;       // rows start 16-byte aligned (c1 is), x is even
     for (int q = threadIdx.x; q < it.nq; q += NT) {
@@ -2021,7 +2017,7 @@ __device__ __forceinline__ void coarse_base_level(const CamDesc* __restrict__ ca
         float ws[4];
         band_quad<TOP, false, PURE, W16>(cams, a, l, x, y, valid, cam_bits, n, ws);
         int up[4][3];
-        if (!TOP) pyrup_quad_lds(s_up, ur.x0, ur.y0, region_pitch(ur), a.cw[l + 1], a.ch[l + 1], x >> 1, y >> 1, up);
+        if (!TOP) pyrup_quad_lds(s_up, ux0, uy0, upitch, a.cw[l + 1], a.ch[l + 1], x >> 1, y >> 1, up);
 #pragma unroll
         for (int ry = 0; ry < 2; ++ry) {
             if (!valid[2 * ry]) continue;
@@ -2052,6 +2048,20 @@ __device__ __forceinline__ void coarse_base_level(const CamDesc* __restrict__ ca
             }
         }
     }
+}
+template <int NT, bool TOP, bool PURE, bool W16 = false>
+__device__ __forceinline__ void coarse_base_level(const CamDesc* __restrict__ cams, const BlendArgs& a, uint32_t cam_bits,
+                                                  const uint2* __restrict__ lds, const int* __restrict__ s_reg,
+                                                  uint2* __restrict__ c1)
+{
+    const QuadIter it(s_reg, 1);
+    Region ur = it.r;
+    const uint2* s_up = nullptr;
+    if (!TOP) {
+        ur = table_region(s_reg, 2);
+        s_up = lds + a.lds_off[2];
+    }
+    base_level_from<NT, TOP, PURE, W16>(cams, a, cam_bits, it, s_up, ur.x0, ur.y0, region_pitch(ur), c1);
 }
 
 // W16 (weight_type CV_16S) is a separate instantiation: its integer divides would otherwise set the register
@@ -2140,6 +2150,34 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
         }
     }
     MST_STAMP(1, 3);
+    if (a.split) {
+        // the tile's interior of the collapsed level 2 -> global memory; k_blend_mid forms level 1 from it
+        const Region r2 = table_region(s_reg, 2);
+        const int pitch2 = region_pitch(r2), cw2 = a.cw[2];
+        const int ix0 = tx * (CC_TW / 2), iy0 = ty * (TH / 2);
+        const int iw = min(CC_TW / 2, cw2 - ix0), ih = min(TH / 2, a.ch[2] - iy0);      // (iw is even: canvas levels below the top are)
+        const uint2* s2 = lds + a.lds_off[2];
+        GPix MST_GLOBAL* c2 = (GPix MST_GLOBAL*)a.c2[set];
+        const int pairs = iw >> 1;
+        for (int i = threadIdx.x; i < pairs * ih; i += CC_THREADS) {
+            const int y = i / pairs, xp = i - y * pairs;
+            const int gx = ix0 + 2 * xp, gy = iy0 + y;
+            const uint4 v = *reinterpret_cast<const uint4*>(s2 + (gy - r2.y0) * pitch2 + (gx - r2.x0));
+            GPix MST_GLOBAL* o = c2 + __mul24(gy, cw2) + gx;
+            if ((cw2 & 1) == 0) {
+                *reinterpret_cast<u32x4_t MST_GLOBAL*>(o) = u32x4_t{v.x, v.y, v.z, v.w};
+            } else {
+                o[0] = GPix{v.x, v.y}; o[1] = GPix{v.z, v.w};
+            }
+        }
+        if (iw & 1)
+            for (int y = threadIdx.x; y < ih; y += CC_THREADS) {
+                const uint2 v = s2[(iy0 + y - r2.y0) * pitch2 + (ix0 + iw - 1 - r2.x0)];
+                c2[__mul24(iy0 + y, cw2) + ix0 + iw - 1] = GPix{v.x, v.y};
+            }
+        MST_STAMP(1, 4);
+        return;
+    }
     // phase 3: level 1, owned outright on every pure tile and on most tiles near -- but not on -- a seam
     const bool own1 = pure || (owned_levels & 2u);
     const uint32_t bits1 = pure ? cam_bits : owner_bits;
@@ -2157,6 +2195,44 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
         else coarse_base_level<CC_THREADS, false, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
     }
     MST_STAMP(1, 4);
+}
+
+// Canvas kernel between the two (round 4, pyramids of three and more levels): level 1, one block per CC_TW x TH tile of
+// level 1 -- the same tiles, flags and launch order as k_blend_coarse, which now stops at level 2.  Level-1 band +
+// pyrUp of the collapsed level-2 canvas (global memory) -> the collapsed level-1 canvas.  No LDS, no barrier: the
+// level-1 pass was 58 of k_blend_coarse's 85 us per 8 frame sets, at 3.6 ps per pixel behind two barrier-separated LDS
+// phases in 256-thread blocks; in k_blend_fine's shape it runs at that kernel's rate.
+#ifndef MST_CM_XCD_GROUP
+#define MST_CM_XCD_GROUP 8
+#endif
+constexpr int CM_XCD_GROUP = MST_CM_XCD_GROUP;
+template <bool W16, int NT, int TH>
+__global__ __launch_bounds__(NT, MST_C_WAVES) void k_blend_mid(const CamDesc* __restrict__ cams_all, BlendArgs a)
+{
+    int q, set;
+    if (!tile_of_block<CM_XCD_GROUP>(a.n_coarse_tiles, a.n_sets, q, set)) return;
+    const CamDesc* __restrict__ cams = cams_all + set * a.n_cams;
+    const uint32_t tile = a.coarse_order[q];
+    const int tx = tile % a.coarse_tiles_x, ty = tile / a.coarse_tiles_x;
+    const uint32_t entry = a.coarse_cams[tile];
+    const bool pure = (entry >> 31) != 0;
+    const uint32_t cam_bits = entry & 0x7FFFFFFFu;
+    const uint32_t own = (MST_ABLATE_C & 512) ? 0u : a.coarse_pure[tile];
+    const uint32_t owned_levels = own & 0xFFFFu, owner_bits = 1u << (own >> 16);
+    const bool own1 = pure || (owned_levels & 2u);
+    const uint32_t bits1 = pure ? cam_bits : owner_bits;
+    const Region r1 = blend_region(a, 1, tx, ty, 1);
+    const C1Ptr c2 = (C1Ptr)a.c2[set];
+    const bool full = r1.x1 - r1.x0 == CC_TW && r1.y1 - r1.y0 == TH && (a.cw[1] & 1) == 0;
+    if (own1 && full && !(MST_ABLATE_C & 64)) {
+        owned_strip<1, 1, false, NT, TH>(cams, a, r1, bits1, c2, 0, 0, a.cw[2], nullptr, nullptr, a.c1[set]);
+        return;
+    }
+    QuadIter it(r1);
+    it.inv = static_cast<uint32_t>(((1 << 20) + it.qw - 1) / max(it.qw, 1));
+    uint2* c1 = reinterpret_cast<uint2*>(a.c1[set]);
+    if (own1) base_level_from<NT, false, true, false>(cams, a, bits1, it, c2, 0, 0, a.cw[2], c1);
+    else base_level_from<NT, false, false, W16>(cams, a, cam_bits, it, c2, 0, 0, a.cw[2], c1);
 }
 
 // Canvas kernel 2 of 2: level 0, one block per C_TW x C_TH tile of the panorama: level-0 band + pyrUp of the
@@ -2338,11 +2414,23 @@ void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, 
     a.n_coarse_tiles = num_coarse;
     a.n_sets = batch;
     if (a.nlev > 1 && (which & 1)) {
-        const int grid = canvas_grid<CC_XCD_GROUP>(num_coarse, batch);
-#define MST_LAUNCH_COARSE(W, TH) hipLaunchKernelGGL((k_blend_coarse<W, TH>), dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, a)
-        if (a.cc_th == 16) { if (a.weights_16s) MST_LAUNCH_COARSE(true, 16); else MST_LAUNCH_COARSE(false, 16); }
-        else { if (a.weights_16s) MST_LAUNCH_COARSE(true, 32); else MST_LAUNCH_COARSE(false, 32); }
+        a.split = (a.nlev >= 3 && a.c2[0] != nullptr) ? 1 : 0;
+        {
+            BlendArgs ac = a;
+            if (a.split && a.coarse_order2) { ac.coarse_order = a.coarse_order2; ac.n_coarse_tiles = a.n_coarse2; }
+            const int grid = canvas_grid<CC_XCD_GROUP>(ac.n_coarse_tiles, batch);
+#define MST_LAUNCH_COARSE(W, TH) hipLaunchKernelGGL((k_blend_coarse<W, TH>), dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, ac)
+            if (a.cc_th == 16) { if (a.weights_16s) MST_LAUNCH_COARSE(true, 16); else MST_LAUNCH_COARSE(false, 16); }
+            else { if (a.weights_16s) MST_LAUNCH_COARSE(true, 32); else MST_LAUNCH_COARSE(false, 32); }
 #undef MST_LAUNCH_COARSE
+        }
+        if (a.split) {
+            const int grid = canvas_grid<CM_XCD_GROUP>(num_coarse, batch);
+#define MST_LAUNCH_MID(W, NT, TH) hipLaunchKernelGGL((k_blend_mid<W, NT, TH>), dim3(grid), dim3(NT), 0, s, d_cams, a)
+            if (a.cc_th == 16) { if (a.weights_16s) MST_LAUNCH_MID(true, 256, 16); else MST_LAUNCH_MID(false, 256, 16); }
+            else { if (a.weights_16s) MST_LAUNCH_MID(true, 128, 32); else MST_LAUNCH_MID(false, 128, 32); }
+#undef MST_LAUNCH_MID
+        }
     }
     if (!(which & 2)) return;
     const int grid = canvas_grid<C_XCD_GROUP>(num_blocks, batch);

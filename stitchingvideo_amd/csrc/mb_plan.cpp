@@ -562,12 +562,15 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
             return (l1_owned ? 6 : 10) + 2 * __builtin_popcount(e);
         });
         if (striped) {        // only the level-1 tiles the strip's panorama tiles read
-            std::vector<uint32_t> kept;
+            std::vector<uint32_t> kept, kept2;
             for (uint32_t tile : ct.order) {
                 const int x = static_cast<int>(tile % ct.tiles_x) * cc_tw;
                 if (x < sx1[1] && x + cc_tw > sx0[1]) kept.push_back(tile);
+                // (level-2 interior of the tile: columns [x / 2, (x + cc_tw) / 2); the strip's level-1 tiles read level 2 over sx0[2] .. sx1[2])
+                if (nlev >= 3 && x / 2 < sx1[2] && (x + cc_tw) / 2 > sx0[2]) kept2.push_back(tile);
             }
             ct.order.swap(kept);
+            ct.order2.swap(kept2);
         }
         int off = 0;
         for (int l = 2; l < nlev; ++l) {

@@ -50,6 +50,9 @@ struct MbPlanHost {
     struct CoarseTiles {
         int th = 0, tiles_x = 0, tiles_y = 0;
         std::vector<uint32_t> cams, pure, order;
+        // strip engines with three and more levels: k_blend_coarse's own launch list -- `order` plus the tiles whose
+        // level-2 interiors the tiles of `order` read as pyrUp halo (k_blend_mid); empty: the same list
+        std::vector<uint32_t> order2;
         int lds_off[kMaxLevels] = {};
         size_t lds_bytes = 0;
     };
