@@ -123,6 +123,16 @@ def cpu_baseline(rig, frames, blend, budget_s=15.0, max_frames=0, threads=0):
     """Time the oracle on the host cores: all cores (capped at 32: its row-parallel loops stop scaling there) and ONE
     thread.  Test infrastructure used as the reported CPU baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    # BASELINE.md section 2: -O3 -march=native (contraction off), compiled on this host by oracle/Makefile's `native` target;
+    # the portable -O2 build the tests use is the fallback when no compiler is at hand
+    os.environ["MST_ORACLE_NATIVE"] = "1"
+    build = "-O3 -march=native -fopenmp -ffp-contract=off, built on this host"
+    try:
+        import oracle_lib
+        oracle_lib.lib()
+    except Exception:
+        os.environ["MST_ORACLE_NATIVE"] = "0"
+        build = "-O2 -fopenmp -ffp-contract=off (portable build; the native target failed to compile here)"
     import helpers as H
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = threads if threads > 0 else min(cores, 32)
@@ -145,7 +155,7 @@ def cpu_baseline(rig, frames, blend, budget_s=15.0, max_frames=0, threads=0):
 
     allc = sample(cores, budget_s, 5, 30)
     one = sample(1, budget_s, 3, 5) if cores > 1 else allc
-    return {"value": allc["mean_fps"], "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": allc["mean_fps"], "unit": "frames/s", "cores": cores, "kind": "port", "build": build,
             "median": allc["median_fps"], "p10": allc["p10_fps"], "p90": allc["p90_fps"],
             "threads_1": {"value": one["median_fps"], "p10": one["p10_fps"], "p90": one["p90_fps"], "frames": one["frames"]},
             "sample": "%d frames of the same workload at %d threads and %d at 1 thread, oracle/ (C, OpenMP over cameras and rows); "
@@ -306,6 +316,8 @@ def main():
         seqs = args.steps * reps
         ms_per_step = wall * 1000.0 / args.steps
         dev_ms_per_seq = dev_ms / seqs
+        # (`traffic` is never measured by this run: it is read from profiles/traffic.json -- the rocprofv3 PMC passes of
+        # tools/profile_gpu.sh -- and only while that file was produced from the kernel sources being run)
         traffic, traffic_note, tj = None, "profiles/traffic.json absent", {}
         wl = args.config + (("+lens-composed" if args.lens_composed else "+undistort") if args.undistort else "")
         try:
@@ -313,7 +325,8 @@ def main():
             if tj.get("kernel_source_sha16") == kernel_source_hash():
                 ent = tj["entries"]["%s/%d" % (wl, batch)]
                 traffic = ent["bytes_per_frame"] * batch
-                traffic_note = ent.get("source", "")
+                traffic_note = "from profiles/traffic.json, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (%s), same kernel sources (sha %s)" % (
+                    ent.get("source", ""), tj.get("kernel_source_sha16"))
             else:
                 traffic_note = "profiles/traffic.json predates the current kernel sources (re-run tools/profile_gpu.sh)"
                 tj = {}
@@ -472,35 +485,71 @@ def main():
         except Exception as e:          # noqa: BLE001
             out["host_buffers"]["nv12_error"] = "%s: %s" % (type(e).__name__, e)
 
-    watchdog = None
-    # ---- N > 1: the north-star split measured beside the headline (C4: 8 cameras, camera i on rank i % N) ----
-    if (world > 1 or args.camera_leg) and not by_camera and not args.no_camera_leg:
-        # Every rank: a hung exchange must not take the headline (or the launcher) with it.  The watchdog stays armed
-        # until the process group has been torn down: when the leg fails on one rank only, its peers sit in the
-        # exchange and this rank would otherwise wait for them in the final barrier.  A run that ends through the
-        # watchdog has still printed the headline, and exits non-zero.
+    # ---- N > 1 legs: each under its own watchdog.  Every rank: a hung exchange must not take the headline (or the launcher)
+    # with it.  A timer is armed per leg and says which leg it caught; none is running while the collective-free work
+    # below (configs, CPU baseline) executes; the last one covers the final barrier and the teardown of the process group
+    # (when a leg fails on one rank only, its peers sit in the exchange and this rank would otherwise wait for them
+    # there).  A run that ends through a watchdog has still printed the headline, and exits non-zero.
+    watchdog = [None]
+
+    def arm(leg, seconds=240.0):
+        if watchdog[0] is not None:
+            watchdog[0].cancel()
+            watchdog[0] = None
+        if leg is None:
+            return
+
         def give_up():
             if rank == 0 and not printed:
-                out["camera_sharded"] = {"error": "timed out after 240 s (exchange or final barrier did not complete)"}
+                out.setdefault(leg, {})
+                if isinstance(out[leg], dict):
+                    out[leg]["error"] = "timed out after %d s in this leg" % int(seconds)
+                else:
+                    out[leg] = {"error": "timed out after %d s in this leg" % int(seconds)}
                 print(json.dumps(out), flush=True)
             os._exit(3)
-        watchdog = threading.Timer(240.0 if rank == 0 else 250.0, give_up)
-        watchdog.daemon = True
-        watchdog.start()
+        watchdog[0] = threading.Timer(seconds if rank == 0 else seconds + 10.0, give_up)
+        watchdog[0].daemon = True
+        watchdog[0].start()
+
+    # ---- N > 1: which ranks and devices RCCL actually spans (the driver's "did it see N ranks" check reads this) ----
+    if world > 1:
+        arm("ranks_seen", 120.0)
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = {"rank": rank, "local_rank": local_rank, "device": props.name,
+                 "uuid": str(getattr(props, "uuid", "")), "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))}
+        seen = [None] * world
+        try:
+            dist.all_gather_object(seen, ident)
+        except Exception as e:          # noqa: BLE001
+            seen = [{"error": "%s: %s" % (type(e).__name__, e)}]
+        if rank == 0:
+            out["ranks_seen"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": seen,
+                                 "distinct_devices": len({(r or {}).get("uuid") or (r or {}).get("pci") for r in seen if isinstance(r, dict)})}
+    # ---- N > 1: the north-star split measured beside the headline (C4: 8 cameras, camera i on rank i % N) ----
+    if (world > 1 or args.camera_leg) and not by_camera and not args.no_camera_leg:
+        arm("camera_sharded")
         try:
             leg = camera_sharded_leg(args, rank, world, local_rank, dev, stream)
         except Exception as e:          # noqa: BLE001  -- the headline must survive a failure of the secondary leg
             leg = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
             out["camera_sharded"] = leg
-    # ---- N > 1: the canvas cut into N column strips, rank r composes strip r, strips concatenated on rank 0 ----
+    # ---- N > 1: the canvas cut into N column strips, rank r composes strip r, strips concatenated on rank 0: the headline
+    # workload (C3) and the north star's 8-camera rig (C4) ----
     if (world > 1 or args.strip_leg) and not by_camera and not args.no_camera_leg:
-        try:
-            leg = strip_sharded_leg(args, rank, world, local_rank, dev, stream)
-        except Exception as e:          # noqa: BLE001
-            leg = {"error": "%s: %s" % (type(e).__name__, e)}
-        if rank == 0:
-            out["strip_sharded"] = leg
+        for cname in ("C3", "C4"):
+            arm("strip_sharded")
+            try:
+                leg = strip_sharded_leg(args, rank, world, local_rank, dev, stream, cname)
+            except Exception as e:          # noqa: BLE001
+                leg = {"error": "%s: %s" % (type(e).__name__, e)}
+            if rank == 0:
+                if cname == "C3":
+                    out["strip_sharded"] = leg
+                else:
+                    out.setdefault("strip_sharded", {})[cname] = leg
+    arm(None)       # nothing below talks to another rank until the final barrier
 
     # ---- the other single-GPU BASELINE configurations, through the same entry points (tools/bench_paths.py) ----
     if rank == 0 and world == 1 and not by_camera and not args.no_configs and args.config == "C3":
@@ -527,10 +576,10 @@ def main():
 
     eng.close()
     if world > 1:
+        arm("final_barrier", 120.0)
         dist.barrier()
         dist.destroy_process_group()
-    if watchdog is not None:
-        watchdog.cancel()
+    arm(None)
 
 
 def host_buffer_leg(eng, host_sets, cw, ch, serial=True):
@@ -635,8 +684,8 @@ def camera_sharded_leg(args_ns, rank, world, local_rank, dev, stream):
             "roofline_frac": round(alg * n / wall / 1e9 / HBM_PEAK_GBS, 5)}
 
 
-def strip_sharded_leg(args_ns, rank, world, local_rank, dev, stream):
-    """The canvas split over the GPUs (second form) on the headline workload C3: rank r's engine composes
+def strip_sharded_leg(args_ns, rank, world, local_rank, dev, stream, config="C3"):
+    """The canvas split over the GPUs (second form) on the headline workload C3 (and on C4): rank r's engine composes
     column strip r of `world` (mst_config.strip_index / strip_count: every kernel restricted to what the strip depends on,
     pixels identical to the whole-canvas run), 8 frame sets per launch sequence, and the strips of every panorama are
     concatenated on rank 0 by one grouped point-to-point step per launch sequence.  Every rank holds the frames of all
@@ -646,7 +695,7 @@ def strip_sharded_leg(args_ns, rank, world, local_rank, dev, stream):
     import stitchingvideo_amd as S
     from stitchingvideo_amd import rig as rigmod
     from stitchingvideo_amd import sharding
-    cfg = rigmod.CONFIGS["C3"]
+    cfg = rigmod.CONFIGS[config]
     rig = rigmod.build_rig(cfg)
     n_cam = len(rig["cameras"])
     batch = 8
@@ -694,13 +743,15 @@ def strip_sharded_leg(args_ns, rank, world, local_rank, dev, stream):
         torch.cuda.synchronize()
         return sharding.max_over_ranks([time.perf_counter() - t0], device=dev)[0]
 
+    # (timed over at least half a second: a region of a few dozen milliseconds reads several per cent low)
     n = max(10, args_ns.camera_leg_steps)
+    n = max(n, int(0.5 / max(timed(10, False) / 10, 1e-6)))
     t_compose = timed(n, False)
     t_total = timed(n, True)
     eng.close()
     alg = rigmod.algorithmic_bytes(rig, (cw, ch))
-    return {"workload": "C3: %dx%dx%d BGR8 streams, spherical warp, gain_blocks, multiband blend (5 bands), canvas %dx%d"
-                        % (n_cam, rig["size"][0], rig["size"][1], cw, ch),
+    return {"workload": "%s: %dx%dx%d BGR8 streams, spherical warp, gain_blocks, multiband blend (5 bands), canvas %dx%d"
+                        % (config, n_cam, rig["size"][0], rig["size"][1], cw, ch),
             "parallelism": "canvas cut into %d column strips, rank r composes strip r (restricted work lists), %d frame sets per launch, "
                            "strips concatenated on rank 0 (one grouped point-to-point step per launch sequence)" % (world, batch),
             "scaling": "strong", "strip_columns": rects,

@@ -204,8 +204,9 @@ typedef struct mst_rect { int32_t x, y, width, height; } mst_rect;
  * runs on the same inputs; a restart without re-registration).  The reference has no such thing.
  * mst_calibration_blob_size: bytes needed, 0 for an invalid calibration.  mst_calibration_save: `written` = bytes used.
  * mst_calibration_load: fills `out` and `cameras` (room for max_cameras); their array pointers point INTO the blob, which
- * must stay alive and unchanged while the calibration is in use (mst_update copies what it needs).  Masks come back
- * tightly packed.  A blob that is truncated, altered or of another version is MST_ERR_INVALID_ARG. */
+ * must stay alive and unchanged while the calibration is in use (mst_update copies what it needs) and must START ON AN
+ * 8-BYTE BOUNDARY (malloc, mmap at a page offset and numpy buffers do; a slice at an odd offset is MST_ERR_INVALID_ARG).
+ * Masks come back tightly packed.  A camera with exactly one of undistort_map1 / undistort_map2 cannot be saved (size 0).  A blob that is truncated, altered or of another version is MST_ERR_INVALID_ARG. */
 size_t mst_calibration_blob_size(const mst_calibration *calib);
 int    mst_calibration_save(const mst_calibration *calib, void *blob, size_t capacity, size_t *written);
 int    mst_calibration_load(const void *blob, size_t bytes, mst_calibration *out, mst_camera *cameras, int max_cameras);

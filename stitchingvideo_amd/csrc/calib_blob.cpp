@@ -77,6 +77,7 @@ size_t mst_calibration_blob_size(const mst_calibration* calib)
         if (c.src_width <= 0 || c.src_height <= 0) return 0;
         if (c.mask && c.mask_stride < static_cast<size_t>(c.mask_width)) return 0;
         if (c.seam_mask && c.seam_mask_stride < static_cast<size_t>(c.seam_mask_width)) return 0;
+        if ((c.undistort_map1 == nullptr) != (c.undistort_map2 == nullptr)) return 0;      // a lone lens map: mst_update rejects it too
         const Sizes s = sizes_of(c);
         total += align8(s.gain) + align8(s.mask) + align8(s.map1) + align8(s.map2) + align8(s.seam);
     }
@@ -128,6 +129,9 @@ int mst_calibration_save(const mst_calibration* calib, void* blob, size_t capaci
 int mst_calibration_load(const void* blob, size_t bytes, mst_calibration* out, mst_camera* cameras, int max_cameras)
 {
     if (!blob || !out || !cameras || bytes < sizeof(BlobHeader)) return MST_ERR_INVALID_ARG;
+    // the records and arrays are handed out as typed pointers INTO the blob (offsets are multiples of 8): the blob itself
+    // must start on an 8-byte boundary (a slice of a larger buffer at an odd offset is refused, not cast)
+    if (reinterpret_cast<uintptr_t>(blob) % 8 != 0) return MST_ERR_INVALID_ARG;
     const uint8_t* base = static_cast<const uint8_t*>(blob);
     BlobHeader h;
     std::memcpy(&h, base, sizeof(h));

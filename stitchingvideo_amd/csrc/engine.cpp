@@ -262,6 +262,14 @@ Engine::Engine(const mst_config& cfg) : cfg_(cfg)
 void Engine::init()
 {
     select_device(cfg_.device);
+    // LDS a block may ask for: the staged samplers size their windows against it (MI355X: 160 KB).  The composites' 40 KB
+    // budget is a compile-time constant of their tables, so a part below it is refused here -- loudly -- instead of
+    // failing at the first launch; the warp kernel's window classes are clipped to it per calibration.
+    int lds = 0;
+    check_hip(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg_.device), "hipDeviceGetAttribute(LDS)");
+    max_lds_bytes_ = static_cast<size_t>(std::max(lds, 0));
+    if (max_lds_bytes_ < static_cast<size_t>(kCompLdsPx) * 4)
+        throw Error{MST_ERR_NO_DEVICE, "this device offers less LDS per block than the staged kernels need (40 KB; written for gfx950)"};
     check_hip(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     check_hip(hipStreamCreateWithFlags(&calib_stream_, hipStreamNonBlocking), "hipStreamCreate");
     check_hip(hipStreamCreateWithFlags(&front_stream_, hipStreamNonBlocking), "hipStreamCreate");
@@ -719,12 +727,17 @@ void Engine::update(const mst_calibration& calib)
             // the blocks per CU follow from it); tiles past the last class stay with the gathering kernel.  C3: 2085 tiles up
             // to 40 KB, 443 (bounding boxes of slanted tiles near the frame corners) up to 72 KB.  With one load per staging
             // trip the 72 KB class was no faster than gathering; with the loads in batches it is: 28.7-29.3 -> 27.5 us.
-            static const std::vector<int> classes_kb = [] {
+            static const std::vector<int> classes_all_kb = [] {
                 std::vector<int> v;
                 const char* e = std::getenv("MST_WARP_LDS_CLASSES");
                 for (const char* p = e ? e : "40,72"; *p;) { v.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
                 return v;
             }();
+            // (classes the device cannot grant are dropped: their tiles stay with the gathering kernel)
+            std::vector<int> classes_kb;
+            for (int kb : classes_all_kb)
+                if (static_cast<size_t>(kb) * 1024 <= max_lds_bytes_) classes_kb.push_back(kb);
+            if (classes_kb.empty()) classes_kb.push_back(static_cast<int>(max_lds_bytes_ / 1024));
             const int budget_px = classes_kb.back() * 256;
             launch_warp_table_lds(st->d_desc, map_kind(), st->warp_list, st->warp_table_lds, st->warp_gain_lds, st->warp_wins,
                                   budget_px, s);
@@ -875,8 +888,10 @@ void Engine::launch_undistort(const CalibState& st, const FrameBatch& src, const
 // The warp kernel (A) over the tiles of cameras [cam0, cam1): the staged form for the tiles that fit it, the gathering
 // kernel for the rest -- and for everything when a frame of the call is off the 4-byte grid (the staged form reads whole
 // dwords) or MST_WARP_GATHER is set (A/B timing).
-void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameBatch& fb, int count, int cam0, int cam1, hipStream_t s)
+void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameBatch& fb, int count, int cam0, int cam1, hipStream_t s,
+                         StageTimer* timer)
 {
+    auto mark = [&](const char* name) { if (timer && name) timer->mark(name, s); };
     static const bool force_gather = [] { const char* v = std::getenv("MST_WARP_GATHER"); return v && v[0] == '1'; }();
     // (one or two frame sets per launch: the gathering kernel's smaller blocks fill the chip better -- 9.5 k against 8.8 k
     // panoramas/s one at a time on C3; from three sets on the staged form wins)
@@ -890,7 +905,7 @@ void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameB
         tl.tiles = st.warp_list.tiles + plan.warp_cam_start[cam0];
         tl.count = plan.warp_cam_start[cam1] - plan.warp_cam_start[cam0];
         tl.first = plan.warp_cam_start[cam0];
-        launch_warp_pyr(desc, st.n, map_kind(), tl, fb, count, st.warp_table, st.warp_blobs, s);
+        mark(launch_warp_pyr(desc, st.n, map_kind(), tl, fb, count, st.warp_table, st.warp_blobs, s));
         return;
     }
     TileList tg{};
@@ -898,11 +913,11 @@ void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameB
     tg.first = 0;
     tg.index = st.d_warp_gathered + st.warp_gathered_start[cam0];
     tg.count = st.warp_gathered_start[cam1] - st.warp_gathered_start[cam0];
-    launch_warp_pyr(desc, st.n, map_kind(), tg, fb, count, st.warp_table, st.warp_blobs, s);     // (the short list first)
+    mark(launch_warp_pyr(desc, st.n, map_kind(), tg, fb, count, st.warp_table, st.warp_blobs, s));     // (the short list first)
     for (int c = static_cast<int>(st.warp_classes.size()) - 1; c >= 0; --c) {       // (the large-window classes first: fewer, longer blocks)
         const CalibState::WarpClass& wc = st.warp_classes[c];
-        launch_warp_pyr_lds(desc, st.n, wc.start[cam1] - wc.start[cam0], fb, count, st.warp_table_lds, st.warp_gain_lds,
-                            wc.d_wins + wc.start[cam0], wc.lds_bytes, s);
+        mark(launch_warp_pyr_lds(desc, st.n, wc.start[cam1] - wc.start[cam0], fb, count, st.warp_table_lds, st.warp_gain_lds,
+                                 wc.d_wins + wc.start[cam0], wc.lds_bytes, s));
     }
 }
 
@@ -1087,6 +1102,24 @@ void Engine::drop_graphs()
     for (GraphEntry& g : graphs_)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     graphs_.clear();
+    for (RetiredGraph& r : retired_graphs_) {
+        if (r.done) { (void)hipEventSynchronize(r.done); (void)hipEventDestroy(r.done); }
+        if (r.exec) (void)hipGraphExecDestroy(r.exec);
+    }
+    retired_graphs_.clear();
+}
+
+// destroy the parked execs whose last launch has completed
+void Engine::reap_graphs()
+{
+    for (size_t i = 0; i < retired_graphs_.size();) {
+        RetiredGraph& r = retired_graphs_[i];
+        if (r.done && hipEventQuery(r.done) != hipSuccess) { ++i; continue; }
+        if (r.done) (void)hipEventDestroy(r.done);
+        else (void)hipDeviceSynchronize();           // (no event could be made: the slow, safe way)
+        (void)hipGraphExecDestroy(r.exec);
+        retired_graphs_.erase(retired_graphs_.begin() + i);
+    }
 }
 
 void Engine::compose_batch(int count, const void* const* d_frames, const size_t* strides, void* const* d_panos,
@@ -1112,17 +1145,38 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
         key.push_back(reinterpret_cast<uint64_t>(d_panos[f]));
         key.push_back(d_masks ? reinterpret_cast<uint64_t>(d_masks[f]) : 0);
     }
-    for (GraphEntry& g : graphs_)
-        if (g.key == key) {
-            check_hip(hipGraphLaunch(g.exec, s), "hipGraphLaunch");
+    reap_graphs();
+    for (size_t i = 0; i < graphs_.size(); ++i)
+        if (graphs_[i].key == key) {
+            check_hip(hipGraphLaunch(graphs_[i].exec, s), "hipGraphLaunch");
+            if (i + 1 != graphs_.size()) std::rotate(graphs_.begin() + i, graphs_.begin() + i + 1, graphs_.end());   // LRU: a hit moves to the back
             set_in_flight(std::move(st));
             return;
         }
+    ++graph_misses_;
+    // An exec that leaves the cache may still be queued or running (its last launch was enqueued microseconds ago):
+    // it is parked behind an event recorded on the launch stream and destroyed once that event has completed.
+    auto retire = [&](size_t i) {
+        RetiredGraph r;
+        r.exec = graphs_[i].exec;
+        if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(r.done, s);
+        else r.done = nullptr;
+        retired_graphs_.push_back(r);
+        graphs_.erase(graphs_.begin() + i);
+    };
     // sequences of older calibrations can never be asked for again
     for (size_t i = 0; i < graphs_.size();)
-        if (graphs_[i].key[0] != st->generation) { (void)hipGraphExecDestroy(graphs_[i].exec); graphs_.erase(graphs_.begin() + i); }
+        if (graphs_[i].key[0] != st->generation) retire(i);
         else ++i;
-    if (graphs_.size() >= 32) { (void)hipGraphExecDestroy(graphs_.front().exec); graphs_.erase(graphs_.begin()); }
+    if (graphs_.size() >= kGraphCacheEntries) {
+        // (a ring of more buffer sets than the cache holds re-captures on every call: say so once)
+        if (!graph_thrash_warned_ && graph_misses_ > 4 * kGraphCacheEntries) {
+            graph_thrash_warned_ = true;
+            std::fprintf(stderr, "[mi355-stitch] MST_FLAG_GRAPH_REPLAY: %llu captures so far -- more than %zu distinct buffer sets per calibration defeat the graph cache\n",
+                         static_cast<unsigned long long>(graph_misses_), kGraphCacheEntries);
+        }
+        retire(0);                   // least recently used
+    }
     hipGraph_t graph = nullptr;
     check_hip(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
     try {
@@ -1180,7 +1234,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
     for (int f = 0; f < count; ++f)
         if (!d_panos[f]) throw Error{MST_ERR_INVALID_ARG, "null panorama pointer"};
 
-    auto mark = [&](const char* name) { if (timer) timer->mark(name, s); };
+    auto mark = [&](const char* name) { if (timer && name) timer->mark(name, s); };      // (nullptr: the launcher had nothing to launch)
     if (timer) timer->begin(s);
     // lens-undistort pre-pass: remap the caller's frames into the engine's buffers of frame sets first_set.. and
     // point the frame table at them (cameras without maps keep the caller's frames)
@@ -1227,8 +1281,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
                     canvas_pending_[k] = false;
                 }
         undistort(first_set, sf);
-        launch_warp(*st, desc, fb, count, 0, st->n, sf);
-        mark("k_warp_pyr");
+        launch_warp(*st, desc, fb, count, 0, st->n, sf, timer);
         // where the frame crosses from the front stream to the caller's stream: after the warp kernel (the small
         // pyramid-chain launches then fill in beside the next frame's warp) or after the chain
         static const bool split_after_warp = [] { const char* v = std::getenv("MST_OVERLAP_SPLIT"); return v && v[0] == '1'; }();
@@ -1242,11 +1295,10 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
             const MbPlanHost::ChainStep& step = st->plan.chain[i];
             if (st->chain_units[i].d[0]) {
                 for (int j = 0; j < step.k; ++j)
-                    launch_pyrdown_stream(desc, st->n, st->chain_units[i].d[j], static_cast<int>(step.units[j].size()), step.base + j, count, sc);
+                    mark(launch_pyrdown_stream(desc, st->n, st->chain_units[i].d[j], static_cast<int>(step.units[j].size()), step.base + j, count, sc));
             } else {
-                launch_pyr_chain(desc, st->n, st->chain_lists[i], step.base, step.k, count, sc);
+                mark(launch_pyr_chain(desc, st->n, st->chain_lists[i], step.base, step.k, count, sc));
             }
-            mark("k_pyr_chain");
         }
         if (overlap && !split_after_warp) cross();
         int n_coarse = 0;
@@ -1264,11 +1316,10 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
             for (int f = 0; f < count; ++f) ba.c2[f] = st->c2[first_set + f];
         const int n_fine = static_cast<int>(st->plan.block_order.size());
         if (ba.nlev > 1) {
-            launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 1);
-            mark("k_blend_coarse");
+            mark(launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 1));
+            if (ba.c2[0]) mark(launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 4));
         }
-        launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 2);
-        mark("k_blend_fine");
+        mark(launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 2));
         if (overlap) {
             check_hip(hipEventRecord(ev_canvas_done_[slot], s), "hipEventRecord");
             canvas_pending_[slot] = true;
@@ -1290,28 +1341,24 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         if (st->compose_general) {
             ca.tiles = st->d_compose_general;
             ca.n_tiles = st->compose_general;
-            launch_compose(ca, fb, 0, true, s);
-            mark("k_compose_general");
+            mark(launch_compose(ca, fb, 0, true, s));
         }
         if (st->compose_direct) {
             ca.tiles = st->d_compose_direct;
             ca.n_tiles = st->compose_direct;
-            launch_compose(ca, fb, 0, false, s);
-            mark("k_compose");
+            mark(launch_compose(ca, fb, 0, false, s));
         }
         if (st->compose_staged && aligned) {
             ca.tiles = st->d_compose_staged;
             ca.n_tiles = st->compose_staged;
-            launch_compose(ca, fb, st->compose_lds_bytes, false, s);
-            mark("k_compose_lds");
+            mark(launch_compose(ca, fb, st->compose_lds_bytes, false, s));
         } else if (st->compose_staged) {
             ca.tiles = st->d_compose_staged;
             ca.n_tiles = st->compose_staged_gatherable;
-            launch_compose(ca, fb, 0, false, s);
+            mark(launch_compose(ca, fb, 0, false, s));
             ca.tiles = st->d_compose_staged + st->compose_staged_gatherable;
             ca.n_tiles = st->compose_staged - st->compose_staged_gatherable;
-            launch_compose(ca, fb, 0, true, s);
-            mark("k_compose");
+            mark(launch_compose(ca, fb, 0, true, s));
         }
     }
     check_hip(hipGetLastError(), "compose kernels");
@@ -1521,8 +1568,14 @@ void Engine::compose_host(const uint8_t* const* frames, const size_t* strides, u
         throw;
     }
     in_host_compose_ = false;
-    copy_rows(pano, pano_stride, d_pano_, prow, prow, st->out_h, hipMemcpyDeviceToHost, stream_);
-    if (pano_mask) copy_rows(pano_mask, mask_stride, d_mask_, mrow, mrow, st->out_h, hipMemcpyDeviceToHost, stream_);
+    // (a strip engine writes its own columns only: those -- and nothing of the rest of the device buffer, which is
+    // uninitialised -- go back to the caller's canvas-shaped buffer)
+    const size_t x0 = cfg_.strip_count > 1 ? static_cast<size_t>(std::min(st->strip_x0, st->out_w)) : 0;
+    const size_t x1 = cfg_.strip_count > 1 ? static_cast<size_t>(std::min(st->strip_x1, st->out_w)) : static_cast<size_t>(st->out_w);
+    if (x1 > x0) {
+        copy_rows(pano + x0 * 3, pano_stride, d_pano_ + x0 * 3, prow, (x1 - x0) * 3, st->out_h, hipMemcpyDeviceToHost, stream_);
+        if (pano_mask) copy_rows(pano_mask + x0, mask_stride, d_mask_ + x0, mrow, x1 - x0, st->out_h, hipMemcpyDeviceToHost, stream_);
+    }
     check_hip(hipStreamSynchronize(stream_), "hipStreamSynchronize(compose)");
 }
 
@@ -1587,7 +1640,12 @@ void Engine::pipeline_submit(const uint8_t* const* frames, const size_t* strides
     check_hip(hipEventRecord(ps.compute_done, stream_), "hipEventRecord");
     // stage 3 (copy-out stream): the panorama back to the caller's buffer
     check_hip(hipStreamWaitEvent(pipe_out_, ps.compute_done, 0), "hipStreamWaitEvent");
-    copy_rows(pano, pano_stride, ps.d_pano, prow, prow, st->out_h, hipMemcpyDeviceToHost, pipe_out_);
+    {
+        const size_t x0 = cfg_.strip_count > 1 ? static_cast<size_t>(std::min(st->strip_x0, st->out_w)) : 0;
+        const size_t x1 = cfg_.strip_count > 1 ? static_cast<size_t>(std::min(st->strip_x1, st->out_w)) : static_cast<size_t>(st->out_w);
+        if (x1 > x0)     // (a strip engine: its own columns only, see compose_host)
+            copy_rows(pano + x0 * 3, pano_stride, ps.d_pano + x0 * 3, prow, (x1 - x0) * 3, st->out_h, hipMemcpyDeviceToHost, pipe_out_);
+    }
     check_hip(hipEventRecord(ps.d2h_done, pipe_out_), "hipEventRecord");
     ps.host_pano = pano;
     ps.canvas = mst_rect{st->canvas.x + st->crop_x, st->canvas.y + st->crop_y, st->out_w, st->out_h};

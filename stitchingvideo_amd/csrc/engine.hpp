@@ -206,15 +206,23 @@ private:
     // which map_px<KIND> the table kernels and the gathering warp kernel are launched with: the projection's own
     // per-axis form, or "read the map" (3) for the non-separable projectors and for MST_FLAG_LENS_COMPOSED
     int map_kind() const { return (cfg_.flags & MST_FLAG_LENS_COMPOSED) ? 3 : (cfg_.warp_kind & 0xFF); }
-    void launch_warp(const CalibState& st, const CamDesc* desc, const FrameBatch& fb, int count, int cam0, int cam1, hipStream_t s);
+    void launch_warp(const CalibState& st, const CamDesc* desc, const FrameBatch& fb, int count, int cam0, int cam1, hipStream_t s,
+                     StageTimer* timer = nullptr);
     void build_compose_plan(CalibState& st, hipStream_t s);     // mst_update, blend kinds NO and FEATHER
     void set_in_flight(std::shared_ptr<CalibState> st);   // keeps `st` alive; the previous one goes to retired_
     void drop_retired();                                   // calibration thread / destructor: tear old states down
     // MST_FLAG_GRAPH_REPLAY: launch sequences captured per (calibration generation, buffers) and replayed
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; };
-    std::vector<GraphEntry> graphs_;
+    std::vector<GraphEntry> graphs_;                     // least recently used first
+    struct RetiredGraph { hipGraphExec_t exec = nullptr; hipEvent_t done = nullptr; };
+    std::vector<RetiredGraph> retired_graphs_;           // left the cache; destroyed once `done` (recorded on their launch stream) has completed
+    static constexpr size_t kGraphCacheEntries = 32;
+    uint64_t graph_misses_ = 0;
+    bool graph_thrash_warned_ = false;
     void drop_graphs();
+    void reap_graphs();
     mst_config cfg_;
+    size_t max_lds_bytes_ = 0;            // hipDeviceAttributeMaxSharedMemoryPerBlock of cfg_.device
     hipStream_t stream_ = nullptr;        // compose stream
     hipStream_t calib_stream_ = nullptr;  // mst_update builds the next state here
     // Frame pipelining (MST_FLAG_OVERLAP_FRAMES): the per-camera kernels of frame t+1 run on front_stream_

@@ -63,24 +63,28 @@ size_t mb_warp_blob_entries(int num_tiles);                                     
 void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, uint32_t* d_blobs,
                        hipStream_t s);
 // `batch` frame sets per launch: set f uses frames.f[f] and the descriptors d_cams[f * n_cams ...]
-void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
-                     int batch, const uint32_t* d_table, const uint32_t* d_blobs, hipStream_t s);
+// (the per-frame launchers return the name of the kernel they launched -- as rocprofv3 prints it -- or nullptr when the
+// list was empty: what the engine's stage timer reports)
+const char* launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
+                            int batch, const uint32_t* d_table, const uint32_t* d_blobs, hipStream_t s);
 // the staged form of the warp kernel (source window through LDS): per-calibration map + gain tables in its lane order and
 // the tiles' windows (flags bit 0: the tile stays with k_warp_pyr), then the per-frame launch over a tile list
 size_t mb_warp_tile_px();
 void launch_warp_table_lds(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, float* d_gain, WarpWin* d_wins,
                            int lds_budget_px, hipStream_t s);
-void launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, int n_tiles, const FrameBatch& frames, int batch,
-                         const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s);
-void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s);
+const char* launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, int n_tiles, const FrameBatch& frames, int batch,
+                                const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s);
+const char* launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s);
 // the streaming form of one pyrDown level (level -> level + 1): units of mb_stream_unit_cols() output columns x mb_stream_unit_rows() output
 // rows (cam << 24 | uy << 12 | ux), one wave each; source levels of even size only
 int  mb_stream_unit_rows();
 int  mb_stream_unit_cols();
-void launch_pyrdown_stream(const CamDesc* d_cams, int n_cams, const uint32_t* d_units, int n_units, int level, int batch, hipStream_t s);
-// which: bit 0 = k_blend_coarse (levels 1 .. top -> collapsed level-1 canvas), bit 1 = k_blend_fine (level 0 -> panorama)
-void launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
-                  hipStream_t s, int which = 3);
+const char* launch_pyrdown_stream(const CamDesc* d_cams, int n_cams, const uint32_t* d_units, int n_units, int level, int batch, hipStream_t s);
+// which: bit 0 = k_blend_coarse (levels 1 .. top -> collapsed level-1 canvas; with a.c2 set: levels 2 .. top -> collapsed
+// level-2 canvas), bit 2 = k_blend_mid (only with a.c2 set: level 1), bit 1 = k_blend_fine (level 0 -> panorama).  Returns the
+// name of the last kernel launched.
+const char* launch_blend(const CamDesc* d_cams, const BlendArgs& a, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
+                         hipStream_t s, int which = 7);
 
 // ---- per-frame hot path: no-blend / driver LUT / feather composites (kernels_compose.hip) ----
 // calibration: bit i of d_out[canvas tile] = camera i contributes to the tile
@@ -95,6 +99,6 @@ void launch_undistort_table(const UndistortCam& u, int tiles_x, int tiles_y, Com
                             int lds_budget_px, hipStream_t s);
 // per frame: a.n_sets frame sets in one launch (a.pano[f], frames.f[f]) over the tile list a.tiles.  general: the
 // per-pixel path; else lds_bytes != 0: the LDS-staged form (every segment of the list must fit), 0: gathers from memory
-void launch_compose(const ComposeArgs& a, const FrameBatch& frames, size_t lds_bytes, bool general, hipStream_t s);
+const char* launch_compose(const ComposeArgs& a, const FrameBatch& frames, size_t lds_bytes, bool general, hipStream_t s);
 
 }  // namespace mst

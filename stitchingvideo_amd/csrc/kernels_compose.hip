@@ -699,33 +699,35 @@ void launch_undistort_table(const UndistortCam& u, int tiles_x, int tiles_y, Com
     hipLaunchKernelGGL(k_undistort_table, dim3(tiles_x * tiles_y), dim3(256), 0, s, u, tiles_x, d_segs, d_tiles, d_table, lds_budget_px);
 }
 
-void launch_compose(const ComposeArgs& a, const FrameBatch& frames, size_t lds_bytes, bool general, hipStream_t s)
+const char* launch_compose(const ComposeArgs& a, const FrameBatch& frames, size_t lds_bytes, bool general, hipStream_t s)
 {
-    if (a.n_tiles <= 0 || a.n_sets <= 0) return;
+    if (a.n_tiles <= 0 || a.n_sets <= 0) return nullptr;
+    // (kernel names as rocprofv3 prints them: MODE 0 = paste / LUT, 2 = feather)
+    static_assert(kCompModePaste == 0 && kCompModeFeather == 2, "kernel names below");
     if (general) {
         const dim3 gg(static_cast<unsigned>(a.n_tiles * a.n_sets * kGeneralSplit));
-        if (a.mode == kCompModeFeather) hipLaunchKernelGGL(k_compose_general<kCompModeFeather>, gg, dim3(256), 0, s, a, frames);
-        else hipLaunchKernelGGL(k_compose_general<kCompModePaste>, gg, dim3(256), 0, s, a, frames);
-        return;
+        if (a.mode == kCompModeFeather) { hipLaunchKernelGGL(k_compose_general<kCompModeFeather>, gg, dim3(256), 0, s, a, frames); return "k_compose_general<2>"; }
+        hipLaunchKernelGGL(k_compose_general<kCompModePaste>, gg, dim3(256), 0, s, a, frames);
+        return "k_compose_general<0>";
     }
     const dim3 grid(static_cast<unsigned>(a.n_tiles * a.n_sets));
     if (lds_bytes) {       // every tile of the list fits the staged form
         static const int rows_env = [] { const char* v = std::getenv("MST_COMPOSE_ROWS"); return v ? std::atoi(v) : 0; }();
         const int rows = rows_env ? rows_env : 2;     // 512 threads over one window: measured best (C3 / C5 LUT +15 % over 256)
-#define MST_LAUNCH_CL(M, R) hipLaunchKernelGGL((k_compose_lds<M, R>), grid, dim3(1024 / R), lds_bytes, s, a, frames)
-        if (a.mode == kCompModeFeather) { if (rows == 1) MST_LAUNCH_CL(kCompModeFeather, 1); else if (rows == 2) MST_LAUNCH_CL(kCompModeFeather, 2); else MST_LAUNCH_CL(kCompModeFeather, 4); }
-        else { if (rows == 1) MST_LAUNCH_CL(kCompModePaste, 1); else if (rows == 2) MST_LAUNCH_CL(kCompModePaste, 2); else MST_LAUNCH_CL(kCompModePaste, 4); }
+#define MST_LAUNCH_CL(M, MN, R) [&] { hipLaunchKernelGGL((k_compose_lds<M, R>), grid, dim3(1024 / R), lds_bytes, s, a, frames); return "k_compose_lds<" #MN ", " #R ">"; }()
+        if (a.mode == kCompModeFeather) return rows == 1 ? MST_LAUNCH_CL(kCompModeFeather, 2, 1) : rows == 2 ? MST_LAUNCH_CL(kCompModeFeather, 2, 2) : MST_LAUNCH_CL(kCompModeFeather, 2, 4);
+        return rows == 1 ? MST_LAUNCH_CL(kCompModePaste, 0, 1) : rows == 2 ? MST_LAUNCH_CL(kCompModePaste, 0, 2) : MST_LAUNCH_CL(kCompModePaste, 0, 4);
 #undef MST_LAUNCH_CL
-        return;
     }
     if (a.n_tiles * a.n_sets < 4096) {      // a short list: four blocks per tile
         const dim3 g4(grid.x * 4);
-        if (a.mode == kCompModeFeather) hipLaunchKernelGGL((k_compose<kCompModeFeather, 1>), g4, dim3(256), 0, s, a, frames);
-        else hipLaunchKernelGGL((k_compose<kCompModePaste, 1>), g4, dim3(256), 0, s, a, frames);
-        return;
+        if (a.mode == kCompModeFeather) { hipLaunchKernelGGL((k_compose<kCompModeFeather, 1>), g4, dim3(256), 0, s, a, frames); return "k_compose<2, 1>"; }
+        hipLaunchKernelGGL((k_compose<kCompModePaste, 1>), g4, dim3(256), 0, s, a, frames);
+        return "k_compose<0, 1>";
     }
-    if (a.mode == kCompModeFeather) hipLaunchKernelGGL((k_compose<kCompModeFeather, 4>), grid, dim3(256), 0, s, a, frames);
-    else hipLaunchKernelGGL((k_compose<kCompModePaste, 4>), grid, dim3(256), 0, s, a, frames);
+    if (a.mode == kCompModeFeather) { hipLaunchKernelGGL((k_compose<kCompModeFeather, 4>), grid, dim3(256), 0, s, a, frames); return "k_compose<2, 4>"; }
+    hipLaunchKernelGGL((k_compose<kCompModePaste, 4>), grid, dim3(256), 0, s, a, frames);
+    return "k_compose<0, 4>";
 }
 
 }  // namespace mst

@@ -2358,14 +2358,17 @@ void launch_warp_table(const CamDesc* d_cams, int kind, const TileList& list, ui
 #undef MST_LAUNCH_T
 }
 
-void launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
-                     int batch, const uint32_t* d_table, const uint32_t* d_blobs, hipStream_t s)
+const char* launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const TileList& list, const FrameBatch& frames,
+                            int batch, const uint32_t* d_table, const uint32_t* d_blobs, hipStream_t s)
 {
-    if (list.count <= 0 || batch <= 0) return;
+    if (list.count <= 0 || batch <= 0) return nullptr;
     static const size_t pad = tuning_env("MST_A_PAD_LDS");
 #define MST_LAUNCH_A(K) \
-    hipLaunchKernelGGL((k_warp_pyr<K>), dim3(list.count * batch), dim3(256), pad, s, d_cams, list, frames, d_table, d_blobs, n_cams, batch)
-    if (kind == 0) MST_LAUNCH_A(0); else if (kind == 1) MST_LAUNCH_A(1); else if (kind == 2) MST_LAUNCH_A(2); else MST_LAUNCH_A(3);
+    [&] { hipLaunchKernelGGL((k_warp_pyr<K>), dim3(list.count * batch), dim3(256), pad, s, d_cams, list, frames, d_table, d_blobs, n_cams, batch); return "k_warp_pyr<" #K ">"; }()
+    if (kind == 0) return MST_LAUNCH_A(0);
+    if (kind == 1) return MST_LAUNCH_A(1);
+    if (kind == 2) return MST_LAUNCH_A(2);
+    return MST_LAUNCH_A(3);
 #undef MST_LAUNCH_A
 }
 
@@ -2380,64 +2383,68 @@ void launch_warp_table_lds(const CamDesc* d_cams, int kind, const TileList& list
 #undef MST_LAUNCH_T2
 }
 
-void launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, int n_tiles, const FrameBatch& frames, int batch,
-                         const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s)
+const char* launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, int n_tiles, const FrameBatch& frames, int batch,
+                                const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s)
 {
-    if (n_tiles <= 0 || batch <= 0) return;
+    if (n_tiles <= 0 || batch <= 0) return nullptr;
     const size_t lds = std::max(lds_bytes, A2_TILE_LDS);
     hipLaunchKernelGGL(k_warp_pyr_lds, dim3(n_tiles * batch), dim3(A2_NT), lds, s, d_cams, n_tiles, frames, d_table, d_gain, d_wins, n_cams, batch);
+    return "k_warp_pyr_lds";
 }
 
-void launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s)
+const char* launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s)
 {
-    if (list.count <= 0 || k <= 0 || batch <= 0) return;
-    if (k == 1) hipLaunchKernelGGL(k_pyr_chain<1>, dim3(list.count, batch), dim3(B_THREADS), 0, s, d_cams, list, base, n_cams);
-    else hipLaunchKernelGGL(k_pyr_chain<2>, dim3(list.count, batch), dim3(B_THREADS), 0, s, d_cams, list, base, n_cams);
+    if (list.count <= 0 || k <= 0 || batch <= 0) return nullptr;
+    if (k == 1) { hipLaunchKernelGGL(k_pyr_chain<1>, dim3(list.count, batch), dim3(B_THREADS), 0, s, d_cams, list, base, n_cams); return "k_pyr_chain<1>"; }
+    hipLaunchKernelGGL(k_pyr_chain<2>, dim3(list.count, batch), dim3(B_THREADS), 0, s, d_cams, list, base, n_cams);
+    return "k_pyr_chain<2>";
 }
 
 int mb_stream_unit_rows() { return PS_R; }
 int mb_stream_unit_cols() { return PS_W; }
 
-void launch_pyrdown_stream(const CamDesc* d_cams, int n_cams, const uint32_t* d_units, int n_units, int level, int batch, hipStream_t s)
+const char* launch_pyrdown_stream(const CamDesc* d_cams, int n_cams, const uint32_t* d_units, int n_units, int level, int batch, hipStream_t s)
 {
-    if (n_units <= 0 || batch <= 0) return;
+    if (n_units <= 0 || batch <= 0) return nullptr;
     hipLaunchKernelGGL(k_pyrdown_stream<PS_R>, dim3((n_units + 3) / 4, batch), dim3(256), 0, s, d_cams, d_units, n_units, level, n_cams);
+    static_assert(PS_R == 8, "kernel name below");
+    return "k_pyrdown_stream<8>";
 }
 
-void launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
-                  hipStream_t s, int which)
+const char* launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
+                         hipStream_t s, int which)
 {
     static const size_t pad = tuning_env("MST_C_PAD_LDS");
-    if (num_blocks <= 0 || batch <= 0) return;
+    if (num_blocks <= 0 || batch <= 0) return nullptr;
+    const char* name = nullptr;
     BlendArgs a = a_in;
     a.n_tiles = num_blocks;
     a.n_coarse_tiles = num_coarse;
     a.n_sets = batch;
+    a.split = (a.nlev >= 3 && a.c2[0] != nullptr) ? 1 : 0;
     if (a.nlev > 1 && (which & 1)) {
-        a.split = (a.nlev >= 3 && a.c2[0] != nullptr) ? 1 : 0;
-        {
-            BlendArgs ac = a;
-            if (a.split && a.coarse_order2) { ac.coarse_order = a.coarse_order2; ac.n_coarse_tiles = a.n_coarse2; }
-            const int grid = canvas_grid<CC_XCD_GROUP>(ac.n_coarse_tiles, batch);
-#define MST_LAUNCH_COARSE(W, TH) hipLaunchKernelGGL((k_blend_coarse<W, TH>), dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, ac)
-            if (a.cc_th == 16) { if (a.weights_16s) MST_LAUNCH_COARSE(true, 16); else MST_LAUNCH_COARSE(false, 16); }
-            else { if (a.weights_16s) MST_LAUNCH_COARSE(true, 32); else MST_LAUNCH_COARSE(false, 32); }
+        BlendArgs ac = a;
+        if (a.split && a.coarse_order2) { ac.coarse_order = a.coarse_order2; ac.n_coarse_tiles = a.n_coarse2; }
+        const int grid = canvas_grid<CC_XCD_GROUP>(ac.n_coarse_tiles, batch);
+#define MST_LAUNCH_COARSE(W, TH) [&] { hipLaunchKernelGGL((k_blend_coarse<W, TH>), dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, ac); return "k_blend_coarse<" #W ", " #TH ">"; }()
+        if (a.cc_th == 16) name = a.weights_16s ? MST_LAUNCH_COARSE(true, 16) : MST_LAUNCH_COARSE(false, 16);
+        else name = a.weights_16s ? MST_LAUNCH_COARSE(true, 32) : MST_LAUNCH_COARSE(false, 32);
 #undef MST_LAUNCH_COARSE
-        }
-        if (a.split) {
-            const int grid = canvas_grid<CM_XCD_GROUP>(num_coarse, batch);
-#define MST_LAUNCH_MID(W, NT, TH) hipLaunchKernelGGL((k_blend_mid<W, NT, TH>), dim3(grid), dim3(NT), 0, s, d_cams, a)
-            if (a.cc_th == 16) { if (a.weights_16s) MST_LAUNCH_MID(true, 256, 16); else MST_LAUNCH_MID(false, 256, 16); }
-            else { if (a.weights_16s) MST_LAUNCH_MID(true, 128, 32); else MST_LAUNCH_MID(false, 128, 32); }
-#undef MST_LAUNCH_MID
-        }
     }
-    if (!(which & 2)) return;
+    if (a.nlev > 1 && a.split && (which & 4)) {
+        const int grid = canvas_grid<CM_XCD_GROUP>(num_coarse, batch);
+#define MST_LAUNCH_MID(W, NT, TH) [&] { hipLaunchKernelGGL((k_blend_mid<W, NT, TH>), dim3(grid), dim3(NT), 0, s, d_cams, a); return "k_blend_mid<" #W ", " #NT ", " #TH ">"; }()
+        if (a.cc_th == 16) name = a.weights_16s ? MST_LAUNCH_MID(true, 256, 16) : MST_LAUNCH_MID(false, 256, 16);
+        else name = a.weights_16s ? MST_LAUNCH_MID(true, 128, 32) : MST_LAUNCH_MID(false, 128, 32);
+#undef MST_LAUNCH_MID
+    }
+    if (!(which & 2)) return name;
     const int grid = canvas_grid<C_XCD_GROUP>(num_blocks, batch);
-#define MST_LAUNCH_FINE(W, NT) hipLaunchKernelGGL((k_blend_fine<W, NT>), dim3(grid), dim3(NT), 0, s, d_cams, a)
-    if (a.fine_threads == 128) { if (a.weights_16s) MST_LAUNCH_FINE(true, 128); else MST_LAUNCH_FINE(false, 128); }
-    else { if (a.weights_16s) MST_LAUNCH_FINE(true, 256); else MST_LAUNCH_FINE(false, 256); }
+#define MST_LAUNCH_FINE(W, NT) [&] { hipLaunchKernelGGL((k_blend_fine<W, NT>), dim3(grid), dim3(NT), 0, s, d_cams, a); return "k_blend_fine<" #W ", " #NT ">"; }()
+    if (a.fine_threads == 128) name = a.weights_16s ? MST_LAUNCH_FINE(true, 128) : MST_LAUNCH_FINE(false, 128);
+    else name = a.weights_16s ? MST_LAUNCH_FINE(true, 256) : MST_LAUNCH_FINE(false, 256);
 #undef MST_LAUNCH_FINE
+    return name;
 }
 
 }  // namespace mst

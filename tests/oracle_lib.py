@@ -61,9 +61,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    if os.environ.get("MST_ORACLE_NATIVE") == "1":
+        # bench.py's cpu_baseline leg: the -O3 -march=native build, compiled on the host that times it (never shipped)
+        path = os.path.join(ORACLE_DIR, "build", "libmst_oracle_native.so")
+        subprocess.check_call(["make", "-s", "-B", "-C", ORACLE_DIR, "native"], stdout=subprocess.DEVNULL)
+    elif not os.path.exists(LIB_PATH):
         build()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
     vp = C.c_void_p
     L.mo_cv_round.restype = C.c_int; L.mo_cv_round.argtypes = [C.c_double]

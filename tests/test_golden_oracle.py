@@ -33,3 +33,18 @@ def test_oracle_lut_golden():
     lut = O.Lut(corners, sizes, [c["mask"] for c in rig["cameras"]])
     rect, pano = lut.compose(imgs, *[float(v) for v in z["crop"]])
     assert rect == tuple(int(v) for v in z["lut_rect"]) and np.array_equal(pano, z["lut_pano"])
+
+
+def test_native_build_matches_goldens():
+    """The -O3 -march=native build that bench.py's cpu_baseline leg times (oracle/Makefile: native) is the same function:
+    every golden case and the round-3 extras through it, in a child process (the flag is read when the library loads)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MST_ORACLE_NATIVE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_golden_oracle.py"), os.path.join(here, "test_golden_round3.py"),
+                        os.path.join(here, "test_oracle_kat.py"), "-k", "not native_build", "-m", "not gpu"],
+                       env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -389,7 +389,12 @@ def test_profile_entry_points_report_every_launch():
     single = eng.profile_stages(ptrs[0], strides[0], panos[0].data_ptr(), panos[0].stride(0))
     batch = eng.profile_stages_batch(ptrs, strides, [p.data_ptr() for p in panos], panos[0].stride(0))
     for stages in (single, batch):
-        assert [n for n, _ in stages] == ["k_warp_pyr", "k_pyr_chain", "k_pyr_chain", "k_blend_coarse", "k_blend_fine"]
+        # one entry per launch, named as rocprofv3 names the kernel: the warp kernel(s), the pyramid levels above level 1
+        # (streaming pyrDown and / or the LDS chain), the two canvas kernels
+        names = [n for n, _ in stages]
+        assert names[0].startswith("k_warp_pyr") and names[-2].startswith("k_blend_coarse<") and names[-1].startswith("k_blend_fine<")
+        pyr = [n for n in names[1:-2] if not n.startswith("k_warp_pyr")]
+        assert pyr and all(n.startswith(("k_pyrdown_stream<", "k_pyr_chain<")) for n in pyr)
         assert all(0.0 < ms < 50.0 for _, ms in stages)
     eng.synchronize()
     for i in range(2):

@@ -82,8 +82,8 @@ if len(sys.argv) > 2 and counters:
         workload += "+undistort"
     # per-frame kernels of every path (calibration kernels -- tables, weight pyramids -- run per mst_update and drop out);
     # launches per sequence come from the run itself
-    per_frame = {"k_warp_pyr", "k_warp_pyr_lds", "k_pyr_chain", "k_blend_coarse", "k_blend_fine", "k_compose", "k_compose_lds",
-                 "k_compose_general", "k_remap_fixed"}
+    per_frame = {"k_warp_pyr", "k_warp_pyr_lds", "k_pyr_chain", "k_pyrdown_stream", "k_blend_coarse", "k_blend_mid", "k_blend_fine",
+                 "k_compose", "k_compose_lds", "k_compose_general", "k_remap_fixed", "k_nv12_to_bgr"}
     frame_kernels = {k: d for k, d in counters.items()
                      if k.split("<")[0] in per_frame and "FETCH_SIZE" in d and "WRITE_SIZE" in d}
     if frame_kernels:
