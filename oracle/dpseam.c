@@ -270,9 +270,15 @@ static void gradients(const Img *im, float **gx, float **gy)
     float *gray = (float *)malloc((size_t)w * h * sizeof(float));
     for (size_t i = 0; i < (size_t)w * h; ++i) {
         float b, g, r;
-        if (im->is_float) { const float *p = (const float *)im->data + 3 * i; b = p[0]; g = p[1]; r = p[2]; }
-        else { const uint8_t *p = (const uint8_t *)im->data + 3 * i; b = p[0]; g = p[1]; r = p[2]; }
-        gray[i] = b * 0.114f + g * 0.587f + r * 0.299f;
+        if (im->is_float) {              /* RGB2Gray<float>, BGR order */
+            const float *p = (const float *)im->data + 3 * i; b = p[0]; g = p[1]; r = p[2];
+            gray[i] = b * 0.114f + g * 0.587f + r * 0.299f;
+        } else {                         /* RGB2Gray<uchar>: 14-bit fixed point, the gray image is CV_8U (found by the second
+                                          * restatement, tests/independent/dpseam_py.py: round 3 used the float form here) */
+            const uint8_t *p = (const uint8_t *)im->data + 3 * i;
+            (void)b; (void)g; (void)r;
+            gray[i] = (float)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
+        }
     }
     float *dxr = (float *)malloc((size_t)w * h * sizeof(float)), *smr = (float *)malloc((size_t)w * h * sizeof(float));
     for (int y = 0; y < h; ++y)

@@ -70,10 +70,14 @@ __global__ __launch_bounds__(256) void k_dp_gray(const void* __restrict__ img, s
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    float b, g, r;
-    if (F32) { const float* p = reinterpret_cast<const float*>(static_cast<const char*>(img) + static_cast<size_t>(y) * stride) + 3 * x; b = p[0]; g = p[1]; r = p[2]; }
-    else { const uint8_t* p = static_cast<const uint8_t*>(img) + static_cast<size_t>(y) * stride + 3 * x; b = p[0]; g = p[1]; r = p[2]; }
-    gray[static_cast<size_t>(y) * w + x] = b * 0.114f + g * 0.587f + r * 0.299f;        // RGB2Gray<float>, BGR order
+    if (F32) {
+        const float* p = reinterpret_cast<const float*>(static_cast<const char*>(img) + static_cast<size_t>(y) * stride) + 3 * x;
+        gray[static_cast<size_t>(y) * w + x] = p[0] * 0.114f + p[1] * 0.587f + p[2] * 0.299f;        // RGB2Gray<float>, BGR order
+    } else {
+        // RGB2Gray<uchar>: 14-bit fixed point (B2Y 1868, G2Y 9617, R2Y 4899), the gray image is CV_8U; Sobel then runs on integers
+        const uint8_t* p = static_cast<const uint8_t*>(img) + static_cast<size_t>(y) * stride + 3 * x;
+        gray[static_cast<size_t>(y) * w + x] = static_cast<float>((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
+    }
 }
 
 // Sobel(CV_32F, ksize 3, BORDER_REFLECT_101): row pass then column pass; the symmetric taps as (a + c) + 2 b
