@@ -484,6 +484,12 @@ def main():
             eng_nv.close()
         except Exception as e:          # noqa: BLE001
             out["host_buffers"]["nv12_error"] = "%s: %s" % (type(e).__name__, e)
+        # SURVEY 8 f3 end to end: one capture process per camera -> shared memory (the reference's DatePacket hand-off) ->
+        # HBM -> compose -> panorama in page-locked host memory, BGR and NV12 packets
+        try:
+            out["host_buffers"]["ingest"] = ingest_leg(rig, blend, local_rank, cw, ch)
+        except Exception as e:          # noqa: BLE001
+            out["host_buffers"]["ingest"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- N > 1 legs: each under its own watchdog.  Every rank: a hung exchange must not take the headline (or the launcher)
     # with it.  A timer is armed per leg and says which leg it caught; none is running while the collective-free work
@@ -621,6 +627,65 @@ def host_buffer_leg(eng, host_sets, cw, ch, serial=True):
             "mb_in_per_frame": round(frame_mb, 1), "mb_out_per_frame": round(ch * cw * 3 / 1e6, 1),
             "note": "PCIe-inclusive; serial = pageable buffers through mst_compose, pipeline = page-locked buffers "
                     "through mst_pipeline_submit/wait (3 slots)"}
+
+
+def ingest_leg(rig, blend, local_rank, cw, ch, seconds=1.5):
+    """N capture processes (python -m stitchingvideo_amd.ingest: synthetic frames, three distinct ones per camera, cycled) publish
+    over POSIX shared memory in the reference's packet format; ingest.IngestStitcher pulls every camera's frame into HBM
+    (all servers fill their segments concurrently, DMA out of the page-locked segments), composes, and copies the panorama
+    into page-locked host memory -- three frame sets in flight.  PCIe-inclusive, never `value`."""
+    import stitchingvideo_amd as S
+    from stitchingvideo_amd import ingest
+    n_cam = len(rig["cameras"])
+    fw, fh = rig["size"]
+    res = {}
+    for fmt in ("bgr", "nv12"):
+        names = ["/mst_bench_%s_%d_%d" % (fmt, os.getpid(), i) for i in range(n_cam)]
+        procs = [subprocess.Popen([sys.executable, "-m", "stitchingvideo_amd.ingest", names[i], str(i), str(fw), str(fh), fmt, "3", "0"],
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, cwd=ROOT) for i in range(n_cam)]
+        eng = None
+        try:
+            for p in procs:
+                if p.stdout.readline().strip() != "ready":
+                    raise RuntimeError("capture process did not come up")
+            eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
+                                   frames_nv12=(fmt == "nv12"))
+            eng.update(rig["scale"], rig["cameras"])
+            st = ingest.IngestStitcher(eng, names, [c["size"] for c in rig["cameras"]], device=local_rank)
+
+            def loop(n):
+                for t in range(n):
+                    if t >= st.depth:
+                        st.wait()
+                    st.submit()
+                while st.completed < st.submitted:
+                    st.wait()
+            loop(6)
+            t0 = time.perf_counter()
+            loop(20)
+            n = max(30, int(seconds / max((time.perf_counter() - t0) / 20, 1e-6)))
+            t0 = time.perf_counter()
+            loop(n)
+            dt = time.perf_counter() - t0
+            st.close()
+            res[fmt] = {"frames": n, "frames_per_s": round(n / dt, 1), "ms_per_frame": round(dt * 1e3 / n, 3),
+                        "mb_in_per_frame": round(st.bytes_in / 1e6, 1), "mb_out_per_frame": round(ch * cw * 3 / 1e6, 1),
+                        "pcie_in_gb_s": round(st.bytes_in * n / dt / 1e9, 2), "pcie_out_gb_s": round(ch * cw * 3 * n / dt / 1e9, 2)}
+        finally:
+            if eng is not None:
+                eng.close()
+            for p in procs:
+                p.kill()
+            for p in procs:
+                p.wait(timeout=30)
+            for nm in names:          # (killed servers leave their segments behind: they live in memory)
+                try:
+                    os.unlink("/dev/shm" + nm)
+                except OSError:
+                    pass
+    res["note"] = ("%d capture processes -> shm (DatePacket) -> HBM -> compose -> page-locked panorama, 3 frame sets in flight; "
+                   "PCIe-inclusive" % n_cam)
+    return res
 
 
 def camera_sharded_leg(args_ns, rank, world, local_rank, dev, stream):

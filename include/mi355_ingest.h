@@ -37,7 +37,7 @@ typedef struct mst_frame_packet {
     char    filePath[120];
     int32_t width;
     int32_t height;
-    int32_t flag;            /* number of pixel bytes that follow (width * height * 3) */
+    int32_t flag;            /* number of pixel bytes that follow (BGR: width * height * 3; NV12: width * height * 3 / 2) */
     int32_t buferPointer;    /* pixels start at (start of this packet) + buferPointer + 1 */
 } mst_frame_packet;
 
@@ -51,6 +51,20 @@ int  mst_shm_serve(const char *name, size_t max_frame_bytes, mst_shm **out);
 int  mst_shm_publish(mst_shm *s, const char *file_path, int width, int height, const uint8_t *bgr, size_t stride,
                      int timeout_ms);
 
+/* Pixel formats of a packet (round 4).  The reference's header has no format field and its server only writes BGR
+ * (stitching_sharemem.cpp:112-115: `flag` = width * height * 3 pixel bytes).  The layout stays the reference's; the
+ * format is what `flag` already says: width * height * 3 bytes -> BGR, width * height * 3 / 2 bytes -> NV12 (height rows
+ * of Y, height / 2 rows of interleaved U V, as decoders deliver it: half the bytes across the host, converted on the
+ * device -- MST_FLAG_FRAMES_NV12 of mi355_stitch.h).  A reference client handed an NV12 packet sees a `flag` that does
+ * not match its BGR Mat and a server that only speaks BGR keeps working unchanged. */
+#define MST_PIXEL_BGR  0
+#define MST_PIXEL_NV12 1
+/* MST_PIXEL_* of a received header, or a negative MST_ERR_* code when `flag` fits neither format */
+int  mst_shm_packet_format(const mst_frame_packet *hdr);
+/* server side: publish an NV12 frame (width and height even; yuv = height * 3 / 2 rows, `stride` bytes apart) */
+int  mst_shm_publish_nv12(mst_shm *s, const char *file_path, int width, int height, const uint8_t *yuv, size_t stride,
+                          int timeout_ms);
+
 /* client side: ShareMemPre() -- attach to the segment the server created */
 int  mst_shm_attach(const char *name, mst_shm **out);
 /* client side: GetMemData() -- ask for a frame, wait for it, copy it out.  dst rows are dst_stride bytes apart and
@@ -62,6 +76,14 @@ int  mst_shm_get(mst_shm *s, mst_frame_packet *hdr, uint8_t *dst, size_t dst_str
  * return, because the server may overwrite the segment as soon as the next frame is requested) */
 int  mst_shm_get_device(mst_shm *s, mst_frame_packet *hdr, void *d_dst, size_t dst_stride, size_t dst_capacity,
                         void *stream, int timeout_ms);
+/* One frame from each of n cameras straight into device memory (DRV:736-741 pulls the cameras one after the other; here
+ * every server is asked first and writes its segment while the others do, then the copies are queued on `stream` as
+ * the frames arrive and awaited once).  d_dst[i]: device buffer of camera i with rows dst_stride[i] bytes apart (BGR:
+ * width * 3 bytes per row; NV12: width bytes per row, height * 3 / 2 rows) and dst_capacity[i] bytes; hdr[i] receives
+ * the header (mst_shm_packet_format tells the format).  On a timeout or a bad packet the remaining cameras' frames
+ * are still consumed, and the first error is returned. */
+int  mst_shm_get_device_multi(mst_shm *const *s, int n, mst_frame_packet *hdr, void *const *d_dst, const size_t *dst_stride,
+                              const size_t *dst_capacity, void *stream, int timeout_ms);
 /* SharememClose(); the server side also unlinks the segment */
 void mst_shm_close(mst_shm *s);
 

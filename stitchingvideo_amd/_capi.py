@@ -53,6 +53,9 @@ EXPORTS = [
     "mst_init_undistort_rectify_map", "mst_compose_lens_maps", "mst_cvt_nv12_bgr", "mst_remap_fixed",
     "mst_calibration_blob_size", "mst_calibration_save", "mst_calibration_load",
     "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame", "mst_gain_map_size", "mst_exposure_feed", "mst_seam_voronoi", "mst_seam_dp",
+    # include/mi355_ingest.h
+    "mst_shm_serve", "mst_shm_publish", "mst_shm_publish_nv12", "mst_shm_packet_format", "mst_shm_attach", "mst_shm_get",
+    "mst_shm_get_device", "mst_shm_get_device_multi", "mst_shm_close",
 ]
 
 

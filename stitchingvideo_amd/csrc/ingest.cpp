@@ -94,12 +94,12 @@ int mst_shm_serve(const char* name, size_t max_frame_bytes, mst_shm** out)
     return MST_OK;
 }
 
-int mst_shm_publish(mst_shm* s, const char* file_path, int width, int height, const uint8_t* bgr, size_t stride,
-                    int timeout_ms)
+namespace {
+// header + `rows` rows of `row` bytes each, packed tightly behind the packet
+int publish_rows(mst_shm* s, const char* file_path, int width, int height, const uint8_t* src, size_t stride, size_t row, size_t rows,
+                 int timeout_ms)
 {
-    if (!s || !s->server || !bgr || width <= 0 || height <= 0 || stride < static_cast<size_t>(width) * 3)
-        return MST_ERR_INVALID_ARG;
-    const size_t row = static_cast<size_t>(width) * 3, nbytes = row * height;
+    const size_t nbytes = row * rows;
     if (nbytes > s->ctl()->max_frame_bytes || nbytes > 0x7FFFFFFFu) return MST_ERR_INVALID_ARG;
     const int rc = wait_sem(&s->ctl()->client_ready, timeout_ms);
     if (rc != MST_OK) return rc;
@@ -113,9 +113,36 @@ int mst_shm_publish(mst_shm* s, const char* file_path, int width, int height, co
     uint8_t* q = s->data();
     std::memcpy(q, &p, sizeof(p));
     uint8_t* px = q + p.buferPointer + 1;
-    for (int y = 0; y < height; ++y) std::memcpy(px + static_cast<size_t>(y) * row, bgr + static_cast<size_t>(y) * stride, row);
+    if (stride == row) std::memcpy(px, src, nbytes);
+    else for (size_t y = 0; y < rows; ++y) std::memcpy(px + y * row, src + y * stride, row);
     sem_post(&s->ctl()->server_wrote);
     return MST_OK;
+}
+}  // namespace
+
+int mst_shm_publish(mst_shm* s, const char* file_path, int width, int height, const uint8_t* bgr, size_t stride,
+                    int timeout_ms)
+{
+    if (!s || !s->server || !bgr || width <= 0 || height <= 0 || stride < static_cast<size_t>(width) * 3)
+        return MST_ERR_INVALID_ARG;
+    return publish_rows(s, file_path, width, height, bgr, stride, static_cast<size_t>(width) * 3, static_cast<size_t>(height), timeout_ms);
+}
+
+int mst_shm_publish_nv12(mst_shm* s, const char* file_path, int width, int height, const uint8_t* yuv, size_t stride,
+                         int timeout_ms)
+{
+    if (!s || !s->server || !yuv || width <= 0 || height <= 0 || (width & 1) || (height & 1) || stride < static_cast<size_t>(width))
+        return MST_ERR_INVALID_ARG;
+    return publish_rows(s, file_path, width, height, yuv, stride, static_cast<size_t>(width), static_cast<size_t>(height) * 3 / 2, timeout_ms);
+}
+
+int mst_shm_packet_format(const mst_frame_packet* hdr)
+{
+    if (!hdr || hdr->width <= 0 || hdr->height <= 0 || hdr->flag < 0) return MST_ERR_INVALID_ARG;
+    const size_t px = static_cast<size_t>(hdr->width) * static_cast<size_t>(hdr->height), flag = static_cast<size_t>(hdr->flag);
+    if (flag == px * 3) return MST_PIXEL_BGR;
+    if (!(hdr->width & 1) && !(hdr->height & 1) && flag == px * 3 / 2) return MST_PIXEL_NV12;
+    return MST_ERR_INVALID_ARG;
 }
 
 int mst_shm_attach(const char* name, mst_shm** out)
@@ -145,11 +172,16 @@ int mst_shm_attach(const char* name, mst_shm** out)
 }
 
 namespace {
-// the common part of GetMemData: request, wait, validate the header the server wrote
-int request_frame(mst_shm* s, mst_frame_packet* hdr, const uint8_t** pixels, int timeout_ms)
+// GetMemData in two halves: raise "client ready" ...
+int post_request(mst_shm* s)
 {
-    if (!s || s->server || !hdr) return MST_ERR_INVALID_ARG;
+    if (!s || s->server) return MST_ERR_INVALID_ARG;
     sem_post(&s->ctl()->client_ready);                                   // SetEvent(hClientReadOver)
+    return MST_OK;
+}
+// ... and wait for "server wrote", then validate the header the server wrote
+int take_frame(mst_shm* s, mst_frame_packet* hdr, const uint8_t** pixels, int timeout_ms)
+{
     const int rc = wait_sem(&s->ctl()->server_wrote, timeout_ms);        // WaitForSingleObject(hServerWriteOver)
     if (rc != MST_OK) {
         // withdraw the request if the server has not taken it; if it has, the frame is on its way and has to be
@@ -163,11 +195,35 @@ int request_frame(mst_shm* s, mst_frame_packet* hdr, const uint8_t** pixels, int
     hdr->filePath[sizeof(hdr->filePath) - 1] = 0;
     const size_t avail = s->bytes - s->ctl()->data_offset;
     if (hdr->width <= 0 || hdr->height <= 0 || hdr->flag < 0 || hdr->buferPointer < 0 ||
-        static_cast<size_t>(hdr->buferPointer) + 1 + static_cast<size_t>(hdr->flag) > avail ||
-        static_cast<size_t>(hdr->flag) != static_cast<size_t>(hdr->width) * hdr->height * 3)
+        static_cast<size_t>(hdr->buferPointer) + 1 + static_cast<size_t>(hdr->flag) > avail || mst_shm_packet_format(hdr) < 0)
         return MST_ERR_INVALID_ARG;
     *pixels = q + hdr->buferPointer + 1;
     return MST_OK;
+}
+int request_frame(mst_shm* s, mst_frame_packet* hdr, const uint8_t** pixels, int timeout_ms)
+{
+    if (!hdr) return MST_ERR_INVALID_ARG;
+    const int rc = post_request(s);
+    return rc != MST_OK ? rc : take_frame(s, hdr, pixels, timeout_ms);
+}
+// rows of a packet's pixel block: bytes per row, number of rows (BGR: h rows of 3 w; NV12: 3 h / 2 rows of w)
+void packet_rows(const mst_frame_packet& h, size_t* row, size_t* rows)
+{
+    const bool nv12 = mst_shm_packet_format(&h) == MST_PIXEL_NV12;
+    *row = static_cast<size_t>(h.width) * (nv12 ? 1 : 3);
+    *rows = nv12 ? static_cast<size_t>(h.height) * 3 / 2 : static_cast<size_t>(h.height);
+}
+// page-lock the segment once: device copies then run as DMA straight out of the shared mapping
+void register_segment(mst_shm* s)
+{
+    if (s->registered) return;
+    s->registered = hipHostRegister(s->base, s->bytes, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+}
+hipError_t queue_copy(void* d_dst, size_t dst_stride, const uint8_t* px, size_t row, size_t rows, hipStream_t st)
+{
+    return dst_stride == row ? hipMemcpyAsync(d_dst, px, row * rows, hipMemcpyHostToDevice, st)
+                             : hipMemcpy2DAsync(d_dst, dst_stride, px, row, row, rows, hipMemcpyHostToDevice, st);
 }
 }  // namespace
 
@@ -176,9 +232,10 @@ int mst_shm_get(mst_shm* s, mst_frame_packet* hdr, uint8_t* dst, size_t dst_stri
     const uint8_t* px = nullptr;
     const int rc = request_frame(s, hdr, &px, timeout_ms);
     if (rc != MST_OK || !dst) return rc;
-    const size_t row = static_cast<size_t>(hdr->width) * 3;
-    if (dst_stride < row || dst_capacity < dst_stride * (hdr->height - 1) + row) return MST_ERR_INVALID_ARG;
-    for (int y = 0; y < hdr->height; ++y) std::memcpy(dst + static_cast<size_t>(y) * dst_stride, px + static_cast<size_t>(y) * row, row);
+    size_t row, rows;
+    packet_rows(*hdr, &row, &rows);
+    if (dst_stride < row || dst_capacity < dst_stride * (rows - 1) + row) return MST_ERR_INVALID_ARG;
+    for (size_t y = 0; y < rows; ++y) std::memcpy(dst + y * dst_stride, px + y * row, row);
     return MST_OK;
 }
 
@@ -189,21 +246,46 @@ int mst_shm_get_device(mst_shm* s, mst_frame_packet* hdr, void* d_dst, size_t ds
     const uint8_t* px = nullptr;
     const int rc = request_frame(s, hdr, &px, timeout_ms);
     if (rc != MST_OK) return rc;
-    const size_t row = static_cast<size_t>(hdr->width) * 3;
-    if (dst_stride < row || dst_capacity < dst_stride * (hdr->height - 1) + row) return MST_ERR_INVALID_ARG;
+    size_t row, rows;
+    packet_rows(*hdr, &row, &rows);
+    if (dst_stride < row || dst_capacity < dst_stride * (rows - 1) + row) return MST_ERR_INVALID_ARG;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MST_ERR_NO_DEVICE;
-    if (!s->registered) {
-        // page-lock the segment once: the copies below then run as DMA straight out of the shared mapping
-        s->registered = hipHostRegister(s->base, s->bytes, hipHostRegisterDefault) == hipSuccess;
-        (void)hipGetLastError();
-    }
+    register_segment(s);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = (dst_stride == row)
-                       ? hipMemcpyAsync(d_dst, px, row * hdr->height, hipMemcpyHostToDevice, st)
-                       : hipMemcpy2DAsync(d_dst, dst_stride, px, row, row, hdr->height, hipMemcpyHostToDevice, st);
+    hipError_t e = queue_copy(d_dst, dst_stride, px, row, rows, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);       // the server may overwrite the segment after the next request
     return e == hipSuccess ? MST_OK : MST_ERR_HIP;
+}
+
+int mst_shm_get_device_multi(mst_shm* const* s, int n, mst_frame_packet* hdr, void* const* d_dst, const size_t* dst_stride,
+                             const size_t* dst_capacity, void* stream, int timeout_ms)
+{
+    if (!s || !hdr || !d_dst || !dst_stride || !dst_capacity || n <= 0) return MST_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!s[i] || s[i]->server || !d_dst[i]) return MST_ERR_INVALID_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MST_ERR_NO_DEVICE;
+    for (int i = 0; i < n; ++i) (void)post_request(s[i]);     // every capture process fills its segment at the same time
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int first = MST_OK;
+    for (int i = 0; i < n; ++i) {
+        const uint8_t* px = nullptr;
+        int rc = take_frame(s[i], &hdr[i], &px, timeout_ms);
+        if (rc == MST_OK) {
+            size_t row, rows;
+            packet_rows(hdr[i], &row, &rows);
+            if (dst_stride[i] < row || dst_capacity[i] < dst_stride[i] * (rows - 1) + row) rc = MST_ERR_INVALID_ARG;
+            else {
+                register_segment(s[i]);
+                if (queue_copy(d_dst[i], dst_stride[i], px, row, rows, st) != hipSuccess) rc = MST_ERR_HIP;
+            }
+        }
+        if (rc != MST_OK && first == MST_OK) first = rc;
+    }
+    // the servers may overwrite their segments as soon as the next frame is requested: the copies are complete on return
+    if (hipStreamSynchronize(st) != hipSuccess && first == MST_OK) first = MST_ERR_HIP;
+    return first;
 }
 
 void mst_shm_close(mst_shm* s)

@@ -8,6 +8,7 @@ import numpy as np
 from . import _capi as capi
 
 ERR_TIMEOUT = -7
+PIXEL_BGR, PIXEL_NV12 = 0, 1
 
 
 class FramePacket(C.Structure):
@@ -30,6 +31,13 @@ def _lib():
         L.mst_shm_get.argtypes = [vp, C.POINTER(FramePacket), vp, C.c_size_t, C.c_size_t, C.c_int]
         L.mst_shm_get_device.restype = C.c_int
         L.mst_shm_get_device.argtypes = [vp, C.POINTER(FramePacket), vp, C.c_size_t, C.c_size_t, vp, C.c_int]
+        L.mst_shm_publish_nv12.restype = C.c_int
+        L.mst_shm_publish_nv12.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t, C.c_int]
+        L.mst_shm_packet_format.restype = C.c_int
+        L.mst_shm_packet_format.argtypes = [C.POINTER(FramePacket)]
+        L.mst_shm_get_device_multi.restype = C.c_int
+        L.mst_shm_get_device_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(FramePacket), C.POINTER(vp), C.POINTER(C.c_size_t),
+                                               C.POINTER(C.c_size_t), vp, C.c_int]
         L.mst_shm_close.restype = None
         L.mst_shm_close.argtypes = [vp]
         L._ingest_ready = True
@@ -74,6 +82,39 @@ class FrameServer(_Handle):
             raise IngestError(rc, "mst_shm_publish")
 
 
+    def publish_nv12(self, yuv, path="", timeout_ms=-1):
+        """An NV12 frame: (h * 3 / 2, w) uint8, h rows of Y then h / 2 rows of interleaved U V."""
+        yuv = np.ascontiguousarray(yuv, np.uint8)
+        h, w = yuv.shape[0] * 2 // 3, yuv.shape[1]
+        rc = self._L.mst_shm_publish_nv12(self._h, path.encode(), w, h, yuv.ctypes.data, yuv.strides[0], timeout_ms)
+        if rc:
+            raise IngestError(rc, "mst_shm_publish_nv12")
+
+
+def packet_format(hdr):
+    """PIXEL_BGR / PIXEL_NV12 of a received FramePacket (its `flag` byte count says which)."""
+    rc = _lib().mst_shm_packet_format(C.byref(hdr))
+    if rc < 0:
+        raise IngestError(rc, "mst_shm_packet_format")
+    return rc
+
+
+def get_device_multi(clients, device_ptrs, strides, capacities, stream=None, timeout_ms=-1):
+    """One frame from every client straight into device memory (mst_shm_get_device_multi): all servers are asked first
+    and fill their segments concurrently -> list of (width, height, format, path)."""
+    n = len(clients)
+    L = _lib()
+    hs = (C.c_void_p * n)(*[c._h for c in clients])
+    hdr = (FramePacket * n)()
+    dp = (C.c_void_p * n)(*device_ptrs)
+    st = (C.c_size_t * n)(*strides)
+    cp = (C.c_size_t * n)(*capacities)
+    rc = L.mst_shm_get_device_multi(hs, n, hdr, dp, st, cp, stream, timeout_ms)
+    if rc:
+        raise IngestError(rc, "mst_shm_get_device_multi")
+    return [(h.width, h.height, packet_format(h), h.filePath.decode(errors="replace")) for h in hdr]
+
+
 class FrameClient(_Handle):
     def __init__(self, name):
         super().__init__()
@@ -100,3 +141,110 @@ class FrameClient(_Handle):
         if rc:
             raise IngestError(rc, "mst_shm_get_device")
         return hdr.width, hdr.height, hdr.filePath.decode(errors="replace")
+
+
+# ---- the whole ingest path: capture processes -> shared memory -> HBM -> compose -> panorama in host memory ---------
+def synth_nv12(cam, frame_index, w, h):
+    """A deterministic synthetic NV12 frame ((h * 3 / 2, w) uint8) for tests and the bench's producers."""
+    rng = np.random.default_rng(1000003 * (cam + 1) + frame_index)
+    return rng.integers(16, 236, size=(h * 3 // 2, w)).astype(np.uint8)
+
+
+def producer_main(argv):
+    """A capture process (GetFromRtsp.exe's role): `python -m stitchingvideo_amd.ingest NAME CAM W H FORMAT DISTINCT COUNT`
+    serves COUNT frames (0: until killed) of DISTINCT pre-generated synthetic frames of camera CAM over segment NAME.
+    Prints "ready" once the segment exists."""
+    import sys
+    from . import rig as rigmod
+    name, cam, w, h, fmt, distinct, count = argv[0], int(argv[1]), int(argv[2]), int(argv[3]), argv[4], int(argv[5]), int(argv[6])
+    nv12 = fmt == "nv12"
+    frames = [synth_nv12(cam, k, w, h) if nv12 else rigmod.synth_frame(cam, k, w, h) for k in range(distinct)]
+    with FrameServer(name, w * h * 3) as srv:
+        print("ready", flush=True)
+        k = 0
+        while count == 0 or k < count:
+            try:
+                (srv.publish_nv12 if nv12 else srv.publish)(frames[k % distinct], path="synthetic://cam%d/%d" % (cam, k), timeout_ms=5000)
+            except IngestError as e:
+                if e.code != ERR_TIMEOUT:
+                    raise
+                if count == 0:
+                    continue        # (idle: keep serving until the parent closes our stdin)
+                break
+            k += 1
+        sys.stdin.read()            # keep the segment alive until the consumer is done
+
+
+class IngestStitcher:
+    """The reference's frame loop (DRV:736-763) fed the reference's way -- every camera's frame pulled from its capture
+    process over shared memory (Stitching_sharemem::GetMemData, DRV:739-740) -- as a three-stage pipeline on the device:
+    stage 1 pulls frame set t + 1 of all cameras into HBM (the capture processes fill their segments concurrently, the
+    copies are DMA out of the page-locked segments), stage 2 composes frame set t, stage 3 copies panorama t - 1 into
+    page-locked host memory.  BGR or NV12 packets (the engine's MST_FLAG_FRAMES_NV12 says which it composes from)."""
+
+    def __init__(self, engine, names, sizes, device=0, depth=3):
+        """engine: a calibrated PanoramaEngine; names: one segment name per camera; sizes: the cameras' (width, height)."""
+        import torch
+        self._torch = torch
+        self.eng = engine
+        self.clients = [FrameClient(n) for n in names]
+        self.dev = torch.device("cuda", device)
+        (self.cx, self.cy, self.cw, self.ch), _ = engine.acquire()
+        self.nv12 = bool(getattr(engine, "_frames_nv12", False))
+        self.depth = depth
+        self.sizes = [(int(w), int(h)) for (w, h) in sizes]
+        self.sets = [[torch.empty((h * 3 // 2, w) if self.nv12 else (h, w, 3), dtype=torch.uint8, device=self.dev) for (w, h) in self.sizes]
+                     for _ in range(depth)]
+        self.d_panos = [torch.empty((self.ch, self.cw, 3), dtype=torch.uint8, device=self.dev) for _ in range(depth)]
+        self.h_panos = [torch.empty((self.ch, self.cw, 3), dtype=torch.uint8, pin_memory=True) for _ in range(depth)]
+        self.s_in, self.s_c, self.s_out = (torch.cuda.Stream(device=self.dev) for _ in range(3))
+        self.ev_in = [torch.cuda.Event() for _ in range(depth)]
+        self.ev_c = [torch.cuda.Event() for _ in range(depth)]
+        self.ev_out = [torch.cuda.Event() for _ in range(depth)]
+        self.submitted = self.completed = 0
+        self.bytes_in = sum(t.numel() for t in self.sets[0])
+
+    def submit(self, timeout_ms=20000):
+        """Pull one frame set from the capture processes and queue its compose and the panorama's copy-out."""
+        torch = self._torch
+        k = self.submitted % self.depth
+        if self.submitted - self.completed >= self.depth:
+            raise RuntimeError("ring full: call wait() first")
+        fs = self.sets[k]
+        # (stage 1 is complete on return: the servers may overwrite their segments at the next request; the slot's frames
+        # were last read by the compose of `depth` submits ago, whose completion wait() has observed)
+        got = get_device_multi(self.clients, [t.data_ptr() for t in fs], [t.stride(0) for t in fs], [t.numel() for t in fs],
+                               stream=self.s_in.cuda_stream, timeout_ms=timeout_ms)
+        want = PIXEL_NV12 if self.nv12 else PIXEL_BGR
+        for (w, h, fmt, _), (ew, eh) in zip(got, self.sizes):
+            if fmt != want or (w, h) != (ew, eh):
+                raise IngestError(-2, "packet of %dx%d format %d where the calibration expects %dx%d format %d" % (w, h, fmt, ew, eh, want))
+        self.ev_in[k].record(self.s_in)
+        self.s_c.wait_event(self.ev_in[k])
+        self.eng.compose_device([t.data_ptr() for t in fs], [t.stride(0) for t in fs], self.d_panos[k].data_ptr(),
+                                self.d_panos[k].stride(0), stream=self.s_c.cuda_stream)
+        self.ev_c[k].record(self.s_c)
+        self.s_out.wait_event(self.ev_c[k])
+        with torch.cuda.stream(self.s_out):
+            self.h_panos[k].copy_(self.d_panos[k], non_blocking=True)
+        self.ev_out[k].record(self.s_out)
+        self.submitted += 1
+
+    def wait(self):
+        """The oldest submitted panorama, complete in page-locked host memory (valid until `depth` more submits)."""
+        if self.completed >= self.submitted:
+            raise RuntimeError("wait() without a submitted frame set")
+        k = self.completed % self.depth
+        self.ev_out[k].synchronize()
+        self.completed += 1
+        return self.h_panos[k].numpy()
+
+    def close(self):
+        self._torch.cuda.synchronize(self.dev)
+        for c in self.clients:
+            c.close()
+
+
+if __name__ == "__main__":
+    import sys as _sys
+    producer_main(_sys.argv[1:])

@@ -99,3 +99,78 @@ def test_frame_lands_in_device_memory():
         cli.get_device(padded.data_ptr(), padded.stride(0), padded.numel())
         assert np.array_equal(padded[:, :1440].cpu().numpy().reshape(270, 480, 3), frame)
         t.join()
+
+
+def test_nv12_packets_cross_the_segment_and_say_their_format():
+    name = "/mst_ingest_nv12_%d" % os.getpid()
+    yuv = ingest.synth_nv12(0, 3, 64, 48)
+    bgr = np.random.default_rng(1).integers(0, 256, (48, 64, 3)).astype(np.uint8)
+    with ingest.FrameServer(name, 64 * 48 * 3) as srv:
+        with pytest.raises(ingest.IngestError):              # odd sizes have no NV12 form
+            srv.publish_nv12(np.zeros((3, 5), np.uint8), timeout_ms=0)
+        t = threading.Thread(target=lambda: (srv.publish_nv12(yuv, path="nv", timeout_ms=20000), srv.publish(bgr, path="bgr", timeout_ms=20000)))
+        t.start()
+        with ingest.FrameClient(name) as cli:
+            hdr = ingest.FramePacket()
+            out = np.zeros((72, 64), np.uint8)
+            L = ingest._lib()
+            assert L.mst_shm_get(cli._h, C.byref(hdr), out.ctypes.data, 64, out.size, 20000) == 0
+            assert (hdr.width, hdr.height, hdr.flag) == (64, 48, 64 * 48 * 3 // 2) and ingest.packet_format(hdr) == ingest.PIXEL_NV12
+            assert np.array_equal(out, yuv)
+            out3 = np.zeros((48, 64, 3), np.uint8)
+            assert L.mst_shm_get(cli._h, C.byref(hdr), out3.ctypes.data, 64 * 3, out3.size, 20000) == 0
+            assert ingest.packet_format(hdr) == ingest.PIXEL_BGR and np.array_equal(out3, bgr)
+        t.join()
+    bad = ingest.FramePacket(width=10, height=10, flag=123)
+    with pytest.raises(ingest.IngestError):
+        ingest.packet_format(bad)
+
+
+def _spawn_producers(prefix, n, w, h, fmt, distinct, count):
+    names = ["%s_%d" % (prefix, i) for i in range(n)]
+    procs = [subprocess.Popen([sys.executable, "-m", "stitchingvideo_amd.ingest", names[i], str(i), str(w), str(h), fmt, str(distinct), str(count)],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, cwd=ROOT) for i in range(n)]
+    for p in procs:
+        assert p.stdout.readline().strip() == "ready"
+    return names, procs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["bgr", "nv12"])
+def test_capture_processes_to_panorama_end_to_end(fmt):
+    """SURVEY 8 f3 as a whole: N capture processes -> shared memory -> HBM -> compose -> panorama in host memory, BGR and NV12
+    packets; every panorama equals the oracle's on the frames the producers sent."""
+    import helpers as H
+    import oracle_lib as O
+    import stitchingvideo_amd as S
+    from stitchingvideo_amd import rig as rigmod
+    rig = rigmod.build_rig(rigmod.scaled_config("C3", 4 if fmt == "nv12" else 8))      # (NV12 needs even sizes: 480 x 270)
+    n = len(rig["cameras"])
+    w, h = rig["size"]
+    eng = S.PanoramaEngine(n, warp=rig["warp"], blend=rig["blend"], expos=rig["expos"], num_bands=5, frames_nv12=(fmt == "nv12"))
+    eng.update(rig["scale"], rig["cameras"])
+    names, procs = _spawn_producers("/mst_e2e_%s_%d" % (fmt, os.getpid()), n, w, h, fmt, 3, 5)
+    try:
+        st = ingest.IngestStitcher(eng, names, [c["size"] for c in rig["cameras"]])
+        got = []
+        for t in range(5):
+            if t >= 3:
+                got.append(st.wait().copy())
+            st.submit()
+        while st.completed < st.submitted:
+            got.append(st.wait().copy())
+        st.close()
+    finally:
+        for p in procs:
+            p.stdin.close()
+        for p in procs:
+            p.wait(timeout=30)
+    assert len(got) == 5
+    for t, pano in enumerate(got):
+        k = t % 3
+        if fmt == "nv12":
+            frames = [O.cvt_nv12_bgr(ingest.synth_nv12(i, k, w, h)) for i in range(n)]
+        else:
+            frames = [rigmod.synth_frame(i, k, w, h) for i in range(n)]
+        assert np.array_equal(pano, H.oracle_compose(rig, frames)[1]), (fmt, t)
+    eng.close()
