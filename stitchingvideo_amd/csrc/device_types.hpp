@@ -66,8 +66,11 @@ struct CamDesc {
     int32_t lw[kMaxLevels], lh[kMaxLevels];   // bordered pyramid level sizes
     int32_t ox[kMaxLevels], oy[kMaxLevels];   // window origin inside the canvas level
     // Gaussian pyramid.  Every level of a CV_8U-sourced pyramid stays in [0,255] ((sum+128)>>8 of
-    // bytes), so a pixel is stored as one dword B | G<<8 | R<<16 instead of three shorts.
-    uint32_t* G[kMaxLevels];       // lh x lw dwords; G[0] = warped + gained + bordered level 0
+    // bytes), so a pixel of levels 1 .. is stored as one dword B | G<<8 | R<<16 instead of three shorts.  Level 0 -- written
+    // once by the warp kernel and read once by k_blend_fine, the two largest streams of the path -- is packed BGR8 (round 4):
+    // three bytes a pixel, rows l0_pitch bytes apart (a multiple of 12: whole groups of four pixels, dword-aligned rows).
+    uint32_t* G[kMaxLevels];       // G[l >= 1]: lh x lw dwords; G[0]: lh[0] rows of l0_pitch bytes = warped + gained + bordered level 0
+    int32_t l0_pitch;
     const float* W[kMaxLevels];    // weight pyramid, lh x lw floats (W[0] = mask/255 with border)
 };
 
@@ -184,7 +187,8 @@ struct BlendArgs {
 };
 
 // One rectangle of a camera's hand-off payload (camera-sharded multi-GPU mode): the interior of a launched tile at
-// one pyramid level, `off` pixels into the camera's packed payload.  Static per calibration.
+// one pyramid level, `off` dwords into the camera's packed payload (levels above 0: a dword a pixel; level 0: packed BGR8,
+// 3 w h bytes rounded up to a dword).  Static per calibration.
 struct PayloadRect {
     int32_t level, x0, y0, w, h;
     uint32_t off;

@@ -128,6 +128,17 @@ CalibState::~CalibState()
 
 // ---- camera descriptor -------------------------------------------------------------------------
 
+// Level 0 of a camera's pyramid is packed BGR8: rows of whole four-pixel groups (12 bytes), so that every group the warp
+// kernel stores and every pixel pair the canvas kernel loads lies inside its row; the levels above are a dword a pixel.
+// A level's footprint in dwords, rounded up so that the next level starts 16-byte aligned and level 0 carries the slack
+// its 8-byte pair loads may touch behind the last pixel.
+int level0_pitch(int lw0) { return ((lw0 + 3) / 4) * 12; }
+size_t level_dwords(const CamDesc& d, int l)
+{
+    const size_t dw = l == 0 ? (static_cast<size_t>(d.l0_pitch) * d.lh[0] + 16 + 3) / 4 : static_cast<size_t>(d.lw[l]) * d.lh[l];
+    return (dw + 3) & ~size_t{3};
+}
+
 void fill_camera_desc(DevicePool& pool, hipStream_t s, const Projector& proj, const Rect& roi, int src_w, int src_h,
                       int expos_kind, const float* gain_map, int gw, int gh, float gain, CamDesc& d)
 {
@@ -585,18 +596,20 @@ void Engine::update(const mst_calibration& calib)
                 d.ox[l] = d.ox[l - 1] / 2; d.oy[l] = d.oy[l - 1] / 2;     // blenders.cpp:327-328
             }
             // one contiguous block per camera for the whole Gaussian pyramid (levels back to back): it is the
-            // unit that travels in the camera-sharded multi-GPU mode (mst_pyramid_buffer)
-            size_t total_px = 0;
-            for (int l = 0; l <= nb; ++l) total_px += static_cast<size_t>(d.lw[l]) * d.lh[l];
-            uint32_t* base = st->pool.alloc<uint32_t>(total_px);
+            // unit that travels in the camera-sharded multi-GPU mode (mst_pyramid_buffer).  Level 0 is packed BGR8 with a
+            // row pitch of whole 12-byte groups; the levels above are a dword a pixel (device_types.hpp)
+            d.l0_pitch = level0_pitch(d.lw[0]);
+            size_t total_dw = 0;
+            for (int l = 0; l <= nb; ++l) total_dw += level_dwords(d, l);
+            uint32_t* base = st->pool.alloc<uint32_t>(total_dw);
             // tiles the work lists skip are never written: keep them deterministic
-            check_hip(hipMemsetAsync(base, 0, total_px * sizeof(uint32_t), s), "hipMemsetAsync");
+            check_hip(hipMemsetAsync(base, 0, total_dw * sizeof(uint32_t), s), "hipMemsetAsync");
             st->pyr_base.push_back(base);
-            st->pyr_bytes.push_back(total_px * sizeof(uint32_t));
+            st->pyr_bytes.push_back(total_dw * sizeof(uint32_t));
             for (int l = 0; l <= nb; ++l) {
                 const size_t px = static_cast<size_t>(d.lw[l]) * d.lh[l];
                 d.G[l] = base;
-                base += px;
+                base += level_dwords(d, l);
                 wpyr[i][l] = st->pool.alloc<float>(px);
                 d.W[l] = wpyr[i][l];
             }
@@ -611,9 +624,9 @@ void Engine::update(const mst_calibration& calib)
             for (int i = 0; i < n; ++i) {
                 CamDesc d = st->desc[i];
                 for (int l = 0; l <= nb; ++l) {
-                    const size_t px = static_cast<size_t>(d.lw[l]) * d.lh[l];
-                    d.G[l] = st->pool.alloc<uint32_t>(px);
-                    check_hip(hipMemsetAsync(d.G[l], 0, px * sizeof(uint32_t), s), "hipMemsetAsync");
+                    const size_t dw = level_dwords(d, l);
+                    d.G[l] = st->pool.alloc<uint32_t>(dw);
+                    check_hip(hipMemsetAsync(d.G[l], 0, dw * sizeof(uint32_t), s), "hipMemsetAsync");
                 }
                 sets.push_back(d);
             }
@@ -1699,10 +1712,21 @@ void Engine::debug_read(int what, int camera, int level, void* buf, size_t buf_b
             if (h) *h = hh;
             if (!buf) return;
             if (buf_bytes < sizeof(int16_t) * 3 * px) throw Error{MST_ERR_INVALID_ARG, "debug buffer too small"};
-            std::vector<uint32_t> packed(px);
-            check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
-            check_hip(hipMemcpy(packed.data(), d.G[level], px * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
             int16_t* out = static_cast<int16_t*>(buf);
+            check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+            if (level == 0) {        // packed BGR8, rows l0_pitch bytes apart
+                std::vector<uint8_t> bytes8(static_cast<size_t>(d.l0_pitch) * hh);
+                check_hip(hipMemcpy(bytes8.data(), d.G[0], bytes8.size(), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+                for (int y = 0; y < hh; ++y)
+                    for (int x = 0; x < ww; ++x) {
+                        const uint8_t* p8 = &bytes8[static_cast<size_t>(y) * d.l0_pitch + 3 * static_cast<size_t>(x)];
+                        const size_t i = static_cast<size_t>(y) * ww + x;
+                        out[i] = p8[0]; out[px + i] = p8[1]; out[2 * px + i] = p8[2];
+                    }
+                return;
+            }
+            std::vector<uint32_t> packed(px);
+            check_hip(hipMemcpy(packed.data(), d.G[level], px * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
             for (size_t i = 0; i < px; ++i) {
                 out[i] = static_cast<int16_t>(packed[i] & 0xFF);
                 out[px + i] = static_cast<int16_t>((packed[i] >> 8) & 0xFF);

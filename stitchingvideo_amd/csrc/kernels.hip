@@ -455,9 +455,33 @@ __global__ __launch_bounds__(256) void k_payload_copy(const CamDesc* __restrict_
 {
     const PayloadRect r = rects[blockIdx.x];
     const CamDesc& c = *cam;
-    uint32_t MST_GLOBAL* __restrict__ g = gp(c.G[r.level]);
     uint32_t MST_GLOBAL* __restrict__ b = gp(buf) + r.off;
-    const int lw = c.lw[r.level], n = r.w * r.h;
+    const int n = r.w * r.h;
+    if (r.level == 0) {
+        // level 0 is packed BGR8 in the pyramid (device_types.hpp) and in the payload: 3 w h bytes, rows back to back.  Rectangles
+        // that start on a four-pixel group and are whole groups wide (every tile interior but the last of a row) move as
+        // 12-byte groups, the others byte by byte.
+        uint8_t MST_GLOBAL* __restrict__ g8 = (uint8_t MST_GLOBAL*)c.G[0];
+        uint8_t MST_GLOBAL* __restrict__ b8 = (uint8_t MST_GLOBAL*)b;
+        if (((r.x0 | r.w) & 3) == 0) {
+            const int gw = r.w >> 2;
+            for (int i = threadIdx.x; i < gw * r.h; i += 256) {
+                const int y = i / gw, g = i - y * gw;
+                u32x3_t MST_GLOBAL* p = (u32x3_t MST_GLOBAL*)(g8 + static_cast<size_t>(r.y0 + y) * c.l0_pitch + 3 * static_cast<size_t>(r.x0 + 4 * g));
+                u32x3_t MST_GLOBAL* q = (u32x3_t MST_GLOBAL*)(b8 + 12 * static_cast<size_t>(i));
+                if (PACK) *q = *p; else *p = *q;
+            }
+        } else {
+            for (int i = threadIdx.x; i < 3 * n; i += 256) {
+                const int y = i / (3 * r.w), xb = i - y * (3 * r.w);
+                uint8_t MST_GLOBAL* p = g8 + static_cast<size_t>(r.y0 + y) * c.l0_pitch + 3 * static_cast<size_t>(r.x0) + xb;
+                if (PACK) b8[i] = *p; else *p = b8[i];
+            }
+        }
+        return;
+    }
+    uint32_t MST_GLOBAL* __restrict__ g = gp(c.G[r.level]);
+    const int lw = c.lw[r.level];
     for (int i = threadIdx.x; i < n; i += 256) {
         const int y = i / r.w, x = i - y * r.w;
         const size_t gi = static_cast<size_t>(r.y0 + y) * lw + (r.x0 + x);

@@ -68,6 +68,31 @@ namespace {
 // two dwords in global memory: a pixel pair of a Gaussian level, or a pixel of the collapsed level-1 canvas (HIP's uint2
 // class cannot be used through address-space pointers)
 typedef uint32_t __attribute__((ext_vector_type(2))) GPix;
+// ---- level 0 of a camera's pyramid: packed BGR8 (device_types.hpp) ----
+// eight bytes at a 2-byte-aligned address (gfx950 under HSA serves unaligned global accesses): a pixel pair's six bytes
+// B0 G0 R0 B1 | G1 R1 . .  (the buffers carry 16 bytes of slack behind the last row)
+typedef GPix __attribute__((aligned(2))) GPixU;
+typedef uint32_t __attribute__((aligned(1))) U32U;
+__device__ __forceinline__ const uint8_t MST_GLOBAL* l0_at(const CamDesc& c, int lx, int ly)
+{
+    return (const uint8_t MST_GLOBAL*)c.G[0] + (__umul24(static_cast<uint32_t>(ly), static_cast<uint32_t>(c.l0_pitch)) + 3u * static_cast<uint32_t>(lx));
+}
+// pixels (lx, ly) and (lx + 1, ly) as the dwords the other levels store (B | G << 8 | R << 16; byte 3 of .x is B1: ignored by
+// every reader, which extract bytes 0 .. 2)
+__device__ __forceinline__ uint2 l0_pair(const CamDesc& c, int lx, int ly)
+{
+    const GPix v = *(const GPixU MST_GLOBAL*)l0_at(c, lx, ly);
+    return make_uint2(v.x, __builtin_amdgcn_alignbyte(v.y, v.x, 3));
+}
+__device__ __forceinline__ uint32_t l0_px(const CamDesc& c, int lx, int ly)
+{
+    return *(const U32U MST_GLOBAL*)l0_at(c, lx, ly);
+}
+// four level-0 pixels (dwords) -> their twelve packed bytes
+__device__ __forceinline__ u32x3_t l0_pack4(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3)
+{
+    return u32x3_t{__builtin_amdgcn_perm(p1, p0, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
+}
 __device__ __forceinline__ uint32_t lanes_br(uint32_t p) { return p & 0x00FF00FFu; }
 __device__ __forceinline__ uint32_t lane_g(uint32_t p) { return (p >> 8) & 0xFFu; }
 
@@ -434,7 +459,6 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     const CamDesc& c = cams[cam];
     const int bw = c.lw[0], bh = c.lh[0], nlev = c.nlev;
     const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;    // level-0 origin of the halo'd tile
-    uint32_t MST_GLOBAL* __restrict__ g0out = gp(c.G[0]);
     uint32_t MST_GLOBAL* __restrict__ g1out = gp(c.G[1]);
     const int lw1 = c.lw[1], lh1 = c.lh[1];
 
@@ -475,7 +499,6 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     // L2 -- which tied the loop to the write latency (11.6 of this kernel's 37.5 us per frame set, by ablation).
     // (Nor a store behind a uniform condition: the branch alone cuts the loop body into basic blocks and pins the
     // loads behind it.  Levels whose rows are not 16-byte aligned -- one band -- take a dword-wide pass instead.)
-    const bool wide_rows = (bw & 3) == 0;
     auto emit = [&](int row, uint32_t px) { s_l0[row][col] = px; };
     const int row_last = row0 + A_ROWS_PER_THREAD - 1;
     const uint32_t* __restrict__ tcol = tab + col;
@@ -540,31 +563,25 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
     MST_STAMP(0, 2);
     __syncthreads();
     const bool store0 = !(t >> 31) || (MST_ABLATE_A & 256);    // (bit 31: nothing reads this tile's level 0 from memory, see mb_plan.cpp)
-    if (!store0) {
-    } else if (!wide_rows) {
-        for (int i = tid; i < A_TH0 * A_TW0; i += 256) {
-            const int r = i / A_TW0, cc = i - r * A_TW0;
-            const int gy = ly0 + 2 + r, gxx = lx0 + 2 + cc;
-            if (gy < bh && gxx < bw) g0out[__umul24(gy, bw) + gxx] = s_l0[2 + r][2 + cc];
-        }
-    } else if (!(MST_ABLATE_A & 128)) {
-        // interior of the tile, four pixels (16 bytes) per lane: a tile row is 31 such groups, and because the level
-        // width is a multiple of four and the tile origin a multiple of 124, a group lies inside the level as a whole
-        // or not at all, and is 16-byte aligned in global memory (8-byte aligned in LDS: the interior starts at column 2)
+    if (store0 && !(MST_ABLATE_A & 128)) {
+        // interior of the tile as packed BGR8, four pixels (twelve bytes) per lane: a tile row is 31 such groups; the tile
+        // origin is a multiple of 124 and the row pitch covers whole groups, so a group that starts inside the level is
+        // stored whole, dword-aligned (8-byte aligned in LDS: the interior starts at column 2)
         constexpr int kGroups = A_TW0 / 4;
+        uint8_t MST_GLOBAL* __restrict__ g0b = (uint8_t MST_GLOBAL*)c.G[0];
+        const uint32_t pitch0 = static_cast<uint32_t>(c.l0_pitch);
         for (int i = tid; i < A_TH0 * kGroups; i += 256) {
             const int r = i / kGroups, g = i - r * kGroups;
             const int gy = ly0 + 2 + r, gx4 = lx0 + 2 + 4 * g;
             if (gy >= bh || gx4 >= bw) continue;
             const uint2 lo = *reinterpret_cast<const uint2*>(&s_l0[2 + r][2 + 4 * g]);
             const uint2 hi = *reinterpret_cast<const uint2*>(&s_l0[2 + r][4 + 4 * g]);
-            typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 #if !defined(MST_NO_NT_STORE)
             // (non-temporal: level 0 is next read a whole batch later, by k_blend_fine; keeping it out of the caches
             // leaves them to the frames and the map table: k_warp_pyr 287.5 -> 274.0 us per 8 frame sets)
-            __builtin_nontemporal_store(u32x4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<u32x4 MST_GLOBAL*>(g0out + __umul24(gy, bw) + gx4));
+            __builtin_nontemporal_store(l0_pack4(lo.x, lo.y, hi.x, hi.y), reinterpret_cast<u32x3_t MST_GLOBAL*>(g0b + __umul24(gy, pitch0) + 3u * gx4));
 #else
-            *reinterpret_cast<u32x4 MST_GLOBAL*>(g0out + __umul24(gy, bw) + gx4) = u32x4{lo.x, lo.y, hi.x, hi.y};
+            *reinterpret_cast<u32x3_t MST_GLOBAL*>(g0b + __umul24(gy, pitch0) + 3u * gx4) = l0_pack4(lo.x, lo.y, hi.x, hi.y);
 #endif
         }
     }
@@ -790,9 +807,11 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
     const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;
     const bool store0 = !(t >> 31);                 // (bit 31: nothing reads this tile's level 0 from memory, see mb_plan.cpp)
     if (store0) {
-        uint32_t MST_GLOBAL* __restrict__ g0out = gp(c.G[0]);
+        // packed BGR8, twelve bytes per group of four pixels (gx is a multiple of four and the row pitch a multiple of twelve
+        // that covers the last group whole: no partial store)
+        uint8_t MST_GLOBAL* __restrict__ g0out = (uint8_t MST_GLOBAL*)c.G[0];
+        const uint32_t pitch0 = static_cast<uint32_t>(c.l0_pitch);
         constexpr int kGroups = A_TW0 / 4;
-        const bool wide = (bw & 3) == 0;
 #pragma unroll
         for (int i0 = 0; i0 < A_TH0 * kGroups; i0 += A2_NT) {
             const int i = i0 + tid;
@@ -801,14 +820,7 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
             const int gy = ly0 + 2 + r, gx = lx0 + 2 + 4 * g;
             if (i >= A_TH0 * kGroups || gy >= bh || gx >= bw) continue;
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(s_mem + (2 + r) * A2_TPITCH + A2_TOFF + 2 + 4 * g);
-            uint32_t MST_GLOBAL* o = g0out + __umul24(gy, bw) + gx;
-            if (wide) {
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t MST_GLOBAL*>(o));
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (gx + k < bw) o[k] = v[k];
-            }
+            __builtin_nontemporal_store(l0_pack4(v.x, v.y, v.z, v.w), reinterpret_cast<u32x3_t MST_GLOBAL*>(g0out + __umul24(gy, pitch0) + 3u * gx));
         }
     }
     if (nlev < 2) return;
@@ -1243,11 +1255,11 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
         if (TOP) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                g[q] = valid[q] ? gp(c.G[l])[__umul24(ly + (q >> 1), lw) + lx + (q & 1)] : 0u;
+                g[q] = !valid[q] ? 0u : FINAL ? l0_px(c, lx + (q & 1), ly + (q >> 1)) : gp(c.G[l])[__umul24(ly + (q >> 1), lw) + lx + (q & 1)];
         } else {
             const uint32_t off = __umul24(ly, lw) + lx;
-            const uint2 g0 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off));
-            const uint2 g1 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off + lw));
+            const uint2 g0 = FINAL ? l0_pair(c, lx, ly) : load_global(reinterpret_cast<const uint2*>(c.G[l] + off));
+            const uint2 g1 = FINAL ? l0_pair(c, lx, ly + 1) : load_global(reinterpret_cast<const uint2*>(c.G[l] + off + lw));
             uint32_t nb[3][3];
             const int sw = c.lw[l + 1], sh = c.lh[l + 1];
             int jm, jp, im, ip;
@@ -1306,7 +1318,7 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
                     } else {
                         w[q] = gp(c.W[l])[off];
                     }
-                    g[q] = gp(c.G[l])[off];
+                    g[q] = FINAL ? l0_px(c, px, py) : gp(c.G[l])[off];
                     any = true;
                 }
             }
@@ -1337,8 +1349,8 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (!valid[q]) w[q] = 0.f;
             if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;   // also adds nothing to ws
-            const uint2 g0 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off));
-            const uint2 g1 = load_global(reinterpret_cast<const uint2*>(c.G[l] + off + lw));
+            const uint2 g0 = FINAL ? l0_pair(c, lx, ly) : load_global(reinterpret_cast<const uint2*>(c.G[l] + off));
+            const uint2 g1 = FINAL ? l0_pair(c, lx, ly + 1) : load_global(reinterpret_cast<const uint2*>(c.G[l] + off + lw));
             {
                 const int sw = c.lw[l + 1], sh = c.lh[l + 1];
                 int jm, jp, im, ip;
@@ -1702,6 +1714,7 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
     static_assert(C_TW == 128 && CC_TW == 128 && (kTileH / 2) % (NT / 64) == 0, "one wave per quad row of the tile");
     static_assert(L == 0 || (NC == 1 && !MASKED), "masks are level-0 weights");
     constexpr int kRows = (kTileH / 2) / (NT / 64);              // quad rows per wave
+    constexpr bool kPair = L == 0 && NC == 1;                    // level 0, one camera: lane pairs share aligned 12-byte loads
     const int lane = static_cast<int>(threadIdx.x & 63u);
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int uw = a.cw[L + 1], uh = a.ch[L + 1];
@@ -1716,7 +1729,9 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
 
     struct Cam {
         const uint32_t MST_GLOBAL* gup;      // Gaussian level L + 1
-        const GPix MST_GLOBAL* gq;           // this lane's quad of level L, upper row (advanced as the strip is walked)
+        const GPix MST_GLOBAL* gq;           // this lane's quad of level L, upper row (advanced as the strip is walked); level 0: the
+                                             // quad's six packed bytes (2-byte aligned), rows gpitch bytes apart
+        uint32_t gpitch;
         const uint8_t MST_GLOBAL* mq;        // MASKED: this lane's quad of the bordered level-0 mask
         int lw, sw, sh, i0, j, je;
     } cam[NC];
@@ -1736,7 +1751,17 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
             k.je = first ? jm : jp;
             k.gup = gp(c.G[L + 1]);
             const uint32_t off = __umul24(ly0, k.lw) + lx;
-            k.gq = (const GPix MST_GLOBAL*)(c.G[L] + off);
+            k.gpitch = L == 0 ? static_cast<uint32_t>(c.l0_pitch) : static_cast<uint32_t>(k.lw) * 4u;
+            // Level 0 (packed BGR8): a lane pair (2 i, 2 i + 1) covers four pixels = twelve bytes per row.  One camera (kPair;
+            // the caller guarantees that a pair's pixels start on a 12-byte group of the camera's rows: window origins are
+            // multiples of 2^bands, i.e. always from two bands on): the even lane loads the upper row's twelve bytes, the odd lane
+            // the lower row's -- ONE aligned load per lane and quad row instead of two -- and the halves are swapped over DPP.
+            // Two cameras: every lane loads its own six bytes of both rows (2-byte aligned 8-byte loads; that path sets the
+            // kernel's register allocation -- 128 VGPRs, four waves per SIMD -- and the pairing's temporaries would push it to 132
+            // and three).  Compile-time, not a flag: a branch around the loads of the unrolled walk costs the overlap of one
+            // quad row's loads with the row before (k_blend_fine 16.5 -> 20.3 us per frame set, measured).
+            if (L == 0) k.gq = (const GPix MST_GLOBAL*)(kPair ? l0_at(c, lx - (odd ? 2 : 0), ly0 + (odd ? 1 : 0)) : l0_at(c, lx, ly0));
+            else k.gq = (const GPix MST_GLOBAL*)(c.G[L] + off);
             k.mq = MASKED ? gp(c.mask_b) + off : nullptr;
         }
     }
@@ -1787,17 +1812,37 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
             q.q0 = GPix{static_cast<uint32_t>(x * 3 + k.j), static_cast<uint32_t>(x * 5 + k.j)};
             q.q1 = GPix{static_cast<uint32_t>(x * 7 + k.j), static_cast<uint32_t>(x * 11 + k.j)};
         } else {
+            // (level 0 of a camera is read exactly once per frame set: streamed past the caches -- non-temporal -- which leaves
+            // them to the level-1 rows the strips above and below re-read: k_blend_fine 169.6 -> 160.4 us per 8 frame sets)
+            if (kPair) {
+                typedef u32x3_t __attribute__((aligned(4))) U32x3A;
 #if !defined(MST_NO_NT_LOAD)
-            // level 0 of a camera is read exactly once per frame set: streamed past the caches (non-temporal), which leaves
-            // them to the level-1 rows the strips above and below re-read (k_blend_fine 169.6 -> 160.4 us per 8 frame sets)
-            if (L == 0) {
-                q.q0 = __builtin_nontemporal_load(k.gq);
-                q.q1 = __builtin_nontemporal_load((const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)k.gq + k.lw));
-            } else
+                const u32x3_t d = __builtin_nontemporal_load((const U32x3A MST_GLOBAL*)k.gq);
+#else
+                const u32x3_t d = *(const U32x3A MST_GLOBAL*)k.gq;
 #endif
-            {
+                // my row's twelve bytes (even lane: upper row, odd lane: lower row) and the partner's
+                const uint32_t p0 = lane_swap1(d.x), p1 = lane_swap1(d.y), p2 = lane_swap1(d.z);
+                // even lane: pixels 0, 1 = bytes 0 .. 5 of both rows; odd lane: pixels 2, 3 = bytes 6 .. 11
+                q.q0.x = odd ? __builtin_amdgcn_alignbyte(p2, p1, 2) : d.x;
+                q.q0.y = odd ? p2 >> 16 : d.y;
+                q.q1.x = odd ? __builtin_amdgcn_alignbyte(d.z, d.y, 2) : p0;
+                q.q1.y = odd ? d.z >> 16 : p1;
+            } else if (L == 0) {
+#if !defined(MST_NO_NT_LOAD)
+                q.q0 = __builtin_nontemporal_load((const GPixU MST_GLOBAL*)k.gq);
+                q.q1 = __builtin_nontemporal_load((const GPixU MST_GLOBAL*)((const uint8_t MST_GLOBAL*)k.gq + k.gpitch));
+#else
+                q.q0 = *(const GPixU MST_GLOBAL*)k.gq;
+                q.q1 = *(const GPixU MST_GLOBAL*)((const uint8_t MST_GLOBAL*)k.gq + k.gpitch);
+#endif
+            } else {
                 q.q0 = k.gq[0];
                 q.q1 = *(const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)k.gq + k.lw);
+            }
+            if (L == 0) {      // B0 G0 R0 B1 | G1 R1 . . -> the second pixel as a dword of its own (byte 3 of either is never read)
+                q.q0.y = __builtin_amdgcn_alignbyte(q.q0.y, q.q0.x, 3);
+                q.q1.y = __builtin_amdgcn_alignbyte(q.q1.y, q.q1.x, 3);
             }
         }
         q.m = 0xFFFFFFFFu;
@@ -1849,7 +1894,7 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
                 load_g(wg[n], cam[n], min(cam[n].i0 + t + 2, cam[n].sh - 1));
-                cam[n].gq = (const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)cam[n].gq + 2 * cam[n].lw);
+                cam[n].gq = (const GPix MST_GLOBAL*)((const uint8_t MST_GLOBAL*)cam[n].gq + 2u * cam[n].gpitch);
                 if (MASKED) cam[n].mq += 2 * cam[n].lw;
                 load_quad(qn[n], cam[n]);
             }
@@ -2237,6 +2282,10 @@ __global__ __launch_bounds__(NT, MST_C_WAVES) void k_blend_mid(const CamDesc* __
 
 // Canvas kernel 2 of 2: level 0, one block per C_TW x C_TH tile of the panorama: level-0 band + pyrUp of the
 // collapsed level-1 canvas (k_blend_coarse) -> crop, mask, convertTo(8U) -> panorama.  No LDS, no barrier.
+// (One kernel for every tile class on purpose.  Round 4 tried one launch per class -- the owned tiles' streaming path then
+// compiles to 84 VGPRs instead of the 128 the two-camera path dictates -- and lost: 25.8 us per frame set against 16.5,
+// the short lists run one after the other with their tails exposed, and the owned tiles alone took as long as everything
+// together did; profiles/r04_experiments.md.)
 template <bool W16, int NT>
 __global__ __launch_bounds__(NT, MST_C_WAVES) void k_blend_fine(const CamDesc* __restrict__ cams_all, BlendArgs a)
 {
@@ -2283,8 +2332,12 @@ __global__ __launch_bounds__(NT, MST_C_WAVES) void k_blend_fine(const CamDesc* _
     const bool full = r0.x1 - r0.x0 == C_TW && r0.y1 - r0.y0 == C_TH && r0.x1 <= a.final_w && r0.y1 <= a.final_h;
     const bool strip = full && !(MST_ABLATE_C & 64);
     const bool binary = !(MST_ABLATE_C & 512) && (entry >> 30) & 1u;      // 0/1 weights, disjoint, windows cover the tile
-    if (own0 && strip) owned_strip<0, 1, false, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
-    else if (binary && strip && (cam_bits & (cam_bits - 1)) == 0) owned_strip<0, 1, true, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    // (the one-camera strips load level 0 by lane pairs: four pixels from a 12-byte group of the camera's rows)
+    const bool one = (cam_bits & (cam_bits - 1)) == 0;
+    const bool pair_ok = one && ((r0.x0 - cams[__builtin_ctz(cam_bits)].ox[0]) & 3) == 0;
+    if (own0 && strip && pair_ok) owned_strip<0, 1, false, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (binary && strip && pair_ok) owned_strip<0, 1, true, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
+    else if (binary && strip && one) final_level<NT, false, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
     else if (binary && strip) owned_strip<0, 2, true, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
     else if (own0) final_level<NT, false, true>(cams, a, r0, cam_bits, c1, pano, pano_mask);
     else final_level<NT, false, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);

@@ -391,7 +391,10 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
                 h = std::min(h, d.lh[level] - y0);
                 if (w <= 0 || h <= 0) return;
                 plan.payload_rects.push_back(PayloadRect{level, x0, y0, w, h, off});
-                off += static_cast<uint32_t>(w) * static_cast<uint32_t>(h);
+                // (`off` counts dwords: a pixel of the levels above 0, three quarters of one -- packed BGR8, rounded up per
+                // rectangle -- on level 0)
+                const uint32_t px = static_cast<uint32_t>(w) * static_cast<uint32_t>(h);
+                off += level == 0 ? (3u * px + 3u) / 4u : px;
             };
             for (int i = plan.warp_cam_start[c]; i < plan.warp_cam_start[c + 1]; ++i) {
                 const uint32_t t = plan.warp_tiles[i];

@@ -68,10 +68,10 @@ def test_full_size_c4_camera_sharded_two_engines():
         e0.stage_canvas(pano.data_ptr(), pano.stride(0), stream=stream.cuda_stream)
     stream.synchronize()
     # the hand-off is the launched tile interiors only: every camera -- the wrap-around one (roi 11308 x 1050, pyramid
-    # block 64 MB) included -- ships a payload of a 1080p camera's size
+    # block 52 MB: level 0 packed BGR8, the levels above a dword a pixel) included -- ships a payload of a 1080p camera's size
     sizes = [e0.payload_bytes(c) for c in range(n)]
     blocks = [e0.pyramid_buffer(c)[1] for c in range(n)]
-    assert max(blocks) > 60e6 and max(sizes) <= 20e6, (sizes, blocks)
+    assert max(blocks) > 45e6 and max(sizes) <= 20e6, (sizes, blocks)
     assert moved == sum(sizes[c] for c in mine1)
     rect, opano, omask = H.oracle_compose(rig, frames, threads=THREADS)
     assert e0.canvas() == rect
