@@ -743,7 +743,7 @@ void Engine::update(const mst_calibration& calib)
             static const std::vector<int> classes_all_kb = [] {
                 std::vector<int> v;
                 const char* e = std::getenv("MST_WARP_LDS_CLASSES");
-                for (const char* p = e ? e : "36,72"; *p;) { v.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+                for (const char* p = e ? e : "40,72"; *p;) { v.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
                 return v;
             }();
             // (classes the device cannot grant are dropped: their tiles stay with the gathering kernel)
@@ -929,13 +929,8 @@ void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameB
     mark(launch_warp_pyr(desc, st.n, map_kind(), tg, fb, count, st.warp_table, st.warp_blobs, s));     // (the short list first)
     for (int c = static_cast<int>(st.warp_classes.size()) - 1; c >= 0; --c) {       // (the large-window classes first: fewer, longer blocks)
         const CalibState::WarpClass& wc = st.warp_classes[c];
-        static const bool no_pipe = [] { const char* v = std::getenv("MST_WARP_PIPE"); return v && v[0] == '0'; }();      // A/B timing
-        if (no_pipe)
-            mark(launch_warp_pyr_lds(desc, st.n, wc.start[cam1] - wc.start[cam0], fb, count, st.warp_table_lds, st.warp_gain_lds,
-                                     wc.d_wins + wc.start[cam0], wc.lds_bytes, s));
-        else
-            mark(launch_warp_pyr_pipe(desc, st.n, wc.start[cam1] - wc.start[cam0], fb, count, st.warp_table_lds, st.warp_gain_lds,
-                                      wc.d_wins + wc.start[cam0], wc.lds_bytes, s));
+        mark(launch_warp_pyr_lds(desc, st.n, wc.start[cam1] - wc.start[cam0], fb, count, st.warp_table_lds, st.warp_gain_lds,
+                                 wc.d_wins + wc.start[cam0], wc.lds_bytes, s));
     }
 }
 

@@ -74,10 +74,6 @@ void launch_warp_table_lds(const CamDesc* d_cams, int kind, const TileList& list
                            int lds_budget_px, hipStream_t s);
 const char* launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, int n_tiles, const FrameBatch& frames, int batch,
                                 const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s);
-// the same tiles by blocks that walk several (tile, frame set) items each, the next item's window and table rows requested
-// while the current one is sampled (k_warp_pyr_pipe); windows it cannot hold in registers go to launch_warp_pyr_lds
-const char* launch_warp_pyr_pipe(const CamDesc* d_cams, int n_cams, int n_tiles, const FrameBatch& frames, int batch,
-                                 const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s);
 const char* launch_pyr_chain(const CamDesc* d_cams, int n_cams, const TileList& list, int base, int k, int batch, hipStream_t s);
 // the streaming form of one pyrDown level (level -> level + 1): units of mb_stream_unit_cols() output columns x mb_stream_unit_rows() output
 // rows (cam << 24 | uy << 12 | ux), one wave each; source levels of even size only

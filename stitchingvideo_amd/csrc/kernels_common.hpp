@@ -406,48 +406,6 @@ __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const
     }
 }
 
-// stage_window in two halves, for blocks that walk several tiles (k_warp_pyr_pipe): stage_issue puts the loads of a whole
-// window into registers -- U trips of NT groups, none awaited -- and stage_commit, any amount of work later, writes the
-// 4-byte pixels into LDS.  Between the two the block samples the window that IS in LDS: the round trip of the next window
-// runs beside the arithmetic of this one.  Plain loads, not asm (round 4 tried the asm form of stage_window first: seven
-// live 96-bit asm operands on top of the sampler's registers made the allocator spill, and every scratch reload is a
-// vmcnt(0) -- which is the wait the scheme exists to avoid): the compiler counts vmcnt itself; what the caller must do is
-// keep every wait of its own away from the span between issue and commit (see k_warp_pyr_pipe).
-typedef u32x3_t __attribute__((aligned(4))) u32x3_a4;
-template <int NT, int U>
-__device__ __forceinline__ void stage_issue(u32x3_t (&d)[U], const uint8_t MST_GLOBAL* __restrict__ base, uint32_t stride, int groups, int rows, int tid)
-{
-    const uint32_t inv = ((1u << 20) + groups - 1) / groups;      // i / groups == (i * inv) >> 20 for i < 4096, groups <= 256
-    const int step_r = static_cast<int>((static_cast<uint32_t>(NT) * inv) >> 20), step_g = NT - step_r * groups;
-    int r = static_cast<int>((static_cast<uint32_t>(tid) * inv) >> 20), g = tid - r * groups;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        // trips past the end re-read the window's last row: a load that is always legal needs no branch around it (and the
-        // number of loads in flight is the same for every window: the compiler's vmcnt counts stay exact)
-        const uint32_t off = static_cast<uint32_t>(min(r, rows - 1)) * stride + static_cast<uint32_t>(g) * 12u;
-        d[u] = *(const u32x3_a4 MST_GLOBAL*)(base + off);
-        r += step_r; g += step_g;
-        if (g >= groups) { g -= groups; ++r; }
-    }
-}
-template <int NT, int U>
-__device__ __forceinline__ void stage_commit(const u32x3_t (&d)[U], uint32_t* __restrict__ s_win, int groups, int rows, int tid)
-{
-    const int n = groups * rows;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int i = tid + u * NT;
-        if (i < n) {
-            u32x4_t p;
-            p.x = d[u].x;                                            // B0 G0 R0 (B1)
-            p.y = __builtin_amdgcn_alignbyte(d[u].y, d[u].x, 3);     // B1 G1 R1 (B2)
-            p.z = __builtin_amdgcn_alignbyte(d[u].z, d[u].y, 2);     // B2 G2 R2 (B3)
-            p.w = d[u].z >> 8;                                       // B3 G3 R3 0
-            *reinterpret_cast<u32x4_t*>(&s_win[i * 4]) = p;          // (row r, group g) sits at r * groups + g == i
-        }
-    }
-}
-
 typedef unsigned short __attribute__((ext_vector_type(2))) us2;
 __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
 {

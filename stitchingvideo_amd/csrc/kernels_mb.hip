@@ -854,164 +854,6 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
     MST_STAMP_VAL(0, 8, static_cast<unsigned long long>(w.groups) * 16u * w.rows);
 }
 
-// ------------------------------------------------------------------------------------------------------
-// A, staged and pipelined (round 4): a block walks A3_WALK consecutive (tile, frame set) items of its XCD's run
-// ------------------------------------------------------------------------------------------------------
-// In-kernel stamps of k_warp_pyr_lds (tools/stamps.sh): of the 18.7 k cycles a block lives, 7.8 k pass between the first
-// table load and the window being in LDS -- two memory round trips in which the block's six waves issue nothing -- and
-// only 5.4 k (sampling, pyrDown) are arithmetic; three to four such blocks per CU leave the vector units idle 43 % of the
-// time.  Deeper batches of staging loads and finer window classes changed nothing (the blocks' phases drift together).
-// Here the round trip of item n + 1 runs beside the arithmetic of item n inside one block: its window is requested into
-// registers (stage_issue: up to A3_U trips of 12 bytes per lane) before item n is sampled, and its table / gain rows
-// right after (into the registers item n's rows have just left); both are awaited once, behind the pyrDown of item n
-// (stage_commit), when they have long arrived.  One LDS buffer as before (window -> tile -> next window).
-// Items of a block are consecutive entries of its XCD's run (xcd_run_index), A3_WALK per block.
-#ifndef MST_A3_WALK
-#define MST_A3_WALK 8
-#endif
-constexpr int A3_WALK = MST_A3_WALK;
-#ifndef MST_A3_WAVES
-#define MST_A3_WAVES 5      // waves per SIMD the register allocation must allow for windows up to 43 KB
-#endif
-template <int U>
-__global__ __launch_bounds__(A2_NT, U <= 7 ? MST_A3_WAVES : 3) void k_warp_pyr_pipe(const CamDesc* __restrict__ cams_all, int n_tiles, FrameBatch batch,
-                                                         const uint32_t* __restrict__ table, const float* __restrict__ gain,
-                                                         const WarpWin* __restrict__ wins, int n_cams, int n_sets)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];     // the staged window, then the level-0 tile [A_LH][A2_TPITCH]
-    const int tid0 = threadIdx.x;
-    // this block's items: A3_WALK consecutive entries of the run of XCD k = blockIdx.x % 8
-    const int n_items = n_tiles * n_sets;
-    const int xk = blockIdx.x & 7, xj = blockIdx.x >> 3;
-    const int run_len = (n_items >> 3) + (xk < (n_items & 7) ? 1 : 0), run_start = xk * (n_items >> 3) + min(xk, n_items & 7);
-    const int first = xj * A3_WALK, count = min(A3_WALK, run_len - first);
-    if (count <= 0) return;
-    typedef float __attribute__((ext_vector_type(4))) f32x4_t;
-    struct Item { WarpWin w; int set; const uint8_t MST_GLOBAL* src; uint32_t stride; };
-    auto item_at = [&](int i) {
-        Item it;
-        const int pair = run_start + first + i;
-        it.set = pair % n_sets;
-        it.w = wins[pair / n_sets];
-        const int cam = (it.w.tile >> 24) & 0x7F;
-        it.stride = batch.f[it.set].stride[cam];
-        it.src = gp(batch.f[it.set].ptr[cam]) + (static_cast<size_t>(it.w.by) * it.stride + static_cast<size_t>(it.w.wx0) * 3u);
-        return it;
-    };
-    auto rows_of = [&](const Item& it, u32x4_t (&e)[A2_ROWS], f32x4_t (&g)[A2_ROWS], int lane, int rgrp) {
-        const size_t tbl = static_cast<size_t>(it.w.index) * (A_LH * A_LW) + (rgrp * A2_ROWS) * A_LW + lane * 4;
-#pragma unroll
-        for (int r = 0; r < A2_ROWS; ++r) {
-            e[r] = *(const u32x4_t MST_GLOBAL*)(table + tbl + r * A_LW);
-            g[r] = *(const f32x4_t MST_GLOBAL*)(gain + tbl + r * A_LW);
-        }
-    };
-    u32x3_t d[U];
-    u32x4_t e_r[A2_ROWS];
-    f32x4_t g_r[A2_ROWS];
-    Item cur = item_at(0);
-    rows_of(cur, e_r, g_r, tid0 & 31, (tid0 >> 6) * 2 + ((tid0 >> 5) & 1));
-    stage_issue<A2_NT, U>(d, cur.src, cur.stride, cur.w.groups, cur.w.rows, tid0);
-    stage_commit<A2_NT, U>(d, s_mem, cur.w.groups, cur.w.rows, tid0);
-#pragma nounroll
-    for (int i = 0; i < count; ++i) {
-        // (the rows' loads are older than everything issued below: declared consumed here, so that the compiler does not
-        // count a wait for them past the window loads of the next item)
-        asm volatile("" : "+v"(e_r[0]), "+v"(e_r[1]), "+v"(e_r[2]), "+v"(g_r[0]), "+v"(g_r[1]), "+v"(g_r[2]));
-        static_assert(A2_ROWS == 3, "operand list above");
-        // Per-thread indices are re-derived from an opaque copy of the thread index in every trip: left visible, the
-        // compiler hoists every LDS / table offset of the body out of the loop and keeps ~40 of them alive across it
-        // (registers the window in flight needs; measured: 112 bytes of scratch per lane at five waves per SIMD).
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 31;
-        const int rgrp = (tid >> 6) * 2 + ((tid >> 5) & 1);
-        __syncthreads();                                // window i is in LDS
-        const bool more = i + 1 < count;
-        Item nxt = cur;
-        if (more) {
-            nxt = item_at(i + 1);
-            stage_issue<A2_NT, U>(d, nxt.src, nxt.stride, nxt.w.groups, nxt.w.rows, tid);
-        }
-        const uint32_t t = cur.w.tile;
-        const int cam = (t >> 24) & 0x7F, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
-        const CamDesc& c = cams_all[cur.set * n_cams + cam];
-        const int bw = c.lw[0], bh = c.lh[0], nlev = c.nlev;
-        const uint32_t pitch_b = static_cast<uint32_t>(cur.w.groups) * 16u;
-        const char* win = reinterpret_cast<const char*>(s_mem);
-        uint32_t px[A2_ROWS][4];
-#pragma unroll
-        for (int it = 0; it < A2_ROWS; ++it)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t e = e_r[it][k];
-                const uint32_t addr = e & (kA2MaxWindowBytes - 1u);
-                const uint32_t* p0 = reinterpret_cast<const uint32_t*>(win + addr);
-                const uint32_t* p1 = reinterpret_cast<const uint32_t*>(win + addr + pitch_b);
-                px[it][k] = sample_taps(p0[0], p0[1], p1[0], p1[1], (e >> 17) & 63u, (e >> 23) & 63u, g_r[it][k]);
-            }
-        // the next item's rows, into the registers this item's have just left (the fence keeps the scheduler from lifting
-        // these loads above the sampling, where they would need 24 registers of their own: spills, and a scratch reload is
-        // a vmcnt(0))
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) rows_of(nxt, e_r, g_r, lane, rgrp);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                // every wave is done with the window: the tile takes its place
-#pragma unroll
-        for (int it = 0; it < A2_ROWS; ++it) {
-            uint32_t* trow = s_mem + (rgrp * A2_ROWS + it) * A2_TPITCH + A2_TOFF + lane;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) trow[32 * k] = px[it][k];
-        }
-        __syncthreads();
-        const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;
-        if (!(t >> 31)) {               // (bit 31: nothing reads this tile's level 0 from memory, see mb_plan.cpp)
-            uint8_t MST_GLOBAL* __restrict__ g0out = (uint8_t MST_GLOBAL*)c.G[0];
-            const uint32_t pitch0 = static_cast<uint32_t>(c.l0_pitch);
-            constexpr int kGroups = A_TW0 / 4;
-#pragma unroll
-            for (int i0 = 0; i0 < A_TH0 * kGroups; i0 += A2_NT) {
-                const int q = i0 + tid;
-                const int r = static_cast<int>((static_cast<uint32_t>(q) * 2115u) >> 16);       // q / 31 for q < 1984
-                const int g = q - r * kGroups;
-                const int gy = ly0 + 2 + r, gx = lx0 + 2 + 4 * g;
-                if (q >= A_TH0 * kGroups || gy >= bh || gx >= bw) continue;
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(s_mem + (2 + r) * A2_TPITCH + A2_TOFF + 2 + 4 * g);
-                __builtin_nontemporal_store(l0_pack4(v.x, v.y, v.z, v.w), reinterpret_cast<u32x3_t MST_GLOBAL*>(g0out + __umul24(gy, pitch0) + 3u * gx));
-            }
-        }
-        if (nlev >= 2) {
-            uint32_t MST_GLOBAL* __restrict__ g1out = gp(c.G[1]);
-            const int lw1 = c.lw[1], lh1 = c.lh[1];
-            const int x1 = tx * A_TW1, y1 = ty * A_TH1;
-            constexpr int R = A_TH1 / 4;
-            if (tid < 4 * A_TW1) {
-                const int g = tid / A_TW1, j = tid - g * A_TW1;
-                uint32_t hbr[2 * R + 3], hg[2 * R + 3];
-#pragma unroll
-                for (int r = 0; r < 2 * R + 3; ++r) {
-                    const uint32_t* p = s_mem + (2 * R * g + r) * A2_TPITCH + A2_TOFF + 2 * j;
-                    const uint2 p01 = *reinterpret_cast<const uint2*>(p);
-                    const uint2 p23 = *reinterpret_cast<const uint2*>(p + 2);
-                    tap5(p01.x, p01.y, p23.x, p23.y, p[4], hbr[r], hg[r]);
-                }
-#pragma unroll
-                for (int o = 0; o < R; ++o) {
-                    const int ii = R * g + o;
-                    if (x1 + j >= lw1 || y1 + ii >= lh1) continue;
-                    const uint32_t vbr = hbr[2 * o] + hbr[2 * o + 4] + 4u * (hbr[2 * o + 1] + hbr[2 * o + 3]) + 6u * hbr[2 * o + 2];
-                    const uint32_t vg = hg[2 * o] + hg[2 * o + 4] + 4u * (hg[2 * o + 1] + hg[2 * o + 3]) + 6u * hg[2 * o + 2];
-                    g1out[__umul24(y1 + ii, lw1) + x1 + j] = pyrdown_finish(vbr, vg);
-                }
-            }
-        }
-        if (!more) break;
-        __syncthreads();                                // every wave is done with the tile: the next window takes its place
-        stage_commit<A2_NT, U>(d, s_mem, nxt.w.groups, nxt.w.rows, tid);
-        cur = nxt;
-    }
-}
-
 // ======================================================================================================
 // B: pyrDown chain level b -> b+1 .. b+k (k <= B_KMAX) inside LDS
 // ======================================================================================================
@@ -2584,26 +2426,6 @@ const char* launch_warp_pyr(const CamDesc* d_cams, int n_cams, int kind, const T
 }
 
 size_t mb_warp_tile_px() { return static_cast<size_t>(A_LH) * A_LW; }
-
-// the pipelined form takes windows of up to U trips of A2_NT groups: 6 -> 36 864 bytes, 12 -> 73 728 bytes
-const char* launch_warp_pyr_pipe(const CamDesc* d_cams, int n_cams, int n_tiles, const FrameBatch& frames, int batch,
-                                 const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s)
-{
-    if (n_tiles <= 0 || batch <= 0) return nullptr;
-    const size_t lds = std::max(lds_bytes, A2_TILE_LDS);
-    const int n_items = n_tiles * batch;
-    const int run_max = (n_items + 7) / 8;                          // the longest XCD run
-    const int grid = 8 * ((run_max + A3_WALK - 1) / A3_WALK);
-    if (lds_bytes <= static_cast<size_t>(6) * A2_NT * 16) {
-        hipLaunchKernelGGL(k_warp_pyr_pipe<6>, dim3(grid), dim3(A2_NT), lds, s, d_cams, n_tiles, frames, d_table, d_gain, d_wins, n_cams, batch);
-        return "k_warp_pyr_pipe<6>";
-    }
-    if (lds_bytes <= static_cast<size_t>(12) * A2_NT * 16) {
-        hipLaunchKernelGGL(k_warp_pyr_pipe<12>, dim3(grid), dim3(A2_NT), lds, s, d_cams, n_tiles, frames, d_table, d_gain, d_wins, n_cams, batch);
-        return "k_warp_pyr_pipe<12>";
-    }
-    return launch_warp_pyr_lds(d_cams, n_cams, n_tiles, frames, batch, d_table, d_gain, d_wins, lds_bytes, s);
-}
 
 void launch_warp_table_lds(const CamDesc* d_cams, int kind, const TileList& list, uint32_t* d_table, float* d_gain, WarpWin* d_wins,
                            int lds_budget_px, hipStream_t s)
