@@ -660,6 +660,9 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
 #ifndef MST_A2_ROWS
 #define MST_A2_ROWS 3
 #endif
+#ifndef MST_ABLATE_A2
+#define MST_ABLATE_A2 0    // timing experiments only (wrong pixels): 1 no sampling arithmetic, 2 no level-0 stores, 4 no pyrDown, 8 no table / gain loads, 16 no gain loads, 32 no table loads
+#endif
 constexpr int A2_ROWS = MST_A2_ROWS, A2_RG = A_LH / A2_ROWS, A2_NT = 32 * A2_RG;      // 3 rows per lane: 12 row groups, 384 threads (2 rows / 576 threads: 230 vs 200 us per 8 frame sets)
 static_assert(A_LW == 128 && A_LH % A2_ROWS == 0 && A_TW0 == 124, "lane layout of the staged warp kernel");
 constexpr uint32_t kWinGeneral = 1u;
@@ -771,8 +774,15 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
     f32x4_t g_r[A2_ROWS];
 #pragma unroll
     for (int it = 0; it < A2_ROWS; ++it) {
-        e_r[it] = *(const u32x4_t MST_GLOBAL*)(table + tbl + it * A_LW);
-        g_r[it] = *(const f32x4_t MST_GLOBAL*)(gain + tbl + it * A_LW);
+        if (MST_ABLATE_A2 & 8) {         // (timing experiments: no table / gain streams)
+            e_r[it] = u32x4_t{static_cast<uint32_t>(lane * 4 + 16 * it) | 5u << 17 | 9u << 23, static_cast<uint32_t>(lane * 4 + 4) | 7u << 17, static_cast<uint32_t>(lane * 4 + 8) | 3u << 23, static_cast<uint32_t>(lane * 4 + 12)};
+            g_r[it] = f32x4_t{1.01f, 0.99f, 1.02f, 1.f};
+            continue;
+        }
+        if (MST_ABLATE_A2 & 32) e_r[it] = u32x4_t{static_cast<uint32_t>(lane * 4 + 16 * it) | 5u << 17 | 9u << 23, static_cast<uint32_t>(lane * 4 + 4) | 7u << 17, static_cast<uint32_t>(lane * 4 + 8) | 3u << 23, static_cast<uint32_t>(lane * 4 + 12)};
+        else e_r[it] = *(const u32x4_t MST_GLOBAL*)(table + tbl + it * A_LW);
+        if (MST_ABLATE_A2 & 16) g_r[it] = f32x4_t{1.01f, 0.99f, 1.02f, 1.f};
+        else g_r[it] = *(const f32x4_t MST_GLOBAL*)(gain + tbl + it * A_LW);
     }
     stage_window<A2_NT, false, MST_STAGE_U_WARP>(s_mem, gp(frames.ptr[cam]) + (static_cast<size_t>(w.by) * stride + static_cast<size_t>(w.wx0) * 3u), stride,
                         w.groups, w.rows);
@@ -790,7 +800,8 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
             const uint32_t addr = e & (kA2MaxWindowBytes - 1u);
             const uint32_t* p0 = reinterpret_cast<const uint32_t*>(win + addr);
             const uint32_t* p1 = reinterpret_cast<const uint32_t*>(win + addr + pitch_b);
-            px[it][k] = sample_taps(p0[0], p0[1], p1[0], p1[1], (e >> 17) & 63u, (e >> 23) & 63u, g_r[it][k]);
+            if (MST_ABLATE_A2 & 1) px[it][k] = p0[0] ^ p1[1] ^ e;          // (timing experiments: taps without the arithmetic)
+            else px[it][k] = sample_taps(p0[0], p0[1], p1[0], p1[1], (e >> 17) & 63u, (e >> 23) & 63u, g_r[it][k]);
         }
     MST_STAMP(0, 3);
     __syncthreads();                                // every wave is done with the window: the tile takes its place
@@ -805,7 +816,7 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
     // level 0, interior of the tile: 31 groups of four pixels per row, 16 bytes each way (16-byte aligned in global memory
     // when the level's width is a multiple of four: 124 * 4 bytes is)
     const int lx0 = tx * A_TW0 - 2, ly0 = ty * A_TH0 - 2;
-    const bool store0 = !(t >> 31);                 // (bit 31: nothing reads this tile's level 0 from memory, see mb_plan.cpp)
+    const bool store0 = !(t >> 31) && !(MST_ABLATE_A2 & 2);     // (bit 31: nothing reads this tile's level 0 from memory, see mb_plan.cpp)
     if (store0) {
         // packed BGR8, twelve bytes per group of four pixels (gx is a multiple of four and the row pitch a multiple of twelve
         // that covers the last group whole: no partial store)
@@ -823,7 +834,7 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
             __builtin_nontemporal_store(l0_pack4(v.x, v.y, v.z, v.w), reinterpret_cast<u32x3_t MST_GLOBAL*>(g0out + __umul24(gy, pitch0) + 3u * gx));
         }
     }
-    if (nlev < 2) return;
+    if (nlev < 2 || (MST_ABLATE_A2 & 4)) return;
     MST_STAMP(0, 5);
     // pyrDown straight from the LDS tile (as in k_warp_pyr): a thread owns one output column and four output rows
     uint32_t MST_GLOBAL* __restrict__ g1out = gp(c.G[1]);
@@ -2440,7 +2451,8 @@ const char* launch_warp_pyr_lds(const CamDesc* d_cams, int n_cams, int n_tiles, 
                                 const uint32_t* d_table, const float* d_gain, const WarpWin* d_wins, size_t lds_bytes, hipStream_t s)
 {
     if (n_tiles <= 0 || batch <= 0) return nullptr;
-    const size_t lds = std::max(lds_bytes, A2_TILE_LDS);
+    static const size_t pad = tuning_env("MST_A2_PAD_LDS");          // occupancy experiments: extra LDS per block
+    const size_t lds = std::max(lds_bytes, A2_TILE_LDS) + pad;
     hipLaunchKernelGGL(k_warp_pyr_lds, dim3(n_tiles * batch), dim3(A2_NT), lds, s, d_cams, n_tiles, frames, d_table, d_gain, d_wins, n_cams, batch);
     return "k_warp_pyr_lds";
 }
