@@ -549,8 +549,14 @@ void Engine::update(const mst_calibration& calib)
         ca.out_w = u.w; ca.out_h = u.h; ca.canvas_w = u.w; ca.canvas_h = u.h; ca.tiles_x = tx;
         ca.pad_w = u.w; ca.pad_h = u.h;
         ca.pano_stride = static_cast<uint32_t>(u.w) * 3u;
-        up.lds_bytes = lds_px * 4;
+        up.lds_bytes = std::max<size_t>(lds_px * 4, static_cast<size_t>(kCompPx) * 4);      // (the window, then the tile on its way out)
         up.staged = true;
+        {
+            std::vector<uint32_t> ids(nt);
+            for (int k = 0; k < nt; ++k) ids[k] = static_cast<uint32_t>(k);
+            launch_compose_permute(st->pool.upload(ids, s), nt, d_table, nullptr, nullptr, s);      // the staged kernel's lane order
+            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(undistort permute)");
+        }
     }
 
     st->canvas = result_roi(rois);
@@ -1075,7 +1081,19 @@ void Engine::build_compose_plan(CalibState& st, hipStream_t s)
     st.compose_staged = static_cast<int>(staged.size());
     st.compose_direct = static_cast<int>(direct.size());
     st.compose_general = static_cast<int>(general.size());
-    st.compose_lds_bytes = std::max<size_t>(lds_px * 4, 16);
+    st.compose_lds_bytes = std::max<size_t>(lds_px * 4, static_cast<size_t>(kCompPx) * 4);      // (the window, then the tile on its way out)
+    {
+        // the staged tiles' table rows into the staged kernel's lane order (k_compose_permute); such tiles can no longer be
+        // read by the gathering kernel: with frames off the 4-byte grid they take the general path
+        std::vector<uint32_t> ids;
+        for (const ComposeTile& t : staged)
+            for (uint32_t k = 0; k < t.seg_count; ++k) ids.push_back(t.seg_first + k);
+        if (!ids.empty()) {
+            launch_compose_permute(st.pool.upload(ids, s), static_cast<int>(ids.size()), d_table, d_gain, d_weight, s);
+            check_hip(hipGetLastError(), "k_compose_permute");
+            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(compose permute)");      // `ids` is local
+        }
+    }
     if (staged.empty()) staged.push_back(ComposeTile{});          // (never launched: the counts above are 0)
     if (direct.empty()) direct.push_back(ComposeTile{});
     if (general.empty()) general.push_back(ComposeTile{});
@@ -1366,11 +1384,10 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
             ca.n_tiles = st->compose_staged;
             mark(launch_compose(ca, fb, st->compose_lds_bytes, false, s));
         } else if (st->compose_staged) {
+            // (frames off the 4-byte grid: the staged tiles' tables are in the staged kernel's lane order, which only that
+            // kernel reads -- they take the per-pixel general path)
             ca.tiles = st->d_compose_staged;
-            ca.n_tiles = st->compose_staged_gatherable;
-            mark(launch_compose(ca, fb, 0, false, s));
-            ca.tiles = st->d_compose_staged + st->compose_staged_gatherable;
-            ca.n_tiles = st->compose_staged - st->compose_staged_gatherable;
+            ca.n_tiles = st->compose_staged;
             mark(launch_compose(ca, fb, 0, true, s));
         }
     }

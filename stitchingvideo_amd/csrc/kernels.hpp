@@ -93,6 +93,9 @@ void launch_compose_mask(const ComposeArgs& a, uint8_t* d_plane, hipStream_t s);
 // calibration: per segment the map / gain / weight tables, window origin and flags; sets the tiles' general-path flag
 void launch_compose_table(const ComposeArgs& a, int kind, int n_segs, ComposeSeg* d_segs, ComposeTile* d_tiles,
                           const uint32_t* d_seg_tile, uint32_t* d_table, float* d_gain, float* d_weight, hipStream_t s);
+// calibration, after the tile classes are known: the table / gain / weight rows of the given segments (those of the staged
+// tiles) into the staged kernel's lane order -- entry of tile column c at slot (c & 31) * 4 + (c >> 5)
+void launch_compose_permute(const uint32_t* d_seg_ids, int n_segs, uint32_t* d_table, float* d_gain, float* d_weight, hipStream_t s);
 // lens-undistort pre-pass in the composites' table form: one tile + segment + 4096 entries per 128 x 32 tile of the frame
 // (tile flag kCompTileGeneral: the camera keeps the gathering k_remap_fixed)
 void launch_undistort_table(const UndistortCam& u, int tiles_x, int tiles_y, ComposeSeg* d_segs, ComposeTile* d_tiles, uint32_t* d_table,

@@ -271,6 +271,34 @@ __global__ __launch_bounds__(256) void k_compose_table(ComposeArgs a, ComposeSeg
     }
 }
 
+// The staged kernel's lanes own the tile columns l, l + 32, l + 64, l + 96 (round 4: the 32 lanes of a tap read then touch
+// neighbouring source pixels -- one LDS bank each -- where four adjacent pixels per lane put them at a stride of four
+// dwords, eight banks four lanes deep; kernels_mb.hip explains).  A lane still fetches its four entries of a row with one
+// 16-byte load: the rows of the segments of every STAGED tile are re-ordered in place, once per calibration, after the
+// tile classes are known: entry of column c -> slot (c & 31) * 4 + (c >> 5).  Tiles of the other classes keep the natural
+// order (k_compose reads four adjacent pixels per lane).
+__global__ __launch_bounds__(256) void k_compose_permute(const uint32_t* __restrict__ seg_ids, uint32_t* __restrict__ table,
+                                                         float* __restrict__ gain, float* __restrict__ weight)
+{
+    const size_t base = static_cast<size_t>(seg_ids[blockIdx.x]) * kCompPx;
+    constexpr int kPer = kCompPx / 256;
+    auto permute = [&](uint32_t* __restrict__ t) {
+        uint32_t v[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) v[j] = t[base + threadIdx.x + 256 * j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = threadIdx.x + 256 * j, row = i / kCompTW, c = i % kCompTW;
+            t[base + row * kCompTW + (c & 31) * 4 + (c >> 5)] = v[j];
+        }
+        __syncthreads();
+    };
+    permute(table);
+    if (gain) permute(reinterpret_cast<uint32_t*>(gain));
+    if (weight) permute(reinterpret_cast<uint32_t*>(weight));
+}
+
 // ---- lens-undistort pre-pass (DRV:232,741) through the staged kernel ------------------------------------------------
 // cv::remap(frame, undistorted, map1 CV_16SC2, map2 CV_16UC1, INTER_LINEAR, BORDER_CONSTANT 0): the integer tap and the
 // 5-bit fractions come ready-made from initUndistortRectifyMap.  Per calibration they are recast into the composites'
@@ -632,7 +660,6 @@ void k_compose_lds(ComposeArgs a, FrameBatch fb)
     }
 #pragma unroll
     for (int it = 0; it < ROWS; ++it) {
-        const int row = rgrp * ROWS + it, oy = ty * kCompTH + row;
         if (MODE == kCompModeFeather) {
             if (pure) {
 #pragma unroll
@@ -648,10 +675,25 @@ void k_compose_lds(ComposeArgs a, FrameBatch fb)
                 }
             }
         }
+    }
+    // A lane holds the columns l + 32 k of its rows; the panorama wants runs of four adjacent pixels (12 bytes) per lane:
+    // the tile goes through LDS once (over the last window: 16 KB, conflict-free both ways)
+    __syncthreads();                                     // every wave is done with the last segment's window
+#pragma unroll
+    for (int it = 0; it < ROWS; ++it) {
+        uint32_t* trow = s_win + (rgrp * ROWS + it) * kCompTW + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) trow[32 * k] = px[it][k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ROWS; ++it) {
+        const int row = rgrp * ROWS + it, oy = ty * kCompTH + row;
         if (oy >= a.out_h || ox >= a.out_w) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(s_win + row * kCompTW + 4 * lane);
         uint8_t* o = pano + __umul24(oy, a.pano_stride) + ox * 3;
         if (ox + 3 < a.out_w) {
-            const uint32_t w0 = px[it][0] | px[it][1] << 24, w1 = px[it][1] >> 8 | px[it][2] << 16, w2 = px[it][2] >> 16 | px[it][3] << 8;
+            const uint32_t w0 = v.x | v.y << 24, w1 = v.y >> 8 | v.z << 16, w2 = v.z >> 16 | v.w << 8;
             if (aligned_rows) *reinterpret_cast<u32x3 MST_GLOBAL*>(gp(o)) = u32x3{w0, w1, w2};
             else *reinterpret_cast<Bytes12*>(o) = Bytes12{w0, w1, w2};
             if (pano_mask)
@@ -659,8 +701,8 @@ void k_compose_lds(ComposeArgs a, FrameBatch fb)
                     *reinterpret_cast<const u32_any*>(a.mask_plane + static_cast<size_t>(oy) * a.out_w + ox);
         } else {
             for (int k = 0; k < 4 && ox + k < a.out_w; ++k) {
-                o[3 * k] = static_cast<uint8_t>(px[it][k]); o[3 * k + 1] = static_cast<uint8_t>(px[it][k] >> 8);
-                o[3 * k + 2] = static_cast<uint8_t>(px[it][k] >> 16);
+                o[3 * k] = static_cast<uint8_t>(v[k]); o[3 * k + 1] = static_cast<uint8_t>(v[k] >> 8);
+                o[3 * k + 2] = static_cast<uint8_t>(v[k] >> 16);
                 if (pano_mask) pano_mask[__umul24(oy, a.mask_stride) + ox + k] = a.mask_plane[static_cast<size_t>(oy) * a.out_w + ox + k];
             }
         }
@@ -682,6 +724,12 @@ void launch_compose_classify(const ComposeArgs& a, int n_canvas_tiles, uint32_t*
 void launch_compose_mask(const ComposeArgs& a, uint8_t* d_plane, hipStream_t s)
 {
     hipLaunchKernelGGL(k_compose_mask, dim3((a.out_w + 63) / 64, (a.out_h + 3) / 4), dim3(256), 0, s, a, d_plane);
+}
+
+void launch_compose_permute(const uint32_t* d_seg_ids, int n_segs, uint32_t* d_table, float* d_gain, float* d_weight, hipStream_t s)
+{
+    if (n_segs <= 0) return;
+    hipLaunchKernelGGL(k_compose_permute, dim3(n_segs), dim3(256), 0, s, d_seg_ids, d_table, d_gain, d_weight);
 }
 
 void launch_compose_table(const ComposeArgs& a, int kind, int n_segs, ComposeSeg* d_segs, ComposeTile* d_tiles,

@@ -4,7 +4,7 @@
 # that those carry it), bench.py (default, --batch 1, --undistort) and mst_update timing.  Outputs under
 # gpurun_out/round and gpurun_out/prof_<tag>; copy what should be judged into profiles/ (tools/collect_profiles.sh).
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out/round
 (time python -m pytest tests -m gpu -x -q) > gpurun_out/round/pytest.log 2>&1
 tail -3 gpurun_out/round/pytest.log
@@ -15,7 +15,11 @@ for p in C2 C5 C3-LUT C5-LUT; do
   bash tools/prof_paths.sh ${TAG}_$p $p > gpurun_out/round/profile_$p.log 2>&1
 done
 cp gpurun_out/traffic.json profiles/traffic.json
-( time python bench.py > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err ) 2>&1 | grep real
+( time python bench.py --strip-leg --camera-leg > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err ) 2>&1 | grep real
+# one strip = the whole canvas: the strip leg must reproduce the headline (same kernels, same lists) within 3 %
+python -c "
+import json, sys; d=json.load(open('gpurun_out/round/bench.json')); s=d['strip_sharded']['frames_per_s_strips_left_in_place']; v=d['value']
+print('strip leg at N = 1: %.1f vs value %.1f (%.1f %%)' % (s, v, 100.0 * (s - v) / v)); sys.exit(0 if abs(s - v) <= 0.03 * v else 1)" || echo "STRIP LEG DOES NOT REPRODUCE THE HEADLINE"
 python -c "
 import json; d=json.load(open('gpurun_out/round/bench.json'))
 print(d['value'], d['roofline']['frac'], d['roofline']['traffic'], [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']], d.get('latency_mode'), d.get('overlapped'), d.get('host_buffers'), d.get('cpu_baseline'))
@@ -27,4 +31,5 @@ import json
 for f in ('bench_batch1','bench_undistort'):
     d=json.load(open('gpurun_out/round/%s.json'%f)); print(f, d['value'], [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']])"
 python tools/strip_model.py > gpurun_out/round/strip_model.jsonl 2>/dev/null
-python tools/time_update.py 2>&1 | tail -4
+python tools/time_update.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/round/time_update.txt | tail -20
+python tests/sweeps/fuzz_parity.py 400 41001 2>&1 | tail -2
