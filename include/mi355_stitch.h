@@ -256,7 +256,10 @@ int  mst_num_bands(const mst_engine *e, int *num_bands);
 int  mst_compose(mst_engine *e, const uint8_t *const *frames, const size_t *frame_strides,
                  uint8_t *pano, size_t pano_stride, uint8_t *pano_mask, size_t pano_mask_stride);
 /* Device buffers already resident in HBM; enqueued on `stream` (a hipStream_t, NULL = the
- * engine's own stream) and asynchronous: call mst_synchronize or sync the stream yourself. */
+ * engine's own stream) and asynchronous: call mst_synchronize or sync the stream yourself.
+ * The engine's own stream is NON-BLOCKING (it does not wait for the legacy default stream): work that
+ * produces the frames or still touches the panorama buffer on another stream -- a decoder's copy, a fill
+ * of a freshly allocated buffer -- must have completed, or the caller passes the stream that work is on. */
 int  mst_compose_device(mst_engine *e, const void *const *d_frames, const size_t *frame_strides,
                         void *d_pano, size_t pano_stride, void *d_pano_mask, size_t pano_mask_stride,
                         void *stream);

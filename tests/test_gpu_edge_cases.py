@@ -153,6 +153,7 @@ def test_device_frames_off_the_dword_grid(blend, lut, pad, shift):
         ptrs.append(p)
         strides.append(s)
     panos = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()          # the fills run on torch's stream, the engine's stream does not wait for it
     eng.compose_device_batch(ptrs, strides, [p.data_ptr() for p in panos], cw * 3)
     torch.cuda.synchronize()
     for f in range(2):

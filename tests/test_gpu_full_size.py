@@ -96,6 +96,7 @@ def test_full_size_c3_in_the_bench_configuration():
     order = [0, 1, 1, 0, 1, 0, 0, 1]
     panos = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in order]
     masks = [torch.zeros((ch, cw), dtype=torch.uint8, device=dev) for _ in order]
+    torch.cuda.synchronize()          # the fills run on torch's stream, the engine's stream does not wait for it
     eng.compose_device_batch([[t.data_ptr() for t in dfr[k]] for k in order], [[t.stride(0) for t in dfr[k]] for k in order],
                              [p.data_ptr() for p in panos], panos[0].stride(0), [m.data_ptr() for m in masks], masks[0].stride(0))
     eng.synchronize()

@@ -298,6 +298,7 @@ def test_recalibration_that_changes_the_canvas_size_while_composing():
             else:                                # device path: explicit latch, then buffers, then compose
                 (_, _, cw, ch), gen = eng.acquire()
                 d_pano = torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()         # the fill runs on torch's stream; the engine's stream does not wait for it
                 eng.compose_device(ptrs, strides, d_pano.data_ptr(), d_pano.stride(0))
                 eng.synchronize()
                 assert eng.canvas()[2:] == (cw, ch)          # still the latched one, whatever was published meanwhile
@@ -423,6 +424,7 @@ def test_unaligned_panorama_and_mask_buffers(base_off, row_pad, mask_off, mask_p
     stride, mstride = cw * 3 + row_pad, cw + mask_pad
     pbuf = torch.full((base_off + ch * stride + 16,), 0x5A, dtype=torch.uint8, device=dev)
     mbuf = torch.full((mask_off + ch * mstride + 16,), 0x5A, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
     eng.compose_device([t.data_ptr() for t in dfr], [t.stride(0) for t in dfr], pbuf.data_ptr() + base_off, stride,
                        mbuf.data_ptr() + mask_off, mstride)
     eng.synchronize()

@@ -28,11 +28,13 @@ def _compose_strips(rig, frames, blend, count, bands=5, lut=False, batch=1):
         assert (sy, shh) == (cy, ch) and cx <= sx and sx + sw <= cx + cw
         canvas = (cx, cy, cw, ch)
         buf = torch.full((ch, max(sw, 1), 3), 77, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()         # fills run on torch's stream; the engine's stream does not wait for it
         if sw > 0:
             if batch == 1:
                 eng.compose_device(ptrs, strides, buf.data_ptr() - (sx - cx) * 3, buf.stride(0))
             else:
                 bufs = [torch.full((ch, sw, 3), 77, dtype=torch.uint8, device=dev) for _ in range(batch)]
+                torch.cuda.synchronize()
                 eng.compose_device_batch([ptrs] * batch, [strides] * batch, [b.data_ptr() - (sx - cx) * 3 for b in bufs], bufs[0].stride(0))
                 torch.cuda.synchronize()
                 assert all(torch.equal(b, bufs[0]) for b in bufs)

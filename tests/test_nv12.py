@@ -79,6 +79,7 @@ def test_compose_from_nv12_frames(blend):
     dev = torch.device("cuda", 0)
     dfr = [[torch.from_numpy(f).to(dev) for f in fr] for fr in sets]
     panos = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(3)]
+    torch.cuda.synchronize()
     eng.compose_device_batch([[t.data_ptr() for t in fr] for fr in dfr], [[t.stride(0) for t in fr] for fr in dfr],
                              [p.data_ptr() for p in panos], panos[0].stride(0))
     eng.synchronize()
