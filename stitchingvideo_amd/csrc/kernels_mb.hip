@@ -1437,7 +1437,7 @@ __device__ __forceinline__ void band_quad(const CamDesc* __restrict__ cams, cons
 #define MST_ABLATE_C 0     // timing experiments only (results are wrong): 1 no coarse bands, 2 no collapse, 4 no final pyrUp,
 #endif                     // 8 no final band, 16 no panorama stores (generic path), 64 no strips, 256 no blocked quad order,
                            // 512 no ownership, 1024 no wide stores; strips: 2048 no level-0 loads, 4096 no panorama
-                           // stores, 8192 no collapsed-level loads
+                           // stores, 8192 no collapsed-level loads; 16384 level 1 of every coarse tile as if owned
 // LDS row pitch (in pixels) of a level region: its width rounded up to even, so that a quad row is one aligned
 // 16-byte access even where the top level's width is odd (the pad column takes the pair's second pixel there)
 __host__ __device__ inline int region_pitch(const Region& r) { return (r.x1 - r.x0 + 1) & ~1; }
@@ -2235,8 +2235,8 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
         return;
     }
     // phase 3: level 1, owned outright on every pure tile and on most tiles near -- but not on -- a seam
-    const bool own1 = pure || (owned_levels & 2u);
-    const uint32_t bits1 = pure ? cam_bits : owner_bits;
+    const bool own1 = pure || (owned_levels & 2u) || (MST_ABLATE_C & 16384);          // (16384: every tile as if owned at level 1 -- timing only)
+    const uint32_t bits1 = pure ? cam_bits : (MST_ABLATE_C & 16384) && !(owned_levels & 2u) ? (cam_bits & (0u - cam_bits)) : owner_bits;
     uint2* c1 = reinterpret_cast<uint2*>(a.c1[set]);
     if (top == 1) {
         if (own1) coarse_base_level<CC_THREADS, true, true>(cams, a, bits1, lds, s_reg, c1);
