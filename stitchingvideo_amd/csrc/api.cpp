@@ -326,6 +326,29 @@ int mst_payload_unpack(mst_engine* e, int camera, const void* d_payload, void* s
     return guarded(e, [&] { e->impl.payload_copy(camera, const_cast<void*>(d_payload), false, static_cast<hipStream_t>(stream)); });
 }
 
+int mst_strip_halo_bytes(mst_engine* e, size_t send_bytes[2], size_t recv_bytes[2])
+{
+    if (!e || !send_bytes || !recv_bytes) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.halo_bytes(send_bytes, recv_bytes); });
+}
+
+int mst_strip_front_batch(mst_engine* e, int count, const void* const* d_frames, const size_t* frame_strides, void* d_send_left,
+                          void* d_send_right, void* stream)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] { e->impl.strip_front(count, d_frames, frame_strides, d_send_left, d_send_right, static_cast<hipStream_t>(stream)); });
+}
+
+int mst_strip_back_batch(mst_engine* e, int count, const void* d_recv_left, const void* d_recv_right, void* const* d_panos,
+                         size_t pano_stride, void* const* d_pano_masks, size_t pano_mask_stride, void* stream)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] {
+        e->impl.strip_back(count, d_recv_left, d_recv_right, d_panos, pano_stride, d_pano_masks, pano_mask_stride,
+                           static_cast<hipStream_t>(stream));
+    });
+}
+
 int mst_stage_select_set(mst_engine* e, int set)
 {
     if (!e) return MST_ERR_INVALID_ARG;

@@ -165,6 +165,10 @@ struct BlendArgs {
     int32_t split;                             // 1: k_blend_coarse -> c2, k_blend_mid -> c1; 0: k_blend_coarse -> c1 (two levels)
     const uint32_t* coarse_order2;             // k_blend_coarse's own launch order when split (a strip engine also needs the
     int32_t n_coarse2;                         // tiles whose level-2 interiors its level-1 tiles read as pyrUp halo)
+    // Canvas strips: the level-1 columns [clip_x0, clip_x1) a strip engine needs (both even; clip_x1 == 0: no clip).  The
+    // level-1 regions of k_blend_coarse's tiles are cut to them, so the tile beside the strip costs its two halo columns
+    // and their dependency cone, not a whole tile.
+    int32_t clip_x0, clip_x1;
     // k_blend_fine, per panorama tile: bit i = camera i has a non-zero level-0 weight under the tile; bit 31 = the
     // tile's level 0 is owned by ONE camera with weight exactly 1 (integer band path) -- then only that camera's bit;
     // bit 30 = one or two cameras with 0/1 weights, never both non-zero on a pixel (integer path with masks)
@@ -193,6 +197,10 @@ struct PayloadRect {
     int32_t level, x0, y0, w, h;
     uint32_t off;
 };
+
+// One rectangle of a strip engine's halo exchange (MST_FLAG_STRIP_HALO): pixels x0 .. x0 + w, rows y0 .. y0 + h of camera
+// `cam`'s Gaussian level at the cut, `off` dwords into the packed payload of one frame set for that neighbour.
+struct HaloRect { int32_t cam, x0, y0, w, h; uint32_t off; };
 
 // Exposure-gain estimation (GainCompensator::feed): images and masks on the device, and one overlapping pair of
 // (block) images: its overlap rectangle's origin inside each parent image, and its size.

@@ -692,7 +692,28 @@ void Engine::update(const mst_calibration& calib)
         ba.alpha = static_cast<float>(1. / 255.);
         ba.weights_16s = cfg_.weight_type == MST_WEIGHT_16S ? 1 : 0;
         strip_columns(cv.cw[0], &st->strip_x0, &st->strip_x1);
-        build_mb_plan(st->desc, wh, ba, (cfg_.flags & MST_FLAG_DEBUG) != 0, st->plan, st->strip_x0, st->strip_x1);
+        const char* split_env = std::getenv("MST_SPLIT");       // (read per calibration: the parity test switches it)
+        const bool split = nb >= 2 && split_env && split_env[0] == '1';
+        ba.split = split ? 1 : 0;                                // (the plan clips a strip's level-1 regions only when not split)
+        MbHalo halo_in{};
+        const bool want_halo = (cfg_.flags & MST_FLAG_STRIP_HALO) && cfg_.strip_count > 1;
+        if (want_halo) {
+            halo_in.level = 2;
+            for (int side = 0; side < 2; ++side) {
+                const int nbr = cfg_.strip_index + (side == 0 ? -1 : 1);
+                halo_in.has[side] = nbr >= 0 && nbr < cfg_.strip_count;
+                if (halo_in.has[side]) strip_columns(cv.cw[0], &halo_in.x0[side], &halo_in.x1[side], nbr);
+                halo_in.has[side] = halo_in.has[side] && halo_in.x1[side] > halo_in.x0[side];
+            }
+        }
+        build_mb_plan(st->desc, wh, ba, (cfg_.flags & MST_FLAG_DEBUG) != 0, st->plan, st->strip_x0, st->strip_x1, want_halo ? &halo_in : nullptr);
+        if (st->plan.halo_level < 0)
+            throw Error{MST_ERR_INVALID_ARG, "MST_FLAG_STRIP_HALO: a strip is narrower than the pyramid halo of its neighbour (fewer strips, or no halo exchange)"};
+        for (int side = 0; side < 2; ++side) {
+            st->d_halo_send[side] = st->plan.halo_send[side].empty() ? nullptr : st->pool.upload(st->plan.halo_send[side], s);
+            st->d_halo_recv[side] = st->plan.halo_recv[side].empty() ? nullptr : st->pool.upload(st->plan.halo_recv[side], s);
+        }
+        ba.clip_x0 = st->plan.clip_x0; ba.clip_x1 = st->plan.clip_x1;
         clk.mark("work-list plan (host)");
         const MbPlanHost& plan = st->plan;
         ba.tiles_x = plan.blend_tiles_x;
@@ -717,10 +738,8 @@ void Engine::update(const mst_calibration& calib)
             // C3 (profiles/r04_experiments.md): k_blend_coarse alone 83 us per 8 frame sets; split 49 + 59: the level-1 pass is
             // no faster in k_blend_fine's shape (most of its tiles carry fractional weights and take the float path either
             // way), and the levels above it cost more than the ablation of round 3 suggested.  Off by default.
-            const char* split_env = std::getenv("MST_SPLIT");       // (read per calibration: the parity test switches it)
-            const bool split = split_env && split_env[0] == '1';
             st->c2.clear();
-            if (nb >= 2 && split) {
+            if (split) {
                 st->c2.assign(st->num_sets, nullptr);
                 for (int k = 0; k < st->num_sets; ++k)
                     st->c2[k] = st->pool.alloc<uint64_t>(static_cast<size_t>(cv.cw[2]) * cv.ch[2]);
@@ -862,10 +881,10 @@ void Engine::update(const mst_calibration& calib)
 
 // Column strip [x0, x1) of this engine inside a canvas `width` columns wide (mst_config.strip_index / strip_count):
 // equal shares, boundaries on multiples of 256 columns (a level-1 canvas tile), the last strip takes the rest.
-void Engine::strip_columns(int width, int* x0, int* x1) const
+void Engine::strip_columns(int width, int* x0, int* x1, int index) const
 {
     *x0 = 0; *x1 = width;
-    const int g = cfg_.strip_count, k = cfg_.strip_index;
+    const int g = cfg_.strip_count, k = index < 0 ? cfg_.strip_index : index;
     if (g <= 1) return;
     auto bound = [&](int i) {
         if (i >= g) return width;
@@ -1229,20 +1248,26 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
 
 // One calibration state for the whole call: callers that size buffers first (compose_host) pass the snapshot they
 // sized them from, so a concurrent mst_update cannot slip a different canvas in between.
+// phase 0: the whole launch sequence.  Strip engines with halo exchange (MST_FLAG_STRIP_HALO) run it as two calls around the
+// exchange: phase 1 = the per-camera kernels up to the cut level + the halo rectangles packed into halo[0] / halo[1] (left /
+// right neighbour; frames are read, no panorama is written); phase 2 = the received rectangles unpacked, the rest of the
+// pyramids, the canvas kernels (no frames are read).
 void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
                               void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
-                              hipStream_t stream, StageTimer* timer)
+                              hipStream_t stream, StageTimer* timer, int phase, void* const* halo)
 {
     select_device(cfg_.device);
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
-    if (!d_frames || !strides || !d_panos) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama table"};
+    const bool front = phase != 2, back = phase != 1;
+    if ((front && (!d_frames || !strides)) || (back && !d_panos)) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama table"};
+    if (phase != 0 && st->blend_kind != MST_BLEND_MULTI_BAND) throw Error{MST_ERR_INVALID_ARG, "the strip halo calls exist for multi-band only"};
     if (count < 1 || count > kMaxBatch) throw Error{MST_ERR_INVALID_ARG, "batch size out of range"};
     const bool nv12 = !st->nv12_frames.empty();
     if ((st->blend_kind == MST_BLEND_MULTI_BAND || st->any_undistort || nv12) && count > 1 && count > st->sets_per_slot)
         throw Error{MST_ERR_INVALID_ARG, "batch larger than mst_config.max_batch"};
     hipStream_t s = stream ? stream : stream_;
     FrameBatch fb{};
-    for (int f = 0; f < count; ++f)
+    for (int f = 0; f < count && front; ++f)
         for (int i = 0; i < st->n; ++i) {
             const void* p = d_frames[f * st->n + i];
             const size_t stride = strides[f * st->n + i];
@@ -1256,13 +1281,15 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         }
     // (an engine that composes one column strip only needs rows that reach from the strip's first to its last column)
     const int strip_w = std::min(st->strip_x1, st->out_w) - std::min(st->strip_x0, st->out_w);
-    if (pano_stride < static_cast<size_t>(cfg_.strip_count > 1 ? strip_w : st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
-    if (pano_stride >= (size_t{1} << 24) || mask_stride >= (size_t{1} << 24))
-        throw Error{MST_ERR_INVALID_ARG, "panorama and mask strides must be below 16 MiB"};
-    if (d_masks && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
-    if (pano_stride * static_cast<size_t>(st->out_h) > 0xFFFFFFFFull)
-        throw Error{MST_ERR_INVALID_ARG, "panoramas of 4 GiB and more are not supported (32-bit byte offsets)"};
-    for (int f = 0; f < count; ++f)
+    if (back) {
+        if (pano_stride < static_cast<size_t>(cfg_.strip_count > 1 ? strip_w : st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
+        if (pano_stride >= (size_t{1} << 24) || mask_stride >= (size_t{1} << 24))
+            throw Error{MST_ERR_INVALID_ARG, "panorama and mask strides must be below 16 MiB"};
+        if (d_masks && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
+        if (pano_stride * static_cast<size_t>(st->out_h) > 0xFFFFFFFFull)
+            throw Error{MST_ERR_INVALID_ARG, "panoramas of 4 GiB and more are not supported (32-bit byte offsets)"};
+    }
+    for (int f = 0; f < count && back; ++f)
         if (!d_panos[f]) throw Error{MST_ERR_INVALID_ARG, "null panorama pointer"};
 
     auto mark = [&](const char* name) { if (timer && name) timer->mark(name, s); };      // (nullptr: the launcher had nothing to launch)
@@ -1298,7 +1325,9 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         // and only wait for the canvas kernel that last read this pyramid set (two frames ago); the canvas kernel
         // (C) stays on the caller's stream behind them.  Frame t+1's A/B therefore overlap frame t's C.
         const bool overlap = (cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && st->num_sets >= 2 * st->sets_per_slot &&
-                             timer == nullptr && !in_host_compose_;
+                             timer == nullptr && !in_host_compose_ && phase == 0;
+        // the last pyramid level the front phase produces (the halo's cut level; everything when the plan made no cut)
+        const int cut = phase == 0 ? 0 : (st->plan.halo_level > 0 ? st->plan.halo_level : kMaxLevels);
         const int slot = overlap ? static_cast<int>(frame_counter_++ & 1u) : 0;
         const int first_set = slot * st->sets_per_slot;           // the slot's run of descriptor / buffer sets
         const CamDesc* desc = st->d_desc + static_cast<size_t>(first_set) * st->n;
@@ -1311,8 +1340,22 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
                     check_hip(hipStreamWaitEvent(s, ev_canvas_done_[k], 0), "hipStreamWaitEvent");
                     canvas_pending_[k] = false;
                 }
-        undistort(first_set, sf);
-        launch_warp(*st, desc, fb, count, 0, st->n, sf, timer);
+        if (front) {
+            undistort(first_set, sf);
+            launch_warp(*st, desc, fb, count, 0, st->n, sf, timer);
+        }
+        auto halo_copy = [&](bool pack) {
+            if (st->plan.halo_level <= 0 || !halo) return;
+            for (int side = 0; side < 2; ++side) {
+                const std::vector<HaloRect>& rects = pack ? st->plan.halo_send[side] : st->plan.halo_recv[side];
+                if (rects.empty()) continue;
+                if (!halo[side]) throw Error{MST_ERR_INVALID_ARG, "null halo buffer for a neighbour this strip exchanges with"};
+                mark(launch_halo_copy(desc, st->n, pack ? st->d_halo_send[side] : st->d_halo_recv[side], static_cast<int>(rects.size()),
+                                      st->plan.halo_level, pack ? st->plan.halo_send_px[side] : st->plan.halo_recv_px[side], count,
+                                      static_cast<uint32_t*>(halo[side]), pack, sf));
+            }
+        };
+        if (phase == 2) halo_copy(false);
         // where the frame crosses from the front stream to the caller's stream: after the warp kernel (the small
         // pyramid-chain launches then fill in beside the next frame's warp) or after the chain
         static const bool split_after_warp = [] { const char* v = std::getenv("MST_OVERLAP_SPLIT"); return v && v[0] == '1'; }();
@@ -1322,14 +1365,23 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         };
         if (overlap && split_after_warp) cross();
         hipStream_t sc = (overlap && !split_after_warp) ? sf : s;
+        // (a launch belongs to the front phase when the level it produces is at or below the cut)
+        auto mine = [&](int produced) { return phase == 0 || (phase == 1) == (produced <= cut); };
         for (size_t i = 0; i < st->chain_lists.size(); ++i) {
             const MbPlanHost::ChainStep& step = st->plan.chain[i];
             if (st->chain_units[i].d[0]) {
                 for (int j = 0; j < step.k; ++j)
-                    mark(launch_pyrdown_stream(desc, st->n, st->chain_units[i].d[j], static_cast<int>(step.units[j].size()), step.base + j, count, sc));
-            } else {
+                    if (mine(step.base + j + 1))
+                        mark(launch_pyrdown_stream(desc, st->n, st->chain_units[i].d[j], static_cast<int>(step.units[j].size()), step.base + j, count, sc));
+            } else if (mine(step.base + 1)) {
                 mark(launch_pyr_chain(desc, st->n, st->chain_lists[i], step.base, step.k, count, sc));
             }
+        }
+        if (phase == 1) {
+            halo_copy(true);
+            check_hip(hipGetLastError(), "strip front kernels");
+            set_in_flight(std::move(st));
+            return;
         }
         if (overlap && !split_after_warp) cross();
         int n_coarse = 0;
@@ -1393,6 +1445,37 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
     }
     check_hip(hipGetLastError(), "compose kernels");
     set_in_flight(std::move(st));
+}
+
+// ---- canvas strips with halo exchange (MST_FLAG_STRIP_HALO): the launch sequence as two calls around the exchange ----
+
+void Engine::halo_bytes(size_t send[2], size_t recv[2])
+{
+    std::shared_ptr<CalibState> st = state();
+    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "no calibration"};
+    for (int side = 0; side < 2; ++side) {
+        send[side] = st->plan.halo_level > 0 ? static_cast<size_t>(st->plan.halo_send_px[side]) * 4 : 0;
+        recv[side] = st->plan.halo_level > 0 ? static_cast<size_t>(st->plan.halo_recv_px[side]) * 4 : 0;
+    }
+}
+
+void Engine::strip_front(int count, const void* const* d_frames, const size_t* strides, void* d_send_left, void* d_send_right, hipStream_t stream)
+{
+    std::shared_ptr<CalibState> st = state();
+    void* bufs[2] = {d_send_left, d_send_right};
+    compose_batch_on(st, count, d_frames, strides, nullptr, 0, nullptr, 0, stream, nullptr, 1, bufs);
+    halo_state_ = st;             // the back half must run against the same calibration and frame sets
+    halo_count_ = count;
+}
+
+void Engine::strip_back(int count, const void* d_recv_left, const void* d_recv_right, void* const* d_panos, size_t pano_stride,
+                        void* const* d_masks, size_t mask_stride, hipStream_t stream)
+{
+    std::shared_ptr<CalibState> st = std::move(halo_state_);
+    halo_state_.reset();
+    if (!st || count != halo_count_) throw Error{MST_ERR_INVALID_ARG, "mst_strip_back_batch without a matching mst_strip_front_batch"};
+    void* bufs[2] = {const_cast<void*>(d_recv_left), const_cast<void*>(d_recv_right)};
+    compose_batch_on(st, count, nullptr, nullptr, d_panos, pano_stride, d_masks, mask_stride, stream, nullptr, 2, bufs);
 }
 
 namespace {

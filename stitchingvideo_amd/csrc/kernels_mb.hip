@@ -1128,6 +1128,10 @@ __host__ __device__ inline Region blend_region(const BlendArgs& a, int base, int
     const int tw = base ? CC_TW : C_TW, th = base ? a.cc_th : C_TH;
     r.x0 = tx * tw; r.y0 = ty * th;
     r.x1 = lo(r.x0 + tw, a.cw[base]); r.y1 = lo(r.y0 + th, a.ch[base]);
+    if (base == 1 && a.clip_x1 > 0) {          // a strip engine: only the level-1 columns its panorama tiles read
+        r.x0 = hi(r.x0, a.clip_x0);
+        r.x1 = hi(r.x0, lo(r.x1, a.clip_x1));
+    }
     for (int l = base + 1; l <= level; ++l) {
         r.x0 = hi(0, ((r.x0 >> 1) - 1) & ~1);
         r.y0 = hi(0, ((r.y0 >> 1) - 1) & ~1);
