@@ -67,7 +67,11 @@ def parse_args():
     ap.add_argument("--overlap", action="store_true",
                     help="pipeline consecutive calls (MST_FLAG_OVERLAP_FRAMES): kernels of two calls then run "
                          "concurrently and per-kernel durations (here and in rocprofv3) stop being comparable")
-    ap.add_argument("--no-overlap", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--no-overlap", action="store_true", help="(kept for older command lines: same as --in-flight 1)")
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="launch sequences in flight in the timed region (mst_config.overlap_depth: whole calls on engine-owned "
+                         "streams, each with its own panorama buffers); 1 = strictly one after the other, what the per-kernel "
+                         "durations and the rocprofv3 profiles are taken with")
     ap.add_argument("--batch", type=int, default=8,
                     help="frame sets per launch sequence (mst_compose_device_batch); 1 = one frame set per sequence")
     ap.add_argument("--strip-leg", action="store_true", help="run the strip-sharded measurement at N = 1 too (one strip = the whole canvas)")
@@ -193,6 +197,15 @@ def main():
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
                            overlap_frames=args.overlap and not args.no_overlap and blend == "multiband" and not by_camera,
                            max_batch=batch, lens_composed=args.undistort and args.lens_composed)
+    in_flight = 1 if (by_camera or args.no_overlap) else (2 if args.overlap else max(1, min(args.in_flight, 8)))
+    if in_flight == 2 and not args.overlap:
+        in_flight = 3                   # (2 is the older two-stream form, multi-band only: --overlap asks for it)
+    # the engine of the timed region: `in_flight` launch sequences in flight; `eng` stays the one-at-a-time engine of the
+    # per-kernel timings and of the other legs
+    eng_p = eng
+    if in_flight > 1 and not args.overlap:
+        eng_p = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
+                                 overlap_frames=True, overlap_depth=in_flight, max_batch=batch, lens_composed=args.undistort and args.lens_composed)
     if args.undistort:
         # the reference's fisheye intrinsics (DRV:209-216, quoted for 1280x720) scaled to the frame size
         fw, fh = rig["size"]
@@ -204,6 +217,9 @@ def main():
             c["undistort"] = und
     eng.update(rig["scale"], rig["cameras"])
     (cx, cy, cw, ch), _ = eng.acquire()
+    if eng_p is not eng:
+        eng_p.update(rig["scale"], rig["cameras"])
+        eng_p.acquire()
 
     # frames resident in HBM: a few distinct sets, each rank its own (frame index offset by rank)
     dev = torch.device("cuda", local_rank)
@@ -214,9 +230,13 @@ def main():
         host_sets.append(fr)
         dev_sets.append([torch.from_numpy(f).to(dev) for f in fr])
     # (--pano-row-pad: rows of cw * 3 + pad bytes, to time panorama strides that are not a multiple of four)
-    pano_rows = [torch.empty((ch, cw * 3 + args.pano_row_pad), dtype=torch.uint8, device=dev) for _ in range(batch)]
-    panos = [p[:, :cw * 3].view(ch, cw, 3) if args.pano_row_pad == 0 else p for p in pano_rows]
+    def make_panos():
+        rows = [torch.empty((ch, cw * 3 + args.pano_row_pad), dtype=torch.uint8, device=dev) for _ in range(batch)]
+        return rows, [p[:, :cw * 3].view(ch, cw, 3) if args.pano_row_pad == 0 else p for p in rows]
+    pano_rows, panos = make_panos()
     pano = panos[0]
+    # calls in flight write different panoramas: a ring of `in_flight` sets of them
+    pano_ring = [panos] + [make_panos()[1] for _ in range(in_flight - 1 if eng_p is not eng else 0)]
     # a real (non-null) stream, made torch's current one: torch.cuda.Event brackets the launches and RCCL's
     # point-to-point operations (camera-sharded mode) order against the same stream as the kernels
     tstream = torch.cuda.Stream(device=dev)
@@ -237,11 +257,12 @@ def main():
             return lambda: stitcher.compose(ptrs, strides, pano.data_ptr(), pano.stride(0), stream=stream)
         calls = [camera_call(ds) for ds in dev_sets]
     elif batch == 1:
-        calls = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),
-                                      pano.stride(0), stream=stream) for ds in dev_sets]
+        calls = [eng_p.make_device_call([t.data_ptr() for t in dev_sets[k % n_sets]], [t.stride(0) for t in dev_sets[k % n_sets]],
+                                        pano_ring[k % len(pano_ring)][0].data_ptr(), pano.stride(0), stream=stream)
+                 for k in range(n_sets * len(pano_ring))]
     else:
-        calls = [eng.make_device_batch_call(*tables(first), [p.data_ptr() for p in panos], pano.stride(0),
-                                            stream=stream) for first in range(n_sets)]
+        calls = [eng_p.make_device_batch_call(*tables(k % n_sets), [p.data_ptr() for p in pano_ring[k % len(pano_ring)]], pano.stride(0),
+                                              stream=stream) for k in range(n_sets * len(pano_ring))]
 
     def barrier():
         if world > 1:
@@ -350,6 +371,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "frames_resident_in_hbm": True, "frame_sets_per_step": batch * reps,
                        "launch_sequences_per_step": reps, "frame_sets_per_launch": batch,
+                       "launch_sequences_in_flight": in_flight,
                        "lens_undistort": ("composed into the warp map" if args.lens_composed else "pre-pass") if args.undistort else False,
                        "timed_region_s": round(wall, 4),
                        "parallelism": "frames sharded over %d rank(s), no collective" % world},
@@ -358,9 +380,10 @@ def main():
                          "algorithmic_bytes_per_frame": alg_bytes,
                          "algorithmic_bytes_per_launch": alg_bytes * batch,
                          "device_ms_per_frame": round(dev_ms_per_seq / batch, 5),
-                         "scope": "whole launch sequence (%d launches over %d frame sets); the dominant kernel alone "
-                                  "moves the same algorithmic bytes in its own duration"
-                                  % (sum(k["launches_per_sequence"] for k in kernels), batch),
+                         "scope": "whole launch sequence (%d launches over %d frame sets), %d sequence(s) in flight; `kernels` are "
+                                  "timed one sequence at a time (events between the launches) -- under overlap a kernel's duration "
+                                  "is not its own; the one-at-a-time rate is in `serial`"
+                                  % (sum(k["launches_per_sequence"] for k in kernels), batch, in_flight),
                          "dominant_kernel": dominant, "kernels": kernels},
         }
         if batch > 1 and not args.no_latency_leg:
@@ -383,46 +406,45 @@ def main():
                                    "roofline_frac": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                    "traffic": tj.get("entries", {}).get("%s/1" % wl, {}).get("bytes_per_frame")}
 
-    # ---- two launch sequences in flight (MST_FLAG_OVERLAP_FRAMES): the warp + chain kernels of sequence t + 1 run
-    # beside the canvas kernels of sequence t on a second stream and a second set of pyramid buffers.  Reported
-    # beside `value`, not as `value`: per-kernel durations under overlap are not comparable with a kernel trace.
-    if rank == 0 and world == 1 and not by_camera and not args.no_latency_leg and blend == "multiband" and batch > 1 \
-            and not args.overlap:
-        eng2 = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
-                                overlap_frames=True, max_batch=batch)
-        eng2.update(rig["scale"], rig["cameras"])
-        eng2.acquire()
-        calls2 = [eng2.make_device_batch_call(*tables(first), [p.data_ptr() for p in panos], pano.stride(0), stream=stream)
-                  for first in range(n_sets)]
+    # ---- the same launch sequences strictly one after the other (`eng`): the rate the per-kernel durations and the
+    # rocprofv3 profiles (tools/profile_gpu.sh runs this file with --in-flight 1) add up to.  Beside `value`, not `value`.
+    if rank == 0 and world == 1 and not by_camera and eng_p is not eng:
+        if batch == 1:
+            calls_s = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(), pano.stride(0), stream=stream)
+                       for ds in dev_sets]
+        else:
+            calls_s = [eng.make_device_batch_call(*tables(first), [p.data_ptr() for p in panos], pano.stride(0), stream=stream)
+                       for first in range(n_sets)]
         for i in range(10):
-            calls2[i % len(calls2)]()
+            calls_s[i % len(calls_s)]()
         torch.cuda.synchronize()
         n2 = max(20, int(0.5 / max(t_seq, 1e-6)))
-        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for i in range(n2):
-            calls2[i % len(calls2)]()
+            calls_s[i % len(calls_s)]()
+        e1.record()
         torch.cuda.synchronize()
-        w2 = time.perf_counter() - t0
-        out["overlapped"] = {"launch_sequences_in_flight": 2, "frame_sets_per_launch": batch, "frames": n2 * batch,
-                             "frames_per_s": round(n2 * batch / w2, 2),
-                             "roofline_frac": round(alg_bytes * n2 * batch / w2 / 1e9 / HBM_PEAK_GBS, 5)}
-        # the same pipelining for the reference's own call shape -- one frame set in, one panorama out per call: the
-        # per-camera kernels of call t + 1 beside the canvas kernels of call t (a frame's latency is unchanged)
-        if "latency_mode" in out:
-            one2 = [eng2.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], panos[k % len(panos)].data_ptr(),
-                                          pano.stride(0), stream=stream) for k, ds in enumerate(dev_sets)]
-            for i in range(20):
-                one2[i % len(one2)]()
-            torch.cuda.synchronize()
-            n3 = max(50, int(0.4 / max(t_seq / batch, 1e-6)))
-            t0 = time.perf_counter()
-            for i in range(n3):
-                one2[i % len(one2)]()
-            torch.cuda.synchronize()
-            w3 = time.perf_counter() - t0
-            out["latency_mode"]["pipelined_calls"] = {"calls_in_flight": 2, "frames": n3, "frames_per_s": round(n3 / w3, 2),
-                                                      "roofline_frac": round(alg_bytes * n3 / w3 / 1e9 / HBM_PEAK_GBS, 5)}
-        eng2.close()
+        ms2 = e0.elapsed_time(e1) / n2
+        out["serial"] = {"launch_sequences_in_flight": 1, "frame_sets_per_launch": batch, "frames": n2 * batch,
+                         "frames_per_s": round(1000.0 * batch / ms2, 2), "device_ms_per_frame": round(ms2 / batch, 5),
+                         "roofline_frac": round(alg_bytes * batch / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    # the reference's own call shape -- one frame set in, one panorama out per call -- with `in_flight` such calls in flight
+    if rank == 0 and world == 1 and not by_camera and eng_p is not eng and "latency_mode" in out:
+        one2 = [eng_p.make_device_call([t.data_ptr() for t in dev_sets[k % n_sets]], [t.stride(0) for t in dev_sets[k % n_sets]],
+                                       pano_ring[k % len(pano_ring)][0].data_ptr(), pano.stride(0), stream=stream)
+                for k in range(n_sets * len(pano_ring))]
+        for i in range(20):
+            one2[i % len(one2)]()
+        torch.cuda.synchronize()
+        n3 = max(50, int(0.4 / max(t_seq / batch, 1e-6)))
+        t0 = time.perf_counter()
+        for i in range(n3):
+            one2[i % len(one2)]()
+        torch.cuda.synchronize()
+        w3 = time.perf_counter() - t0
+        out["latency_mode"]["pipelined_calls"] = {"calls_in_flight": in_flight, "frames": n3, "frames_per_s": round(n3 / w3, 2),
+                                                  "roofline_frac": round(alg_bytes * n3 / w3 / 1e9 / HBM_PEAK_GBS, 5)}
 
     # ---- the one-frame-set call replayed as a hipGraph (MST_FLAG_GRAPH_REPLAY): same kernels, one hipGraphLaunch per call ----
     if rank == 0 and world == 1 and not by_camera and "latency_mode" in out:
@@ -506,7 +528,7 @@ def main():
                 call()
             torch.cuda.synchronize()
             fps_nv = nn * batch / (time.perf_counter() - t0)
-            out["nv12_resident"] = {"frames_per_s": round(fps_nv, 1), "of_bgr_rate": round(fps_nv / out["value"], 4),
+            out["nv12_resident"] = {"frames_per_s": round(fps_nv, 1), "of_bgr_rate": round(fps_nv / out.get("serial", {}).get("frames_per_s", out["value"]), 4),
                                     "note": "frames resident in HBM as NV12 (1.5 bytes a pixel), k_nv12_to_bgr ahead of every launch sequence"}
             eng_nv.close()
             del nv_dev, pn
@@ -590,7 +612,10 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_paths
         eng.close()
-        del dev_sets, pano_rows, panos
+        if eng_p is not eng:
+            eng_p.close()
+            eng_p = eng
+        del dev_sets, pano_rows, panos, pano_ring, calls
         torch.cuda.empty_cache()
         cfgs = {}
         for nm in ("C2", "C5", "C3-LUT", "C5-LUT"):
@@ -608,6 +633,8 @@ def main():
         print(json.dumps(out), flush=True)
         printed = True
 
+    if eng_p is not eng:
+        eng_p.close()
     eng.close()
     if world > 1:
         arm("final_barrier", 120.0)

@@ -162,6 +162,12 @@ typedef struct mst_config {
      * buffer keeps the whole canvas's geometry (pointer = canvas column 0; only the strip's columns are written and the
      * row stride only has to cover the strip's last column).  strip_count 0 or 1: the whole canvas. */
     int32_t  strip_index, strip_count;
+    /* MST_FLAG_OVERLAP_FRAMES: calls in flight.  0 .. 2: the two-stream form described at the flag.  3 .. 8: every call runs
+     * WHOLE on one of that many engine-owned streams, round-robin, with its own run of pyramid / pre-pass buffer sets, and
+     * the caller's stream waits for it -- independent launch sequences fill each other's launch boundaries and tails (C3,
+     * 4 in flight: one-frame-set calls 9.5 k -> 14.6 k panoramas/s, batches of 8 15.9 k -> 18.5 k).  Same contract as the
+     * flag; this form also serves the feather / paste / LUT composites.  Memory: overlap_depth x max_batch buffer sets. */
+    int32_t  overlap_depth;
 } mst_config;
 
 typedef struct mst_camera {

@@ -67,7 +67,8 @@ class Config(C.Structure):
                 ("expos_kind", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("upblack", C.c_float), ("downblack", C.c_float), ("leftblack", C.c_float),
                 ("rightblack", C.c_float), ("max_batch", C.c_int32), ("weight_type", C.c_int32),
-                ("warp_a", C.c_float), ("warp_b", C.c_float), ("strip_index", C.c_int32), ("strip_count", C.c_int32)]
+                ("warp_a", C.c_float), ("warp_b", C.c_float), ("strip_index", C.c_int32), ("strip_count", C.c_int32),
+                ("overlap_depth", C.c_int32)]
 
 
 class Camera(C.Structure):

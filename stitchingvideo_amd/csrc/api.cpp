@@ -106,6 +106,7 @@ int mst_create(const mst_config* cfg, mst_engine** out)
         require(cfg->struct_size == static_cast<int32_t>(sizeof(mst_config)), "mst_config.struct_size mismatch");
         require(cfg->strip_count >= 0 && cfg->strip_count <= 64 && cfg->strip_index >= 0 &&
                 (cfg->strip_count <= 1 ? cfg->strip_index == 0 : cfg->strip_index < cfg->strip_count), "bad strip_index / strip_count");
+        require(cfg->overlap_depth >= 0 && cfg->overlap_depth <= 8, "overlap_depth out of range (0 .. 8)");
         require(cfg->num_cameras >= 1 && cfg->num_cameras <= MST_MAX_CAMERAS, "num_cameras out of range");
         require(valid_warp(cfg->warp_kind), "unknown warp kind");
         require((cfg->warp_kind & MST_WARP_AB_CUSTOM) != MST_WARP_AB_CUSTOM || (cfg->warp_a > 0.f && cfg->warp_b > 0.f),

@@ -284,7 +284,10 @@ void Engine::init()
     check_hip(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     check_hip(hipStreamCreateWithFlags(&calib_stream_, hipStreamNonBlocking), "hipStreamCreate");
     check_hip(hipStreamCreateWithFlags(&front_stream_, hipStreamNonBlocking), "hipStreamCreate");
-    for (int i = 0; i < 2; ++i) {
+    overlap_depth_ = cfg_.overlap_depth >= 3 ? std::min<int>(kMaxOverlap, cfg_.overlap_depth) : 2;
+    if (const char* v = std::getenv("MST_OVERLAP_DEPTH")) overlap_depth_ = std::max(2, std::min(kMaxOverlap, std::atoi(v)));      // (A/B runs)
+    for (int i = 0; i < kMaxOverlap; ++i) {
+        if (overlap_depth_ > 2) check_hip(hipStreamCreateWithFlags(&call_streams_[i], hipStreamNonBlocking), "hipStreamCreate");
         check_hip(hipEventCreateWithFlags(&ev_front_done_[i], hipEventDisableTiming), "hipEventCreate");
         check_hip(hipEventCreateWithFlags(&ev_canvas_done_[i], hipEventDisableTiming), "hipEventCreate");
     }
@@ -315,7 +318,8 @@ Engine::~Engine()
     if (stream_) (void)hipStreamDestroy(stream_);
     if (calib_stream_) (void)hipStreamDestroy(calib_stream_);
     if (front_stream_) (void)hipStreamDestroy(front_stream_);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kMaxOverlap; ++i) {
+        if (call_streams_[i]) (void)hipStreamDestroy(call_streams_[i]);
         if (ev_front_done_[i]) (void)hipEventDestroy(ev_front_done_[i]);
         if (ev_canvas_done_[i]) (void)hipEventDestroy(ev_canvas_done_[i]);
     }
@@ -477,7 +481,8 @@ void Engine::update(const mst_calibration& calib)
     // (pipelining alternates between two halves of the sets, each as large as a batch)
     st->sets_per_slot = std::max(1, std::min<int>(cfg_.max_batch, kMaxBatch));
     st->num_sets = st->sets_per_slot;
-    if ((cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && cfg_.blend_kind == MST_BLEND_MULTI_BAND) st->num_sets = 2 * st->sets_per_slot;
+    if ((cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && (cfg_.blend_kind == MST_BLEND_MULTI_BAND || overlap_depth_ > 2))
+        st->num_sets = overlap_depth_ * st->sets_per_slot;
 
     if (cfg_.flags & MST_FLAG_FRAMES_NV12) {        // the BGR frames the callers' NV12 frames are converted into
         std::vector<int2> sizes(n);
@@ -1248,6 +1253,21 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
 
 // One calibration state for the whole call: callers that size buffers first (compose_host) pass the snapshot they
 // sized them from, so a concurrent mst_update cannot slip a different canvas in between.
+// Deep form of MST_FLAG_OVERLAP_FRAMES: calls on different slots run on different streams.  Two of them that write the same
+// panorama (or mask) buffer must not overlap: the later one waits for the earlier one's completion event, which restores
+// the order of the calls for that buffer (exact pointer matches only -- buffers that merely overlap are the caller's to keep apart).
+void Engine::order_after_writers(int slot, hipStream_t s, const std::vector<const void*>& outs)
+{
+    for (int k = 0; k < kMaxOverlap; ++k) {
+        if (k == slot || !canvas_pending_[k]) continue;
+        bool shared = false;
+        for (const void* p : slot_outputs_[k])
+            for (const void* q : outs) shared = shared || (p && p == q);
+        if (shared) check_hip(hipStreamWaitEvent(s, ev_canvas_done_[k], 0), "hipStreamWaitEvent");
+    }
+    slot_outputs_[slot] = outs;
+}
+
 // phase 0: the whole launch sequence.  Strip engines with halo exchange (MST_FLAG_STRIP_HALO) run it as two calls around the
 // exchange: phase 1 = the per-camera kernels up to the cut level + the halo rectangles packed into halo[0] / halo[1] (left /
 // right neighbour; frames are read, no panorama is written); phase 2 = the received rectangles unpacked, the rest of the
@@ -1328,14 +1348,24 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
                              timer == nullptr && !in_host_compose_ && phase == 0;
         // the last pyramid level the front phase produces (the halo's cut level; everything when the plan made no cut)
         const int cut = phase == 0 ? 0 : (st->plan.halo_level > 0 ? st->plan.halo_level : kMaxLevels);
-        const int slot = overlap ? static_cast<int>(frame_counter_++ & 1u) : 0;
+        // deep form (MST_OVERLAP_DEPTH > 2): the whole call on the slot's own stream; the caller's stream only waits for it
+        const int slots = st->num_sets / st->sets_per_slot;
+        const bool deep = overlap && overlap_depth_ > 2 && slots > 2;
+        hipStream_t caller = s;
+        const int slot = overlap ? static_cast<int>(frame_counter_++ % (deep ? slots : 2)) : 0;
+        if (deep) {
+            s = call_streams_[slot];
+            std::vector<const void*> outs;
+            for (int f = 0; f < count; ++f) { outs.push_back(d_panos[f]); if (d_masks) outs.push_back(d_masks[f]); }
+            order_after_writers(slot, s, outs);
+        }
         const int first_set = slot * st->sets_per_slot;           // the slot's run of descriptor / buffer sets
         const CamDesc* desc = st->d_desc + static_cast<size_t>(first_set) * st->n;
-        hipStream_t sf = overlap ? front_stream_ : s;
-        if (overlap && canvas_pending_[slot])
+        hipStream_t sf = deep ? s : overlap ? front_stream_ : s;
+        if (overlap && !deep && canvas_pending_[slot])
             check_hip(hipStreamWaitEvent(sf, ev_canvas_done_[slot], 0), "hipStreamWaitEvent");
         if (!overlap)          // a batch (or a timed frame) re-uses the sets an earlier pipelined frame may still read
-            for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < kMaxOverlap; ++k)
                 if (canvas_pending_[k]) {
                     check_hip(hipStreamWaitEvent(s, ev_canvas_done_[k], 0), "hipStreamWaitEvent");
                     canvas_pending_[k] = false;
@@ -1363,7 +1393,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
             check_hip(hipEventRecord(ev_front_done_[slot], sf), "hipEventRecord");
             check_hip(hipStreamWaitEvent(s, ev_front_done_[slot], 0), "hipStreamWaitEvent");
         };
-        if (overlap && split_after_warp) cross();
+        if (overlap && !deep && split_after_warp) cross();
         hipStream_t sc = (overlap && !split_after_warp) ? sf : s;
         // (a launch belongs to the front phase when the level it produces is at or below the cut)
         auto mine = [&](int produced) { return phase == 0 || (phase == 1) == (produced <= cut); };
@@ -1383,7 +1413,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
             set_in_flight(std::move(st));
             return;
         }
-        if (overlap && !split_after_warp) cross();
+        if (overlap && !deep && !split_after_warp) cross();
         int n_coarse = 0;
         size_t lds_bytes = 0;
         BlendArgs ba = st->blend_for(count, &n_coarse, &lds_bytes);
@@ -1406,9 +1436,39 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         if (overlap) {
             check_hip(hipEventRecord(ev_canvas_done_[slot], s), "hipEventRecord");
             canvas_pending_[slot] = true;
+            if (deep) check_hip(hipStreamWaitEvent(caller, ev_canvas_done_[slot], 0), "hipStreamWaitEvent");
         }
     } else {
-        undistort(0, s);
+        // the single-pass composites: the deep form of MST_FLAG_OVERLAP_FRAMES only (a call is one or two launches; the slot
+        // owns the pre-pass buffers of its frame sets)
+        const int slots = st->num_sets / st->sets_per_slot;
+        const bool deep = (cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && overlap_depth_ > 2 && slots > 2 && timer == nullptr && !in_host_compose_;
+        hipStream_t caller = s;
+        int slot = 0;
+        if (deep) {
+            slot = static_cast<int>(frame_counter_++ % slots);
+            s = call_streams_[slot];
+            std::vector<const void*> outs;
+            for (int f = 0; f < count; ++f) { outs.push_back(d_panos[f]); if (d_masks) outs.push_back(d_masks[f]); }
+            order_after_writers(slot, s, outs);
+        } else {
+            for (int k = 0; k < kMaxOverlap; ++k)
+                if (canvas_pending_[k]) {
+                    check_hip(hipStreamWaitEvent(s, ev_canvas_done_[k], 0), "hipStreamWaitEvent");
+                    canvas_pending_[k] = false;
+                }
+        }
+        struct Join {            // (every exit of this branch, the throwing ones included, leaves the caller's stream behind the slot's)
+            Engine* e; bool on; int slot; hipStream_t from, to;
+            ~Join() {
+                if (!on) return;
+                if (hipEventRecord(e->ev_canvas_done_[slot], from) == hipSuccess) {
+                    e->canvas_pending_[slot] = true;
+                    (void)hipStreamWaitEvent(to, e->ev_canvas_done_[slot], 0);
+                }
+            }
+        } join{this, deep, slot, s, caller};
+        undistort(slot * st->sets_per_slot, s);
         ComposeArgs ca = st->compose;
         ca.n_sets = count;
         bool aligned = true;       // the staged form reads whole dwords: frames on a 4-byte grid (any cv::Mat of 4n columns is)

@@ -237,9 +237,16 @@ private:
     // Frame pipelining (MST_FLAG_OVERLAP_FRAMES): the per-camera kernels of frame t+1 run on front_stream_
     // while the canvas kernel of frame t runs on the caller's stream; two pyramid sets alternate.
     hipStream_t front_stream_ = nullptr;
-    hipEvent_t ev_front_done_[2] = {nullptr, nullptr};   // per-camera work of the slot finished
-    hipEvent_t ev_canvas_done_[2] = {nullptr, nullptr};  // canvas kernel that read the slot finished
-    bool canvas_pending_[2] = {false, false};
+    static constexpr int kMaxOverlap = 8;
+    hipEvent_t ev_front_done_[kMaxOverlap] = {};     // per-camera work of the slot finished
+    hipEvent_t ev_canvas_done_[kMaxOverlap] = {};    // canvas kernel that read the slot finished
+    bool canvas_pending_[kMaxOverlap] = {};
+    // MST_OVERLAP_DEPTH = 3 or 4 (experiment): whole calls on their own streams, round-robin, one pyramid slot each
+    int overlap_depth_ = 2;
+    hipStream_t call_streams_[kMaxOverlap] = {};
+    std::vector<const void*> slot_outputs_[kMaxOverlap];   // panorama / mask buffers the slot's latest call writes
+    // a deep call on `slot` about to write `outs`: wait for every other slot whose latest call writes one of the same buffers
+    void order_after_writers(int slot, hipStream_t s, const std::vector<const void*>& outs);
     bool in_host_compose_ = false;
     uint64_t frame_counter_ = 0;
     int stage_set_ = 0;

@@ -405,7 +405,7 @@ class PanoramaEngine:
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
                  feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False,
-                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None, lens_composed=False, frames_nv12=False, graph_replay=False, strip_halo=False):
+                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None, lens_composed=False, frames_nv12=False, graph_replay=False, strip_halo=False, overlap_depth=0):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -427,6 +427,7 @@ class PanoramaEngine:
         if warp_ab is not None:          # CompressedRectilinear* / Panini* with arbitrary (A, B)
             cfg.warp_kind = (cfg.warp_kind & 0xFF) | capi.WARP_AB_CUSTOM
             cfg.warp_a, cfg.warp_b = float(warp_ab[0]), float(warp_ab[1])
+        cfg.overlap_depth = int(overlap_depth)         # with overlap_frames: calls in flight (3..8: whole calls on own streams)
         if strip is not None:            # (index, count): this engine composes one column strip of the canvas (canvas split over GPUs)
             cfg.strip_index, cfg.strip_count = int(strip[0]), int(strip[1])
         self.num_cameras = num_cameras

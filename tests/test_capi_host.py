@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header_sizes():
     # the C side checks struct_size; these are the sizes an LP64 compiler produces for the header
-    assert C.sizeof(capi.Config) == 76          # 15 x 4-byte fields + warp_a, warp_b + strip_index, strip_count
+    assert C.sizeof(capi.Config) == 80          # 15 x 4-byte fields + warp_a, warp_b + strip_index, strip_count + overlap_depth
     assert C.sizeof(capi.Camera) == 8 + 36 + 36 + 12 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 16 + 8 + 8 + 8
     assert C.sizeof(capi.Calibration) == 24
 

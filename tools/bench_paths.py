@@ -30,7 +30,7 @@ PATHS = {
 _RIGS = {}
 
 
-def measure(name, batch=8, min_time=0.4, latency_leg=True, expos=None):
+def measure(name, batch=8, min_time=0.4, latency_leg=True, expos=None, in_flight=4):
     import torch
     import stitchingvideo_amd as S
     from stitchingvideo_amd import rig as rigmod
@@ -97,6 +97,34 @@ def measure(name, batch=8, min_time=0.4, latency_leg=True, expos=None):
            "ms_per_frame": round(ms_seq / batch, 5), "algorithmic_bytes_per_frame": alg,
            "roofline_frac": round(alg * batch / (ms_seq * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "kernels": kernels,
            "mst_update_s": round(t_update, 3)}
+    if in_flight > 1:
+        # the same calls with `in_flight` launch sequences in flight (mst_config.overlap_depth): whole calls on engine-owned
+        # streams, each with its own panorama buffers; this is the rate the top-level fields report, the serial one moves to "serial"
+        eng_d = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=expos or rig["expos"], num_bands=5, device=0,
+                                 driver_lut=lut, max_batch=batch, overlap_frames=True, overlap_depth=max(3, in_flight))
+        eng_d.update(rig["scale"], rig["cameras"])
+        eng_d.acquire()
+        ring = [panos] + [[torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(batch)] for _ in range(max(3, in_flight) - 1)]
+        calls_d = [eng_d.make_device_batch_call(*tables(k % n_sets), [p.data_ptr() for p in ring[k % len(ring)]], panos[0].stride(0), stream=stream)
+                   for k in range(len(ring) * n_sets)]
+        for i in range(2 * len(ring)):
+            calls_d[i % len(calls_d)]()
+        torch.cuda.synchronize()
+        ms_d = timed(calls_d, max(10, int(min_time * 1e3 / max(ms_seq, 1e-3))))
+        out["serial"] = {"frames_per_s": out["frames_per_s"], "ms_per_frame": out["ms_per_frame"], "roofline_frac": out["roofline_frac"]}
+        out.update({"launch_sequences_in_flight": max(3, in_flight), "frames_per_s": round(1000.0 * batch / ms_d, 2),
+                    "ms_per_frame": round(ms_d / batch, 5), "roofline_frac": round(alg * batch / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
+        if latency_leg and batch > 1:
+            one_d = [eng_d.make_device_call([t.data_ptr() for t in dev_sets[k % n_sets]], [t.stride(0) for t in dev_sets[k % n_sets]],
+                                            ring[k % len(ring)][0].data_ptr(), panos[0].stride(0), stream=stream) for k in range(len(ring) * n_sets)]
+            for i in range(2 * len(ring)):
+                one_d[i % len(one_d)]()
+            torch.cuda.synchronize()
+            ms1d = timed(one_d, max(40, int(0.3 * 1e3 / max(ms_seq / batch, 1e-3))))
+            out["one_frame_set_calls_in_flight"] = {"calls_in_flight": max(3, in_flight), "frames_per_s": round(1000.0 / ms1d, 2),
+                                                    "roofline_frac": round(alg / (ms1d * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        eng_d.close()
+        del ring, calls_d
     if latency_leg and batch > 1:
         one = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], panos[0].data_ptr(),
                                     panos[0].stride(0), stream=stream) for ds in dev_sets]
@@ -128,10 +156,11 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--min-time", type=float, default=0.4)
     ap.add_argument("--no-latency-leg", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=4, help="launch sequences in flight for the top-level rate (1: serial only)")
     ap.add_argument("--expos", default=None, help="override the rig's exposure compensation (no | gain | gain_blocks): ablation runs")
     args = ap.parse_args()
     for nm in (args.names or list(PATHS)):
         try:
-            print(json.dumps(measure(nm, batch=args.batch, min_time=args.min_time, latency_leg=not args.no_latency_leg, expos=args.expos)), flush=True)
+            print(json.dumps(measure(nm, batch=args.batch, min_time=args.min_time, latency_leg=not args.no_latency_leg, expos=args.expos, in_flight=args.in_flight)), flush=True)
         except Exception as e:      # noqa: BLE001
             print(json.dumps({"name": nm, "error": "%s: %s" % (type(e).__name__, e)}), flush=True)

@@ -2,7 +2,7 @@
 # rocprofv3 passes over one path of tools/bench_paths.py on the GPU box: tools/prof_paths.sh <tag> <path name> [bench_paths args]
 TAG=$1; NAME=$2; shift 2
 OUT=$PWD/gpurun_out/prof_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-BENCH="python3 $PWD/tools/bench_paths.py $NAME --min-time 0.1 --no-latency-leg $@"
+BENCH="python3 $PWD/tools/bench_paths.py $NAME --in-flight 1 --min-time 0.1 --no-latency-leg $@"
 echo "$BENCH" | sed "s|$PWD/||g" > "$OUT/command.txt"
 REPO=$PWD
 cd /tmp

@@ -9,7 +9,7 @@ EXTRA="$@"
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 10 --warmup 3 --min-time 0.1 --no-cpu-baseline --no-latency-leg --no-configs $EXTRA"
+BENCH="python3 $PWD/bench.py --in-flight 1 --steps 10 --warmup 3 --min-time 0.1 --no-cpu-baseline --no-latency-leg --no-configs $EXTRA"
 REPO=$PWD
 echo "$BENCH" | sed "s|$PWD/||" > "$OUT/command.txt"
 cd /tmp

@@ -18,18 +18,18 @@ cp gpurun_out/traffic.json profiles/traffic.json
 ( time python bench.py --strip-leg --camera-leg > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err ) 2>&1 | grep real
 # one strip = the whole canvas: the strip leg must reproduce the headline (same kernels, same lists) within 3 %
 python -c "
-import json, sys; d=json.load(open('gpurun_out/round/bench.json')); s=d['strip_sharded']['frames_per_s_strips_left_in_place']; v=d['value']
-print('strip leg at N = 1: %.1f vs value %.1f (%.1f %%)' % (s, v, 100.0 * (s - v) / v)); sys.exit(0 if abs(s - v) <= 0.03 * v else 1)" || echo "STRIP LEG DOES NOT REPRODUCE THE HEADLINE"
+import json, sys; d=json.load(open('gpurun_out/round/bench.json')); s=d['strip_sharded']['frames_per_s_strips_left_in_place']; v=d.get('serial', {}).get('frames_per_s', d['value'])
+print('strip leg at N = 1: %.1f vs the one-at-a-time rate %.1f (%.1f %%)' % (s, v, 100.0 * (s - v) / v)); sys.exit(0 if abs(s - v) <= 0.03 * v else 1)" || echo "STRIP LEG DOES NOT REPRODUCE THE HEADLINE"
 python -c "
 import json; d=json.load(open('gpurun_out/round/bench.json'))
-print(d['value'], d['roofline']['frac'], d['roofline']['traffic'], [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']], d.get('latency_mode'), d.get('overlapped'), d.get('host_buffers'), d.get('cpu_baseline'))
-for k,v in d.get('configs',{}).items(): print(k, v.get('frames_per_s'), v.get('roofline_frac'), v.get('traffic'), v.get('latency_mode',{}).get('roofline_frac'))"
+print(d['value'], d['roofline']['frac'], d['roofline']['traffic'], [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']], d.get('latency_mode'), d.get('serial'), d.get('host_buffers'), d.get('cpu_baseline'))
+for k,v in d.get('configs',{}).items(): print(k, v.get('frames_per_s'), v.get('roofline_frac'), v.get('serial'), v.get('traffic'), v.get('latency_mode',{}).get('roofline_frac'), v.get('one_frame_set_calls_in_flight'))"
 python bench.py --batch 1 --no-cpu-baseline --no-configs > gpurun_out/round/bench_batch1.json 2>/dev/null
 python bench.py --undistort --no-cpu-baseline --no-configs --no-latency-leg > gpurun_out/round/bench_undistort.json 2>/dev/null
 python -c "
 import json
 for f in ('bench_batch1','bench_undistort'):
-    d=json.load(open('gpurun_out/round/%s.json'%f)); print(f, d['value'], [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']])"
+    d=json.load(open('gpurun_out/round/%s.json'%f)); print(f, d['value'], d.get('serial'), [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']])"
 python tools/strip_model.py > gpurun_out/round/strip_model.jsonl 2>/dev/null
 python tools/time_update.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/round/time_update.txt | tail -20
 python tests/sweeps/fuzz_parity.py 400 41001 2>&1 | tail -2

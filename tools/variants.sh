@@ -7,7 +7,7 @@ for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   W=/tmp/mst_var_$name; rm -rf $W; mkdir -p $W; cp -r $SRC/stitchingvideo_amd $SRC/include $SRC/tools $SRC/bench.py $SRC/tests $SRC/oracle $W/ 2>/dev/null
   (cd $W/stitchingvideo_amd/csrc && rm -rf build && make -j16 CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $flags" > $W/build.log 2>&1) || { echo "$name: build failed"; tail -5 $W/build.log; continue; }
-  (cd $W && python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-latency-leg --min-time 0.4 $BENCH_ARGS 2>/dev/null | show "$name")
+  (cd $W && python3 bench.py --steps 20 --warmup 5 --in-flight 1 --no-cpu-baseline --no-configs --no-latency-leg --min-time 0.4 $BENCH_ARGS 2>/dev/null | show "$name")
   # VARIANT_PATHS="C2 C3-LUT": the other single-GPU paths through tools/bench_paths.py as well
   [ -n "$VARIANT_PATHS" ] && (cd $W && python3 tools/bench_paths.py $VARIANT_PATHS --no-latency-leg 2>/dev/null | python3 -c "
 import sys,json
