@@ -206,9 +206,12 @@ void fill_camera_desc(DevicePool& pool, hipStream_t s, const Projector& proj, co
     check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
 }
 
-BlendArgs CalibState::blend_for(int frame_sets, int* n_coarse, size_t* lds_bytes) const
+// busy: other launch sequences run beside this one (mst_config.overlap_depth >= 3) -- the canvas kernels then take the
+// large-batch shape (fewer, longer blocks) at any batch size: what the small-batch shape buys a lone launch, filling the chip,
+// the neighbours already provide (C3, one-frame-set calls, 4 in flight: 15.0 k -> 16.0 k panoramas/s)
+BlendArgs CalibState::blend_for(int frame_sets, int* n_coarse, size_t* lds_bytes, bool busy) const
 {
-    const int v = mb_launch_variant(frame_sets);
+    const int v = busy ? 1 : mb_launch_variant(frame_sets);
     const MbPlanHost::CoarseTiles& ct = plan.coarse[v];
     BlendArgs ba = blend;
     ba.cc_th = ct.th;
@@ -938,7 +941,8 @@ void Engine::launch_warp(const CalibState& st, const CamDesc* desc, const FrameB
     static const bool force_gather = [] { const char* v = std::getenv("MST_WARP_GATHER"); return v && v[0] == '1'; }();
     // (one or two frame sets per launch: the gathering kernel's smaller blocks fill the chip better -- 9.5 k against 8.8 k
     // panoramas/s one at a time on C3; from three sets on the staged form wins)
-    bool aligned = !force_gather && count > 2;
+    static const int staged_min = [] { const char* v = std::getenv("MST_WARP_STAGED_MIN"); return v ? std::atoi(v) : 3; }();      // (A/B runs)
+    bool aligned = !force_gather && count >= staged_min;
     for (int f = 0; f < count && aligned; ++f)
         for (int i = cam0; i < cam1; ++i)
             if (fb.f[f].ptr[i]) aligned &= ((reinterpret_cast<uintptr_t>(fb.f[f].ptr[i]) | fb.f[f].stride[i]) & 3u) == 0;
@@ -1416,7 +1420,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         if (overlap && !deep && !split_after_warp) cross();
         int n_coarse = 0;
         size_t lds_bytes = 0;
-        BlendArgs ba = st->blend_for(count, &n_coarse, &lds_bytes);
+        BlendArgs ba = st->blend_for(count, &n_coarse, &lds_bytes, deep);
         for (int f = 0; f < count; ++f) {
             ba.pano[f] = static_cast<uint8_t*>(d_panos[f]);
             ba.pano_mask[f] = d_masks ? static_cast<uint8_t*>(d_masks[f]) : nullptr;

@@ -104,7 +104,7 @@ struct CalibState {
     struct CoarseDev { const uint32_t* cams = nullptr; const uint32_t* pure = nullptr; const uint32_t* order = nullptr; const uint32_t* order2 = nullptr; };
     CoarseDev coarse_dev[2];               // k_blend_coarse tile tables of plan.coarse[v] on the device
     // `blend` completed for a launch of `frame_sets` frame sets: the tile tables / LDS layout of its launch variant
-    BlendArgs blend_for(int frame_sets, int* n_coarse, size_t* lds_bytes) const;
+    BlendArgs blend_for(int frame_sets, int* n_coarse, size_t* lds_bytes, bool busy = false) const;
     std::vector<uint64_t*> c1;               // per buffer set: collapsed level-1 canvas (k_blend_coarse / k_blend_mid -> k_blend_fine)
     std::vector<uint64_t*> c2;               // per buffer set: collapsed level-2 canvas (k_blend_coarse -> k_blend_mid), three and more levels
     // MST_FLAG_FRAMES_NV12: num_sets x n engine-owned BGR frames the callers' NV12 frames are converted into, (w, h) per camera

@@ -2397,7 +2397,11 @@ int mb_coarse_tile_width() { return CC_TW; }
 
 int mb_coarse_tile_height(int variant) { return variant == 0 ? 16 : 32; }
 
-int mb_launch_variant(int frame_sets) { return frame_sets <= 2 ? 0 : 1; }
+int mb_launch_variant(int frame_sets)
+{
+    static const int big_min = [] { const char* v = std::getenv("MST_VARIANT_MIN"); return v ? std::atoi(v) : 3; }();      // (A/B runs)
+    return frame_sets < big_min ? 0 : 1;
+}
 
 int mb_fine_threads(int variant) { return variant == 0 ? 256 : 128; }
 

@@ -81,11 +81,37 @@ def main():
                 halo_times.append(e0.elapsed_time(e1) / 20)
                 halo_bytes.append([batch * b for b in send_b])
                 eng.close()
-            extra = {}
+            # ... and with four launch sequences in flight per strip engine (mst_config.overlap_depth): a strip's sequence is a small
+            # grid, its launch boundaries are most of what it loses
+            fl_times = []
+            for k in range(g):
+                eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend="multiband", expos=rig["expos"], num_bands=5, max_batch=batch, strip=(k, g),
+                                       overlap_frames=True, overlap_depth=4)
+                eng.update(rig["scale"], rig["cameras"])
+                (cx, cy, cw, ch), _ = eng.acquire()
+                sx, _, sw, _ = eng.strip()
+                ring = [[torch.empty((ch, max(sw, 1), 3), dtype=torch.uint8, device=dev) for _ in range(batch)] for _ in range(4)]
+                calls = [eng.make_device_batch_call(ptrs, strides, [b.data_ptr() - (sx - cx) * 3 for b in r], r[0].stride(0), stream=stream) for r in ring]
+                for i in range(8):
+                    calls[i % 4]()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(40):
+                    calls[i % 4]()
+                e1.record()
+                torch.cuda.synchronize()
+                fl_times.append(e0.elapsed_time(e1) / 40)
+                eng.close()
+                del ring, calls
+            extra = {"in_flight_4_ms_per_launch_sequence": [round(t, 4) for t in fl_times], "in_flight_4_max_ms": round(max(fl_times), 4),
+                     "in_flight_4_sum_ms": round(sum(fl_times), 4),
+                     "in_flight_4_predicted_frames_per_s_one_strip_per_gpu": round(batch * 1000.0 / max(fl_times), 1)}
             if halo_times:
-                extra = {"halo_ms_per_launch_sequence": [round(t, 4) for t in halo_times], "halo_max_ms": round(max(halo_times), 4),
+                extra.update(
+{"halo_ms_per_launch_sequence": [round(t, 4) for t in halo_times], "halo_max_ms": round(max(halo_times), 4),
                          "halo_sum_ms": round(sum(halo_times), 4), "halo_send_bytes_per_launch_sequence_left_right": halo_bytes,
-                         "halo_predicted_frames_per_s_one_strip_per_gpu": round(batch * 1000.0 / max(halo_times), 1)}
+                         "halo_predicted_frames_per_s_one_strip_per_gpu": round(batch * 1000.0 / max(halo_times), 1)})
             print(json.dumps({**extra, "config": name, "strips": g, "frame_sets_per_launch": batch, "strip_widths": widths,
                               "ms_per_launch_sequence": [round(t, 4) for t in times], "max_ms": round(max(times), 4), "sum_ms": round(sum(times), 4),
                               "predicted_frames_per_s_one_strip_per_gpu": round(batch * 1000.0 / max(times), 1),
