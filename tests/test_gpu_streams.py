@@ -262,8 +262,10 @@ def test_recalibration_from_a_second_thread_while_composing():
     eng.close()
 
 
-def test_recalibration_that_changes_the_canvas_size_while_composing():
-    """A recalibration that moves R / scale changes the canvas rectangle.  The frame thread latches the calibration
+@pytest.mark.parametrize("depth", [0, 4])
+def test_recalibration_that_changes_the_canvas_size_while_composing(depth):
+    """(depth = 4: the same on an engine with mst_config.overlap_depth = 4 -- device calls run on the engine's own streams.)
+    A recalibration that moves R / scale changes the canvas rectangle.  The frame thread latches the calibration
     (mst_acquire_calibration = `if (Upflag) UpdateMat();`, DRV:835-836), sizes its buffers from the latched canvas and
     composes against exactly that state, while a second thread keeps publishing calibrations of two different canvas
     sizes: every panorama must be one of the two oracle panoramas at its own size (host-buffer and device paths)."""
@@ -276,7 +278,7 @@ def test_recalibration_that_changes_the_canvas_size_while_composing():
     rect_a, pano_a, _ = H.oracle_compose(rig_a, host)
     rect_b, pano_b, _ = H.oracle_compose(rig_b, host)
     assert rect_a[2:] != rect_b[2:] and rect_b[3] > rect_a[3]          # B is wider AND taller than A
-    eng = H.make_engine(rig_a)
+    eng = H.make_engine(rig_a, overlap_frames=depth > 0, overlap_depth=depth)
     dev = torch.device("cuda", 0)
     dfr = [torch.from_numpy(f).to(dev) for f in host]
     ptrs, strides = [t.data_ptr() for t in dfr], [t.stride(0) for t in dfr]
