@@ -119,6 +119,10 @@ int mst_create(const mst_config* cfg, mst_engine** out)
                 "MST_FLAG_DRIVER_LUT requires MST_BLEND_NO");
         require(!(cfg->flags & MST_FLAG_OVERLAP_FRAMES) || !(cfg->flags & MST_FLAG_DEBUG),
                 "MST_FLAG_OVERLAP_FRAMES cannot be combined with MST_FLAG_DEBUG");
+        require(!(cfg->flags & MST_FLAG_STRIP_HALO) || cfg->blend_kind == MST_BLEND_MULTI_BAND,
+                "MST_FLAG_STRIP_HALO is for the multi-band blend (the other blends have no pyramid halo)");
+        require(!(cfg->flags & MST_FLAG_STRIP_HALO) || !(cfg->flags & (MST_FLAG_OVERLAP_FRAMES | MST_FLAG_GRAPH_REPLAY | MST_FLAG_DEBUG)),
+                "MST_FLAG_STRIP_HALO cannot be combined with MST_FLAG_OVERLAP_FRAMES, MST_FLAG_GRAPH_REPLAY or MST_FLAG_DEBUG");
         require(cfg->max_batch >= 0 && cfg->max_batch <= MST_MAX_BATCH, "max_batch out of range");
         require(cfg->weight_type == MST_WEIGHT_32F || cfg->weight_type == MST_WEIGHT_16S, "weight_type must be CV_32F or CV_16S");
         static_assert(MST_MAX_BATCH == mst::kMaxBatch, "public and device batch limits differ");
