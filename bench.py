@@ -869,6 +869,27 @@ def strip_sharded_leg(args_ns, rank, world, local_rank, dev, stream, config="C3"
     t_compose = timed(n, False)
     t_total = timed(n, True)
     eng.close()
+    # the same strips with four launch sequences in flight per strip engine (a strip's sequence is a small grid: most of what it
+    # loses, it loses at launch boundaries -- DESIGN.md 4a' / 6), strips left in place
+    t_flight = None
+    if sw > 0:
+        eng4 = S.PanoramaEngine(n_cam, warp=rig["warp"], blend="multiband", expos=rig["expos"], num_bands=5, device=local_rank,
+                                max_batch=batch, strip=(rank, world), overlap_frames=True, overlap_depth=4)
+        eng4.update(rig["scale"], rig["cameras"])
+        eng4.acquire()
+        ring = [strips] + [[torch.empty_like(b) for b in strips] for _ in range(3)]
+        calls4 = [eng4.make_device_batch_call([[t.data_ptr() for t in ds] for ds in sets], [[t.stride(0) for t in ds] for ds in sets],
+                                              [b.data_ptr() - x0 * 3 for b in r], strips[0].stride(0), stream=stream) for r in ring]
+        state = {"i": 0}
+
+        def call4():
+            calls4[state["i"] % 4]()
+            state["i"] += 1
+        call = call4
+        t_flight = timed(n, False)
+        eng4.close()
+    elif world > 1:
+        t_flight = timed(n, False)          # (a rank without columns still takes part in the timing reduction)
     alg = rigmod.algorithmic_bytes(rig, (cw, ch))
     return {"workload": "%s: %dx%dx%d BGR8 streams, spherical warp, gain_blocks, multiband blend (5 bands), canvas %dx%d"
                         % (config, n_cam, rig["size"][0], rig["size"][1], cw, ch),
@@ -876,6 +897,7 @@ def strip_sharded_leg(args_ns, rank, world, local_rank, dev, stream, config="C3"
                            "strips concatenated on rank 0 (one grouped point-to-point step per launch sequence)" % (world, batch),
             "scaling": "strong", "strip_columns": rects,
             "frames_per_s": round(n * batch / t_total, 2), "frames_per_s_strips_left_in_place": round(n * batch / t_compose, 2),
+            "frames_per_s_strips_left_in_place_4_sequences_in_flight": round(n * batch / t_flight, 2) if t_flight else None,
             "roofline_frac": round(alg * n * batch / t_total / 1e9 / HBM_PEAK_GBS, 5)}
 
 
