@@ -51,8 +51,12 @@ def one_case(rng, idx):
     wt = "16s" if (blend == "multiband" and rng.integers(0, 3) == 0) else "32f"
     # lens maps either as the reference's pre-pass (two resamplings) or composed into the warp map (one)
     composed = any(m is not None for m in maps) and bool(rng.integers(0, 2))
+    # calls in flight (mst_config.overlap_depth): every fourth case runs its two calls on the engine's own streams -- they write
+    # the same panoramas, so the engine has to order them (chosen from the case index: the random stream stays what it was)
+    depth = (0, 3, 0, 5, 0, 0, 4, 0)[idx % 8]
+    overlap = bool(rng.integers(0, 2)) and blend == "multiband"
     eng = H.make_engine(rig, blend=blend, num_bands=bands, max_batch=count, weight_type=wt,
-                        overlap_frames=bool(rng.integers(0, 2)) and blend == "multiband", lens_composed=composed)
+                        overlap_frames=overlap or depth >= 3, overlap_depth=depth, lens_composed=composed)
     _, _, cw, ch = eng.canvas()
     dev = torch.device("cuda", 0)
     host = [rigmod.frames_for(rig, int(rng.integers(0, 1000))) for _ in range(count)]
@@ -74,6 +78,6 @@ def one_case(rng, idx):
             rect, opano, omask = H.oracle_compose(rig, und, blend=blend, num_bands=bands, weight_type=wt)
         ok &= eng.canvas() == rect and np.array_equal(panos[f].cpu().numpy(), opano) and np.array_equal(masks[f].cpu().numpy(), omask)
     eng.close()
-    desc = "%s n=%d %dx%d f=%.0f s=%.0f %s %s/%s b=%d seams=%d batch=%d lens=%d%s canvas=%dx%d" % (
-        warp, n, w, h, focal, scale, expos, blend, wt, bands, seams, count, sum(m is not None for m in maps), "c" if composed else "", cw, ch)
+    desc = "%s n=%d %dx%d f=%.0f s=%.0f %s %s/%s b=%d seams=%d batch=%d lens=%d%s flight=%d canvas=%dx%d" % (
+        warp, n, w, h, focal, scale, expos, blend, wt, bands, seams, count, sum(m is not None for m in maps), "c" if composed else "", depth, cw, ch)
     return ("ok   " if ok else "FAIL ") + desc
