@@ -81,27 +81,31 @@ def test_full_size_c4_camera_sharded_two_engines():
     e0.close(); e1.close()
 
 
-def test_full_size_c3_in_the_bench_configuration():
+@pytest.mark.parametrize("in_flight", [1, 4])
+def test_full_size_c3_in_the_bench_configuration(in_flight):
     """C3 exactly as bench.py times it: an engine created with max_batch = 8 (which also selects the taller canvas
-    tiles of the batched mode) composing eight frame sets in one launch sequence -- every panorama against the
-    oracle (two distinct frame sets, alternated)."""
+    tiles of the batched mode) composing eight frame sets in one launch sequence -- and, in_flight = 4, with
+    mst_config.overlap_depth = 4 and four such launch sequences in flight, each writing its own eight panoramas (the
+    default of bench.py since round 4) -- every panorama against the oracle (two distinct frame sets, alternated)."""
     import torch
     rig = rigmod.build_rig(rigmod.CONFIGS["C3"])
-    eng = H.make_engine(rig, max_batch=8)
+    eng = H.make_engine(rig, max_batch=8, overlap_frames=in_flight > 1, overlap_depth=in_flight if in_flight > 1 else 0)
     _, _, cw, ch = eng.canvas()
     assert (cw, ch) == (7852, 1020)                          # SURVEY.md 8d
     dev = torch.device("cuda", 0)
     host = [rigmod.frames_for(rig, i) for i in range(2)]
     dfr = [[torch.from_numpy(f).to(dev) for f in fr] for fr in host]
-    order = [0, 1, 1, 0, 1, 0, 0, 1]
-    panos = [torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in order]
-    masks = [torch.zeros((ch, cw), dtype=torch.uint8, device=dev) for _ in order]
+    orders = [[0, 1, 1, 0, 1, 0, 0, 1], [1, 1, 0, 0, 1, 0, 1, 0], [0, 0, 0, 1, 1, 1, 0, 1], [1, 0, 1, 0, 0, 1, 1, 0], [0, 1, 0, 1, 1, 0, 0, 0]][:in_flight + (in_flight > 1)]
+    panos = [[torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in order] for order in orders]
+    masks = [[torch.zeros((ch, cw), dtype=torch.uint8, device=dev) for _ in order] for order in orders]
     torch.cuda.synchronize()          # the fills run on torch's stream, the engine's stream does not wait for it
-    eng.compose_device_batch([[t.data_ptr() for t in dfr[k]] for k in order], [[t.stride(0) for t in dfr[k]] for k in order],
-                             [p.data_ptr() for p in panos], panos[0].stride(0), [m.data_ptr() for m in masks], masks[0].stride(0))
+    for order, pn, mk in zip(orders, panos, masks):          # (five calls on four slots: the fifth waits for the first's buffers)
+        eng.compose_device_batch([[t.data_ptr() for t in dfr[k]] for k in order], [[t.stride(0) for t in dfr[k]] for k in order],
+                                 [p.data_ptr() for p in pn], pn[0].stride(0), [m.data_ptr() for m in mk], mk[0].stride(0))
     eng.synchronize()
     expect = [H.oracle_compose(rig, fr, threads=THREADS) for fr in host]
-    for i, k in enumerate(order):
-        assert np.array_equal(masks[i].cpu().numpy(), expect[k][2]), "frame set %d mask" % i
-        assert np.array_equal(panos[i].cpu().numpy(), expect[k][1]), "frame set %d: %s" % (i, H.diff_report(panos[i].cpu().numpy(), expect[k][1]))
+    for c, order in enumerate(orders):
+        for i, k in enumerate(order):
+            assert np.array_equal(masks[c][i].cpu().numpy(), expect[k][2]), "call %d frame set %d mask" % (c, i)
+            assert np.array_equal(panos[c][i].cpu().numpy(), expect[k][1]), "call %d frame set %d: %s" % (c, i, H.diff_report(panos[c][i].cpu().numpy(), expect[k][1]))
     eng.close()
