@@ -95,3 +95,22 @@ def test_compose_from_nv12_frames(blend):
     with pytest.raises(capi.StitchError):
         eng.stage_cameras([0], {0: dfr[0][0].data_ptr()}, {0: dfr[0][0].stride(0)})
     eng.close()
+    # calls in flight (mst_config.overlap_depth): every call converts into its own slot's BGR frames; with lens maps on two
+    # cameras the undistort pre-pass runs per slot as well.  Nine one-frame-set calls, three panorama buffers in rotation.
+    K = np.array([[0.55 * w, 0, 0.5 * w], [0, 0.55 * w, 0.5 * h], [0, 0, 1]])
+    und = S.init_undistort_rectify_map(K, [-0.3, 0.12, 0.002, -0.001], (w, h))
+    for c in rig["cameras"][:2]:
+        c["undistort"] = und
+    exp_u = []
+    for fr in sets:
+        bgr = [O.cvt_nv12_bgr(f) for f in fr]
+        bgr = [O.remap_fixed(b, und[0], und[1]) if i < 2 else b for i, b in enumerate(bgr)]
+        exp_u.append(H.oracle_compose(rig, bgr))
+    eng = H.make_engine(rig, frames_nv12=True, overlap_frames=True, overlap_depth=3)
+    for k in range(9):
+        i = k % 3
+        eng.compose_device([t.data_ptr() for t in dfr[i]], [t.stride(0) for t in dfr[i]], panos[i].data_ptr(), panos[i].stride(0))
+    eng.synchronize()
+    for i in range(3):
+        assert np.array_equal(panos[i].cpu().numpy(), exp_u[i][1]), "in flight, frame set %d: %s" % (i, H.diff_report(panos[i].cpu().numpy(), exp_u[i][1]))
+    eng.close()
