@@ -706,8 +706,9 @@ def ingest_leg(rig, blend, local_rank, cw, ch, seconds=1.5):
             for p in procs:
                 if p.stdout.readline().strip() != "ready":
                     raise RuntimeError("capture process did not come up")
+            # (the engine of the headline: calls in flight; IngestStitcher hands every call its frames-ready / panorama-free events)
             eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
-                                   frames_nv12=(fmt == "nv12"))
+                                   frames_nv12=(fmt == "nv12"), overlap_frames=True, overlap_depth=4)
             eng.update(rig["scale"], rig["cameras"])
             st = ingest.IngestStitcher(eng, names, [c["size"] for c in rig["cameras"]], device=local_rank)
 
@@ -741,8 +742,8 @@ def ingest_leg(rig, blend, local_rank, cw, ch, seconds=1.5):
                     os.unlink("/dev/shm" + nm)
                 except OSError:
                     pass
-    res["note"] = ("%d capture processes -> shm (DatePacket) -> HBM -> compose -> page-locked panorama, 3 frame sets in flight; "
-                   "PCIe-inclusive" % n_cam)
+    res["note"] = ("%d capture processes -> shm (DatePacket) -> HBM -> compose (overlap_depth 4, mst_compose_device_batch_ex with "
+                   "frames-ready / panorama-free events) -> page-locked panorama, 3 frame sets in flight; PCIe-inclusive" % n_cam)
     return res
 
 

@@ -125,8 +125,12 @@ int mst_warp_kind_from_name(const char *name);
                                       running on the caller's stream (two runs of pyramid sets alternate).  Results and
                                       their order on `stream` are unchanged.  Contract: the frames passed to a call
                                       must be complete in device memory when the call is made (they are read without
-                                      waiting for work still queued on `stream`), and must stay untouched until
-                                      the panorama of that call is complete.  Multi-band only; not with MST_FLAG_DEBUG. */
+                                      waiting for work still queued on `stream`) -- or the call is made through
+                                      mst_compose_device_batch_ex with a `frames_ready` event -- and must stay untouched until
+                                      the panorama of that call is complete.  With overlap_depth >= 3 the panorama is WRITTEN
+                                      on an engine-owned stream as well: a buffer that is passed again must have no pending
+                                      reader on any stream (`outputs_free`, see mst_compose_device_batch_ex).
+                                      Multi-band only; not with MST_FLAG_DEBUG. */
 
 /* MultiBandBlender weight pyramid type (blenders.cpp:189-194): CV_32F (default) or CV_16S (weights 0, 2..256,
  * integer pyrDown, `dst += short((src * w) >> 8)`, normalise `(v << 8) / (w + 1)`; blenders.cpp:289-292,331-355,406-423) */
@@ -220,6 +224,20 @@ size_t mst_calibration_blob_size(const mst_calibration *calib);
 int    mst_calibration_save(const mst_calibration *calib, void *blob, size_t capacity, size_t *written);
 int    mst_calibration_load(const void *blob, size_t bytes, mst_calibration *out, mst_camera *cameras, int max_cameras);
 
+/* ---- what this library binary is ------------------------------------------------------------
+ * The kernel sources carry compile-time switches for timing experiments (-DMST_ABLATE_*: a part of a kernel removed to see what it
+ * costs -- the pixels are WRONG) and for in-kernel phase stamps (-DMST_STAMPS).  A library built with any of them says so here,
+ * and mst_create prints a warning to stderr: such a binary is for tools/variants.sh, never for a product or a recorded number
+ * (tests/test_capi_host.py asserts that the shipped library has none).  struct_size = sizeof(mst_build) on entry. */
+typedef struct mst_build {
+    int32_t  struct_size;
+    int32_t  version;          /* MST_VERSION of the library */
+    uint32_t timing_build;     /* 0 = product build; bits: 1 MST_ABLATE_A, 2 MST_ABLATE_A2, 4 MST_ABLATE_C, 8 MST_ABLATE_STAGE, 16 MST_STAMPS */
+    int32_t  level0_packed;    /* level 0 of the per-camera pyramids: 1 packed BGR8 (default), 0 a dword a pixel (-DMST_L0_PACKED=0) */
+    char     description[160];
+} mst_build;
+int  mst_build_info(mst_build *out);
+
 /* ---- engine lifetime ------------------------------------------------------------------- */
 int  mst_create(const mst_config *cfg, mst_engine **out);
 void mst_destroy(mst_engine *e);
@@ -281,6 +299,24 @@ int  mst_compose_device(mst_engine *e, const void *const *d_frames, const size_t
 int  mst_compose_device_batch(mst_engine *e, int count, const void *const *d_frames, const size_t *frame_strides,
                               void *const *d_panos, size_t pano_stride, void *const *d_pano_masks,
                               size_t pano_mask_stride, void *stream);
+/* mst_compose_device_batch for a host whose frames ARRIVE on a stream (hipMemcpyAsync from a capture buffer, a decoder: the
+ * reference's GetMemData -> compose shape, DRV:739-756 / stitching_sharemem.cpp:96-123) and whose panoramas are READ on one (an
+ * asynchronous copy to the display / encoder), without a host synchronisation per call:
+ *   frames_ready   a hipEvent_t recorded behind the last write of this call's frames (on the copy / decode stream), or NULL.
+ *                  The call's first kernel waits for it -- on whichever stream the engine runs the call.
+ *   outputs_free   a hipEvent_t recorded behind the last READ of the panorama / mask buffers passed to this call (the consumer's
+ *                  copy of what an earlier call left in them), or NULL.  The call's kernels wait for it before they write.
+ * With both NULL this is mst_compose_device_batch.  They matter with calls in flight (MST_FLAG_OVERLAP_FRAMES, overlap_depth >= 3):
+ * such a call runs on an engine-owned stream that is NOT ordered behind work queued earlier on `stream`, so (a) frames that are
+ * still being written by work queued on any stream need `frames_ready` (or must be complete when the call is made), and (b) an
+ * output buffer must have no pending reader on any stream when it is passed again -- give `outputs_free`, or keep a ring of more
+ * buffers than calls can be in flight and synchronise the consumer.  Writers are ordered by the engine itself: two calls in flight
+ * whose output byte ranges overlap run in call order.  Results appear on `stream` in call order, as always.  The events are only
+ * waited for; the engine neither records nor destroys them, and they may be re-recorded
+ * once the call has returned (a wait captures the event's state at the time it is queued). */
+int  mst_compose_device_batch_ex(mst_engine *e, int count, const void *const *d_frames, const size_t *frame_strides,
+                                 void *const *d_panos, size_t pano_stride, void *const *d_pano_masks,
+                                 size_t pano_mask_stride, void *stream, void *frames_ready, void *outputs_free);
 /* The host-buffer frame loop as a three-stage pipeline: while the kernels of frame t run, frame t+1 is copied in and
  * the panorama of frame t-1 is copied out (three streams, a ring of MST_PIPELINE_DEPTH device frame sets).  The
  * reference's loop is strictly serial (GetMemData -> remap ... -> imshow per frame, DRV:736-763); with host

@@ -45,7 +45,7 @@ DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, 
 
 EXPORTS = [
     "mst_warp_kind_from_name", "mst_create", "mst_destroy", "mst_last_error", "mst_update", "mst_acquire_calibration", "mst_release_calibration", "mst_canvas", "mst_strip", "mst_camera_roi", "mst_camera_mask",
-    "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_device_batch", "mst_compose_profile",
+    "mst_num_bands", "mst_compose", "mst_compose_device", "mst_compose_device_batch", "mst_compose_device_batch_ex", "mst_build_info", "mst_compose_profile",
     "mst_compose_profile_batch", "mst_synchronize", "mst_warp_roi",
     "mst_host_alloc", "mst_host_free", "mst_pipeline_submit", "mst_pipeline_wait", "mst_pipeline_pending",
     "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
@@ -59,6 +59,11 @@ EXPORTS = [
     "mst_shm_serve", "mst_shm_publish", "mst_shm_publish_nv12", "mst_shm_packet_format", "mst_shm_attach", "mst_shm_get",
     "mst_shm_get_device", "mst_shm_get_device_multi", "mst_shm_close",
 ]
+
+
+class Build(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("version", C.c_int32), ("timing_build", C.c_uint32),
+                ("level0_packed", C.c_int32), ("description", C.c_char * 160)]
 
 
 class Config(C.Structure):
@@ -154,6 +159,11 @@ def load():
     L.mst_compose_device_batch.restype = C.c_int
     L.mst_compose_device_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                            C.c_size_t, C.POINTER(vp), C.c_size_t, vp]
+    L.mst_compose_device_batch_ex.restype = C.c_int
+    L.mst_compose_device_batch_ex.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
+                                              C.c_size_t, C.POINTER(vp), C.c_size_t, vp, vp, vp]
+    L.mst_build_info.restype = C.c_int
+    L.mst_build_info.argtypes = [C.POINTER(Build)]
     L.mst_compose_profile_batch.restype = C.c_int
     L.mst_compose_profile_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                             C.c_size_t, vp, C.c_int, vp, fp, ip]
@@ -236,6 +246,15 @@ def load():
     L.mst_synth_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
     _lib = L
     return L
+
+
+def build_info():
+    """mst_build_info as a dict: {'version', 'timing_build', 'level0_packed', 'description'}."""
+    b = Build()
+    b.struct_size = C.sizeof(Build)
+    check(load().mst_build_info(C.byref(b)))
+    return {"version": b.version, "timing_build": int(b.timing_build), "level0_packed": b.level0_packed,
+            "description": b.description.decode()}
 
 
 def check(rc, handle=None):

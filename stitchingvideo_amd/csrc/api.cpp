@@ -100,6 +100,16 @@ int mst_warp_kind_from_name(const char* name)
 int mst_create(const mst_config* cfg, mst_engine** out)
 {
     if (out) *out = nullptr;
+    {
+        // a timing build (-DMST_ABLATE_*: wrong pixels) or a stamped one must never pass for the product silently
+        static const bool warned = [] {
+            const uint32_t bits = mst::mb_build_ablations() | mst::compose_build_ablations();
+            if (bits) std::fprintf(stderr, "[mi355-stitch] WARNING: this library is a TIMING / DIAGNOSTIC build (mst_build_info.timing_build = %u): "
+                                           "its pixels may be wrong; not for production or recorded measurements\n", bits);
+            return true;
+        }();
+        (void)warned;
+    }
     mst_engine* created = nullptr;
     int rc = guarded(nullptr, [&] {
         require(cfg && out, "null config or output pointer");
@@ -256,6 +266,18 @@ int mst_compose_device_batch(mst_engine* e, int count, const void* const* d_fram
     return guarded(e, [&] {
         e->impl.compose_batch(count, d_frames, frame_strides, d_panos, pano_stride, d_pano_masks, pano_mask_stride,
                               static_cast<hipStream_t>(stream));
+    });
+}
+
+int mst_compose_device_batch_ex(mst_engine* e, int count, const void* const* d_frames, const size_t* frame_strides,
+                                void* const* d_panos, size_t pano_stride, void* const* d_pano_masks,
+                                size_t pano_mask_stride, void* stream, void* frames_ready, void* outputs_free)
+{
+    if (!e) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] {
+        e->impl.compose_batch(count, d_frames, frame_strides, d_panos, pano_stride, d_pano_masks, pano_mask_stride,
+                              static_cast<hipStream_t>(stream), nullptr, static_cast<hipEvent_t>(frames_ready),
+                              static_cast<hipEvent_t>(outputs_free));
     });
 }
 
@@ -659,6 +681,19 @@ int mst_multiband_geometry(mst_rect canvas, int num_bands, mst_rect image, mst_r
             out[4] = g.top; out[5] = g.left; out[6] = g.bottom; out[7] = g.right;
         }
     });
+}
+
+int mst_build_info(mst_build* out)
+{
+    if (!out || out->struct_size != static_cast<int32_t>(sizeof(mst_build))) return MST_ERR_INVALID_ARG;
+    out->version = MST_VERSION;
+    out->timing_build = mst::mb_build_ablations() | mst::compose_build_ablations();
+    out->level0_packed = MST_L0_PACKED;
+    std::snprintf(out->description, sizeof(out->description), "mi355-stitch %d gfx950%s%s%s", MST_VERSION,
+                  MST_L0_PACKED ? " l0=bgr8" : " l0=dword",
+                  (out->timing_build & 15u) ? " TIMING-BUILD(-DMST_ABLATE_*: wrong pixels)" : "",
+                  (out->timing_build & 16u) ? " STAMPS" : "");
+    return MST_OK;
 }
 
 // Diagnostic builds only (make CXXFLAGS+=-DMST_STAMPS): in-kernel phase stamps of the last launches of kernels A (0)

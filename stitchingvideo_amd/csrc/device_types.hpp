@@ -9,6 +9,15 @@ namespace mst {
 constexpr int kMaxCams = 16;
 constexpr int kMaxLevels = 11;   // MST_MAX_BANDS + 1
 
+// Level 0 of a camera's pyramid in memory: packed BGR8 (3 bytes a pixel, round 4) or a dword a pixel like the levels above
+// (B | G << 8 | R << 16, rounds 1-3).  A compile-time switch so that the two can be timed in one run on one box
+// (tools/variants.sh "dword:-DMST_L0_PACKED=0"; profiles/r05_experiments.md); both are parity-tested.  Rows are whole groups
+// of four pixels either way (12 or 16 bytes), so every group the warp kernel stores is aligned and inside its row.
+#ifndef MST_L0_PACKED
+#define MST_L0_PACKED 1
+#endif
+constexpr int kL0Bpp = MST_L0_PACKED ? 3 : 4;      // bytes per level-0 pixel
+
 // Per roi column / row constants of the backward map and of the gain field, laid out so that a
 // thread fetches everything it needs for one axis with 16-byte loads.
 //

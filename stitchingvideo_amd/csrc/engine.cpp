@@ -132,7 +132,7 @@ CalibState::~CalibState()
 // kernel stores and every pixel pair the canvas kernel loads lies inside its row; the levels above are a dword a pixel.
 // A level's footprint in dwords, rounded up so that the next level starts 16-byte aligned and level 0 carries the slack
 // its 8-byte pair loads may touch behind the last pixel.
-int level0_pitch(int lw0) { return ((lw0 + 3) / 4) * 12; }
+int level0_pitch(int lw0) { return ((lw0 + 3) / 4) * 4 * kL0Bpp; }
 size_t level_dwords(const CamDesc& d, int l)
 {
     const size_t dw = l == 0 ? (static_cast<size_t>(d.l0_pitch) * d.lh[0] + 16 + 3) / 4 : static_cast<size_t>(d.lw[l]) * d.lh[l];
@@ -1183,18 +1183,22 @@ void Engine::reap_graphs()
 
 void Engine::compose_batch(int count, const void* const* d_frames, const size_t* strides, void* const* d_panos,
                            size_t pano_stride, void* const* d_masks, size_t mask_stride, hipStream_t stream,
-                           StageTimer* timer)
+                           StageTimer* timer, hipEvent_t frames_ready, hipEvent_t outputs_free)
 {
     std::shared_ptr<CalibState> st = state();
     const bool replay = (cfg_.flags & MST_FLAG_GRAPH_REPLAY) && !(cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && !timer && st &&
                         d_frames && strides && d_panos && count >= 1 && count <= kMaxBatch;
     if (!replay) {
-        compose_batch_on(std::move(st), count, d_frames, strides, d_panos, pano_stride, d_masks, mask_stride, stream, timer);
+        compose_batch_on(std::move(st), count, d_frames, strides, d_panos, pano_stride, d_masks, mask_stride, stream, timer, 0, nullptr,
+                         frames_ready, outputs_free);
         return;
     }
     // the launch sequence depends on the calibration and on every pointer / stride of the call: that is the key
     select_device(cfg_.device);
     hipStream_t s = stream ? stream : stream_;
+    // (the caller's events stay outside the captured sequence: they differ from call to call)
+    if (frames_ready) check_hip(hipStreamWaitEvent(s, frames_ready, 0), "hipStreamWaitEvent(frames_ready)");
+    if (outputs_free) check_hip(hipStreamWaitEvent(s, outputs_free, 0), "hipStreamWaitEvent(outputs_free)");
     std::vector<uint64_t> key;
     key.reserve(6 + 3 * static_cast<size_t>(count) * (st->n + 1));
     key.push_back(st->generation); key.push_back(static_cast<uint64_t>(count));
@@ -1208,18 +1212,24 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
     for (size_t i = 0; i < graphs_.size(); ++i)
         if (graphs_[i].key == key) {
             check_hip(hipGraphLaunch(graphs_[i].exec, s), "hipGraphLaunch");
+            graphs_[i].last_stream = s;
             if (i + 1 != graphs_.size()) std::rotate(graphs_.begin() + i, graphs_.begin() + i + 1, graphs_.end());   // LRU: a hit moves to the back
             set_in_flight(std::move(st));
             return;
         }
     ++graph_misses_;
     // An exec that leaves the cache may still be queued or running (its last launch was enqueued microseconds ago):
-    // it is parked behind an event recorded on the launch stream and destroyed once that event has completed.
+    // it is parked behind an event recorded on the stream of ITS last launch (which need not be this call's stream) and
+    // destroyed once that event has completed.
     auto retire = [&](size_t i) {
         RetiredGraph r;
         r.exec = graphs_[i].exec;
-        if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(r.done, s);
-        else r.done = nullptr;
+        hipStream_t on = graphs_[i].last_stream ? graphs_[i].last_stream : s;
+        if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) == hipSuccess && hipEventRecord(r.done, on) == hipSuccess) {
+        } else {
+            if (r.done) (void)hipEventDestroy(r.done);
+            r.done = nullptr;            // (reap_graphs then synchronises the device before destroying the exec)
+        }
         retired_graphs_.push_back(r);
         graphs_.erase(graphs_.begin() + i);
     };
@@ -1252,21 +1262,24 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
     (void)hipGraphDestroy(graph);
     check_hip(ie, "hipGraphInstantiate");
     check_hip(hipGraphLaunch(e.exec, s), "hipGraphLaunch");
+    e.last_stream = s;
     graphs_.push_back(std::move(e));
 }
 
 // One calibration state for the whole call: callers that size buffers first (compose_host) pass the snapshot they
 // sized them from, so a concurrent mst_update cannot slip a different canvas in between.
-// Deep form of MST_FLAG_OVERLAP_FRAMES: calls on different slots run on different streams.  Two of them that write the same
-// panorama (or mask) buffer must not overlap: the later one waits for the earlier one's completion event, which restores
-// the order of the calls for that buffer (exact pointer matches only -- buffers that merely overlap are the caller's to keep apart).
-void Engine::order_after_writers(int slot, hipStream_t s, const std::vector<const void*>& outs)
+// Deep form of MST_FLAG_OVERLAP_FRAMES: calls on different slots run on different streams.  Two of them that write overlapping
+// bytes -- the same panorama or mask buffer, or sub-views of one allocation that share rows -- must not overlap in time: the
+// later one waits for the earlier one's completion event, which restores the order of the calls for those bytes.  A buffer
+// counts as the byte interval from its first row to the end of its last row (rows that interleave without sharing a byte are
+// ordered too: conservative, never wrong).
+void Engine::order_after_writers(int slot, hipStream_t s, const std::vector<ByteRange>& outs)
 {
     for (int k = 0; k < kMaxOverlap; ++k) {
         if (k == slot || !canvas_pending_[k]) continue;
         bool shared = false;
-        for (const void* p : slot_outputs_[k])
-            for (const void* q : outs) shared = shared || (p && p == q);
+        for (const ByteRange& p : slot_outputs_[k])
+            for (const ByteRange& q : outs) shared = shared || (p.lo < q.hi && q.lo < p.hi);
         if (shared) check_hip(hipStreamWaitEvent(s, ev_canvas_done_[k], 0), "hipStreamWaitEvent");
     }
     slot_outputs_[slot] = outs;
@@ -1278,7 +1291,8 @@ void Engine::order_after_writers(int slot, hipStream_t s, const std::vector<cons
 // pyramids, the canvas kernels (no frames are read).
 void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
                               void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
-                              hipStream_t stream, StageTimer* timer, int phase, void* const* halo)
+                              hipStream_t stream, StageTimer* timer, int phase, void* const* halo,
+                              hipEvent_t frames_ready, hipEvent_t outputs_free)
 {
     select_device(cfg_.device);
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
@@ -1316,6 +1330,30 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
     for (int f = 0; f < count && back; ++f)
         if (!d_panos[f]) throw Error{MST_ERR_INVALID_ARG, "null panorama pointer"};
 
+    // the bytes this call writes (deep form: what order_after_writers compares between calls in flight)
+    auto output_ranges = [&] {
+        std::vector<ByteRange> outs;
+        const size_t rows = static_cast<size_t>(std::max(st->out_h, 1));
+        // (a strip engine's panorama pointer is canvas column 0; it writes its own columns only)
+        const size_t x0 = cfg_.strip_count > 1 ? static_cast<size_t>(std::min(st->strip_x0, st->out_w)) : 0;
+        const size_t x1 = cfg_.strip_count > 1 ? static_cast<size_t>(std::min(st->strip_x1, st->out_w)) : static_cast<size_t>(st->out_w);
+        const size_t mask_row = static_cast<size_t>(st->out_w);
+        for (int f = 0; f < count; ++f) {
+            const uintptr_t p = reinterpret_cast<uintptr_t>(d_panos[f]);
+            outs.push_back(ByteRange{p + x0 * 3, p + (rows - 1) * pano_stride + x1 * 3});
+            if (d_masks && d_masks[f]) {
+                const uintptr_t m = reinterpret_cast<uintptr_t>(d_masks[f]);
+                outs.push_back(ByteRange{m, m + (rows - 1) * mask_stride + mask_row});
+            }
+        }
+        return outs;
+    };
+    // the caller's events (mst_compose_device_batch_ex): `on_frames` = the stream of the call's first frame-reading kernel,
+    // `on_outputs` = the stream its panorama-writing kernels run on (the same stream except in the two-stream form)
+    auto wait_for_caller = [&](hipStream_t on_frames, hipStream_t on_outputs) {
+        if (frames_ready) check_hip(hipStreamWaitEvent(on_frames, frames_ready, 0), "hipStreamWaitEvent(frames_ready)");
+        if (outputs_free) check_hip(hipStreamWaitEvent(on_outputs, outputs_free, 0), "hipStreamWaitEvent(outputs_free)");
+    };
     auto mark = [&](const char* name) { if (timer && name) timer->mark(name, s); };      // (nullptr: the launcher had nothing to launch)
     if (timer) timer->begin(s);
     // lens-undistort pre-pass: remap the caller's frames into the engine's buffers of frame sets first_set.. and
@@ -1359,10 +1397,22 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         const int slot = overlap ? static_cast<int>(frame_counter_++ % (deep ? slots : 2)) : 0;
         if (deep) {
             s = call_streams_[slot];
-            std::vector<const void*> outs;
-            for (int f = 0; f < count; ++f) { outs.push_back(d_panos[f]); if (d_masks) outs.push_back(d_masks[f]); }
-            order_after_writers(slot, s, outs);
+            order_after_writers(slot, s, output_ranges());
         }
+        // (every exit of the deep form, the throwing ones included, leaves the caller's stream behind the slot's: whatever was
+        // queued on the slot's stream still completes before anything the caller queues next)
+        struct Join {
+            Engine* e; bool on; int slot; hipStream_t from, to; bool done = false;
+            void now() {
+                if (!on || done) return;
+                done = true;
+                if (hipEventRecord(e->ev_canvas_done_[slot], from) == hipSuccess) {
+                    e->canvas_pending_[slot] = true;
+                    (void)hipStreamWaitEvent(to, e->ev_canvas_done_[slot], 0);
+                }
+            }
+            ~Join() { now(); }
+        } join{this, deep, slot, s, caller};
         const int first_set = slot * st->sets_per_slot;           // the slot's run of descriptor / buffer sets
         const CamDesc* desc = st->d_desc + static_cast<size_t>(first_set) * st->n;
         hipStream_t sf = deep ? s : overlap ? front_stream_ : s;
@@ -1374,6 +1424,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
                     check_hip(hipStreamWaitEvent(s, ev_canvas_done_[k], 0), "hipStreamWaitEvent");
                     canvas_pending_[k] = false;
                 }
+        wait_for_caller(sf, s);
         if (front) {
             undistort(first_set, sf);
             launch_warp(*st, desc, fb, count, 0, st->n, sf, timer);
@@ -1437,10 +1488,11 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
             if (ba.c2[0]) mark(launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 4));
         }
         mark(launch_blend(desc, ba, n_fine, n_coarse, count, lds_bytes, s, 2));
-        if (overlap) {
+        if (deep) {
+            join.now();
+        } else if (overlap) {
             check_hip(hipEventRecord(ev_canvas_done_[slot], s), "hipEventRecord");
             canvas_pending_[slot] = true;
-            if (deep) check_hip(hipStreamWaitEvent(caller, ev_canvas_done_[slot], 0), "hipStreamWaitEvent");
         }
     } else {
         // the single-pass composites: the deep form of MST_FLAG_OVERLAP_FRAMES only (a call is one or two launches; the slot
@@ -1452,9 +1504,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         if (deep) {
             slot = static_cast<int>(frame_counter_++ % slots);
             s = call_streams_[slot];
-            std::vector<const void*> outs;
-            for (int f = 0; f < count; ++f) { outs.push_back(d_panos[f]); if (d_masks) outs.push_back(d_masks[f]); }
-            order_after_writers(slot, s, outs);
+            order_after_writers(slot, s, output_ranges());
         } else {
             for (int k = 0; k < kMaxOverlap; ++k)
                 if (canvas_pending_[k]) {
@@ -1472,6 +1522,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
                 }
             }
         } join{this, deep, slot, s, caller};
+        wait_for_caller(s, s);
         undistort(slot * st->sets_per_slot, s);
         ComposeArgs ca = st->compose;
         ca.n_sets = count;
@@ -1878,12 +1929,12 @@ void Engine::debug_read(int what, int camera, int level, void* buf, size_t buf_b
             if (buf_bytes < sizeof(int16_t) * 3 * px) throw Error{MST_ERR_INVALID_ARG, "debug buffer too small"};
             int16_t* out = static_cast<int16_t*>(buf);
             check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
-            if (level == 0) {        // packed BGR8, rows l0_pitch bytes apart
+            if (level == 0) {        // packed BGR8 (or B G R x dwords, MST_L0_PACKED=0), rows l0_pitch bytes apart
                 std::vector<uint8_t> bytes8(static_cast<size_t>(d.l0_pitch) * hh);
                 check_hip(hipMemcpy(bytes8.data(), d.G[0], bytes8.size(), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
                 for (int y = 0; y < hh; ++y)
                     for (int x = 0; x < ww; ++x) {
-                        const uint8_t* p8 = &bytes8[static_cast<size_t>(y) * d.l0_pitch + 3 * static_cast<size_t>(x)];
+                        const uint8_t* p8 = &bytes8[static_cast<size_t>(y) * d.l0_pitch + kL0Bpp * static_cast<size_t>(x)];
                         const size_t i = static_cast<size_t>(y) * ww + x;
                         out[i] = p8[0]; out[px + i] = p8[1]; out[2 * px + i] = p8[2];
                     }

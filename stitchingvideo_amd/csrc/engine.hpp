@@ -166,9 +166,11 @@ public:
     void compose_device(const void* const* d_frames, const size_t* strides, void* d_pano, size_t pano_stride,
                         void* d_mask, size_t mask_stride, hipStream_t stream, StageTimer* timer = nullptr);
     // `count` frame sets (frame set f's camera i at index f * n + i) -> `count` panoramas, one launch sequence
+    // frames_ready / outputs_free (mst_compose_device_batch_ex): events the call's first kernel waits for, on whichever stream
+    // the engine runs it
     void compose_batch(int count, const void* const* d_frames, const size_t* strides, void* const* d_panos,
                        size_t pano_stride, void* const* d_masks, size_t mask_stride, hipStream_t stream,
-                       StageTimer* timer = nullptr);
+                       StageTimer* timer = nullptr, hipEvent_t frames_ready = nullptr, hipEvent_t outputs_free = nullptr);
     void compose_host(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride,
                       uint8_t* pano_mask, size_t mask_stride);
     void stage_cameras(uint32_t camera_mask, const void* const* d_frames, const size_t* strides, hipStream_t stream);
@@ -207,7 +209,8 @@ public:
 private:
     void compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
                           void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
-                          hipStream_t stream, StageTimer* timer, int phase = 0, void* const* halo = nullptr);
+                          hipStream_t stream, StageTimer* timer, int phase = 0, void* const* halo = nullptr,
+                          hipEvent_t frames_ready = nullptr, hipEvent_t outputs_free = nullptr);
     void strip_columns(int width, int* x0, int* x1, int index = -1) const;
     std::shared_ptr<CalibState> halo_state_;      // between mst_strip_front_batch and mst_strip_back_batch
     int halo_count_ = 0;
@@ -221,7 +224,7 @@ private:
     void set_in_flight(std::shared_ptr<CalibState> st);   // keeps `st` alive; the previous one goes to retired_
     void drop_retired();                                   // calibration thread / destructor: tear old states down
     // MST_FLAG_GRAPH_REPLAY: launch sequences captured per (calibration generation, buffers) and replayed
-    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; };
+    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; hipStream_t last_stream = nullptr; };
     std::vector<GraphEntry> graphs_;                     // least recently used first
     struct RetiredGraph { hipGraphExec_t exec = nullptr; hipEvent_t done = nullptr; };
     std::vector<RetiredGraph> retired_graphs_;           // left the cache; destroyed once `done` (recorded on their launch stream) has completed
@@ -244,9 +247,10 @@ private:
     // MST_OVERLAP_DEPTH = 3 or 4 (experiment): whole calls on their own streams, round-robin, one pyramid slot each
     int overlap_depth_ = 2;
     hipStream_t call_streams_[kMaxOverlap] = {};
-    std::vector<const void*> slot_outputs_[kMaxOverlap];   // panorama / mask buffers the slot's latest call writes
-    // a deep call on `slot` about to write `outs`: wait for every other slot whose latest call writes one of the same buffers
-    void order_after_writers(int slot, hipStream_t s, const std::vector<const void*>& outs);
+    struct ByteRange { uintptr_t lo, hi; };                // [lo, hi)
+    std::vector<ByteRange> slot_outputs_[kMaxOverlap];     // panorama / mask bytes the slot's latest call writes
+    // a deep call on `slot` about to write `outs`: wait for every other slot whose latest call writes bytes that overlap them
+    void order_after_writers(int slot, hipStream_t s, const std::vector<ByteRange>& outs);
     bool in_host_compose_ = false;
     uint64_t frame_counter_ = 0;
     int stage_set_ = 0;

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_payload_copy(const CamDesc* __restrict_
         // 12-byte groups, the others byte by byte.
         uint8_t MST_GLOBAL* __restrict__ g8 = (uint8_t MST_GLOBAL*)c.G[0];
         uint8_t MST_GLOBAL* __restrict__ b8 = (uint8_t MST_GLOBAL*)b;
-        if (((r.x0 | r.w) & 3) == 0) {
+        if (MST_L0_PACKED && ((r.x0 | r.w) & 3) == 0) {
             const int gw = r.w >> 2;
             for (int i = threadIdx.x; i < gw * r.h; i += 256) {
                 const int y = i / gw, g = i - y * gw;
@@ -474,7 +474,9 @@ __global__ __launch_bounds__(256) void k_payload_copy(const CamDesc* __restrict_
         } else {
             for (int i = threadIdx.x; i < 3 * n; i += 256) {
                 const int y = i / (3 * r.w), xb = i - y * (3 * r.w);
-                uint8_t MST_GLOBAL* p = g8 + static_cast<size_t>(r.y0 + y) * c.l0_pitch + 3 * static_cast<size_t>(r.x0) + xb;
+                // (the payload is packed BGR8 whatever the pyramid's level 0 is: byte xb of the row is channel xb % 3 of pixel xb / 3)
+                const size_t in_row = MST_L0_PACKED ? static_cast<size_t>(xb) : static_cast<size_t>(xb / 3) * 4 + static_cast<size_t>(xb % 3);
+                uint8_t MST_GLOBAL* p = g8 + static_cast<size_t>(r.y0 + y) * c.l0_pitch + kL0Bpp * static_cast<size_t>(r.x0) + in_row;
                 if (PACK) b8[i] = *p; else *p = b8[i];
             }
         }

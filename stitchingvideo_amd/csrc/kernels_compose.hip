@@ -747,6 +747,15 @@ void launch_undistort_table(const UndistortCam& u, int tiles_x, int tiles_y, Com
     hipLaunchKernelGGL(k_undistort_table, dim3(tiles_x * tiles_y), dim3(256), 0, s, u, tiles_x, d_segs, d_tiles, d_table, lds_budget_px);
 }
 
+uint32_t compose_build_ablations()
+{
+#if defined(MST_ABLATE_STAGE)
+    return 8u;
+#else
+    return 0u;
+#endif
+}
+
 const char* launch_compose(const ComposeArgs& a, const FrameBatch& frames, size_t lds_bytes, bool general, hipStream_t s)
 {
     if (a.n_tiles <= 0 || a.n_sets <= 0) return nullptr;

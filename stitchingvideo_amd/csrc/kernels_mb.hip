@@ -75,23 +75,52 @@ typedef GPix __attribute__((aligned(2))) GPixU;
 typedef uint32_t __attribute__((aligned(1))) U32U;
 __device__ __forceinline__ const uint8_t MST_GLOBAL* l0_at(const CamDesc& c, int lx, int ly)
 {
-    return (const uint8_t MST_GLOBAL*)c.G[0] + (__umul24(static_cast<uint32_t>(ly), static_cast<uint32_t>(c.l0_pitch)) + 3u * static_cast<uint32_t>(lx));
+    return (const uint8_t MST_GLOBAL*)c.G[0] + (__umul24(static_cast<uint32_t>(ly), static_cast<uint32_t>(c.l0_pitch)) + static_cast<uint32_t>(kL0Bpp) * static_cast<uint32_t>(lx));
 }
 // pixels (lx, ly) and (lx + 1, ly) as the dwords the other levels store (B | G << 8 | R << 16; byte 3 of .x is B1: ignored by
 // every reader, which extract bytes 0 .. 2)
 __device__ __forceinline__ uint2 l0_pair(const CamDesc& c, int lx, int ly)
 {
+#if MST_L0_PACKED
     const GPix v = *(const GPixU MST_GLOBAL*)l0_at(c, lx, ly);
     return make_uint2(v.x, __builtin_amdgcn_alignbyte(v.y, v.x, 3));
+#else            // (dword level 0: lx is even wherever pairs are read, rows are 16-byte aligned)
+    const GPix v = *(const GPix MST_GLOBAL*)l0_at(c, lx, ly);
+    return make_uint2(v.x, v.y);
+#endif
 }
 __device__ __forceinline__ uint32_t l0_px(const CamDesc& c, int lx, int ly)
 {
+#if MST_L0_PACKED
     return *(const U32U MST_GLOBAL*)l0_at(c, lx, ly);
+#else
+    return *(const uint32_t MST_GLOBAL*)l0_at(c, lx, ly);
+#endif
 }
 // four level-0 pixels (dwords) -> their twelve packed bytes
 __device__ __forceinline__ u32x3_t l0_pack4(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3)
 {
     return u32x3_t{__builtin_amdgcn_perm(p1, p0, 0x04020100u), __builtin_amdgcn_perm(p2, p1, 0x05040201u), __builtin_amdgcn_perm(p3, p2, 0x06050402u)};
+}
+// a group of four level-0 pixels (column gx, a multiple of four; row gy) leaves a warp tile: one non-temporal 12- or 16-byte store
+// (non-temporal: level 0 is next read a whole batch later, by k_blend_fine; keeping it out of the caches leaves them to the
+// frames and the map table: k_warp_pyr 287.5 -> 274.0 us per 8 frame sets)
+__device__ __forceinline__ void l0_store4(uint8_t MST_GLOBAL* g0, uint32_t pitch0, int gx, int gy, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3)
+{
+    uint8_t MST_GLOBAL* o = g0 + (__umul24(static_cast<uint32_t>(gy), pitch0) + static_cast<uint32_t>(kL0Bpp) * static_cast<uint32_t>(gx));
+#if MST_L0_PACKED
+#if !defined(MST_NO_NT_STORE)
+    __builtin_nontemporal_store(l0_pack4(p0, p1, p2, p3), reinterpret_cast<u32x3_t MST_GLOBAL*>(o));
+#else
+    *reinterpret_cast<u32x3_t MST_GLOBAL*>(o) = l0_pack4(p0, p1, p2, p3);
+#endif
+#else
+#if !defined(MST_NO_NT_STORE)
+    __builtin_nontemporal_store(u32x4_t{p0, p1, p2, p3}, reinterpret_cast<u32x4_t MST_GLOBAL*>(o));
+#else
+    *reinterpret_cast<u32x4_t MST_GLOBAL*>(o) = u32x4_t{p0, p1, p2, p3};
+#endif
+#endif
 }
 __device__ __forceinline__ uint32_t lanes_br(uint32_t p) { return p & 0x00FF00FFu; }
 __device__ __forceinline__ uint32_t lane_g(uint32_t p) { return (p >> 8) & 0xFFu; }
@@ -576,13 +605,7 @@ __global__ __launch_bounds__(256, MST_A_WAVES) void k_warp_pyr(const CamDesc* __
             if (gy >= bh || gx4 >= bw) continue;
             const uint2 lo = *reinterpret_cast<const uint2*>(&s_l0[2 + r][2 + 4 * g]);
             const uint2 hi = *reinterpret_cast<const uint2*>(&s_l0[2 + r][4 + 4 * g]);
-#if !defined(MST_NO_NT_STORE)
-            // (non-temporal: level 0 is next read a whole batch later, by k_blend_fine; keeping it out of the caches
-            // leaves them to the frames and the map table: k_warp_pyr 287.5 -> 274.0 us per 8 frame sets)
-            __builtin_nontemporal_store(l0_pack4(lo.x, lo.y, hi.x, hi.y), reinterpret_cast<u32x3_t MST_GLOBAL*>(g0b + __umul24(gy, pitch0) + 3u * gx4));
-#else
-            *reinterpret_cast<u32x3_t MST_GLOBAL*>(g0b + __umul24(gy, pitch0) + 3u * gx4) = l0_pack4(lo.x, lo.y, hi.x, hi.y);
-#endif
+            l0_store4(g0b, pitch0, gx4, gy, lo.x, lo.y, hi.x, hi.y);
         }
     }
     if (nlev < 2 || (MST_ABLATE_A & 4)) return;
@@ -831,7 +854,7 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
             const int gy = ly0 + 2 + r, gx = lx0 + 2 + 4 * g;
             if (i >= A_TH0 * kGroups || gy >= bh || gx >= bw) continue;
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(s_mem + (2 + r) * A2_TPITCH + A2_TOFF + 2 + 4 * g);
-            __builtin_nontemporal_store(l0_pack4(v.x, v.y, v.z, v.w), reinterpret_cast<u32x3_t MST_GLOBAL*>(g0out + __umul24(gy, pitch0) + 3u * gx));
+            l0_store4(g0out, pitch0, gx, gy, v.x, v.y, v.z, v.w);
         }
     }
     if (nlev < 2 || (MST_ABLATE_A2 & 4)) return;
@@ -1729,7 +1752,7 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
     static_assert(C_TW == 128 && CC_TW == 128 && (kTileH / 2) % (NT / 64) == 0, "one wave per quad row of the tile");
     static_assert(L == 0 || (NC == 1 && !MASKED), "masks are level-0 weights");
     constexpr int kRows = (kTileH / 2) / (NT / 64);              // quad rows per wave
-    constexpr bool kPair = L == 0 && NC == 1;                    // level 0, one camera: lane pairs share aligned 12-byte loads
+    constexpr bool kPair = L == 0 && NC == 1 && MST_L0_PACKED;   // packed level 0, one camera: lane pairs share aligned 12-byte loads
     const int lane = static_cast<int>(threadIdx.x & 63u);
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int uw = a.cw[L + 1], uh = a.ch[L + 1];
@@ -1844,18 +1867,20 @@ __device__ __forceinline__ void owned_strip(const CamDesc* __restrict__ cams, co
                 q.q1.x = odd ? __builtin_amdgcn_alignbyte(d.z, d.y, 2) : p0;
                 q.q1.y = odd ? d.z >> 16 : p1;
             } else if (L == 0) {
+                // (packed: 2-byte aligned pairs; dword level 0: aligned 8-byte pairs)
+                typedef std::conditional_t<MST_L0_PACKED != 0, GPixU, GPix> L0Pair;
 #if !defined(MST_NO_NT_LOAD)
-                q.q0 = __builtin_nontemporal_load((const GPixU MST_GLOBAL*)k.gq);
-                q.q1 = __builtin_nontemporal_load((const GPixU MST_GLOBAL*)((const uint8_t MST_GLOBAL*)k.gq + k.gpitch));
+                q.q0 = __builtin_nontemporal_load((const L0Pair MST_GLOBAL*)k.gq);
+                q.q1 = __builtin_nontemporal_load((const L0Pair MST_GLOBAL*)((const uint8_t MST_GLOBAL*)k.gq + k.gpitch));
 #else
-                q.q0 = *(const GPixU MST_GLOBAL*)k.gq;
-                q.q1 = *(const GPixU MST_GLOBAL*)((const uint8_t MST_GLOBAL*)k.gq + k.gpitch);
+                q.q0 = *(const L0Pair MST_GLOBAL*)k.gq;
+                q.q1 = *(const L0Pair MST_GLOBAL*)((const uint8_t MST_GLOBAL*)k.gq + k.gpitch);
 #endif
             } else {
                 q.q0 = k.gq[0];
                 q.q1 = *(const GPix MST_GLOBAL*)((const uint32_t MST_GLOBAL*)k.gq + k.lw);
             }
-            if (L == 0) {      // B0 G0 R0 B1 | G1 R1 . . -> the second pixel as a dword of its own (byte 3 of either is never read)
+            if (L == 0 && MST_L0_PACKED) {      // B0 G0 R0 B1 | G1 R1 . . -> the second pixel as a dword of its own (byte 3 of either is never read)
                 q.q0.y = __builtin_amdgcn_alignbyte(q.q0.y, q.q0.x, 3);
                 q.q1.y = __builtin_amdgcn_alignbyte(q.q1.y, q.q1.x, 3);
             }
@@ -2349,7 +2374,7 @@ __global__ __launch_bounds__(NT, MST_C_WAVES) void k_blend_fine(const CamDesc* _
     const bool binary = !(MST_ABLATE_C & 512) && (entry >> 30) & 1u;      // 0/1 weights, disjoint, windows cover the tile
     // (the one-camera strips load level 0 by lane pairs: four pixels from a 12-byte group of the camera's rows)
     const bool one = (cam_bits & (cam_bits - 1)) == 0;
-    const bool pair_ok = one && ((r0.x0 - cams[__builtin_ctz(cam_bits)].ox[0]) & 3) == 0;
+    const bool pair_ok = one && (!MST_L0_PACKED || ((r0.x0 - cams[__builtin_ctz(cam_bits)].ox[0]) & 3) == 0);
     if (own0 && strip && pair_ok) owned_strip<0, 1, false, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
     else if (binary && strip && pair_ok) owned_strip<0, 1, true, NT, C_TH>(cams, a, r0, cam_bits, c1, 0, 0, a.cw[1], pano, pano_mask, nullptr);
     else if (binary && strip && one) final_level<NT, false, false, W16>(cams, a, r0, cam_bits, c1, pano, pano_mask);
@@ -2391,6 +2416,23 @@ int mb_read_stamps(int which, unsigned long long* out, size_t n)
     (void)which; (void)out; (void)n;
     return -3;       // not a diagnostic build
 #endif
+}
+
+// What this translation unit was built with (mst_build_info): a non-zero word means a TIMING build whose pixels are wrong
+// (-DMST_ABLATE_*, tools/variants.sh) or a diagnostic one (-DMST_STAMPS) -- never to be shipped or timed for the record.
+uint32_t mb_build_ablations()
+{
+    uint32_t bits = 0;
+    if (MST_ABLATE_A != 0) bits |= 1u;
+    if (MST_ABLATE_A2 != 0) bits |= 2u;
+    if (MST_ABLATE_C != 0) bits |= 4u;
+#if defined(MST_ABLATE_STAGE)
+    bits |= 8u;
+#endif
+#if defined(MST_STAMPS)
+    bits |= 16u;
+#endif
+    return bits;
 }
 
 int mb_coarse_tile_width() { return CC_TW; }

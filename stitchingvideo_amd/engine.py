@@ -592,6 +592,16 @@ class PanoramaEngine:
                 self._check(rc)
         return call
 
+    def compose_device_batch_ex(self, frame_ptrs, frame_strides, pano_ptrs, pano_stride, mask_ptrs=None, mask_stride=0,
+                                stream=None, frames_ready=None, outputs_free=None):
+        """compose_device_batch behind explicit dependencies (mst_compose_device_batch_ex): `frames_ready` / `outputs_free` are raw
+        hipEvent_t handles (torch.cuda.Event().cuda_event after record()) the call's kernels wait for -- the producer's event
+        behind the last write of these frames, the consumer's behind the last read of these panorama buffers.  With calls in
+        flight (overlap_depth >= 3) nothing else orders a call behind work queued on other streams."""
+        count, ptrs, strides, panos, masks = self._batch_tables(frame_ptrs, frame_strides, pano_ptrs, mask_ptrs)
+        self._check(self._L.mst_compose_device_batch_ex(self._h, count, ptrs, strides, panos, pano_stride, masks,
+                                                        mask_stride, stream, frames_ready, outputs_free))
+
     def profile_stages_batch(self, frame_ptrs, frame_strides, pano_ptrs, pano_stride, stream=None, max_stages=64):
         """One batched launch sequence with a HIP event between consecutive launches -> [(kernel name, ms), ...]."""
         count, ptrs, strides, panos, _ = self._batch_tables(frame_ptrs, frame_strides, pano_ptrs, None)

@@ -220,9 +220,14 @@ class IngestStitcher:
             if fmt != want or (w, h) != (ew, eh):
                 raise IngestError(-2, "packet of %dx%d format %d where the calibration expects %dx%d format %d" % (w, h, fmt, ew, eh, want))
         self.ev_in[k].record(self.s_in)
-        self.s_c.wait_event(self.ev_in[k])
-        self.eng.compose_device([t.data_ptr() for t in fs], [t.stride(0) for t in fs], self.d_panos[k].data_ptr(),
-                                self.d_panos[k].stride(0), stream=self.s_c.cuda_stream)
+        # The compose call waits for ITS frames (the copies just queued on the ingest stream) and for the copy-out that last
+        # read this slot's panorama buffer -- explicit events (mst_compose_device_batch_ex), so that an engine with calls in
+        # flight (overlap_depth >= 3: the call runs on an engine-owned stream, not ordered behind the compose stream) needs no
+        # host synchronisation per frame set; an engine without them waits for the same events on the compose stream.
+        out_free = self.ev_out[k].cuda_event if self.submitted >= self.depth else None
+        self.eng.compose_device_batch_ex([[t.data_ptr() for t in fs]], [[t.stride(0) for t in fs]], [self.d_panos[k].data_ptr()],
+                                         self.d_panos[k].stride(0), stream=self.s_c.cuda_stream,
+                                         frames_ready=self.ev_in[k].cuda_event, outputs_free=out_free)
         self.ev_c[k].record(self.s_c)
         self.s_out.wait_event(self.ev_c[k])
         with torch.cuda.stream(self.s_out):

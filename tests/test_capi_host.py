@@ -26,14 +26,26 @@ def test_library_exports_every_declared_symbol():
         header = open(os.path.join(ROOT, "include", h)).read()
         header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)    # (prose in comments mentions calls too)
         declared |= set(re.findall(r"\b(mst_[a-z_0-9]+)\s*\(", header))
-    declared -= {"mst_config", "mst_camera", "mst_calibration", "mst_rect", "mst_engine", "mst_shm", "mst_frame_packet"}
+    declared -= {"mst_config", "mst_camera", "mst_calibration", "mst_rect", "mst_engine", "mst_shm", "mst_frame_packet", "mst_build"}
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     lib = capi.load()
     for name in declared:
         assert hasattr(lib, name), name
 
 
+def test_shipped_library_is_a_product_build():
+    """No -DMST_ABLATE_* (timing experiments: wrong pixels) and no -DMST_STAMPS in the library the tests and the bench load."""
+    info = capi.build_info()
+    assert info["timing_build"] == 0, info
+    assert info["level0_packed"] in (0, 1)
+    assert "TIMING" not in info["description"] and "STAMPS" not in info["description"], info
+    bad = capi.Build()
+    bad.struct_size = 8
+    assert capi.load().mst_build_info(C.byref(bad)) == capi.ERR_INVALID_ARG
+
+
 def test_struct_layouts_match_header_sizes():
+    assert C.sizeof(capi.Build) == 16 + 160
     # the C side checks struct_size; these are the sizes an LP64 compiler produces for the header
     assert C.sizeof(capi.Config) == 80          # 15 x 4-byte fields + warp_a, warp_b + strip_index, strip_count + overlap_depth
     assert C.sizeof(capi.Camera) == 8 + 36 + 36 + 12 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 16 + 8 + 8 + 8

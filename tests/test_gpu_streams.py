@@ -553,3 +553,88 @@ def test_deep_overlap_batches_match_oracle(blend, lut):
             if i not in cache:
                 cache[i] = want(r, i)
             assert np.array_equal(got, cache[i]), (blend, i, H.diff_report(got, cache[i]))
+
+
+@pytest.mark.parametrize("blend,batch", [("multiband", 1), ("multiband", 2), ("feather", 1)])
+def test_calls_in_flight_behind_a_producer_and_a_consumer_stream(blend, batch):
+    """mst_compose_device_batch_ex with overlap_depth = 4: the frames of call t + 1 land by asynchronous H2D copies on a copy
+    stream while call t runs, the panoramas leave by asynchronous D2H copies on a reader stream, and the panorama ring holds
+    exactly overlap_depth buffers -- nothing but the two events per call orders a call (which runs on an engine-owned stream)
+    behind its producer and its consumer.  200 calls, no host synchronisation in the loop, every panorama against the oracle.
+    Both side streams are slowed down by a large device copy in front of every transfer, so that frames arrive late and
+    panoramas are read late: a call that did not wait would read stale frames / overwrite a panorama still being read."""
+    import torch
+    depth, n_calls, distinct = 4, 200, 3
+    rig = rigmod.build_rig(rigmod.scaled_config("C3" if blend == "multiband" else "C2", 8))
+    eng = H.make_engine(rig, overlap_frames=True, overlap_depth=depth, max_batch=batch)
+    _, _, cw, ch = eng.canvas()
+    dev = torch.device("cuda", 0)
+    n = len(rig["cameras"])
+    host = [rigmod.frames_for(rig, i) for i in range(distinct)]
+    expected = [H.oracle_compose(rig, fr)[1] for fr in host]
+    pinned = [[torch.from_numpy(f).pin_memory() for f in fr] for fr in host]
+    ring = depth                                   # frame and panorama slots: exactly as many as calls can be in flight
+    d_frames = [[[torch.zeros_like(t, device=dev) for t in pinned[0]] for _ in range(batch)] for _ in range(ring)]
+    d_panos = [[torch.zeros((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(batch)] for _ in range(ring)]
+    out = torch.zeros((n_calls, batch, ch, cw, 3), dtype=torch.uint8).pin_memory()
+    ballast_a, ballast_b = (torch.empty(48 << 20, dtype=torch.uint8, device=dev) for _ in range(2))
+    s_copy, s_call, s_read = (torch.cuda.Stream(device=dev) for _ in range(3))
+    ev_ready = [torch.cuda.Event() for _ in range(ring)]
+    ev_done = [torch.cuda.Event() for _ in range(ring)]
+    ev_read = [torch.cuda.Event() for _ in range(ring)]
+    torch.cuda.synchronize()
+    for t in range(n_calls):
+        k = t % ring
+        with torch.cuda.stream(s_copy):
+            if t >= ring:
+                s_copy.wait_event(ev_done[k])       # the slot's frames were last read by call t - ring (the caller's duty, as ever)
+            ballast_b.copy_(ballast_a, non_blocking=True)                      # (the frames arrive late)
+            for f in range(batch):
+                for i in range(n):
+                    d_frames[k][f][i].copy_(pinned[(t + f) % distinct][i], non_blocking=True)
+            ev_ready[k].record(s_copy)
+        eng.compose_device_batch_ex([[x.data_ptr() for x in fs] for fs in d_frames[k]], [[x.stride(0) for x in fs] for fs in d_frames[k]],
+                                    [p.data_ptr() for p in d_panos[k]], d_panos[k][0].stride(0), stream=s_call.cuda_stream,
+                                    frames_ready=ev_ready[k].cuda_event, outputs_free=ev_read[k].cuda_event if t >= ring else None)
+        ev_done[k].record(s_call)
+        with torch.cuda.stream(s_read):
+            s_read.wait_event(ev_done[k])
+            ballast_b.copy_(ballast_a, non_blocking=True) if t % 3 == 0 else None  # (some panoramas are read late)
+            for f in range(batch):
+                out[t, f].copy_(d_panos[k][f], non_blocking=True)
+            ev_read[k].record(s_read)
+    torch.cuda.synchronize()
+    got = out.numpy()
+    for t in range(n_calls):
+        for f in range(batch):
+            assert np.array_equal(got[t, f], expected[(t + f) % distinct]), "call %d frame set %d: %s" % (t, f, H.diff_report(got[t, f], expected[(t + f) % distinct]))
+    eng.close()
+
+
+def test_calls_in_flight_order_writers_of_overlapping_views():
+    """Two calls in flight whose panoramas are sub-views of ONE allocation that share rows (the second starts a few rows into the
+    first) write overlapping bytes: the engine orders them like calls on the same pointer (byte intervals, not pointer equality),
+    so the bytes both write hold the LATER call's pixels."""
+    import torch
+    rig = rigmod.build_rig(rigmod.scaled_config("C3", 8))
+    eng = H.make_engine(rig, overlap_frames=True, overlap_depth=4)
+    _, _, cw, ch = eng.canvas()
+    dev = torch.device("cuda", 0)
+    host = [rigmod.frames_for(rig, i) for i in range(4)]
+    exp = [H.oracle_compose(rig, fr)[1] for fr in host]
+    dfr = [[torch.from_numpy(f).to(dev) for f in fr] for fr in host]
+    shift = 5                                       # rows
+    big = torch.zeros((ch + shift, cw, 3), dtype=torch.uint8, device=dev)
+    views = [big[:ch], big[shift:shift + ch]]
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for rep in range(10):
+        for i in range(4):
+            v = views[i % 2]
+            eng.compose_device([t.data_ptr() for t in dfr[i]], [t.stride(0) for t in dfr[i]], v.data_ptr(), v.stride(0), stream=stream.cuda_stream)
+    stream.synchronize()
+    got = big.cpu().numpy()
+    # the last call (i = 3) wrote view 1 whole; view 0's rows above the overlap still hold call i = 2
+    assert np.array_equal(got[shift:], exp[3])
+    assert np.array_equal(got[:shift], exp[2][:shift])
+    eng.close()

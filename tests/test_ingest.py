@@ -136,8 +136,9 @@ def _spawn_producers(prefix, n, w, h, fmt, distinct, count):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("depth", [0, 4])
 @pytest.mark.parametrize("fmt", ["bgr", "nv12"])
-def test_capture_processes_to_panorama_end_to_end(fmt):
+def test_capture_processes_to_panorama_end_to_end(fmt, depth):
     """SURVEY 8 f3 as a whole: N capture processes -> shared memory -> HBM -> compose -> panorama in host memory, BGR and NV12
     packets; every panorama equals the oracle's on the frames the producers sent."""
     import helpers as H
@@ -147,13 +148,17 @@ def test_capture_processes_to_panorama_end_to_end(fmt):
     rig = rigmod.build_rig(rigmod.scaled_config("C3", 4 if fmt == "nv12" else 8))      # (NV12 needs even sizes: 480 x 270)
     n = len(rig["cameras"])
     w, h = rig["size"]
-    eng = S.PanoramaEngine(n, warp=rig["warp"], blend=rig["blend"], expos=rig["expos"], num_bands=5, frames_nv12=(fmt == "nv12"))
+    # depth 4: the engine's calls-in-flight mode (every call whole on an engine-owned stream): IngestStitcher orders each call
+    # behind its own frames and behind the copy-out of the panorama buffer it re-uses with events, not with host waits
+    eng = S.PanoramaEngine(n, warp=rig["warp"], blend=rig["blend"], expos=rig["expos"], num_bands=5, frames_nv12=(fmt == "nv12"),
+                           overlap_frames=depth > 0, overlap_depth=depth)
     eng.update(rig["scale"], rig["cameras"])
-    names, procs = _spawn_producers("/mst_e2e_%s_%d" % (fmt, os.getpid()), n, w, h, fmt, 3, 5)
+    n_sets = 5 if depth == 0 else 9
+    names, procs = _spawn_producers("/mst_e2e_%s_%d_%d" % (fmt, depth, os.getpid()), n, w, h, fmt, 3, n_sets)
     try:
         st = ingest.IngestStitcher(eng, names, [c["size"] for c in rig["cameras"]])
         got = []
-        for t in range(5):
+        for t in range(n_sets):
             if t >= 3:
                 got.append(st.wait().copy())
             st.submit()
@@ -165,12 +170,15 @@ def test_capture_processes_to_panorama_end_to_end(fmt):
             p.stdin.close()
         for p in procs:
             p.wait(timeout=30)
-    assert len(got) == 5
+    assert len(got) == n_sets
+    expected = {}
     for t, pano in enumerate(got):
         k = t % 3
         if fmt == "nv12":
             frames = [O.cvt_nv12_bgr(ingest.synth_nv12(i, k, w, h)) for i in range(n)]
         else:
             frames = [rigmod.synth_frame(i, k, w, h) for i in range(n)]
-        assert np.array_equal(pano, H.oracle_compose(rig, frames)[1]), (fmt, t)
+        if k not in expected:
+            expected[k] = H.oracle_compose(rig, frames)[1]
+        assert np.array_equal(pano, expected[k]), (fmt, depth, t)
     eng.close()
