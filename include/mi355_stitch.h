@@ -117,9 +117,6 @@ int mst_warp_kind_from_name(const char *name);
                                       raw frame -- no pre-pass, the plain rate.  Not the reference's pixels (it resamples twice,
                                       DRV:741 then DRV:752): one interpolation blur less; parity is against the oracle's
                                       statement of the same composition. */
-#define MST_FLAG_STRIP_HALO 64u    /* canvas strips (strip_count > 1, multi-band): neighbouring strips exchange the halo of the
-                                      cameras' Gaussian level 2 instead of each recomputing it (mst_strip_front_batch /
-                                      mst_strip_back_batch below).  Every engine of the job must set it. */
 #define MST_FLAG_OVERLAP_FRAMES 4u /* throughput mode for mst_compose_device(_batch): the per-camera kernels of call t+1
                                       run on an engine-owned stream while the canvas kernel of call t is still
                                       running on the caller's stream (two runs of pyramid sets alternate).  Results and
@@ -374,29 +371,6 @@ int  mst_stage_select_set(mst_engine *e, int set);
 /* The buffer belongs to the calibration the call resolves to (see mst_acquire_calibration) and is freed when that
  * calibration is retired: query it again after every mst_update / mst_acquire_calibration, never cache it across. */
 int  mst_pyramid_buffer(mst_engine *e, int camera, void **d_ptr, size_t *bytes);
-
-/* ---- canvas strips with halo exchange (MST_FLAG_STRIP_HALO; multi-band only) ------------------------------
- * A strip engine on its own (mst_config.strip_index / strip_count) computes every Gaussian pixel its canvas regions read:
- * the coarse pyramid levels reach a few hundred panorama columns past the strip, per side and camera, and with eight strips
- * that halo is as much work as the strip itself.  With this flag the launch sequence is cut at pyramid level 2: what a
- * strip reads of that level outside its own columns is computed by the neighbour that owns those columns and shipped --
- * one rectangle per camera and side, static per calibration, derived identically on both sides from the same calibration
- * -- and the levels above are reduced from it as before.  Per batch of `count` frame sets:
- *   mst_strip_front_batch   warp + pyramids up to level 2 of this strip's own columns; the rectangles the left / right
- *                           neighbour asked for packed into d_send_left / d_send_right (count x send_bytes[side] each)
- *   ... the job exchanges the buffers (RCCL send/recv between neighbours; sharding.StripStitcher does) ...
- *   mst_strip_back_batch    the received rectangles (count x recv_bytes[side]) scattered into the pyramids, the rest of the
- *                           pyramids, the canvas kernels; the strip's panorama columns come out as from mst_compose_device_batch.
- * A side without a neighbour (or with nothing to exchange) has 0 bytes and takes a NULL buffer.  The pixels are the whole-canvas
- * engine's, bit for bit.  Rigs whose pyramids cannot be cut (fewer than four levels, odd level sizes) exchange nothing and
- * stay self-sufficient; a strip narrower than its neighbour's halo is refused at mst_update.  Not with
- * MST_FLAG_OVERLAP_FRAMES or MST_FLAG_GRAPH_REPLAY; latch the calibration (mst_acquire_calibration) around the pair. */
-int  mst_strip_halo_bytes(mst_engine *e, size_t send_bytes[2], size_t recv_bytes[2]);   /* per frame set; [0] left, [1] right */
-int  mst_strip_front_batch(mst_engine *e, int count, const void *const *d_frames, const size_t *frame_strides,
-                           void *d_send_left, void *d_send_right, void *stream);
-int  mst_strip_back_batch(mst_engine *e, int count, const void *d_recv_left, const void *d_recv_right,
-                          void *const *d_panos, size_t pano_stride, void *const *d_pano_masks, size_t pano_mask_stride,
-                          void *stream);
 
 /* ---- stage-level entry points (the reference's plugin interfaces) ------------------------ */
 /* RotationWarper::warpRoi -- host only, no device needed */

@@ -38,7 +38,6 @@ FLAG_OVERLAP_FRAMES = 4
 FLAG_LENS_COMPOSED = 8
 FLAG_FRAMES_NV12 = 16
 FLAG_GRAPH_REPLAY = 32
-FLAG_STRIP_HALO = 64
 MAX_CAMERAS, MAX_BANDS = 16, 10
 DBG_CAM_WARPED_S16, DBG_CAM_GAUSS_S16, DBG_CAM_WEIGHT_F32, DBG_BAND_WEIGHT_F32, DBG_CANVAS_S16, DBG_CAM_NEED_U8 = \
     1, 2, 3, 4, 5, 6
@@ -50,7 +49,6 @@ EXPORTS = [
     "mst_host_alloc", "mst_host_free", "mst_pipeline_submit", "mst_pipeline_wait", "mst_pipeline_pending",
     "mst_stage_cameras", "mst_stage_canvas", "mst_pyramid_buffer",
     "mst_payload_bytes", "mst_payload_pack", "mst_payload_unpack", "mst_stage_select_set",
-    "mst_strip_halo_bytes", "mst_strip_front_batch", "mst_strip_back_batch",
     "mst_build_maps", "mst_build_maps_host", "mst_warp", "mst_exposure_apply",
     "mst_init_undistort_rectify_map", "mst_compose_lens_maps", "mst_cvt_nv12_bgr", "mst_remap_fixed",
     "mst_calibration_blob_size", "mst_calibration_save", "mst_calibration_load",
@@ -205,12 +203,6 @@ def load():
     L.mst_payload_unpack.argtypes = [vp, C.c_int, vp, vp]
     L.mst_stage_select_set.restype = C.c_int
     L.mst_stage_select_set.argtypes = [vp, C.c_int]
-    L.mst_strip_halo_bytes.restype = C.c_int
-    L.mst_strip_halo_bytes.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
-    L.mst_strip_front_batch.restype = C.c_int
-    L.mst_strip_front_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), vp, vp, vp]
-    L.mst_strip_back_batch.restype = C.c_int
-    L.mst_strip_back_batch.argtypes = [vp, C.c_int, vp, vp, C.POINTER(vp), C.c_size_t, C.POINTER(vp), C.c_size_t, vp]
     L.mst_pyramid_buffer.restype = C.c_int
     L.mst_pyramid_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.mst_compose_profile.restype = C.c_int

@@ -129,10 +129,7 @@ int mst_create(const mst_config* cfg, mst_engine** out)
                 "MST_FLAG_DRIVER_LUT requires MST_BLEND_NO");
         require(!(cfg->flags & MST_FLAG_OVERLAP_FRAMES) || !(cfg->flags & MST_FLAG_DEBUG),
                 "MST_FLAG_OVERLAP_FRAMES cannot be combined with MST_FLAG_DEBUG");
-        require(!(cfg->flags & MST_FLAG_STRIP_HALO) || cfg->blend_kind == MST_BLEND_MULTI_BAND,
-                "MST_FLAG_STRIP_HALO is for the multi-band blend (the other blends have no pyramid halo)");
-        require(!(cfg->flags & MST_FLAG_STRIP_HALO) || !(cfg->flags & (MST_FLAG_OVERLAP_FRAMES | MST_FLAG_GRAPH_REPLAY | MST_FLAG_DEBUG)),
-                "MST_FLAG_STRIP_HALO cannot be combined with MST_FLAG_OVERLAP_FRAMES, MST_FLAG_GRAPH_REPLAY or MST_FLAG_DEBUG");
+        require(!(cfg->flags & 64u), "flag 64 (the round-4 strip halo exchange) was removed: strips are self-sufficient");
         require(cfg->max_batch >= 0 && cfg->max_batch <= MST_MAX_BATCH, "max_batch out of range");
         require(cfg->weight_type == MST_WEIGHT_32F || cfg->weight_type == MST_WEIGHT_16S, "weight_type must be CV_32F or CV_16S");
         static_assert(MST_MAX_BATCH == mst::kMaxBatch, "public and device batch limits differ");
@@ -351,29 +348,6 @@ int mst_payload_unpack(mst_engine* e, int camera, const void* d_payload, void* s
 {
     if (!e) return MST_ERR_INVALID_ARG;
     return guarded(e, [&] { e->impl.payload_copy(camera, const_cast<void*>(d_payload), false, static_cast<hipStream_t>(stream)); });
-}
-
-int mst_strip_halo_bytes(mst_engine* e, size_t send_bytes[2], size_t recv_bytes[2])
-{
-    if (!e || !send_bytes || !recv_bytes) return MST_ERR_INVALID_ARG;
-    return guarded(e, [&] { e->impl.halo_bytes(send_bytes, recv_bytes); });
-}
-
-int mst_strip_front_batch(mst_engine* e, int count, const void* const* d_frames, const size_t* frame_strides, void* d_send_left,
-                          void* d_send_right, void* stream)
-{
-    if (!e) return MST_ERR_INVALID_ARG;
-    return guarded(e, [&] { e->impl.strip_front(count, d_frames, frame_strides, d_send_left, d_send_right, static_cast<hipStream_t>(stream)); });
-}
-
-int mst_strip_back_batch(mst_engine* e, int count, const void* d_recv_left, const void* d_recv_right, void* const* d_panos,
-                         size_t pano_stride, void* const* d_pano_masks, size_t pano_mask_stride, void* stream)
-{
-    if (!e) return MST_ERR_INVALID_ARG;
-    return guarded(e, [&] {
-        e->impl.strip_back(count, d_recv_left, d_recv_right, d_panos, pano_stride, d_pano_masks, pano_mask_stride,
-                           static_cast<hipStream_t>(stream));
-    });
 }
 
 int mst_stage_select_set(mst_engine* e, int set)

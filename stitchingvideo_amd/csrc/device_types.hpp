@@ -207,10 +207,6 @@ struct PayloadRect {
     uint32_t off;
 };
 
-// One rectangle of a strip engine's halo exchange (MST_FLAG_STRIP_HALO): pixels x0 .. x0 + w, rows y0 .. y0 + h of camera
-// `cam`'s Gaussian level at the cut, `off` dwords into the packed payload of one frame set for that neighbour.
-struct HaloRect { int32_t cam, x0, y0, w, h; uint32_t off; };
-
 // Exposure-gain estimation (GainCompensator::feed): images and masks on the device, and one overlapping pair of
 // (block) images: its overlap rectangle's origin inside each parent image, and its size.
 struct FeedImage { const uint8_t* img; const uint8_t* mask; uint32_t istride, mstride; };

@@ -703,24 +703,7 @@ void Engine::update(const mst_calibration& calib)
         const char* split_env = std::getenv("MST_SPLIT");       // (read per calibration: the parity test switches it)
         const bool split = nb >= 2 && split_env && split_env[0] == '1';
         ba.split = split ? 1 : 0;                                // (the plan clips a strip's level-1 regions only when not split)
-        MbHalo halo_in{};
-        const bool want_halo = (cfg_.flags & MST_FLAG_STRIP_HALO) && cfg_.strip_count > 1;
-        if (want_halo) {
-            halo_in.level = 2;
-            for (int side = 0; side < 2; ++side) {
-                const int nbr = cfg_.strip_index + (side == 0 ? -1 : 1);
-                halo_in.has[side] = nbr >= 0 && nbr < cfg_.strip_count;
-                if (halo_in.has[side]) strip_columns(cv.cw[0], &halo_in.x0[side], &halo_in.x1[side], nbr);
-                halo_in.has[side] = halo_in.has[side] && halo_in.x1[side] > halo_in.x0[side];
-            }
-        }
-        build_mb_plan(st->desc, wh, ba, (cfg_.flags & MST_FLAG_DEBUG) != 0, st->plan, st->strip_x0, st->strip_x1, want_halo ? &halo_in : nullptr);
-        if (st->plan.halo_level < 0)
-            throw Error{MST_ERR_INVALID_ARG, "MST_FLAG_STRIP_HALO: a strip is narrower than the pyramid halo of its neighbour (fewer strips, or no halo exchange)"};
-        for (int side = 0; side < 2; ++side) {
-            st->d_halo_send[side] = st->plan.halo_send[side].empty() ? nullptr : st->pool.upload(st->plan.halo_send[side], s);
-            st->d_halo_recv[side] = st->plan.halo_recv[side].empty() ? nullptr : st->pool.upload(st->plan.halo_recv[side], s);
-        }
+        build_mb_plan(st->desc, wh, ba, (cfg_.flags & MST_FLAG_DEBUG) != 0, st->plan, st->strip_x0, st->strip_x1);
         ba.clip_x0 = st->plan.clip_x0; ba.clip_x1 = st->plan.clip_x1;
         clk.mark("work-list plan (host)");
         const MbPlanHost& plan = st->plan;
@@ -1189,7 +1172,7 @@ void Engine::compose_batch(int count, const void* const* d_frames, const size_t*
     const bool replay = (cfg_.flags & MST_FLAG_GRAPH_REPLAY) && !(cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && !timer && st &&
                         d_frames && strides && d_panos && count >= 1 && count <= kMaxBatch;
     if (!replay) {
-        compose_batch_on(std::move(st), count, d_frames, strides, d_panos, pano_stride, d_masks, mask_stride, stream, timer, 0, nullptr,
+        compose_batch_on(std::move(st), count, d_frames, strides, d_panos, pano_stride, d_masks, mask_stride, stream, timer,
                          frames_ready, outputs_free);
         return;
     }
@@ -1285,27 +1268,20 @@ void Engine::order_after_writers(int slot, hipStream_t s, const std::vector<Byte
     slot_outputs_[slot] = outs;
 }
 
-// phase 0: the whole launch sequence.  Strip engines with halo exchange (MST_FLAG_STRIP_HALO) run it as two calls around the
-// exchange: phase 1 = the per-camera kernels up to the cut level + the halo rectangles packed into halo[0] / halo[1] (left /
-// right neighbour; frames are read, no panorama is written); phase 2 = the received rectangles unpacked, the rest of the
-// pyramids, the canvas kernels (no frames are read).
 void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
                               void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
-                              hipStream_t stream, StageTimer* timer, int phase, void* const* halo,
-                              hipEvent_t frames_ready, hipEvent_t outputs_free)
+                              hipStream_t stream, StageTimer* timer, hipEvent_t frames_ready, hipEvent_t outputs_free)
 {
     select_device(cfg_.device);
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
-    const bool front = phase != 2, back = phase != 1;
-    if ((front && (!d_frames || !strides)) || (back && !d_panos)) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama table"};
-    if (phase != 0 && st->blend_kind != MST_BLEND_MULTI_BAND) throw Error{MST_ERR_INVALID_ARG, "the strip halo calls exist for multi-band only"};
+    if (!d_frames || !strides || !d_panos) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama table"};
     if (count < 1 || count > kMaxBatch) throw Error{MST_ERR_INVALID_ARG, "batch size out of range"};
     const bool nv12 = !st->nv12_frames.empty();
     if ((st->blend_kind == MST_BLEND_MULTI_BAND || st->any_undistort || nv12) && count > 1 && count > st->sets_per_slot)
         throw Error{MST_ERR_INVALID_ARG, "batch larger than mst_config.max_batch"};
     hipStream_t s = stream ? stream : stream_;
     FrameBatch fb{};
-    for (int f = 0; f < count && front; ++f)
+    for (int f = 0; f < count; ++f)
         for (int i = 0; i < st->n; ++i) {
             const void* p = d_frames[f * st->n + i];
             const size_t stride = strides[f * st->n + i];
@@ -1319,15 +1295,13 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         }
     // (an engine that composes one column strip only needs rows that reach from the strip's first to its last column)
     const int strip_w = std::min(st->strip_x1, st->out_w) - std::min(st->strip_x0, st->out_w);
-    if (back) {
-        if (pano_stride < static_cast<size_t>(cfg_.strip_count > 1 ? strip_w : st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
-        if (pano_stride >= (size_t{1} << 24) || mask_stride >= (size_t{1} << 24))
-            throw Error{MST_ERR_INVALID_ARG, "panorama and mask strides must be below 16 MiB"};
-        if (d_masks && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
-        if (pano_stride * static_cast<size_t>(st->out_h) > 0xFFFFFFFFull)
-            throw Error{MST_ERR_INVALID_ARG, "panoramas of 4 GiB and more are not supported (32-bit byte offsets)"};
-    }
-    for (int f = 0; f < count && back; ++f)
+    if (pano_stride < static_cast<size_t>(cfg_.strip_count > 1 ? strip_w : st->out_w) * 3) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
+    if (pano_stride >= (size_t{1} << 24) || mask_stride >= (size_t{1} << 24))
+        throw Error{MST_ERR_INVALID_ARG, "panorama and mask strides must be below 16 MiB"};
+    if (d_masks && mask_stride < static_cast<size_t>(st->out_w)) throw Error{MST_ERR_INVALID_ARG, "mask stride too small"};
+    if (pano_stride * static_cast<size_t>(st->out_h) > 0xFFFFFFFFull)
+        throw Error{MST_ERR_INVALID_ARG, "panoramas of 4 GiB and more are not supported (32-bit byte offsets)"};
+    for (int f = 0; f < count; ++f)
         if (!d_panos[f]) throw Error{MST_ERR_INVALID_ARG, "null panorama pointer"};
 
     // the bytes this call writes (deep form: what order_after_writers compares between calls in flight)
@@ -1387,9 +1361,7 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         // and only wait for the canvas kernel that last read this pyramid set (two frames ago); the canvas kernel
         // (C) stays on the caller's stream behind them.  Frame t+1's A/B therefore overlap frame t's C.
         const bool overlap = (cfg_.flags & MST_FLAG_OVERLAP_FRAMES) && st->num_sets >= 2 * st->sets_per_slot &&
-                             timer == nullptr && !in_host_compose_ && phase == 0;
-        // the last pyramid level the front phase produces (the halo's cut level; everything when the plan made no cut)
-        const int cut = phase == 0 ? 0 : (st->plan.halo_level > 0 ? st->plan.halo_level : kMaxLevels);
+                             timer == nullptr && !in_host_compose_;
         // deep form (MST_OVERLAP_DEPTH > 2): the whole call on the slot's own stream; the caller's stream only waits for it
         const int slots = st->num_sets / st->sets_per_slot;
         const bool deep = overlap && overlap_depth_ > 2 && slots > 2;
@@ -1425,22 +1397,8 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
                     canvas_pending_[k] = false;
                 }
         wait_for_caller(sf, s);
-        if (front) {
-            undistort(first_set, sf);
-            launch_warp(*st, desc, fb, count, 0, st->n, sf, timer);
-        }
-        auto halo_copy = [&](bool pack) {
-            if (st->plan.halo_level <= 0 || !halo) return;
-            for (int side = 0; side < 2; ++side) {
-                const std::vector<HaloRect>& rects = pack ? st->plan.halo_send[side] : st->plan.halo_recv[side];
-                if (rects.empty()) continue;
-                if (!halo[side]) throw Error{MST_ERR_INVALID_ARG, "null halo buffer for a neighbour this strip exchanges with"};
-                mark(launch_halo_copy(desc, st->n, pack ? st->d_halo_send[side] : st->d_halo_recv[side], static_cast<int>(rects.size()),
-                                      st->plan.halo_level, pack ? st->plan.halo_send_px[side] : st->plan.halo_recv_px[side], count,
-                                      static_cast<uint32_t*>(halo[side]), pack, sf));
-            }
-        };
-        if (phase == 2) halo_copy(false);
+        undistort(first_set, sf);
+        launch_warp(*st, desc, fb, count, 0, st->n, sf, timer);
         // where the frame crosses from the front stream to the caller's stream: after the warp kernel (the small
         // pyramid-chain launches then fill in beside the next frame's warp) or after the chain
         static const bool split_after_warp = [] { const char* v = std::getenv("MST_OVERLAP_SPLIT"); return v && v[0] == '1'; }();
@@ -1450,23 +1408,14 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         };
         if (overlap && !deep && split_after_warp) cross();
         hipStream_t sc = (overlap && !split_after_warp) ? sf : s;
-        // (a launch belongs to the front phase when the level it produces is at or below the cut)
-        auto mine = [&](int produced) { return phase == 0 || (phase == 1) == (produced <= cut); };
         for (size_t i = 0; i < st->chain_lists.size(); ++i) {
             const MbPlanHost::ChainStep& step = st->plan.chain[i];
             if (st->chain_units[i].d[0]) {
                 for (int j = 0; j < step.k; ++j)
-                    if (mine(step.base + j + 1))
-                        mark(launch_pyrdown_stream(desc, st->n, st->chain_units[i].d[j], static_cast<int>(step.units[j].size()), step.base + j, count, sc));
-            } else if (mine(step.base + 1)) {
+                    mark(launch_pyrdown_stream(desc, st->n, st->chain_units[i].d[j], static_cast<int>(step.units[j].size()), step.base + j, count, sc));
+            } else {
                 mark(launch_pyr_chain(desc, st->n, st->chain_lists[i], step.base, step.k, count, sc));
             }
-        }
-        if (phase == 1) {
-            halo_copy(true);
-            check_hip(hipGetLastError(), "strip front kernels");
-            set_in_flight(std::move(st));
-            return;
         }
         if (overlap && !deep && !split_after_warp) cross();
         int n_coarse = 0;
@@ -1560,37 +1509,6 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
     }
     check_hip(hipGetLastError(), "compose kernels");
     set_in_flight(std::move(st));
-}
-
-// ---- canvas strips with halo exchange (MST_FLAG_STRIP_HALO): the launch sequence as two calls around the exchange ----
-
-void Engine::halo_bytes(size_t send[2], size_t recv[2])
-{
-    std::shared_ptr<CalibState> st = state();
-    if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "no calibration"};
-    for (int side = 0; side < 2; ++side) {
-        send[side] = st->plan.halo_level > 0 ? static_cast<size_t>(st->plan.halo_send_px[side]) * 4 : 0;
-        recv[side] = st->plan.halo_level > 0 ? static_cast<size_t>(st->plan.halo_recv_px[side]) * 4 : 0;
-    }
-}
-
-void Engine::strip_front(int count, const void* const* d_frames, const size_t* strides, void* d_send_left, void* d_send_right, hipStream_t stream)
-{
-    std::shared_ptr<CalibState> st = state();
-    void* bufs[2] = {d_send_left, d_send_right};
-    compose_batch_on(st, count, d_frames, strides, nullptr, 0, nullptr, 0, stream, nullptr, 1, bufs);
-    halo_state_ = st;             // the back half must run against the same calibration and frame sets
-    halo_count_ = count;
-}
-
-void Engine::strip_back(int count, const void* d_recv_left, const void* d_recv_right, void* const* d_panos, size_t pano_stride,
-                        void* const* d_masks, size_t mask_stride, hipStream_t stream)
-{
-    std::shared_ptr<CalibState> st = std::move(halo_state_);
-    halo_state_.reset();
-    if (!st || count != halo_count_) throw Error{MST_ERR_INVALID_ARG, "mst_strip_back_batch without a matching mst_strip_front_batch"};
-    void* bufs[2] = {const_cast<void*>(d_recv_left), const_cast<void*>(d_recv_right)};
-    compose_batch_on(st, count, nullptr, nullptr, d_panos, pano_stride, d_masks, mask_stride, stream, nullptr, 2, bufs);
 }
 
 namespace {

@@ -125,8 +125,6 @@ struct CalibState {
     struct StreamUnits { const uint32_t* d[2] = {nullptr, nullptr}; };
     std::vector<StreamUnits> chain_units;   // per plan.chain step: the streaming kernel's unit lists (null: k_pyr_chain runs the step)
     PayloadRect* d_payload_rects = nullptr;   // camera-sharded hand-off (plan.payload_*)
-    const HaloRect* d_halo_send[2] = {nullptr, nullptr};   // strip halo exchange (plan.halo_*)
-    const HaloRect* d_halo_recv[2] = {nullptr, nullptr};
     BlendArgs blend{};                  // canvas kernels (pano pointers filled per frame)
     // feather
     float* d_feather_ws = nullptr;
@@ -177,11 +175,6 @@ public:
     void stage_canvas(void* d_pano, size_t pano_stride, void* d_mask, size_t mask_stride, hipStream_t stream);
     void pyramid_buffer(int camera, void** d_ptr, size_t* bytes);
     // camera-sharded hand-off: the packed tile interiors of one camera (see mb_plan.hpp)
-    // canvas strips with halo exchange (MST_FLAG_STRIP_HALO)
-    void halo_bytes(size_t send[2], size_t recv[2]);
-    void strip_front(int count, const void* const* d_frames, const size_t* strides, void* d_send_left, void* d_send_right, hipStream_t stream);
-    void strip_back(int count, const void* d_recv_left, const void* d_recv_right, void* const* d_panos, size_t pano_stride,
-                    void* const* d_masks, size_t mask_stride, hipStream_t stream);
     size_t payload_bytes(int camera);
     void payload_copy(int camera, void* d_buf, bool pack, hipStream_t stream);
     void select_stage_set(int set);                  // which pyramid set the mst_stage_* / mst_payload_* calls use
@@ -209,11 +202,8 @@ public:
 private:
     void compose_batch_on(std::shared_ptr<CalibState> st, int count, const void* const* d_frames, const size_t* strides,
                           void* const* d_panos, size_t pano_stride, void* const* d_masks, size_t mask_stride,
-                          hipStream_t stream, StageTimer* timer, int phase = 0, void* const* halo = nullptr,
-                          hipEvent_t frames_ready = nullptr, hipEvent_t outputs_free = nullptr);
+                          hipStream_t stream, StageTimer* timer, hipEvent_t frames_ready = nullptr, hipEvent_t outputs_free = nullptr);
     void strip_columns(int width, int* x0, int* x1, int index = -1) const;
-    std::shared_ptr<CalibState> halo_state_;      // between mst_strip_front_batch and mst_strip_back_batch
-    int halo_count_ = 0;
     void launch_undistort(const CalibState& st, const FrameBatch& src, const FrameBatch& dst, int count, uint32_t camera_mask, hipStream_t s);
     // which map_px<KIND> the table kernels and the gathering warp kernel are launched with: the projection's own
     // per-axis form, or "read the map" (3) for the non-separable projectors and for MST_FLAG_LENS_COMPOSED

@@ -492,27 +492,6 @@ __global__ __launch_bounds__(256) void k_payload_copy(const CamDesc* __restrict_
     }
 }
 
-// Strip halo exchange: rectangles of the cameras' Gaussian level `level` <-> one packed buffer per neighbour, all frame sets of
-// the launch in one go (set f at f * px_per_set dwords).  grid: (rectangle, frame set, row chunk).
-template <bool PACK>
-__global__ __launch_bounds__(256) void k_halo_copy(const CamDesc* __restrict__ cams_all, int n_cams, const HaloRect* __restrict__ rects,
-                                                   int level, uint32_t px_per_set, uint32_t* __restrict__ buf)
-{
-    const HaloRect r = rects[blockIdx.x];
-    const CamDesc& c = cams_all[blockIdx.y * n_cams + r.cam];
-    uint32_t MST_GLOBAL* __restrict__ b = gp(buf) + static_cast<size_t>(blockIdx.y) * px_per_set + r.off;
-    uint32_t MST_GLOBAL* __restrict__ g = gp(c.G[level]);
-    const int lw = c.lw[level];
-    const int rows = (r.h + static_cast<int>(gridDim.z) - 1) / static_cast<int>(gridDim.z);
-    const int y0 = static_cast<int>(blockIdx.z) * rows, y1 = min(r.h, y0 + rows);
-    for (int i = y0 * r.w + static_cast<int>(threadIdx.x); i < y1 * r.w; i += 256) {
-        const int y = i / r.w, x = i - y * r.w;
-        const size_t gi = static_cast<size_t>(r.y0 + y) * lw + (r.x0 + x);
-        if (PACK) b[i] = g[gi];
-        else g[gi] = b[i];
-    }
-}
-
 // What the work-list planner needs to know about a weight pyramid level, one byte per pixel: bit 0 = non-zero
 // (short(laplacian * 0.f) == 0: such a pixel cannot reach the panorama), bit 1 = exactly the weight of a fully owned
 // pixel (the integer band path applies).  A quarter of the float pyramid's bytes crosses to the host.
@@ -715,16 +694,6 @@ void launch_payload_copy(const CamDesc* d_cam, const PayloadRect* d_rects, int n
     if (n_rects <= 0) return;
     if (pack) hipLaunchKernelGGL(k_payload_copy<true>, dim3(n_rects), dim3(256), 0, s, d_cam, d_rects, d_buf);
     else hipLaunchKernelGGL(k_payload_copy<false>, dim3(n_rects), dim3(256), 0, s, d_cam, d_rects, d_buf);
-}
-
-const char* launch_halo_copy(const CamDesc* d_cams, int n_cams, const HaloRect* d_rects, int n_rects, int level, uint32_t px_per_set,
-                             int frame_sets, uint32_t* d_buf, bool pack, hipStream_t s)
-{
-    if (n_rects == 0 || frame_sets == 0) return nullptr;
-    const dim3 grid(n_rects, frame_sets, 8);
-    if (pack) { hipLaunchKernelGGL(k_halo_copy<true>, grid, dim3(256), 0, s, d_cams, n_cams, d_rects, level, px_per_set, d_buf); return "k_halo_copy<pack>"; }
-    hipLaunchKernelGGL(k_halo_copy<false>, grid, dim3(256), 0, s, d_cams, n_cams, d_rects, level, px_per_set, d_buf);
-    return "k_halo_copy<unpack>";
 }
 
 void launch_weight_class(const float* d_w, uint8_t* d_out, size_t n, float unit, hipStream_t s)

@@ -57,8 +57,6 @@ int mb_launch_variant(int frame_sets);
 int mb_coarse_tile_height(int variant);                                            // (BlendArgs::cc_th: 16 or 32)
 int mb_fine_threads(int variant);                                                  // (BlendArgs::fine_threads: 256 or 128)
 // region of tile (tx, ty) -- a panorama tile (base 0) or a level-1 tile (base 1) -- at `level` >= base: x0, y0, x1, y1
-const char* launch_halo_copy(const CamDesc* d_cams, int n_cams, const HaloRect* d_rects, int n_rects, int level, uint32_t px_per_set,
-                             int frame_sets, uint32_t* d_buf, bool pack, hipStream_t s);
 void mb_blend_region(const BlendArgs& a, int base, int tx, int ty, int level, int out[4]);
 int  mb_blend_region_lds_pixels(const BlendArgs& a, int base, int tx, int ty, int level);   // LDS footprint of that region
 size_t mb_warp_table_entries(int num_tiles);                                         // 32-bit entries for `num_tiles` tiles

@@ -209,7 +209,7 @@ void mark_footprint(const std::vector<uint8_t>& coarse, int cw, int ch, std::vec
 
 
 void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<uint8_t>>>& weight_class,
-                   const BlendArgs& blend, bool keep_level0, MbPlanHost& plan, int strip_x0, int strip_x1, const MbHalo* halo)
+                   const BlendArgs& blend, bool keep_level0, MbPlanHost& plan, int strip_x0, int strip_x1)
 {
     const int n = static_cast<int>(desc.size());
     const int nlev = blend.nlev, nb = nlev - 1;
@@ -280,119 +280,10 @@ void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vect
             if (l < nb) mark_footprint(cn.need[l + 1], d.lw[l + 1], d.lh[l + 1], cn.need[l], d.lw[l], d.lh[l]);
         }
     };
-    // Halo exchange between neighbouring strips (MbHalo).  Without it a strip computes every Gaussian
-    // pixel its canvas regions read: the coarse levels reach a few level-5 pixels past the strip, and the pyrDown chain under
-    // them pulls in level 0 some 200 columns further still, per side and camera.  With it the cut is made at level
-    // `halo->level` (2): what the strip needs of that level OUTSIDE its own columns is computed by the neighbour that owns
-    // those columns -- it needs most of it itself -- and shipped (one rectangle per camera and side); the levels above are
-    // reduced from level 2 as before, the levels below shrink to what the strip's own columns need.
-    // (the cut falls between two launches of the streaming pyrDown: levels 1 .. cut must have even sizes in every camera, as that
-    // kernel requires; otherwise the strip stays self-sufficient and exchanges nothing -- every rank decides the same)
-    bool cut_ok = halo && striped && halo->level >= 1 && halo->level < nb && halo->level <= 2 && nb - 1 >= mb_chain_depth();
-    for (int c = 0; c < n && cut_ok; ++c)
-        for (int l = 1; l <= halo->level; ++l) cut_ok = cut_ok && desc[c].lw[l] % 2 == 0 && desc[c].lh[l] % 2 == 0;
-    const int hk = cut_ok ? halo->level : 0;
-    plan.halo_level = 0;
-    if (hk > 0) {
-        const int own0 = strip_x0 >> hk, own1 = (strip_x1 + (1 << hk) - 1) >> hk;        // own columns at the cut level
-        // what a strip lacks of camera c's level hk on `side` (0: left of its columns, 1: right): the bounding rectangle
-        auto outside = [&](int c, const MbCameraNeed& cn, int c0, int c1, int side, HaloRect& r) {
-            const CamDesc& d = desc[c];
-            const int lw = d.lw[hk], lh = d.lh[hk];
-            const int xa = side == 0 ? 0 : std::max(0, std::min(lw, c1 - d.ox[hk])), xb = side == 0 ? std::max(0, std::min(lw, c0 - d.ox[hk])) : lw;
-            int bx0 = lw, bx1 = 0, by0 = lh, by1 = 0;
-            for (int y = 0; y < lh && xa < xb; ++y) {
-                const uint8_t* row = cn.need[hk].data() + static_cast<size_t>(y) * lw;
-                const int first = next_set(row, xa, xb);
-                if (first >= xb) continue;
-                int last = xb - 1;
-                while (!row[last]) --last;
-                bx0 = std::min(bx0, first); bx1 = std::max(bx1, last + 1);
-                by0 = std::min(by0, y); by1 = y + 1;
-            }
-            if (bx0 >= bx1) return false;
-            r = HaloRect{c, bx0, by0, bx1 - bx0, by1 - by0, 0u};
-            return true;
-        };
-        bool ok = true;
-        parallel_for(n, 16, [&](int c) {
-            fill_nz(c, plan.cams[c], 0, striped, sx0, sx1);
-            fill_need(c, plan.cams[c], nb, hk);
-        });
-        std::vector<HaloRect> recv[2], send[2];
-        for (int side = 0; side < 2; ++side) {
-            if (!halo->has[side]) continue;
-            const int nb0 = halo->x0[side] >> hk, nb1 = (halo->x1[side] + (1 << hk) - 1) >> hk;      // the neighbour's own columns
-            for (int c = 0; c < n; ++c) {
-                HaloRect r;
-                if (!outside(c, plan.cams[c], own0, own1, side, r)) continue;
-                // (the whole rectangle must lie in the neighbour's own columns: it computes nothing else of that level)
-                if (r.x0 + desc[c].ox[hk] < nb0 || r.x0 + r.w + desc[c].ox[hk] > nb1) ok = false;
-                recv[side].push_back(r);
-            }
-            // what that neighbour lacks on its side towards this strip: the same walk over its strip
-            std::vector<int> t0, t1;
-            strip_levels(halo->x0[side], halo->x1[side], t0, t1);
-            std::vector<MbCameraNeed> theirs(n);
-            parallel_for(n, 16, [&](int c) {
-                fill_nz(c, theirs[c], hk - 1, true, t0, t1);
-                fill_need(c, theirs[c], nb, hk);
-            });
-            for (int c = 0; c < n; ++c) {
-                HaloRect r;
-                if (!outside(c, theirs[c], nb0, nb1, 1 - side, r)) continue;
-                if (r.x0 + desc[c].ox[hk] < own0 || r.x0 + r.w + desc[c].ox[hk] > own1) ok = false;
-                send[side].push_back(r);
-            }
-        }
-        // (a rectangle without a neighbour to serve it -- the canvas edge -- cannot occur: need[] never leaves the strip's regions,
-        // and those end at the canvas edge)
-        for (int side = 0; side < 2 && ok; ++side)
-            if (!halo->has[side])
-                for (int c = 0; c < n; ++c) {
-                    HaloRect r;
-                    if (outside(c, plan.cams[c], own0, own1, side, r)) ok = false;
-                }
-        if (ok) {
-            plan.halo_level = hk;
-            for (int side = 0; side < 2; ++side) {
-                uint32_t off = 0;
-                for (HaloRect& r : recv[side]) { r.off = off; off += static_cast<uint32_t>(r.w) * r.h; }
-                plan.halo_recv_px[side] = off;
-                off = 0;
-                for (HaloRect& r : send[side]) { r.off = off; off += static_cast<uint32_t>(r.w) * r.h; }
-                plan.halo_send_px[side] = off;
-                plan.halo_recv[side] = recv[side];
-                plan.halo_send[side] = send[side];
-            }
-            // this strip computes of the cut level: what it needs inside its own columns, and what the neighbours asked for
-            parallel_for(n, 16, [&](int c) {
-                const CamDesc& d = desc[c];
-                MbCameraNeed& cn = plan.cams[c];
-                cn.need_cut = cn.need[hk];                    // (everything the strip reads of that level: computed here or received)
-                const int lw = d.lw[hk];
-                const int lo = std::max(0, std::min(lw, own0 - d.ox[hk])), hi = std::max(lo, std::min(lw, own1 - d.ox[hk]));
-                for (int y = 0; y < d.lh[hk]; ++y) {
-                    uint8_t* row = cn.need[hk].data() + static_cast<size_t>(y) * lw;
-                    std::memset(row, 0, lo);
-                    std::memset(row + hi, 0, lw - hi);
-                }
-                for (int side = 0; side < 2; ++side)
-                    for (const HaloRect& r : send[side])
-                        if (r.cam == c)
-                            for (int y = r.y0; y < r.y0 + r.h; ++y) std::memset(cn.need[hk].data() + static_cast<size_t>(y) * lw + r.x0, 1, r.w);
-                fill_need(c, cn, hk - 1, 0);
-            });
-        } else {
-            plan.halo_level = -1;              // strips narrower than the halo: the caller refuses the configuration
-            parallel_for(n, 16, [&](int c) { fill_need(c, plan.cams[c], hk - 1, 0); });
-        }
-    } else {
-        parallel_for(n, 16, [&](int c) {
-            fill_nz(c, plan.cams[c], 0, striped, sx0, sx1);
-            fill_need(c, plan.cams[c], nb, 0);
-        });
-    }
+    parallel_for(n, 16, [&](int c) {
+        fill_nz(c, plan.cams[c], 0, striped, sx0, sx1);
+        fill_need(c, plan.cams[c], nb, 0);
+    });
 
     mark("nz / need per camera");
     // ---- kernel A: level-0 tiles of a_tw0 x a_th0 pixels

@@ -25,12 +25,7 @@ namespace mst {
 struct MbCameraNeed {
     // [level] -> lh*lw bytes
     std::vector<std::vector<uint8_t>> nz, need;
-    std::vector<uint8_t> need_cut;        // halo exchange: everything the strip reads of the cut level (need[cut] = what it computes)
 };
-
-// Halo exchange between neighbouring strip engines (build_mb_plan): the cut level and the neighbours' panorama columns
-// ([0] left, [1] right).  HaloRect (device_types.hpp): one rectangle of a camera's Gaussian level `level`.
-struct MbHalo { int level; bool has[2]; int x0[2], x1[2]; };
 
 struct MbPlanHost {
     std::vector<uint32_t> warp_tiles;                         // kernel A, grouped by camera: cam << 24 | ty << 12 | tx, bit 31 =
@@ -69,12 +64,6 @@ struct MbPlanHost {
     std::vector<uint32_t> payload_px;                         // pixels (dwords) per camera
     std::vector<MbCameraNeed> cams;
     int clip_x0 = 0, clip_x1 = 0;                             // strip engines: BlendArgs::clip_x0 / clip_x1 (0, 0: whole canvas)
-    // halo exchange: 0 = none; > 0 = the cut level; -1 = asked for but the strips are narrower than the halo.
-    // halo_recv[side]: what this strip receives from the neighbour on that side (and does not compute); halo_send[side]: what
-    // it computes for that neighbour.  The neighbour derives the same rectangles from the same calibration.
-    int halo_level = 0;
-    std::vector<HaloRect> halo_send[2], halo_recv[2];
-    uint32_t halo_send_px[2] = {0, 0}, halo_recv_px[2] = {0, 0};
 };
 
 // weight_class[c][l]: one byte per pixel of camera c's weight pyramid level l -- bit 0: the weight is non-zero,
@@ -85,7 +74,6 @@ struct MbPlanHost {
 // strip_x0 / strip_x1: the columns [x0, x1) of the (padded) canvas this engine composes (canvas split over GPUs); every
 // list is restricted to what those panorama columns can depend on.  0 / cw[0]: everything.
 void build_mb_plan(const std::vector<CamDesc>& desc, const std::vector<std::vector<std::vector<uint8_t>>>& weight_class,
-                   const BlendArgs& blend, bool keep_level0, MbPlanHost& plan, int strip_x0 = 0, int strip_x1 = 1 << 30,
-                   const MbHalo* halo = nullptr);
+                   const BlendArgs& blend, bool keep_level0, MbPlanHost& plan, int strip_x0 = 0, int strip_x1 = 1 << 30);
 
 }  // namespace mst

@@ -405,7 +405,7 @@ class PanoramaEngine:
 
     def __init__(self, num_cameras, warp="spherical", blend="multiband", expos="gain_blocks", num_bands=5,
                  feather_sharpness=0.02, device=0, driver_lut=False, crop=(0.1, 0.1, 10.0, 10.0), debug=False,
-                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None, lens_composed=False, frames_nv12=False, graph_replay=False, strip_halo=False, overlap_depth=0):
+                 overlap_frames=False, max_batch=0, weight_type="32f", warp_ab=None, strip=None, lens_composed=False, frames_nv12=False, graph_replay=False, overlap_depth=0):
         self._L = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -419,7 +419,7 @@ class PanoramaEngine:
         cfg.device = device
         cfg.flags = (capi.FLAG_DRIVER_LUT if driver_lut else 0) | (capi.FLAG_DEBUG if debug else 0) | \
             (capi.FLAG_OVERLAP_FRAMES if overlap_frames else 0) | (capi.FLAG_LENS_COMPOSED if lens_composed else 0) | (capi.FLAG_FRAMES_NV12 if frames_nv12 else 0) | \
-            (capi.FLAG_GRAPH_REPLAY if graph_replay else 0) | (capi.FLAG_STRIP_HALO if strip_halo else 0)
+            (capi.FLAG_GRAPH_REPLAY if graph_replay else 0)
         self._frames_nv12 = bool(frames_nv12)
         cfg.upblack, cfg.downblack, cfg.leftblack, cfg.rightblack = crop
         cfg.max_batch = max_batch
@@ -612,28 +612,6 @@ class PanoramaEngine:
                                                       max_stages, C.cast(names, C.c_void_p), ms, C.byref(num)))
         k = min(num.value, max_stages)
         return [(names[i].value.decode(), float(ms[i])) for i in range(k)]
-
-    # ---- canvas strips with halo exchange (strip=(k, g), strip_halo=True) ----
-    def halo_bytes(self):
-        """((send_left, send_right), (recv_left, recv_right)) bytes per frame set."""
-        send, recv = (C.c_size_t * 2)(), (C.c_size_t * 2)()
-        self._check(self._L.mst_strip_halo_bytes(self._h, send, recv))
-        return (int(send[0]), int(send[1])), (int(recv[0]), int(recv[1]))
-
-    def strip_front_batch(self, frame_ptrs, frame_strides, send_left=None, send_right=None, stream=None):
-        """Per-camera kernels up to the cut level of `count` frame sets + the neighbours' rectangles packed into the send buffers
-        (device pointers, count x send bytes each; None where there is nothing to send)."""
-        n = self.num_cameras
-        count = len(frame_ptrs)
-        ptrs = (C.c_void_p * (count * n))(*[p for fs in frame_ptrs for p in fs])
-        strides = (C.c_size_t * (count * n))(*[s for fs in frame_strides for s in fs])
-        self._check(self._L.mst_strip_front_batch(self._h, count, ptrs, strides, send_left, send_right, stream))
-        return count
-
-    def strip_back_batch(self, count, pano_ptrs, pano_stride, recv_left=None, recv_right=None, stream=None):
-        """The received rectangles unpacked, the rest of the pyramids, the canvas kernels -> this strip's panorama columns."""
-        panos = (C.c_void_p * count)(*pano_ptrs)
-        self._check(self._L.mst_strip_back_batch(self._h, count, recv_left, recv_right, panos, pano_stride, None, 0, stream))
 
     # ---- camera streams sharded over GPUs: per-camera stage, pyramid hand-off, canvas stage ----
     def stage_cameras(self, cameras, frame_ptrs, frame_strides, stream=None):

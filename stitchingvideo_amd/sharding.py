@@ -276,24 +276,6 @@ def gather_strips_to_root(strip, rects, root, rank, pano=None):
     return pano
 
 
-def exchange_strip_halos(send, recv, rank, world):
-    """The exchange between mst_strip_front_batch and mst_strip_back_batch: rank r sends send[0] to r - 1 and send[1] to
-    r + 1 and receives recv[0] from r - 1 and recv[1] from r + 1 (1-D uint8 tensors; None or empty where there is no
-    neighbour or nothing to exchange -- both sides derive the sizes from the same calibration, so none travel).  All four
-    transfers of a rank go out as ONE batch_isend_irecv (a grouped RCCL call: the two neighbours sit on two different xGMI
-    links).  Tags: 200 = towards the right neighbour, 201 = towards the left."""
-    ops = []
-    for side, peer in ((0, rank - 1), (1, rank + 1)):
-        if peer < 0 or peer >= world:
-            continue
-        if recv[side] is not None and recv[side].numel() > 0:
-            ops.append(dist.P2POp(dist.irecv, recv[side], peer, tag=200 + side))          # what the peer sent towards me
-        if send[side] is not None and send[side].numel() > 0:
-            ops.append(dist.P2POp(dist.isend, send[side], peer, tag=200 + (1 - side)))
-    for w in (dist.batch_isend_irecv(ops) if ops else []):
-        w.wait()
-
-
 class StripStitcher:
     """Canvas strips sharded one-per-rank.  Every rank creates its PanoramaEngine with strip=(rank, world), publishes
     the same calibration and holds the frames of the cameras that reach its strip (here: all of them -- the capture
@@ -337,28 +319,6 @@ class StripStitcher:
         self.engine.compose_device(frame_ptrs, frame_strides, self.strip_buf.data_ptr() - self.x0 * 3, self.strip_buf.stride(0),
                                    stream=stream)
         return self.strip_buf
-
-    def compose_with_halo(self, frame_ptrs, frame_strides, stream=None):
-        """The same strip through the halo exchange (engines created with strip_halo=True on every rank): front half, one grouped
-        send/recv with the two neighbours, back half.  frame_ptrs / frame_strides: one table per frame set of the batch; returns
-        the list of strip buffers, one per frame set."""
-        if self.generation is None:
-            self.refresh()
-        count = len(frame_ptrs)
-        if getattr(self, "_halo_gen", None) != (self.generation, count):
-            send_b, recv_b = self.engine.halo_bytes()
-            self.halo_send = [torch.empty(count * b, dtype=torch.uint8, device=self.device) if b else None for b in send_b]
-            self.halo_recv = [torch.empty(count * b, dtype=torch.uint8, device=self.device) if b else None for b in recv_b]
-            self.strip_bufs = [torch.empty_like(self.strip_buf) for _ in range(count)]
-            self._halo_gen = (self.generation, count)
-        ptr = lambda t: t.data_ptr() if t is not None else None        # noqa: E731
-        self.engine.strip_front_batch(frame_ptrs, frame_strides, ptr(self.halo_send[0]), ptr(self.halo_send[1]), stream=stream)
-        self.engine.synchronize() if stream is None else torch.cuda.current_stream().synchronize()
-        exchange_strip_halos(self.halo_send, self.halo_recv, self.rank, self.world)
-        if self.w > 0:
-            self.engine.strip_back_batch(count, [b.data_ptr() - self.x0 * 3 for b in self.strip_bufs], self.strip_bufs[0].stride(0),
-                                         ptr(self.halo_recv[0]), ptr(self.halo_recv[1]), stream=stream)
-        return self.strip_bufs
 
     def gather(self, pano=None):
         if self.rects is None:

@@ -202,47 +202,3 @@ def test_gloo_world2_strips_concatenate_to_the_oracle_panorama():
         p.join(timeout=60)
     assert all(ok is True for _, ok in res), res
     assert all(p.exitcode == 0 for p in procs)
-
-
-def _halo_worker(rank, world, port, q):
-    """exchange_strip_halos, the step between mst_strip_front_batch and mst_strip_back_batch: every rank sends a distinct
-    payload to each neighbour (sizes differ per direction and per boundary, one direction of one boundary is empty) and
-    must hold exactly what its neighbours sent towards it."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        # bytes from rank a towards rank b (|a - b| == 1), known to both sides as the plan's rectangles are
-        size = lambda a, b: 0 if (a, b) == (2, 1) else 1000 + 37 * a + 501 * b          # noqa: E731
-        fill = lambda a, b: (17 * a + 5 * b + 3) % 251                                   # noqa: E731
-        send, recv = [None, None], [None, None]
-        for side, peer in ((0, rank - 1), (1, rank + 1)):
-            if 0 <= peer < world:
-                send[side] = torch.full((size(rank, peer),), fill(rank, peer), dtype=torch.uint8)
-                recv[side] = torch.full((size(peer, rank),), 255, dtype=torch.uint8)
-        sh.exchange_strip_halos(send, recv, rank, world)
-        ok = True
-        for side, peer in ((0, rank - 1), (1, rank + 1)):
-            if 0 <= peer < world:
-                ok = ok and recv[side].numel() == size(peer, rank) and bool((recv[side] == fill(peer, rank)).all())
-        dist.barrier()
-        q.put((rank, ok))
-    except Exception as e:          # noqa: BLE001
-        q.put((rank, "%s: %s" % (type(e).__name__, e)))
-        raise
-    finally:
-        dist.destroy_process_group()
-
-
-def test_gloo_world3_strip_halo_exchange():
-    world = 3
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-    assert all(ok is True for _, ok in res), res
-    assert all(p.exitcode == 0 for p in procs)

@@ -53,34 +53,6 @@ def main():
                             acc[nm] = acc.get(nm, 0.0) + ms / 5
                     kernels = {nm: round(v, 4) for nm, v in acc.items()}
                 eng.close()
-            # the same strips with MST_FLAG_STRIP_HALO: front + back halves back to back (the exchange itself is priced from the bytes)
-            halo_times, halo_bytes = [], []
-            for k in range(g if g > 1 else 0):
-                eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend="multiband", expos=rig["expos"], num_bands=5, max_batch=batch, strip=(k, g), strip_halo=True)
-                eng.update(rig["scale"], rig["cameras"])
-                (cx, cy, cw, ch), _ = eng.acquire()
-                sx, _, sw, _ = eng.strip()
-                send_b, recv_b = eng.halo_bytes()
-                sb = [torch.empty(max(1, batch * b), dtype=torch.uint8, device=dev) for b in send_b]
-                rb = [torch.zeros(max(1, batch * b), dtype=torch.uint8, device=dev) for b in recv_b]       # (timing only: zeros stand in for the neighbours' pixels)
-                bufs = [torch.empty((ch, max(sw, 1), 3), dtype=torch.uint8, device=dev) for _ in range(batch)]
-                pp = [b.data_ptr() - (sx - cx) * 3 for b in bufs]
-
-                def call():
-                    eng.strip_front_batch(ptrs, strides, sb[0].data_ptr() if send_b[0] else None, sb[1].data_ptr() if send_b[1] else None, stream=stream)
-                    eng.strip_back_batch(batch, pp, bufs[0].stride(0), rb[0].data_ptr() if recv_b[0] else None, rb[1].data_ptr() if recv_b[1] else None, stream=stream)
-                for _ in range(3):
-                    call()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    call()
-                e1.record()
-                torch.cuda.synchronize()
-                halo_times.append(e0.elapsed_time(e1) / 20)
-                halo_bytes.append([batch * b for b in send_b])
-                eng.close()
             # ... and with four launch sequences in flight per strip engine (mst_config.overlap_depth): a strip's sequence is a small
             # grid, its launch boundaries are most of what it loses
             fl_times = []
@@ -107,11 +79,6 @@ def main():
             extra = {"in_flight_4_ms_per_launch_sequence": [round(t, 4) for t in fl_times], "in_flight_4_max_ms": round(max(fl_times), 4),
                      "in_flight_4_sum_ms": round(sum(fl_times), 4),
                      "in_flight_4_predicted_frames_per_s_one_strip_per_gpu": round(batch * 1000.0 / max(fl_times), 1)}
-            if halo_times:
-                extra.update(
-{"halo_ms_per_launch_sequence": [round(t, 4) for t in halo_times], "halo_max_ms": round(max(halo_times), 4),
-                         "halo_sum_ms": round(sum(halo_times), 4), "halo_send_bytes_per_launch_sequence_left_right": halo_bytes,
-                         "halo_predicted_frames_per_s_one_strip_per_gpu": round(batch * 1000.0 / max(halo_times), 1)})
             print(json.dumps({**extra, "config": name, "strips": g, "frame_sets_per_launch": batch, "strip_widths": widths,
                               "ms_per_launch_sequence": [round(t, 4) for t in times], "max_ms": round(max(times), 4), "sum_ms": round(sum(times), 4),
                               "predicted_frames_per_s_one_strip_per_gpu": round(batch * 1000.0 / max(times), 1),
