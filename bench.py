@@ -75,6 +75,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=8,
                     help="frame sets per launch sequence (mst_compose_device_batch); 1 = one frame set per sequence")
     ap.add_argument("--strip-leg", action="store_true", help="run the strip-sharded measurement at N = 1 too (one strip = the whole canvas)")
+    ap.add_argument("--strip-headline", action="store_true",
+                    help="N = 1: time the headline through the N > 1 code path (this rank's engine composes strip 0 of 1 = the whole canvas)")
     ap.add_argument("--shard", default="frames", choices=["frames", "cameras"],
                     help="N > 1 headline: frames = every rank stitches its own frame sets (default, no collective); "
                          "cameras = camera i on rank i %% N, payload sent to rank 0 over RCCL, rank 0 blends (SURVEY 8e)")
@@ -194,9 +196,14 @@ def main():
     n_cam = len(rig["cameras"])
     by_camera = args.shard == "cameras" and blend == "multiband"
     batch = 1 if by_camera else max(1, min(args.batch, 8))
+    # N > 1: the headline is the STRONG-scaling mode -- the canvas cut into N column strips, rank r composes strip r of every
+    # panorama (mst_config.strip_index / strip_count; no data-path collective).  The trivial mode (every
+    # GPU stitches its own frame sets, "replicas") is reported beside it, not as `value`.
+    strip_mode = (world > 1 or args.strip_headline) and not by_camera and blend == "multiband"
+    strip_kw = {"strip": (rank, world)} if strip_mode else {}
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
                            overlap_frames=args.overlap and not args.no_overlap and blend == "multiband" and not by_camera,
-                           max_batch=batch, lens_composed=args.undistort and args.lens_composed)
+                           max_batch=batch, lens_composed=args.undistort and args.lens_composed, **strip_kw)
     in_flight = 1 if (by_camera or args.no_overlap) else (2 if args.overlap else max(1, min(args.in_flight, 8)))
     if in_flight == 2 and not args.overlap:
         in_flight = 3                   # (2 is the older two-stream form, multi-band only: --overlap asks for it)
@@ -205,7 +212,8 @@ def main():
     eng_p = eng
     if in_flight > 1 and not args.overlap:
         eng_p = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
-                                 overlap_frames=True, overlap_depth=in_flight, max_batch=batch, lens_composed=args.undistort and args.lens_composed)
+                                 overlap_frames=True, overlap_depth=in_flight, max_batch=batch, lens_composed=args.undistort and args.lens_composed,
+                                 **strip_kw)
     if args.undistort:
         # the reference's fisheye intrinsics (DRV:209-216, quoted for 1280x720) scaled to the frame size
         fw, fh = rig["size"]
@@ -220,19 +228,31 @@ def main():
     if eng_p is not eng:
         eng_p.update(rig["scale"], rig["cameras"])
         eng_p.acquire()
+    # the columns this rank writes: the whole canvas, or its strip.  A strip engine addresses a panorama from canvas column 0
+    # and writes its own columns only: it is handed a strip-sized buffer shifted left by the strip's origin (`pptr`).
+    x0, sw = 0, cw
+    if strip_mode:
+        sx_, _, sw, _ = eng.strip()
+        x0 = sx_ - cx
 
     # frames resident in HBM: a few distinct sets, each rank its own (frame index offset by rank)
     dev = torch.device("cuda", local_rank)
     host_sets, dev_sets = [], []
     n_sets = max(args.frame_sets, batch)
     for s in range(n_sets):
-        fr = rigmod.frames_for(rig, frame_index=sharding.global_frame_index(rank, world, s))
+        # (strip mode: every rank composes ITS COLUMNS of the same panoramas, so every rank holds the same frame sets)
+        fr = rigmod.frames_for(rig, frame_index=s if strip_mode else sharding.global_frame_index(rank, world, s))
         host_sets.append(fr)
         dev_sets.append([torch.from_numpy(f).to(dev) for f in fr])
     # (--pano-row-pad: rows of cw * 3 + pad bytes, to time panorama strides that are not a multiple of four)
+    pw = max(sw, 1)
+
     def make_panos():
-        rows = [torch.empty((ch, cw * 3 + args.pano_row_pad), dtype=torch.uint8, device=dev) for _ in range(batch)]
-        return rows, [p[:, :cw * 3].view(ch, cw, 3) if args.pano_row_pad == 0 else p for p in rows]
+        rows = [torch.empty((ch, pw * 3 + args.pano_row_pad), dtype=torch.uint8, device=dev) for _ in range(batch)]
+        return rows, [p[:, :pw * 3].view(ch, pw, 3) if args.pano_row_pad == 0 else p for p in rows]
+
+    def pptr(t):
+        return t.data_ptr() - x0 * 3
     pano_rows, panos = make_panos()
     pano = panos[0]
     # calls in flight write different panoramas: a ring of `in_flight` sets of them
@@ -256,12 +276,14 @@ def main():
             strides = {c: ds[c].stride(0) for c in stitcher.mine}
             return lambda: stitcher.compose(ptrs, strides, pano.data_ptr(), pano.stride(0), stream=stream)
         calls = [camera_call(ds) for ds in dev_sets]
+    elif sw <= 0:
+        calls = [lambda: None]           # (more ranks than 256-column strips: this rank has no columns; it still takes part in the timing)
     elif batch == 1:
         calls = [eng_p.make_device_call([t.data_ptr() for t in dev_sets[k % n_sets]], [t.stride(0) for t in dev_sets[k % n_sets]],
-                                        pano_ring[k % len(pano_ring)][0].data_ptr(), pano.stride(0), stream=stream)
+                                        pptr(pano_ring[k % len(pano_ring)][0]), pano.stride(0), stream=stream)
                  for k in range(n_sets * len(pano_ring))]
     else:
-        calls = [eng_p.make_device_batch_call(*tables(k % n_sets), [p.data_ptr() for p in pano_ring[k % len(pano_ring)]], pano.stride(0),
+        calls = [eng_p.make_device_batch_call(*tables(k % n_sets), [pptr(p) for p in pano_ring[k % len(pano_ring)]], pano.stride(0),
                                               stream=stream) for k in range(n_sets * len(pano_ring))]
 
     def barrier():
@@ -322,11 +344,11 @@ def main():
         # per-kernel durations: HIP events between launches on the compose stream, averaged over a few sequences
         reps_prof = 10
         acc, order = {}, []
-        for i in range(reps_prof):
+        for i in range(reps_prof if sw > 0 else 0):
             # (a plain call queued right in front: the profiled sequence's first event is then recorded behind running kernels and
             # its first kernel's figure is the kernel, not the launch latency into an idle queue -- 30 us at one frame set per call)
-            eng.compose_device_batch(*tables((i + 1) % n_sets), [p.data_ptr() for p in panos], pano.stride(0), stream=stream)
-            st = eng.profile_stages_batch(*tables(i % n_sets), [p.data_ptr() for p in panos], pano.stride(0),
+            eng.compose_device_batch(*tables((i + 1) % n_sets), [pptr(p) for p in panos], pano.stride(0), stream=stream)
+            st = eng.profile_stages_batch(*tables(i % n_sets), [pptr(p) for p in panos], pano.stride(0),
                                           stream=stream)
             for name, ms in st:
                 if name not in acc:
@@ -358,17 +380,20 @@ def main():
             pass
         # one launch of a kernel processes `batch` frame sets: algorithmic bytes per launch = batch x frame.
         # Whole-step figure: all launches of a sequence together move those bytes once.
+        # (strip mode: the N ranks compose the SAME panoramas, a strip each -- `achieved` is the whole job's rate on the whole
+        # job's algorithmic bytes, `peak` the N GPUs' HBM)
         achieved = alg_bytes * batch / (dev_ms_per_seq * 1e-3) / 1e9
+        peak = HBM_PEAK_GBS * (world if strip_mode else 1)
         out = {
             "metric": METRIC,
-            "value": round(sharding.aggregate_throughput(world, seqs * batch, wall), 3),
+            "value": round(seqs * batch / wall if strip_mode else sharding.aggregate_throughput(world, seqs * batch, wall), 3),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strip_mode else "weak",
             "vs_baseline": None,
             "dtype": "u8/s16 fixed-point (f32 weights)",
             "data": "synthetic",
@@ -377,9 +402,11 @@ def main():
                        "launch_sequences_in_flight": in_flight,
                        "lens_undistort": ("composed into the warp map" if args.lens_composed else "pre-pass") if args.undistort else False,
                        "timed_region_s": round(wall, 4),
-                       "parallelism": "frames sharded over %d rank(s), no collective" % world},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
+                       "parallelism": ("canvas cut into %d column strip(s), rank r composes strip r of every panorama (restricted work lists, "
+                                       "pixels identical to the whole-canvas run), strips left in place: no data-path collective" % world)
+                                      if strip_mode else "frames sharded over %d rank(s), no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
+                         "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_frame": alg_bytes,
                          "algorithmic_bytes_per_launch": alg_bytes * batch,
                          "device_ms_per_frame": round(dev_ms_per_seq / batch, 5),
@@ -608,6 +635,15 @@ def main():
                     out["strip_sharded"] = leg
                 else:
                     out.setdefault("strip_sharded", {})[cname] = leg
+    # ---- N > 1: the trivial mode beside the headline -- every GPU stitches its own frame sets, whole canvas, no exchange ("weak") ----
+    if world > 1 and strip_mode:
+        arm("replicas")
+        try:
+            leg = replicas_leg(rank, world, local_rank, dev, stream, rig, blend, dev_sets, batch, in_flight, args.undistort and args.lens_composed)
+        except Exception as e:          # noqa: BLE001
+            leg = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            out["replicas"] = leg
     arm(None)       # nothing below talks to another rank until the final barrier
 
     # ---- the other single-GPU BASELINE configurations, through the same entry points (tools/bench_paths.py) ----
@@ -745,6 +781,49 @@ def ingest_leg(rig, blend, local_rank, cw, ch, seconds=1.5):
     res["note"] = ("%d capture processes -> shm (DatePacket) -> HBM -> compose (overlap_depth 4, mst_compose_device_batch_ex with "
                    "frames-ready / panorama-free events) -> page-locked panorama, 3 frame sets in flight; PCIe-inclusive" % n_cam)
     return res
+
+
+def replicas_leg(rank, world, local_rank, dev, stream, rig, blend, dev_sets, batch, in_flight, lens_composed, seconds=0.6):
+    """Every rank composes whole panoramas of the frame sets it holds (calls in flight as in the headline), nothing crosses ranks:
+    the aggregate of N independent stitchers.  Weak scaling by construction; reported beside the strip-mode headline at N > 1."""
+    import torch
+    import torch.distributed as dist
+    import stitchingvideo_amd as S
+    from stitchingvideo_amd import sharding
+    n_cam = len(rig["cameras"])
+    eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
+                           overlap_frames=in_flight > 2, overlap_depth=in_flight if in_flight > 2 else 0, max_batch=batch, lens_composed=lens_composed)
+    eng.update(rig["scale"], rig["cameras"])
+    (_, _, cw, ch), _ = eng.acquire()
+    ring = [[torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev) for _ in range(batch)] for _ in range(max(in_flight, 1))]
+    n_sets = len(dev_sets)
+    sets = [[dev_sets[(first + k) % n_sets] for k in range(batch)] for first in range(n_sets)]
+    calls = [eng.make_device_batch_call([[t.data_ptr() for t in ds] for ds in sets[k % n_sets]], [[t.stride(0) for t in ds] for ds in sets[k % n_sets]],
+                                        [p.data_ptr() for p in ring[k % len(ring)]], ring[0][0].stride(0), stream=stream)
+             for k in range(n_sets * len(ring))]
+
+    def run(n):
+        for i in range(n):
+            calls[i % len(calls)]()
+    run(10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(10)
+    torch.cuda.synchronize()
+    n = max(20, int(seconds / max((time.perf_counter() - t0) / 10, 1e-6)))
+    n = int(sharding.max_over_ranks([float(n)], device=dev)[0])
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(n)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = sharding.max_over_ranks([time.perf_counter() - t0], device=dev)[0]
+    eng.close()
+    return {"scaling": "weak", "frames_per_s": round(sharding.aggregate_throughput(world, n * batch, wall), 2), "frame_sets_per_launch": batch,
+            "launch_sequences_in_flight": in_flight, "launch_sequences_per_rank": n,
+            "parallelism": "frames sharded over %d rank(s): every rank stitches its own frame sets, no collective" % world}
 
 
 def camera_sharded_leg(args_ns, rank, world, local_rank, dev, stream):

@@ -20,8 +20,9 @@
  *                                                  equal centre distances are ordered differently by an introsort: not restated.
  *   cvRound(double)                                round-half-even (cvtsd2si)
  *   cvtColor(BGR2GRAY) on CV_32F                   b * 0.114f + g * 0.587f + r * 0.299f, left to right
- *   Sobel(CV_32F, ksize 3, BORDER_REFLECT_101)     row pass (s[x+1] - s[x-1]  or  s[x-1] + 2 s[x] + s[x+1]) then column pass, the
- *                                                  symmetric one as (top + bottom) + 2 * mid -- COLOR_GRAD only
+ *   Sobel(CV_32F, ksize 3, BORDER_REFLECT_101)     row pass (s[x+1] - s[x-1]  or  s[x-1] + 2 s[x] + s[x+1]) then column pass; the
+ *                                                  three-term sums associated as 2.4.11's SSE bodies / scalar tails do, by
+ *                                                  column position (see gradients()) -- COLOR_GRAD only
  *
  * Images are CV_32FC3 (what Stitcher / the command-line sample feed it: images_warped[i].convertTo(..., CV_32F),
  * CLI:488-489) or CV_8UC3, tightly packed, BGR; masks CV_8U tightly packed, updated in place.
@@ -280,19 +281,44 @@ static void gradients(const Img *im, float **gx, float **gy)
             gray[i] = (float)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
         }
     }
+    /* cv::Sobel(CV_32F -> CV_32F, ksize 3) = sepFilter2D with SymmRowSmallFilter<float, float, SymmRowSmallVec_32f> and
+     * SymmColumnSmallFilter<Cast<float, float>, SymmColumnSmallVec_32f> (OpenCV 2.4.11 modules/imgproc/src/filter.cpp,
+     * getLinearRowFilter / getLinearColumnFilter for ksize <= 5 / == 3).  The [-1 0 1] pass is one subtraction whatever code
+     * runs it; the [1 2 1] pass is a sum of three floats whose ASSOCIATION depends on which loop of the filter produced the
+     * element, and on non-integer data the forms differ by one ulp (round 4 used one form everywhere; on 8-bit sources every
+     * form is exact).  With W = the image width (cn = 1), W8 = W & ~7, R = W - W8, as the x64 SSE2 build runs them:
+     *   row [1 2 1]   x < W8                 SSE body, 8 per trip    a + ((m + m) + c)          _mm_add_ps(x0, _mm_add_ps(_mm_add_ps(x1, x1), x2))
+     *                 W8 <= x < W8 + (R & ~1) scalar pairs            (a + m * 2) + c            S[-cn] + S[0]*2 + S[cn]
+     *                 x == W - 1, R odd       generic tail            m * 2 + (c + a)            kx[0]*S[0] + kx[1]*(S[j] + S[-j])
+     *   col [1 2 1]   x < W8                 SSE body                t + (b + (m + m))          _mm_add_ps(s0, _mm_add_ps(s4, _mm_add_ps(s2, s2)))
+     *                 W8 <= x < W8 + (R & ~3) unrolled by four        (t + m * 2) + b            S0[i] + S1[i]*2 + S2[i] + _delta
+     *                 the rest                                        (t + b) + m * 2            (S0[i] + S2[i])*f1 + S1[i]*f0 + _delta
+     * (a / c: left / right neighbour, t / b: row above / below, REFLECT_101 at the borders; _delta = 0 adds nothing).  Restated
+     * from the published 2.4.11 source as the builder recalls it -- parity unpinned like the rest of this oracle; a second,
+     * separately written statement lives in tests/independent/dpseam_py.py. */
+    const int w8 = w & ~7, rem = w - w8;
     float *dxr = (float *)malloc((size_t)w * h * sizeof(float)), *smr = (float *)malloc((size_t)w * h * sizeof(float));
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             const float a = gray[(size_t)y * w + reflect101(x - 1, w)], c = gray[(size_t)y * w + reflect101(x + 1, w)], m = gray[(size_t)y * w + x];
             dxr[(size_t)y * w + x] = c - a;
-            smr[(size_t)y * w + x] = (a + c) + m * 2.f;
+            float s;
+            if (x < w8) { const float t = m + m; const float u = t + c; s = a + u; }
+            else if (x < w8 + (rem & ~1)) { const float t = m * 2.f; const float u = a + t; s = u + c; }
+            else { const float t = m * 2.f; const float u = c + a; s = t + u; }
+            smr[(size_t)y * w + x] = s;
         }
     *gx = (float *)malloc((size_t)w * h * sizeof(float));
     *gy = (float *)malloc((size_t)w * h * sizeof(float));
     for (int y = 0; y < h; ++y) {
         const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
         for (int x = 0; x < w; ++x) {
-            (*gx)[(size_t)y * w + x] = (dxr[(size_t)ym * w + x] + dxr[(size_t)yp * w + x]) + dxr[(size_t)y * w + x] * 2.f;
+            const float t = dxr[(size_t)ym * w + x], b = dxr[(size_t)yp * w + x], m = dxr[(size_t)y * w + x];
+            float s;
+            if (x < w8) { const float u = m + m; const float v = b + u; s = t + v; }
+            else if (x < w8 + (rem & ~3)) { const float u = m * 2.f; const float v = t + u; s = v + b; }
+            else { const float u = t + b; const float v = m * 2.f; s = u + v; }
+            (*gx)[(size_t)y * w + x] = s;
             (*gy)[(size_t)y * w + x] = smr[(size_t)yp * w + x] - smr[(size_t)ym * w + x];
         }
     }
@@ -603,6 +629,19 @@ static void process_pair(int cost_func, const Img *im1, const Img *im2, int tl1x
 }
 
 /* seam_finders.cpp:163-189.  images[i]: float32 (is_float) or uint8 BGR, sizes_wh[2i] x sizes_wh[2i+1], tight. */
+/* computeGradients of one image (test hook): gx, gy are h x w floats */
+void mo_dp_gradients(const void *image, int is_float, int w, int h, float *gx, float *gy)
+{
+    Img im;
+    memset(&im, 0, sizeof im);
+    im.data = image; im.is_float = is_float; im.w = w; im.h = h;
+    float *x = NULL, *y = NULL;
+    gradients(&im, &x, &y);
+    memcpy(gx, x, (size_t)w * h * sizeof(float));
+    memcpy(gy, y, (size_t)w * h * sizeof(float));
+    free(x); free(y);
+}
+
 void mo_dp_seams(int n, const int *corners_xy, const int *sizes_wh, const void *const *images, int is_float, int cost_func,
                  uint8_t *const *masks)
 {

@@ -175,6 +175,8 @@ void mo_voronoi_seams(int n, const int *corners_xy, const int *sizes_wh, uint8_t
  * 1 = COLOR_GRAD; masks tightly packed, updated in place ---- */
 void mo_dp_seams(int n, const int *corners_xy, const int *sizes_wh, const void *const *images, int is_float, int cost_func,
                  uint8_t *const *masks);
+/* DpSeamFinder::computeGradients (seam_finders.cpp:519-543) of one image: BGR2GRAY + Sobel(CV_32F, ksize 3) x 2 -> h x w floats */
+void mo_dp_gradients(const void *image, int is_float, int w, int h, float *gx, float *gy);
 
 /* ---- util (a10) -------------------------------------------------------------- */
 mo_rect mo_result_roi(const int *corners_xy, const int *sizes_wh, int n);

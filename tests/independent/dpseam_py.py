@@ -15,9 +15,9 @@ for the C++ ones whose iteration order is the result --
 OpenCV 2.4.11 primitives used by computeGradients (`:519-543`) are restated from the published algorithm: BGR2GRAY for
 CV_8UC3 in 14-bit fixed point (1868 / 9617 / 4899, + 2^13, >> 14), for CV_32FC3 as b*0.114f + g*0.587f + r*0.299f
 evaluated left to right in float; Sobel(ksize 3, CV_32F, BORDER_REFLECT_101) as the separable [-1 0 1] x [1 2 1]
-filter, rows first, in float32 -- exact for 8-bit sources; for float sources the order of the three-term sums is the
-scalar code's `(a + 2 b) + c` (the SSE body of the 2.4.11 filters associates differently: one ulp, recorded in
-DESIGN.md section 2).
+filter, rows first, in float32 -- exact for 8-bit sources; for float sources the three-term sums are associated by column
+position as the 2.4.11 filters' SSE bodies, scalar pair / unrolled loops and generic tails do (`_sum121_row`, `_sum121_col`;
+round 5 -- before, this file used the scalar pair form everywhere and the oracle the generic tail's).
 
 The reference's quirks are kept: `cy2 = cvRound(sum[j].y / size1)` (`:608`), contour pixels taking the LAST matching
 neighbour's component (`:912-934`), flood fills that run over pixels of other labels inside the bounding box and the
@@ -96,16 +96,42 @@ def _reflect101(p, n):
     return p
 
 
+def _sum121_row(l, c, r, w):
+    """[1 2 1] along a row as SymmRowSmallFilter<float, float, SymmRowSmallVec_32f> (2.4.11 filter.cpp) leaves it: the SSE body
+    covers columns [0, w & ~7) with l + ((c + c) + r), the scalar pair loop the next even count with (l + c*2) + r, and a last odd
+    column goes through the generic loop: kx[0]*S[0] + kx[1]*(S[+1] + S[-1]) = c*2 + (r + l)."""
+    w8 = w & ~7
+    pairs_end = w8 + ((w - w8) & ~1)
+    out = np.empty_like(c)
+    out[:, :w8] = (l[:, :w8] + ((c[:, :w8] + c[:, :w8]).astype(F) + r[:, :w8]).astype(F)).astype(F)
+    out[:, w8:pairs_end] = ((l[:, w8:pairs_end] + (c[:, w8:pairs_end] * F(2)).astype(F)).astype(F) + r[:, w8:pairs_end]).astype(F)
+    out[:, pairs_end:] = ((c[:, pairs_end:] * F(2)).astype(F) + (r[:, pairs_end:] + l[:, pairs_end:]).astype(F)).astype(F)
+    return out
+
+
+def _sum121_col(u, m, d, w):
+    """[1 2 1] down a column as SymmColumnSmallFilter<Cast<float, float>, SymmColumnSmallVec_32f> leaves it: SSE body on columns
+    [0, w & ~7): u + (d + (m + m)); then the loop unrolled by four: (u + m*2) + d; the rest: (u + d)*1 + m*2."""
+    w8 = w & ~7
+    fours_end = w8 + ((w - w8) & ~3)
+    out = np.empty_like(m)
+    out[:, :w8] = (u[:, :w8] + (d[:, :w8] + (m[:, :w8] + m[:, :w8]).astype(F)).astype(F)).astype(F)
+    out[:, w8:fours_end] = ((u[:, w8:fours_end] + (m[:, w8:fours_end] * F(2)).astype(F)).astype(F) + d[:, w8:fours_end]).astype(F)
+    out[:, fours_end:] = ((u[:, fours_end:] + d[:, fours_end:]).astype(F) + (m[:, fours_end:] * F(2)).astype(F)).astype(F)
+    return out
+
+
 def sobel(gray, dx, dy):
-    """cv::Sobel(gray, dst, CV_32F, dx, dy) with ksize 3, (dx, dy) = (1, 0) or (0, 1)."""
+    """cv::Sobel(gray, dst, CV_32F, dx, dy) with ksize 3, (dx, dy) = (1, 0) or (0, 1): rows first, then columns; the difference
+    pass is a single subtraction, the smoothing pass associates by column position (see the two helpers)."""
     g = gray.astype(F)
     h, w = g.shape
     xi = [[_reflect101(x + k, w) for x in range(w)] for k in (-1, 0, 1)]
     yi = [[_reflect101(y + k, h) for y in range(h)] for k in (-1, 0, 1)]
     l, c, r = g[:, xi[0]], g[:, xi[1]], g[:, xi[2]]
-    row = (r - l).astype(F) if dx == 1 else ((l + c * F(2)).astype(F) + r).astype(F)
+    row = (r - l).astype(F) if dx == 1 else _sum121_row(l, c, r, w)
     u, m, d = row[yi[0], :], row[yi[1], :], row[yi[2], :]
-    return (d - u).astype(F) if dy == 1 else ((u + m * F(2)).astype(F) + d).astype(F)
+    return (d - u).astype(F) if dy == 1 else _sum121_col(u, m, d, w)
 
 
 class _Pair:

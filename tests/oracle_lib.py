@@ -377,6 +377,19 @@ def dp_seams(corners, images, masks, cost="color"):
     return out
 
 
+def dp_gradients(image):
+    """DpSeamFinder::computeGradients of one CV_32FC3 / CV_8UC3 image -> (gx, gy) float32 (h, w)."""
+    is_float = image.dtype != np.uint8
+    im = np.ascontiguousarray(image, np.float32 if is_float else np.uint8)
+    h, w = im.shape[:2]
+    gx, gy = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+    f = lib().mo_dp_gradients
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    f(im.ctypes.data, 1 if is_float else 0, w, h, gx.ctypes.data, gy.ctypes.data)
+    return gx, gy
+
+
 def dilate3x3(mask):
     mask = np.ascontiguousarray(mask, np.uint8)
     dst = np.empty_like(mask)

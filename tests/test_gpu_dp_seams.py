@@ -75,3 +75,43 @@ def test_dp_seams_feed_the_engine():
     _, opano, omask = H.oracle_compose(rig2, frames, num_bands=4)
     assert np.array_equal(pano, opano) and np.array_equal(mask, omask)
     eng.close()
+
+
+def _float_case(seed):
+    """2 - 4 CV_32F images with NON-integer values (the association of Sobel's three-term sums matters) and coarse content (costs
+    tie often: the DP's tie order decides), widths over every residue mod 8, ragged masks."""
+    rng = np.random.default_rng(9100 + seed)
+    n = 2 + seed % 3
+    imgs, masks, corners = [], [], []
+    x = 0
+    for i in range(n):
+        w, h = int(rng.integers(24, 70)), int(rng.integers(20, 48))
+        corners.append((x + int(rng.integers(-3, 4)), int(rng.integers(-6, 7))))
+        x += int(w * rng.uniform(0.45, 0.8))
+        levels = 3 if seed % 2 == 0 else 17
+        base = rng.integers(0, levels, size=(h, w, 3)).astype(np.float32) * np.float32(255.0 / (levels - 1) + 0.3)
+        if seed % 3 == 0:
+            base += rng.uniform(-0.4, 0.4, size=base.shape).astype(np.float32)
+        m = np.full((h, w), 255, np.uint8)
+        for yy in range(h):
+            m[yy, :max(int(2 + 2 * np.sin(yy / 4.0 + i)), 0)] = 0
+            m[yy, w - max(int(2 + 2 * np.cos(yy / 5.0)), 0):] = 0
+        imgs.append(base.astype(np.float32)); masks.append(m)
+    return corners, imgs, masks
+
+
+@pytest.mark.parametrize("block", range(10))
+def test_dp_colorgrad_float_images_tie_heavy(block):
+    """100 random CV_32F COLOR_GRAD cases (ten per test): non-integer gray levels, so Sobel's [1 2 1] sums take the association of
+    2.4.11's SSE body / scalar pairs / unrolled fours / tail by column position in k_dp_sobel and in the oracle alike; coarse
+    content, so equal costs are common and the recurrence's tie order decides the seam."""
+    carved = 0
+    for seed in range(10 * block, 10 * block + 10):
+        corners, imgs, masks = _float_case(seed)
+        want = O.dp_seams(corners, imgs, masks, "color_grad")
+        got = [m.copy() for m in masks]
+        S.DpSeamFinder("color_grad").find(imgs, corners, got)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert np.array_equal(g, w), (seed, i, int((g != w).sum()))
+        carved += int(any((g != m).any() for g, m in zip(got, masks)))
+    assert carved >= 5

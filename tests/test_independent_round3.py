@@ -130,3 +130,38 @@ def test_dp_gray_is_fixed_point_for_8bit_images():
     g = P.bgr2gray(np.array([[[255, 255, 255], [0, 0, 0], [10, 200, 30], [1, 2, 3]]], np.uint8))
     assert g.dtype == np.uint8 and g.tolist() == [[255, 0, 128, 2]]
     assert (10 * 1868 + 200 * 9617 + 30 * 4899 + 8192) >> 14 == 128
+
+
+# ---- Sobel on float images: the association of the [1 2 1] sums by column position (round 5) -----------------------
+@pytest.mark.parametrize("w", list(range(3, 29)) + [37, 64, 71])
+def test_sobel_float_forms_by_column_position(w):
+    """computeGradients on CV_32F images with NON-integer gray levels: the oracle's gradients() and the second restatement's sobel()
+    were written separately from the same reading of 2.4.11's SymmRowSmallFilter / SymmColumnSmallFilter<float> (SSE body on the
+    first w & ~7 columns, scalar pairs / unrolled fours, generic tail) and must agree bit for bit for every width residue."""
+    rng = np.random.default_rng(500 + w)
+    img = rng.uniform(0, 255, size=(11, w, 3)).astype(np.float32)
+    gx, gy = O.dp_gradients(img)
+    g = P.bgr2gray(img)
+    assert np.array_equal(gx.view(np.uint32), P.sobel(g, 1, 0).view(np.uint32))
+    assert np.array_equal(gy.view(np.uint32), P.sobel(g, 0, 1).view(np.uint32))
+
+
+def test_sobel_float_forms_known_answers():
+    """Hand-checked: a = 2^24, m = 0.5, c = 1 split the three row forms (float32, ties to even):
+    SSE body  a + ((m + m) + c) = 2^24 + 2;  scalar pairs  (a + 2 m) + c = (2^24 + 1 -> 2^24) + 1 -> 2^24;  tail  2 m + (c + a) =
+    1 + (2^24 + 1 -> 2^24) -> 2^24.  Placed at column 1 of a 9-wide row the centre takes the SSE form, at column 8 the tail's."""
+    F = np.float32
+    a, m, c = F(2.0 ** 24), F(0.5), F(1.0)
+    sse = F(a + F(F(m + m) + c))
+    pairs = F(F(a + F(m * F(2))) + c)
+    tail = F(F(m * F(2)) + F(c + a))
+    assert (sse, pairs, tail) == (F(16777218.0), F(16777216.0), F(16777216.0))
+    # a 1 x 9 gray row [.., a, m, c, ..] placed so that the centre m sits at column 1 (SSE body, w8 = 8) and at column 8 (tail)
+    row = np.zeros((1, 9), np.float32)
+    row[0, 0:3] = [a, m, c]
+    s = P._sum121_row(row[:, [1, 0, 1, 2, 3, 4, 5, 6, 7]], row, row[:, [1, 2, 3, 4, 5, 6, 7, 8, 7]], 9)
+    assert s[0, 1] == sse
+    row2 = np.zeros((1, 9), np.float32)
+    row2[0, 7], row2[0, 8] = a, m                    # column 8: left = a, right = reflect101(9) = column 7 = a
+    s2 = P._sum121_row(row2[:, [1, 0, 1, 2, 3, 4, 5, 6, 7]], row2, row2[:, [1, 2, 3, 4, 5, 6, 7, 8, 7]], 9)
+    assert s2[0, 8] == F(F(m * F(2)) + F(a + a))
