@@ -117,6 +117,68 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+class ClockSampler:
+    """The shader clock and board power while the timed region runs, from sysfs (tools/clock_watch.py does the same around any
+    command): a box may show several cards, the busiest one is the job's.  Never touches the HIP runtime."""
+
+    def __init__(self, period=0.02):
+        import glob
+        self.period, self.cards = period, {}
+        for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+            card = hw.split("/")[4]
+            src = {}
+            for key, names in (("sclk_hz", ["freq1_input"]), ("power_uw", ["power1_average", "power1_input"])):
+                for n in names:
+                    if os.path.exists("%s/%s" % (hw, n)):
+                        src.setdefault(key, "%s/%s" % (hw, n))
+            busy = "/sys/class/drm/%s/device/gpu_busy_percent" % card
+            if os.path.exists(busy):
+                src["busy_pct"] = busy
+            if "sclk_hz" in src and "busy_pct" in src:
+                self.cards[card] = src
+        self.samples = {c: {k: [] for k in src} for c, src in self.cards.items()}
+        self.stop = threading.Event()
+        self.thread = None
+
+    def __enter__(self):
+        def loop():
+            while not self.stop.is_set():
+                for c, src in self.cards.items():
+                    for k, p in src.items():
+                        try:
+                            self.samples[c][k].append(int(open(p).read().strip()))
+                        except (OSError, ValueError):
+                            self.samples[c][k].append(-1)
+                time.sleep(self.period)
+        if self.cards:
+            self.thread = threading.Thread(target=loop, daemon=True)
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        if self.thread:
+            self.thread.join()
+
+    def report(self):
+        def mean_busy(c):
+            b = [x for x in self.samples[c]["busy_pct"] if x >= 0]
+            return sum(b) / len(b) if b else -1.0
+        if not self.cards:
+            return None
+        card = max(self.cards, key=mean_busy)
+        sm = self.samples[card]
+        hot = [i for i, b in enumerate(sm["busy_pct"]) if b >= 90]
+        if len(hot) < 3:
+            return None
+        out = {"card": card, "samples_under_load": len(hot)}
+        for k in ("sclk_hz", "power_uw"):
+            v = sorted(sm[k][i] for i in hot if k in sm and i < len(sm[k]) and sm[k][i] >= 0)
+            if v:
+                out[k.replace("_hz", "_mhz").replace("_uw", "_w")] = {"median": round(v[len(v) // 2] / 1e6, 1), "min": round(v[0] / 1e6, 1), "max": round(v[-1] / 1e6, 1)}
+        return out
+
+
 def kernel_source_hash():
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
@@ -312,15 +374,17 @@ def main():
     barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        run(reps, i * reps)
-    ev1.record()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    clocks = ClockSampler()
+    with clocks:                    # (a sysfs reader on its own thread: what clock and power the timed steps ran at)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(args.steps):
+            run(reps, i * reps)
+        ev1.record()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     wall, dev_ms = sharding.max_over_ranks([wall, dev_ms], device=dev)     # slowest rank sets the job time
 
@@ -416,6 +480,32 @@ def main():
                                   % (sum(k["launches_per_sequence"] for k in kernels), batch, in_flight),
                          "dominant_kernel": dominant, "kernels": kernels},
         }
+        # ---- the ceiling that binds this path: instruction issue, not HBM.  Wave-instruction counts per
+        # frame set from the rocprofv3 PMC passes behind profiles/traffic.json (same kernel sources), cycles per VALU
+        # wave-instruction from tools/ubench/valu_rate.hip (this path's mix: ~3.0), the clock the timed steps actually ran at.
+        clk = clocks.report()
+        ent = tj.get("entries", {}).get("%s/%d" % (wl, batch), {}) if world == 1 or not strip_mode else {}
+        if "valu_winst_per_frame" in ent:
+            sclk_ghz = (clk or {}).get("sclk_mhz", {}).get("median", 2400.0) / 1e3
+            n_simd, n_cu, cyc_valu = 1024, 256, 3.0
+            valu_us = ent["valu_winst_per_frame"] * cyc_valu / (n_simd * sclk_ghz * 1e3)
+            lds_us = ent.get("lds_active_cycles_per_frame", 0) / (n_cu * sclk_ghz * 1e3)
+            out["roofline"]["issue"] = {
+                "bound": "instruction issue (VALU + LDS share a SIMD's issue and register ports; vector-memory instructions ride on top)",
+                "valu_winst_per_frame": ent["valu_winst_per_frame"], "lds_winst_per_frame": ent.get("lds_winst_per_frame"),
+                "vmem_winst_per_frame": (ent.get("vmem_rd_winst_per_frame", 0) + ent.get("vmem_wr_winst_per_frame", 0)) or None,
+                "salu_winst_per_frame": ent.get("salu_winst_per_frame"),
+                "lds_active_cycles_per_frame": ent.get("lds_active_cycles_per_frame"),
+                "lds_conflict_cycles_per_frame": ent.get("lds_conflict_cycles_per_frame"),
+                "cycles_per_valu_winst": cyc_valu, "simds": n_simd, "cus": n_cu, "sclk_ghz": round(sclk_ghz, 3),
+                "valu_issue_us_per_frame": round(valu_us, 2), "lds_issue_us_per_frame": round(lds_us, 2),
+                "issue_bound_us_per_frame": round(valu_us + lds_us, 2),
+                "measured_us_per_frame": round(dev_ms_per_seq / batch * 1e3, 2),
+                "frac_of_issue_bound": round((valu_us + lds_us) / (dev_ms_per_seq / batch * 1e3), 4),
+                "note": "counters: rocprofv3 --pmc passes of tools/profile_gpu.sh (SQ_INSTS_VALU / SQ_INSTS_LDS / SQ_INSTS_VMEM_* / SQ_LDS_IDX_ACTIVE, "
+                        "one sequence at a time), not measured in this run; cycles per instruction: tools/ubench/valu_rate.hip"}
+        if clk:
+            out["roofline"]["clocks_under_load"] = clk
         if batch > 1 and not args.no_latency_leg:
             # latency mode on the same engine: one frame set per launch sequence, as the reference's StitchingAll()
             one = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),

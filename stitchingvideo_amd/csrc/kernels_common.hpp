@@ -394,6 +394,24 @@ __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const
             const int i = i0 + u * NT;
             if (i < n) {
                 if (PAD && !ok[u]) d[u] = u32x3_t{0u, 0u, 0u};
+#ifdef MST_ABLATE_NV12STAGE      // (timing experiment, round 5: what converting NV12 inside the staging loop would cost kernel A.  The group's first dword
+                                 // stands in for four luma bytes, the second for two U V pairs; the arithmetic is cvtColor(COLOR_YUV2BGR_NV12)'s, per pixel,
+                                 // as k_nv12_to_bgr does it.  The pixels are wrong -- mst_build_info reports the build)
+                {
+                    const uint32_t yy = d[u].x, uv = d[u].y;
+                    uint32_t px4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cu = static_cast<int>((uv >> (16 * (q >> 1))) & 0xFFu) - 128, cv = static_cast<int>((uv >> (16 * (q >> 1) + 8)) & 0xFFu) - 128;
+                        const int ruv = (1 << 19) + 1673527 * cv, guv = (1 << 19) - 852492 * cv - 409993 * cu, buv = (1 << 19) + 2116026 * cu;
+                        const int y0 = max(0, static_cast<int>((yy >> (8 * q)) & 0xFFu) - 16) * 1220542;
+                        const int b = min(max((y0 + buv) >> 20, 0), 255), g = min(max((y0 + guv) >> 20, 0), 255), r = min(max((y0 + ruv) >> 20, 0), 255);
+                        px4[q] = static_cast<uint32_t>(b) | static_cast<uint32_t>(g) << 8 | static_cast<uint32_t>(r) << 16;
+                    }
+                    *reinterpret_cast<u32x4_t*>(&s_win[i * 4]) = u32x4_t{px4[0], px4[1], px4[2], px4[3]};
+                    continue;
+                }
+#endif
                 u32x4_t p;
                 p.x = d[u].x;                                            // B0 G0 R0 (B1)
                 p.y = __builtin_amdgcn_alignbyte(d[u].y, d[u].x, 3);     // B1 G1 R1 (B2)

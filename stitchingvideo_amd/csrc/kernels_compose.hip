@@ -749,7 +749,7 @@ void launch_undistort_table(const UndistortCam& u, int tiles_x, int tiles_y, Com
 
 uint32_t compose_build_ablations()
 {
-#if defined(MST_ABLATE_STAGE)
+#if defined(MST_ABLATE_STAGE) || defined(MST_ABLATE_NV12STAGE)
     return 8u;
 #else
     return 0u;

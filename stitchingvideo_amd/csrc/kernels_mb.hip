@@ -2189,8 +2189,8 @@ template <int G> __device__ __forceinline__ bool tile_of_block(int n_tiles, int 
 // Level 1 and above hold a quarter of the pixels but -- with the halo every level adds around a tile -- took three
 // quarters of the time of the single canvas kernel this replaces: tiles four times as large in panorama terms
 // halve the halo at every level, and level 0 runs as a streaming kernel of its own with no LDS and no barrier.
-template <bool W16, int TH>
-__global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const CamDesc* __restrict__ cams_all, BlendArgs a)
+template <bool W16, int TH, int NT = CC_THREADS>
+__global__ __launch_bounds__(NT, MST_C_WAVES) void k_blend_coarse(const CamDesc* __restrict__ cams_all, BlendArgs a)
 {
     int q, set;
     if (!tile_of_block<CC_XCD_GROUP>(a.n_coarse_tiles, a.n_sets, q, set)) return;
@@ -2213,8 +2213,8 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
     __syncthreads();
     if (top >= 2) {
         // phase 1: every band above level 1, independent of each other -> no barrier until all are in LDS
-        if (pure) band_levels<CC_THREADS, true>(cams, a, top, tx, ty, cam_bits, lds, s_reg, 2);
-        else band_levels<CC_THREADS, false, W16>(cams, a, top, tx, ty, cam_bits, lds, s_reg, 2, owned_levels, owner_bits);
+        if (pure) band_levels<NT, true>(cams, a, top, tx, ty, cam_bits, lds, s_reg, 2);
+        else band_levels<NT, false, W16>(cams, a, top, tx, ty, cam_bits, lds, s_reg, 2, owned_levels, owner_bits);
         MST_STAMP(1, 1);
         __syncthreads();
         MST_STAMP(1, 2);
@@ -2222,7 +2222,7 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
         if (a.dbg_C[top]) {
             const QuadIter it(s_reg, top);
             const uint2* s = lds + a.lds_off[top];
-            for (int i = threadIdx.x; i < it.rw * (it.r.y1 - it.r.y0); i += CC_THREADS) {
+            for (int i = threadIdx.x; i < it.rw * (it.r.y1 - it.r.y0); i += NT) {
                 const int py = it.r.y0 + i / it.rw, px = it.r.x0 + i % it.rw;
                 const uint2 n = s[(py - it.r.y0) * it.pitch + (px - it.r.x0)];
                 const int v[3] = {s16_lo(n.x), s16_hi(n.x), s16_lo(n.y)};
@@ -2230,7 +2230,7 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
             }
         }
         for (int l = top - 1; l >= 2; --l) {
-            if (!(MST_ABLATE_C & 2)) collapse_level<CC_THREADS>(a, l, tx, ty, lds, s_reg);       // (timing experiments)
+            if (!(MST_ABLATE_C & 2)) collapse_level<NT>(a, l, tx, ty, lds, s_reg);       // (timing experiments)
             __syncthreads();
         }
     }
@@ -2244,7 +2244,7 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
         const uint2* s2 = lds + a.lds_off[2];
         GPix MST_GLOBAL* c2 = (GPix MST_GLOBAL*)a.c2[set];
         const int pairs = iw >> 1;
-        for (int i = threadIdx.x; i < pairs * ih; i += CC_THREADS) {
+        for (int i = threadIdx.x; i < pairs * ih; i += NT) {
             const int y = i / pairs, xp = i - y * pairs;
             const int gx = ix0 + 2 * xp, gy = iy0 + y;
             const uint4 v = *reinterpret_cast<const uint4*>(s2 + (gy - r2.y0) * pitch2 + (gx - r2.x0));
@@ -2256,7 +2256,7 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
             }
         }
         if (iw & 1)
-            for (int y = threadIdx.x; y < ih; y += CC_THREADS) {
+            for (int y = threadIdx.x; y < ih; y += NT) {
                 const uint2 v = s2[(iy0 + y - r2.y0) * pitch2 + (ix0 + iw - 1 - r2.x0)];
                 c2[__mul24(iy0 + y, cw2) + ix0 + iw - 1] = GPix{v.x, v.y};
             }
@@ -2268,16 +2268,16 @@ __global__ __launch_bounds__(CC_THREADS, MST_C_WAVES) void k_blend_coarse(const 
     const uint32_t bits1 = pure ? cam_bits : (MST_ABLATE_C & 16384) && !(owned_levels & 2u) ? (cam_bits & (0u - cam_bits)) : owner_bits;
     uint2* c1 = reinterpret_cast<uint2*>(a.c1[set]);
     if (top == 1) {
-        if (own1) coarse_base_level<CC_THREADS, true, true>(cams, a, bits1, lds, s_reg, c1);
-        else coarse_base_level<CC_THREADS, true, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
+        if (own1) coarse_base_level<NT, true, true>(cams, a, bits1, lds, s_reg, c1);
+        else coarse_base_level<NT, true, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
     } else {
         const Region r1 = table_region(s_reg, 1), ur = table_region(s_reg, 2);
         const bool full = r1.x1 - r1.x0 == CC_TW && r1.y1 - r1.y0 == TH && (a.cw[1] & 1) == 0;
         if (own1 && full && !(MST_ABLATE_C & 64))
-            owned_strip<1, 1, false, CC_THREADS, TH>(cams, a, r1, bits1, static_cast<const uint2*>(lds + a.lds_off[2]), ur.x0, ur.y0, region_pitch(ur),
+            owned_strip<1, 1, false, NT, TH>(cams, a, r1, bits1, static_cast<const uint2*>(lds + a.lds_off[2]), ur.x0, ur.y0, region_pitch(ur),
                            nullptr, nullptr, a.c1[set]);
-        else if (own1) coarse_base_level<CC_THREADS, false, true>(cams, a, bits1, lds, s_reg, c1);
-        else coarse_base_level<CC_THREADS, false, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
+        else if (own1) coarse_base_level<NT, false, true>(cams, a, bits1, lds, s_reg, c1);
+        else coarse_base_level<NT, false, false, W16>(cams, a, cam_bits, lds, s_reg, c1);
     }
     MST_STAMP(1, 4);
 }
@@ -2426,7 +2426,7 @@ uint32_t mb_build_ablations()
     if (MST_ABLATE_A != 0) bits |= 1u;
     if (MST_ABLATE_A2 != 0) bits |= 2u;
     if (MST_ABLATE_C != 0) bits |= 4u;
-#if defined(MST_ABLATE_STAGE)
+#if defined(MST_ABLATE_STAGE) || defined(MST_ABLATE_NV12STAGE)
     bits |= 8u;
 #endif
 #if defined(MST_STAMPS)
@@ -2541,9 +2541,13 @@ const char* launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_b
         BlendArgs ac = a;
         if (a.split && a.coarse_order2) { ac.coarse_order = a.coarse_order2; ac.n_coarse_tiles = a.n_coarse2; }
         const int grid = canvas_grid<CC_XCD_GROUP>(ac.n_coarse_tiles, batch);
-#define MST_LAUNCH_COARSE(W, TH) [&] { hipLaunchKernelGGL((k_blend_coarse<W, TH>), dim3(grid), dim3(CC_THREADS), lds_bytes + pad, s, d_cams, ac); return "k_blend_coarse<" #W ", " #TH ">"; }()
-        if (a.cc_th == 16) name = a.weights_16s ? MST_LAUNCH_COARSE(true, 16) : MST_LAUNCH_COARSE(false, 16);
-        else name = a.weights_16s ? MST_LAUNCH_COARSE(true, 32) : MST_LAUNCH_COARSE(false, 32);
+#define MST_LAUNCH_COARSE(W, TH, NT) [&] { hipLaunchKernelGGL((k_blend_coarse<W, TH, NT>), dim3(grid), dim3(NT), lds_bytes + pad, s, d_cams, ac); return "k_blend_coarse<" #W ", " #TH ", " #NT ">"; }()
+        // (round 5 experiment, MST_CC16_THREADS=512: the 16-row tiles of launches of one or two frame sets with 512 threads -- half the
+        // rounds of the band and level-1 phases per block.  Measured SLOWER on a lone call: 26.7 against 23.4 us, profiles/r05_experiments.md)
+        static const int cc16_threads = [] { const char* v = std::getenv("MST_CC16_THREADS"); return v ? std::atoi(v) : 256; }();
+        if (a.cc_th == 16 && cc16_threads == 512) name = a.weights_16s ? MST_LAUNCH_COARSE(true, 16, 512) : MST_LAUNCH_COARSE(false, 16, 512);
+        else if (a.cc_th == 16) name = a.weights_16s ? MST_LAUNCH_COARSE(true, 16, 256) : MST_LAUNCH_COARSE(false, 16, 256);
+        else name = a.weights_16s ? MST_LAUNCH_COARSE(true, 32, 256) : MST_LAUNCH_COARSE(false, 32, 256);
 #undef MST_LAUNCH_COARSE
     }
     if (a.nlev > 1 && a.split && (which & 4)) {

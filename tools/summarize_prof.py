@@ -96,8 +96,19 @@ if len(sys.argv) > 2 and counters:
             w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) * 1024
             launches = round(len(d["FETCH_SIZE"]) / n_seq)
             per[k] = {"bytes_per_frame": int((f + w) * launches / batch), "launches_per_sequence": launches}
+            # instruction-issue side (round 5): wave-instructions and LDS-busy cycles per frame set, where the passes collected them
+            for c, key in (("SQ_INSTS_VALU", "valu_winst_per_frame"), ("SQ_INSTS_LDS", "lds_winst_per_frame"), ("SQ_INSTS_SALU", "salu_winst_per_frame"),
+                           ("SQ_INSTS_VMEM_RD", "vmem_rd_winst_per_frame"), ("SQ_INSTS_VMEM_WR", "vmem_wr_winst_per_frame"),
+                           ("SQ_LDS_IDX_ACTIVE", "lds_active_cycles_per_frame"), ("SQ_LDS_BANK_CONFLICT", "lds_conflict_cycles_per_frame"),
+                           ("SQ_WAVES", "waves_per_frame")):
+                if c in d:
+                    per[k][key] = int(sum(d[c]) / len(d[c]) * launches / batch)
         entry = {"bytes_per_frame": sum(v["bytes_per_frame"] for v in per.values()), "frame_sets_per_launch": batch,
                  "per_kernel": per, "source": "tools/summarize_prof.py (%s)" % os.path.basename(root.rstrip("/"))}
+        for key in ("valu_winst_per_frame", "lds_winst_per_frame", "salu_winst_per_frame", "vmem_rd_winst_per_frame", "vmem_wr_winst_per_frame",
+                    "lds_active_cycles_per_frame", "lds_conflict_cycles_per_frame"):
+            if all(key in v for v in per.values()):
+                entry[key] = sum(v[key] for v in per.values())
         try:
             out = json.load(open(sys.argv[2]))
             if out.get("kernel_source_sha16") != sha:

@@ -10,7 +10,8 @@ show() { python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read())
 print('$1', 'in-flight', d['value'], d['roofline']['frac'], '| serial', d.get('serial',{}).get('frames_per_s'), d.get('serial',{}).get('roofline_frac'),
-      '|', [(k['name'], k['ms_per_frame']) for k in d['roofline']['kernels']], '| lone', d.get('latency_mode',{}).get('frames_per_s'))"; }
+      '|', [(k['name'], k['ms_per_frame']) for k in d['roofline']['kernels']], '| lone', d.get('latency_mode',{}).get('frames_per_s'),
+      'one-per-call in flight', d.get('latency_mode',{}).get('pipelined_calls',{}).get('frames_per_s'))"; }
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   W=/tmp/mst_var_$name
@@ -19,7 +20,9 @@ for spec in "$@"; do
     (cd $W/stitchingvideo_amd/csrc && rm -rf build && make -j16 CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $flags" > $W/build.log 2>&1) || { echo "$name: build failed"; tail -5 $W/build.log; continue; }
     case " $VARIANT_PARITY " in *" $name "*) (cd $W && python3 -m pytest tests -m gpu -x -q 2>&1 | tail -2 | sed "s/^/$name parity: /");; esac
   fi
-  (cd $W && python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-latency-leg --min-time 0.4 $BENCH_ARGS 2>/dev/null | show "$name")
+  # VARIANT_LATENCY=1: with the one-frame-set legs (latency_mode) -- the host-buffer and ingest legs ride along, so it takes longer
+  LAT="--no-latency-leg"; [ -n "$VARIANT_LATENCY" ] && LAT=""
+  (cd $W && python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs $LAT --min-time 0.4 $BENCH_ARGS 2>/dev/null | show "$name")
   [ -n "$VARIANT_PATHS" ] && (cd $W && python3 tools/bench_paths.py $VARIANT_PATHS --no-latency-leg 2>/dev/null | python3 -c "
 import sys,json
 print('$name', ' '.join('%s %.4f' % (d['name'], d.get('roofline_frac', -1)) for d in map(json.loads, filter(lambda l: l.startswith('{'), sys.stdin))))")
