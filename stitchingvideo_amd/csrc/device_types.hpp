@@ -225,7 +225,8 @@ struct TileList {
 // The source window of one warp-kernel tile as it is staged in LDS (k_warp_pyr_lds): columns [wx0, wx0 + 4 * groups),
 // rows [by, by + rows) of the camera's frame; the tile's table entries are relative to (bx, by).
 struct WarpWin {
-    int32_t wx0, by, groups, rows, bx;
+    int32_t wx0, by, groups, rows;
+    int32_t pitch;                 // LDS row pitch in groups (>= groups; padded so that the taps of a slanted canvas row stay on distinct banks)
     uint32_t flags;                // bit 0: the tile cannot take the staged form (k_warp_pyr handles it)
     // filled in for the launch-ordered copies the staged kernel reads (one scalar load gives the block everything):
     uint32_t tile;                 // cam << 24 | ty << 12 | tx (| bit 31), the tile-list word

@@ -785,7 +785,7 @@ void Engine::update(const mst_calibration& calib)
                 st->warp_gathered_start[i] = static_cast<int>(gathered.size());
                 for (int k = plan.warp_cam_start[i]; k < plan.warp_cam_start[i + 1]; ++k) {
                     if (wins[k].flags & 1u) { gathered.push_back(static_cast<uint32_t>(k)); continue; }
-                    const size_t bytes = static_cast<size_t>(wins[k].groups) * 16 * wins[k].rows;
+                    const size_t bytes = static_cast<size_t>(wins[k].pitch) * 16 * wins[k].rows;      // (rows at the padded LDS pitch)
                     int c = 0;
                     while (c + 1 < ncls && bytes > static_cast<size_t>(classes_kb[c]) * 1024) ++c;
                     WarpWin ww = wins[k];
@@ -810,7 +810,7 @@ void Engine::update(const mst_calibration& calib)
                 std::fprintf(stderr, "[mst_update] warp tiles: %d, %d staged in LDS (%d size classes), %d gathered\n", nt, n_staged, ncls,
                              st->warp_gathered_start[n]);
                 int hist[12] = {0};
-                for (int k = 0; k < nt; ++k) hist[std::min<size_t>(11, static_cast<size_t>(wins[k].groups) * 16 * wins[k].rows / 8192)]++;
+                for (int k = 0; k < nt; ++k) hist[std::min<size_t>(11, static_cast<size_t>(wins[k].pitch) * 16 * wins[k].rows / 8192)]++;
                 std::fprintf(stderr, "[mst_update] warp window bytes, 8 KB bins:");
                 for (int b = 0; b < 12; ++b) std::fprintf(stderr, " %d", hist[b]);
                 std::fprintf(stderr, "\n");

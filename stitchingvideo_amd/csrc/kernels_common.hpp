@@ -332,11 +332,14 @@ typedef uint32_t __attribute__((ext_vector_type(4))) u32x4_t;
 // write needs the data): a 6 K pixel window over 512 threads is three round trips in a row -- with the staging loads
 // ablated the LUT composite ran 42 % faster.  The trips are therefore taken U at a time: U loads issued back to back,
 // then U LDS writes.  Same box, same run: kernel A 31.1 -> 29.1 us per frame set, C3 / C5 LUT 0.459 / 0.529 -> 0.474 / 0.551.
+// pitch: the LDS row pitch in groups (0: = groups, rows back to back).  Kernel A pads it (round 5) so that a row step inside a
+// half-wave's taps does not change the bank of a column.
 template <int NT, bool PAD = false, int U = 4>
 __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const uint8_t MST_GLOBAL* __restrict__ base, uint32_t stride,
-                                             int groups, int rows, int wx0 = 0, int wy0 = 0, int fw = 0, int fh = 0)
+                                             int groups, int rows, int wx0 = 0, int wy0 = 0, int fw = 0, int fh = 0, int pitch = 0)
 {
     const int n = groups * rows;
+    if (pitch == 0) pitch = groups;
     if constexpr (U == 1) {      // one load per trip, scheduled by the compiler (fewest registers: the feather blend's choice)
         for (int i = threadIdx.x; i < n; i += NT) {
             const int r = i / groups, g = i - r * groups;
@@ -345,7 +348,7 @@ __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const
                 d = *(const u32x3_t MST_GLOBAL*)(base + static_cast<ptrdiff_t>(r) * static_cast<ptrdiff_t>(stride) + static_cast<ptrdiff_t>(g) * 12);
             u32x4_t p;
             p.x = d.x; p.y = __builtin_amdgcn_alignbyte(d.y, d.x, 3); p.z = __builtin_amdgcn_alignbyte(d.z, d.y, 2); p.w = d.z >> 8;
-            *reinterpret_cast<u32x4_t*>(&s_win[i * 4]) = p;
+            *reinterpret_cast<u32x4_t*>(&s_win[(r * pitch + g) * 4]) = p;
         }
         return;
     } else {
@@ -360,6 +363,7 @@ __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const
     for (int i0 = threadIdx.x; i0 < n; i0 += NT * U) {
         u32x3_t d[U];
         bool ok[U];
+        int at[U];               // the group's place in LDS: row * pitch + group
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             // trips past the end re-read the window's last row, groups outside the frame (PAD) the nearest one inside:
@@ -368,6 +372,7 @@ __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const
             // shuffling for ds_write_b128) and every trip waits for its own round trip again.
             int rr = min(r, rows - 1), gg = g;
             ok[u] = true;
+            at[u] = r * pitch + g;
             if (PAD) {
                 ok[u] = static_cast<unsigned>(wy0 + rr) < static_cast<unsigned>(fh) && static_cast<unsigned>(wx0 + 4 * gg) < static_cast<unsigned>(fw);
                 rr = min(max(wy0 + rr, 0), fh - 1) - wy0;
@@ -408,7 +413,7 @@ __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const
                         const int b = min(max((y0 + buv) >> 20, 0), 255), g = min(max((y0 + guv) >> 20, 0), 255), r = min(max((y0 + ruv) >> 20, 0), 255);
                         px4[q] = static_cast<uint32_t>(b) | static_cast<uint32_t>(g) << 8 | static_cast<uint32_t>(r) << 16;
                     }
-                    *reinterpret_cast<u32x4_t*>(&s_win[i * 4]) = u32x4_t{px4[0], px4[1], px4[2], px4[3]};
+                    *reinterpret_cast<u32x4_t*>(&s_win[at[u] * 4]) = u32x4_t{px4[0], px4[1], px4[2], px4[3]};
                     continue;
                 }
 #endif
@@ -417,7 +422,7 @@ __device__ __forceinline__ void stage_window(uint32_t* __restrict__ s_win, const
                 p.y = __builtin_amdgcn_alignbyte(d[u].y, d[u].x, 3);     // B1 G1 R1 (B2)
                 p.z = __builtin_amdgcn_alignbyte(d[u].z, d[u].y, 2);     // B2 G2 R2 (B3)
                 p.w = d[u].z >> 8;                                       // B3 G3 R3 0
-                *reinterpret_cast<u32x4_t*>(&s_win[i * 4]) = p;          // (row r, group g) sits at r * groups + g == i
+                *reinterpret_cast<u32x4_t*>(&s_win[at[u] * 4]) = p;      // (row r, group g) sits at r * pitch + g
             }
         }
     }

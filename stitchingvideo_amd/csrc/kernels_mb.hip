@@ -695,6 +695,10 @@ constexpr uint32_t kWinGeneral = 1u;
 constexpr int A2_TPITCH = 132, A2_TOFF = 2;
 constexpr size_t A2_TILE_LDS = static_cast<size_t>(A_LH) * A2_TPITCH * sizeof(uint32_t);
 constexpr uint32_t kA2MaxWindowBytes = 1u << 17;     // the entry's offset field
+#ifndef MST_A2_PITCH_ALIGN
+#define MST_A2_PITCH_ALIGN 1      // groups of four pixels; 1 = rows back to back.  16 (64 dwords: a column keeps its bank on every row) was
+#endif                            // measured in round 5: conflicts 0.38 -> 0.33, no time -- the replays are the 37-column span of a tap read, not its row steps
+constexpr int A2_PITCH_ALIGN = MST_A2_PITCH_ALIGN;
 
 __device__ __forceinline__ int a2_slot_of_col(int col)        // position of tile column `col` in a table row
 {
@@ -738,7 +742,12 @@ __global__ __launch_bounds__(256) void k_warp_table_lds(const CamDesc* __restric
     const int wx0 = bx & ~3;
     const int groups = s_max[0] == INT_MIN ? 0 : (s_max[0] - wx0 + 4) / 4;
     const int rows = s_max[1] == INT_MIN ? 0 : s_max[1] - by + 1;
-    const uint32_t pitch_b = static_cast<uint32_t>(groups) * 16u;
+    // LDS row pitch: a multiple of A2_PITCH_ALIGN groups (1: rows back to back).  Round 5 tried 16 -- a column then keeps its bank
+    // on every window row, so the row steps of a slanted canvas row cannot put two lanes of a tap read on one bank -- and measured
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.38 -> 0.33 and no time at all: what replays is the 37-column span of 32 lanes
+    // at 1.17 source pixels per canvas pixel, as round 4 read it (profiles/r05_experiments.md).
+    const int pitch_g = (groups + A2_PITCH_ALIGN - 1) / A2_PITCH_ALIGN * A2_PITCH_ALIGN;
+    const uint32_t pitch_b = static_cast<uint32_t>(pitch_g) * 16u;
     const bool addressable = static_cast<uint64_t>(pitch_b) * static_cast<uint32_t>(rows) <= kA2MaxWindowBytes;
     const size_t base = static_cast<size_t>(list.first + blockIdx.x) * (A_LH * A_LW);
     for (int it = 0; it < A_ROWS_PER_THREAD; ++it) {
@@ -761,11 +770,12 @@ __global__ __launch_bounds__(256) void k_warp_table_lds(const CamDesc* __restric
     __syncthreads();
     if (tid == 0) {
         WarpWin w;
-        w.wx0 = wx0; w.by = by; w.bx = bx;
+        w.wx0 = wx0; w.by = by;
         w.groups = groups;
         w.rows = rows;
+        w.pitch = pitch_g;
         const bool overrun = w.wx0 + 4 * w.groups > c.src_w && by + w.rows >= c.src_h;
-        w.flags = (s_general || w.groups * 4 * w.rows > lds_budget_px || w.groups > 256 || w.groups == 0 || overrun) ? kWinGeneral : 0u;
+        w.flags = (s_general || pitch_g * 4 * w.rows > lds_budget_px || w.groups > 256 || w.groups == 0 || overrun) ? kWinGeneral : 0u;
         w.tile = 0; w.index = 0;
         wins[list.first + blockIdx.x] = w;
     }
@@ -808,11 +818,11 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
         else g_r[it] = *(const f32x4_t MST_GLOBAL*)(gain + tbl + it * A_LW);
     }
     stage_window<A2_NT, false, MST_STAGE_U_WARP>(s_mem, gp(frames.ptr[cam]) + (static_cast<size_t>(w.by) * stride + static_cast<size_t>(w.wx0) * 3u), stride,
-                        w.groups, w.rows);
+                        w.groups, w.rows, 0, 0, 0, 0, w.pitch);
     MST_STAMP(0, 1);
     __syncthreads();
     MST_STAMP(0, 2);
-    const uint32_t pitch_b = static_cast<uint32_t>(w.groups) * 16u;
+    const uint32_t pitch_b = static_cast<uint32_t>(w.pitch) * 16u;
     const char* win = reinterpret_cast<const char*>(s_mem);
     uint32_t px[A2_ROWS][4];
 #pragma unroll
@@ -885,7 +895,7 @@ __global__ __launch_bounds__(A2_NT) void k_warp_pyr_lds(const CamDesc* __restric
         }
     }
     MST_STAMP(0, 6);
-    MST_STAMP_VAL(0, 8, static_cast<unsigned long long>(w.groups) * 16u * w.rows);
+    MST_STAMP_VAL(0, 8, static_cast<unsigned long long>(w.pitch) * 16u * w.rows);
 }
 
 // ======================================================================================================
