@@ -244,8 +244,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # MST_BENCH_SMOKE_BACKEND=gloo: a test hook for boxes with fewer GPUs than ranks -- the ranks share the visible devices and the
+    # timing reductions travel over gloo on host tensors.  It exercises the N > 1 code path (strip-mode headline, replicas leg);
+    # its numbers mean nothing and its line says so.  RCCL refuses two ranks of a communicator on one device.
+    smoke_backend = os.environ.get("MST_BENCH_SMOKE_BACKEND", "") if world > 1 else ""
+    if smoke_backend:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and smoke_backend:
+        dist.init_process_group(backend=smoke_backend)
+    elif world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import stitchingvideo_amd as S
@@ -299,6 +307,7 @@ def main():
 
     # frames resident in HBM: a few distinct sets, each rank its own (frame index offset by rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = None if smoke_backend else dev          # where the timing reductions' tensors live
     host_sets, dev_sets = [], []
     n_sets = max(args.frame_sets, batch)
     for s in range(n_sets):
@@ -364,7 +373,7 @@ def main():
     run(probe)
     torch.cuda.synchronize()
     t_seq = (time.perf_counter() - t0) / probe
-    t_seq = sharding.max_over_ranks([t_seq], device=dev)[0]
+    t_seq = sharding.max_over_ranks([t_seq], device=red_dev)[0]
     # (sized 25 % long: the probe runs right after the first launches and reads slower than the steady state)
     reps = max(1, int(math.ceil(1.25 * args.min_time / max(args.steps, 1) / max(t_seq, 1e-6))))
 
@@ -386,7 +395,7 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    wall, dev_ms = sharding.max_over_ranks([wall, dev_ms], device=dev)     # slowest rank sets the job time
+    wall, dev_ms = sharding.max_over_ranks([wall, dev_ms], device=red_dev)     # slowest rank sets the job time
 
     workload = "%s: %dx%dx%d BGR8 streams, %s warp, gain_blocks, %s blend (5 bands), canvas %dx%d" % (
         args.config, n_cam, rig["size"][0], rig["size"][1], rig["warp"], blend, cw, ch)
@@ -506,6 +515,9 @@ def main():
                         "one sequence at a time), not measured in this run; cycles per instruction: tools/ubench/valu_rate.hip"}
         if clk:
             out["roofline"]["clocks_under_load"] = clk
+        if smoke_backend:
+            out["smoke"] = "MST_BENCH_SMOKE_BACKEND=%s: %d ranks on %d visible device(s) -- a code-path smoke test, the numbers mean nothing" % (
+                smoke_backend, world, torch.cuda.device_count())
         if batch > 1 and not args.no_latency_leg:
             # latency mode on the same engine: one frame set per launch sequence, as the reference's StitchingAll()
             one = [eng.make_device_call([t.data_ptr() for t in ds], [t.stride(0) for t in ds], pano.data_ptr(),
@@ -729,7 +741,8 @@ def main():
     if world > 1 and strip_mode:
         arm("replicas")
         try:
-            leg = replicas_leg(rank, world, local_rank, dev, stream, rig, blend, dev_sets, batch, in_flight, args.undistort and args.lens_composed)
+            leg = replicas_leg(rank, world, local_rank, dev, stream, rig, blend, dev_sets, batch, in_flight, args.undistort and args.lens_composed,
+                               red_dev=red_dev)
         except Exception as e:          # noqa: BLE001
             leg = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
@@ -873,7 +886,7 @@ def ingest_leg(rig, blend, local_rank, cw, ch, seconds=1.5):
     return res
 
 
-def replicas_leg(rank, world, local_rank, dev, stream, rig, blend, dev_sets, batch, in_flight, lens_composed, seconds=0.6):
+def replicas_leg(rank, world, local_rank, dev, stream, rig, blend, dev_sets, batch, in_flight, lens_composed, seconds=0.6, red_dev="same"):
     """Every rank composes whole panoramas of the frame sets it holds (calls in flight as in the headline), nothing crosses ranks:
     the aggregate of N independent stitchers.  Weak scaling by construction; reported beside the strip-mode headline at N > 1."""
     import torch
@@ -901,7 +914,8 @@ def replicas_leg(rank, world, local_rank, dev, stream, rig, blend, dev_sets, bat
     run(10)
     torch.cuda.synchronize()
     n = max(20, int(seconds / max((time.perf_counter() - t0) / 10, 1e-6)))
-    n = int(sharding.max_over_ranks([float(n)], device=dev)[0])
+    red_dev = dev if red_dev == "same" else red_dev
+    n = int(sharding.max_over_ranks([float(n)], device=red_dev)[0])
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -909,7 +923,7 @@ def replicas_leg(rank, world, local_rank, dev, stream, rig, blend, dev_sets, bat
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    wall = sharding.max_over_ranks([time.perf_counter() - t0], device=dev)[0]
+    wall = sharding.max_over_ranks([time.perf_counter() - t0], device=red_dev)[0]
     eng.close()
     return {"scaling": "weak", "frames_per_s": round(sharding.aggregate_throughput(world, n * batch, wall), 2), "frame_sets_per_launch": batch,
             "launch_sequences_in_flight": in_flight, "launch_sequences_per_rank": n,
