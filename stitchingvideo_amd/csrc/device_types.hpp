@@ -202,25 +202,6 @@ struct BlendArgs {
 // One rectangle of a camera's hand-off payload (camera-sharded multi-GPU mode): the interior of a launched tile at
 // one pyramid level, `off` dwords into the camera's packed payload (levels above 0: a dword a pixel; level 0: packed BGR8,
 // 3 w h bytes rounded up to a dword).  Static per calibration.
-// k_pyr_fused (kernels_mb.hip): every pyrDown step of a launch sequence as one launch.  A segment = one step's unit / tile list;
-// a queue = the items of the cameras that share an XCD (camera c -> queue c % 8), step after step.
-struct PyrFusedSeg {
-    int32_t kind;                  // 0: streaming units of level `level` -> level + 1; 1 / 2: k_pyr_chain<1 / 2> from level `level`
-    int32_t level;
-    const uint32_t* items;         // the step's units / tiles (grouped by camera)
-};
-constexpr int kPyrFusedSegs = 6;
-struct PyrFusedArgs {
-    PyrFusedSeg seg[kPyrFusedSegs];
-    int32_t n_seg, n_cams, blocks_per_set;        // blocks_per_set = 8 x the longest queue
-    int32_t queue_first[8], queue_items[8];       // per queue: its slice of `items`
-    const uint32_t* items;         // segment << 28 | units (1 .. 4) << 24 | first unit / tile of the segment's list
-    uint32_t epoch[8];             // per frame set of the launch (kMaxBatch): fused launches of that buffer set so far, this one included
-    uint32_t* counters;            // [frame set of the launch][segment][kMaxCams]: finished items, never reset
-    const uint32_t* expect;        // [segment][kMaxCams]: items (units / tiles) of that camera in the segment
-    uint32_t* status;              // host-visible: bit 0 a wait timed out, bit 1 a block ran on another XCD than its index says
-};
-
 struct PayloadRect {
     int32_t level, x0, y0, w, h;
     uint32_t off;

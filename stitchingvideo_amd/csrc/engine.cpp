@@ -287,34 +287,6 @@ void Engine::init()
     check_hip(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     check_hip(hipStreamCreateWithFlags(&calib_stream_, hipStreamNonBlocking), "hipStreamCreate");
     check_hip(hipStreamCreateWithFlags(&front_stream_, hipStreamNonBlocking), "hipStreamCreate");
-    // k_pyr_fused hands pixels between blocks of one launch through an XCD's L2, so a camera's chain has to stay on one XCD: it
-    // takes block b for XCD b % 8.  Probe that dealing once (and give the kernel a host-visible word to report through); without
-    // either, the pyramid steps simply stay separate launches.
-    if (hipHostMalloc(reinterpret_cast<void**>(&fused_status_), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
-        *fused_status_ = 0u;
-        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d_fused_status_), fused_status_, 0) != hipSuccess) {
-            (void)hipHostFree(fused_status_);
-            fused_status_ = nullptr;
-        }
-    } else {
-        (void)hipGetLastError();
-        fused_status_ = nullptr;
-    }
-    if (fused_status_) {
-        constexpr int kProbe = 2048;
-        uint32_t* d_ids = nullptr;
-        if (hipMalloc(reinterpret_cast<void**>(&d_ids), kProbe * sizeof(uint32_t)) == hipSuccess) {
-            std::vector<uint32_t> ids(kProbe, 0xFFu);
-            launch_xcc_probe(d_ids, kProbe, stream_);
-            if (hipMemcpyAsync(ids.data(), d_ids, kProbe * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_) == hipSuccess &&
-                hipStreamSynchronize(stream_) == hipSuccess) {
-                xcc_round_robin_ = true;
-                for (int b = 0; b < kProbe; ++b) xcc_round_robin_ = xcc_round_robin_ && ids[b] == static_cast<uint32_t>(b & 7);
-            }
-            (void)hipFree(d_ids);
-        }
-        (void)hipGetLastError();
-    }
     overlap_depth_ = cfg_.overlap_depth >= 3 ? std::min<int>(kMaxOverlap, cfg_.overlap_depth) : 2;
     if (const char* v = std::getenv("MST_OVERLAP_DEPTH")) overlap_depth_ = std::max(2, std::min(kMaxOverlap, std::atoi(v)));      // (A/B runs)
     for (int i = 0; i < kMaxOverlap; ++i) {
@@ -337,7 +309,6 @@ Engine::~Engine()
     if (d_pano_) (void)hipFree(d_pano_);
     if (d_mask_) (void)hipFree(d_mask_);
     if (cls_host_) (void)hipHostFree(cls_host_);
-    if (fused_status_) (void)hipHostFree(fused_status_);
     for (PipeSlot& ps : pipe_) {
         for (uint8_t* p : ps.d_frames) if (p) (void)hipFree(p);
         if (ps.d_pano) (void)hipFree(ps.d_pano);
@@ -864,59 +835,6 @@ void Engine::update(const mst_calibration& calib)
                 }
             st->chain_units.push_back(su);
         }
-        // the same steps as the segments and per-XCD queues of the one fused launch (k_pyr_fused)
-        {
-            PyrFusedArgs& pf = st->pyr_fused;
-            pf = PyrFusedArgs{};
-            std::vector<uint32_t> expect(static_cast<size_t>(kPyrFusedSegs) * kMaxCams, 0u);
-            std::vector<std::vector<uint32_t>> queue(8);
-            bool ok = xcc_round_robin_ && !fused_disabled_;
-            int nseg = 0;
-            // one segment: its unit / tile list (grouped by camera: cam_start) cut into items, each camera's into the queue c % 8
-            auto add = [&](int kind, int level, const uint32_t* items, int n_items, const std::vector<int>& cam_start) {
-                if (nseg >= kPyrFusedSegs || n_items <= 0 || n_items >= (1 << 24) || static_cast<int>(cam_start.size()) != n + 1) { ok = false; return; }
-                PyrFusedSeg& sg = pf.seg[nseg];
-                sg.kind = kind; sg.level = level; sg.items = items;
-                for (int c = 0; c < n; ++c) {
-                    const int c0 = cam_start[c], c1 = cam_start[c + 1];
-                    expect[static_cast<size_t>(nseg) * kMaxCams + c] = static_cast<uint32_t>(c1 - c0);
-                    const int per = kind == 0 ? 4 : 1;          // four streaming units (one per wave) or one chain tile per block
-                    for (int k = c0; k < c1; k += per)
-                        queue[c & 7].push_back(static_cast<uint32_t>(nseg) << 28 | static_cast<uint32_t>(std::min(per, c1 - k)) << 24 | static_cast<uint32_t>(k));
-                }
-                ++nseg;
-            };
-            for (size_t i = 0; i < plan.chain.size() && ok; ++i) {
-                const MbPlanHost::ChainStep& step = plan.chain[i];
-                if (st->chain_units[i].d[0]) {
-                    for (int j = 0; j < step.k && ok; ++j)
-                        add(0, step.base + j, st->chain_units[i].d[j], static_cast<int>(step.units[j].size()), step.unit_cam_start[j]);
-                } else {
-                    add(step.k, step.base, st->chain_lists[i].tiles, st->chain_lists[i].count, step.cam_start);
-                }
-            }
-            st->pyr_fused_ok = ok && nseg >= 2 && fused_status_ != nullptr;      // (a single step gains nothing from being "fused")
-            if (st->pyr_fused_ok) {
-                std::vector<uint32_t> all;
-                size_t longest = 0;
-                for (int q = 0; q < 8; ++q) {
-                    pf.queue_first[q] = static_cast<int32_t>(all.size());
-                    pf.queue_items[q] = static_cast<int32_t>(queue[q].size());
-                    longest = std::max(longest, queue[q].size());
-                    all.insert(all.end(), queue[q].begin(), queue[q].end());
-                }
-                if (all.empty()) all.push_back(0u);
-                pf.n_seg = nseg; pf.n_cams = n; pf.blocks_per_set = static_cast<int32_t>(8 * longest);
-                pf.items = st->pool.upload(all, s);
-                pf.expect = st->pool.upload(expect, s);
-                const size_t words = static_cast<size_t>(st->num_sets) * kPyrFusedSegs * kMaxCams;
-                st->d_pyr_counters = st->pool.alloc<uint32_t>(words);
-                check_hip(hipMemsetAsync(st->d_pyr_counters, 0, words * sizeof(uint32_t), s), "hipMemsetAsync(pyr counters)");
-                pf.status = d_fused_status_;
-                st->pyr_epoch.assign(static_cast<size_t>(st->num_sets), 0u);
-                check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");      // (`all`, `expect` are local)
-            }
-        }
         check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");      // (the padded unit lists are local)
     } else {
         st->d_desc = st->pool.upload(st->desc, s);
@@ -1357,13 +1275,6 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
     select_device(cfg_.device);
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_compose before a successful mst_update"};
     if (!d_frames || !strides || !d_panos) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama table"};
-    if (fused_status_ && *static_cast<volatile uint32_t*>(fused_status_) != 0u) {
-        const uint32_t why = *static_cast<volatile uint32_t*>(fused_status_);
-        *static_cast<volatile uint32_t*>(fused_status_) = 0u;
-        fused_disabled_ = true;              // (from here on the pyramid steps are separate launches again)
-        throw Error{MST_ERR_HIP, std::string("k_pyr_fused: ") + ((why & 2u) ? "a block ran on another XCD than its index says" : "a block gave up waiting for its producer blocks") +
-                                 " in an earlier call -- that call's panorama may be wrong; the fused pyramid launch is now off for this engine"};
-    }
     if (count < 1 || count > kMaxBatch) throw Error{MST_ERR_INVALID_ARG, "batch size out of range"};
     const bool nv12 = !st->nv12_frames.empty();
     if ((st->blend_kind == MST_BLEND_MULTI_BAND || st->any_undistort || nv12) && count > 1 && count > st->sets_per_slot)
@@ -1497,16 +1408,6 @@ void Engine::compose_batch_on(std::shared_ptr<CalibState> st, int count, const v
         };
         if (overlap && !deep && split_after_warp) cross();
         hipStream_t sc = (overlap && !split_after_warp) ? sf : s;
-        // launches of one or two frame sets: every pyrDown step as ONE launch whose blocks wait for their producers on the same
-        // XCD (k_pyr_fused) -- three short launches behind their boundaries were a quarter of a lone call.  Not under graph replay
-        // (the launch carries a per-call epoch).  MST_PYR_FUSED_MAX: the largest frame-set count that takes the fused form (0: never).
-        static const int fused_max = [] { const char* v = std::getenv("MST_PYR_FUSED_MAX"); return v ? std::atoi(v) : 2; }();
-        if (st->pyr_fused_ok && !fused_disabled_ && count <= fused_max && !(cfg_.flags & MST_FLAG_GRAPH_REPLAY)) {
-            PyrFusedArgs pa = st->pyr_fused;
-            for (int f = 0; f < count; ++f) pa.epoch[f] = ++st->pyr_epoch[static_cast<size_t>(first_set + f)];
-            pa.counters = st->d_pyr_counters + static_cast<size_t>(first_set) * kPyrFusedSegs * kMaxCams;
-            mark(launch_pyr_fused(desc, pa, count, sc));
-        } else
         for (size_t i = 0; i < st->chain_lists.size(); ++i) {
             const MbPlanHost::ChainStep& step = st->plan.chain[i];
             if (st->chain_units[i].d[0]) {

@@ -124,13 +124,6 @@ struct CalibState {
     std::vector<TileList> chain_lists;  // kernel B, one per plan.chain step
     struct StreamUnits { const uint32_t* d[2] = {nullptr, nullptr}; };
     std::vector<StreamUnits> chain_units;   // per plan.chain step: the streaming kernel's unit lists (null: k_pyr_chain runs the step)
-    // every pyrDown step of a sequence as ONE launch (k_pyr_fused; launches of one or two frame sets): the segments, the per-XCD
-    // queues, the per-camera item counts, the completion counters [num_sets][kPyrFusedSegs][kMaxCams] (never reset: a set's fused
-    // launches are counted)
-    PyrFusedArgs pyr_fused{};
-    bool pyr_fused_ok = false;
-    uint32_t* d_pyr_counters = nullptr;
-    std::vector<uint32_t> pyr_epoch;          // per buffer set: fused launches so far
     PayloadRect* d_payload_rects = nullptr;   // camera-sharded hand-off (plan.payload_*)
     BlendArgs blend{};                  // canvas kernels (pano pointers filled per frame)
     // feather
@@ -279,12 +272,6 @@ private:
     PipeSlot pipe_[kPipeDepth];
     hipStream_t pipe_in_ = nullptr, pipe_out_ = nullptr;
     long pipe_submitted_ = 0, pipe_completed_ = 0;
-    // k_pyr_fused: its distress word (page-locked host memory the kernel writes: bit 0 a wait timed out, bit 1 a block ran on another
-    // XCD than its index says) and whether this device deals workgroups to its XCDs round-robin by index (probed once at init)
-    uint32_t* fused_status_ = nullptr;        // host pointer
-    uint32_t* d_fused_status_ = nullptr;      // the same word as the device sees it
-    bool xcc_round_robin_ = false;
-    bool fused_disabled_ = false;
     // mst_update: page-locked landing zone of the weight-class bytes (calibration thread only)
     uint8_t* cls_host_ = nullptr; size_t cls_host_bytes_ = 0;
 };

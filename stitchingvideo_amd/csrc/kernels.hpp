@@ -47,8 +47,6 @@ void launch_feather_weight_sum(const CamDesc* d_cams, int n_cams, float* d_ws, i
 // ---- per-frame hot path: multi-band (kernels_mb.hip) ----
 void mb_tile_dims(int* a_tw0, int* a_th0, int* b_t, int* c_tw, int* c_th);
 int  mb_read_stamps(int which, unsigned long long* out, size_t n);                // diagnostic builds (-DMST_STAMPS) only
-const char* launch_pyr_fused(const CamDesc* d_cams, const PyrFusedArgs& a, int batch, hipStream_t s);   // all pyrDown steps of a sequence, one launch
-void launch_xcc_probe(uint32_t* d_out, int n_blocks, hipStream_t s);             // out[b] = XCC id block b ran on
 uint32_t mb_build_ablations();      // kernels_mb.hip / kernels_compose.hip: bit mask of the -DMST_ABLATE_* / -DMST_STAMPS switches compiled in
 uint32_t compose_build_ablations();
 int  mb_read_stamps(int which, unsigned long long* out, size_t n);                // diagnostic builds (-DMST_STAMPS) only

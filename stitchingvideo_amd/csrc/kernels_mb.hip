@@ -930,39 +930,11 @@ constexpr int chain_pitch(int es, int en)
 }
 constexpr int even_up(int v) { return (v + 1) & ~1; }
 
-// Pixels that cross between blocks of ONE launch (k_pyr_fused): producer and consumer run on the SAME XCD (see k_pyr_fused), whose
-// L2 they share -- the producer's plain stores are written through its CU's L1 into that L2, the consumer reads them with
-// device-scope loads (sc1: past its own CU's L1, served by the L2).  COH = false: the ordinary cached access.
-template <bool COH> __device__ __forceinline__ uint32_t pyr_ld(const uint32_t MST_GLOBAL* p)
+template <int K>
+__global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restrict__ cams_all, TileList list, int base,
+                                                         int n_cams)
 {
-    if (COH) return __hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool COH> __device__ __forceinline__ uint2 pyr_ld2(const uint32_t MST_GLOBAL* p)       // 8-byte aligned pixel pair
-{
-    if (COH) {
-        const uint64_t v = __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_uint2(static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32));
-    }
-    const GPix v = *(const GPix MST_GLOBAL*)p;
-    return make_uint2(v.x, v.y);
-}
-template <bool COH> __device__ __forceinline__ void pyr_st(uint32_t MST_GLOBAL* p, uint32_t v)
-{
-    (void)COH;          // (a plain store either way: the CU's L1 is write-through, the XCD's L2 is where the consumer looks)
-    *p = v;
-}
-
-// one tile `t` (cam << 24 | ty << 12 | tx) of a K-deep chain from level `base` of the cameras `cams`; s_all: the block's LDS
-template <int K> struct ChainLds {
-    static constexpr int e0 = K == 2 ? B_E0 : 2 * (B_T / 2) + 3, e1 = K == 2 ? B_E1 : B_T / 2, e2 = B_T / 4;
-    static constexpr int pitch0 = chain_pitch(e0, even_up(e1)), pitch1 = chain_pitch(e1, even_up(e2));
-    static constexpr int off1 = (pitch0 * e0 + 3) & ~3;
-    static constexpr int dwords = off1 + pitch1 * e1;
-};
-template <int K, bool COH_IN = false, bool COH_OUT = false>
-__device__ __forceinline__ void pyr_chain_tile(const CamDesc* __restrict__ cams, uint32_t t, int base, uint32_t* __restrict__ s_all)
-{
+    const CamDesc* __restrict__ cams = cams_all + blockIdx.y * n_cams;
     constexpr int k = K;
     // extents e[j] (compile-time) of the regions each level covers, and their LDS pitches
     constexpr int e[B_KMAX + 1] = {K == 2 ? B_E0 : 2 * (B_T / 2) + 3, K == 2 ? B_E1 : B_T / 2, B_T / 4};
@@ -970,9 +942,10 @@ __device__ __forceinline__ void pyr_chain_tile(const CamDesc* __restrict__ cams,
     static_assert(pitch[0] % 2 == 0 && pitch[1] % 2 == 0, "8-byte aligned pixel pairs need an even pitch");
     // regions of levels base and base+1, back to back
     constexpr int kOff1 = (pitch[0] * e[0] + 3) & ~3;
-    static_assert(kOff1 + pitch[1] * e[1] == ChainLds<K>::dwords, "LDS layout of the chain");
+    __shared__ __attribute__((aligned(16))) uint32_t s_all[kOff1 + pitch[1] * e[1]];
     uint32_t* const s_e0 = s_all;
 
+    const uint32_t t = list.tiles[xcd_run_index(blockIdx.x, list.count)];
     const int cam = (t >> 24) & 0x7F, ty = (t >> 12) & 0xFFF, tx = t & 0xFFF;
     const CamDesc& c = cams[cam];
     const int tid = threadIdx.x;
@@ -1003,7 +976,7 @@ __device__ __forceinline__ void pyr_chain_tile(const CamDesc* __restrict__ cams,
             v[u] = 0;
             if (idx < n0 && static_cast<unsigned>(gx) < static_cast<unsigned>(w) &&
                 static_cast<unsigned>(gy) < static_cast<unsigned>(h))
-                v[u] = pyr_ld<COH_IN>(g + (__umul24(gy, w) + gx));
+                v[u] = g[__umul24(gy, w) + gx];
         }
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
@@ -1066,18 +1039,10 @@ __device__ __forceinline__ void pyr_chain_tile(const CamDesc* __restrict__ cams,
             const uint32_t v = pyrdown_finish(vbr, vg);
             if (d && j + 1 < k) d[yy * pitch[(j + 1 < B_KMAX) ? j + 1 : 0] + xx] = v;
             if (ox >= ix0 && ox < ix0 + isz && oy >= iy0 && oy < iy0 + isz)
-                pyr_st<COH_OUT>(gout + (__umul24(oy, dw) + ox), v);
+                gout[__umul24(oy, dw) + ox] = v;
         }
         __syncthreads();
     }
-}
-
-template <int K>
-__global__ __launch_bounds__(B_THREADS) void k_pyr_chain(const CamDesc* __restrict__ cams_all, TileList list, int base,
-                                                         int n_cams)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t s_all[ChainLds<K>::dwords];
-    pyr_chain_tile<K>(cams_all + blockIdx.y * n_cams, list.tiles[xcd_run_index(blockIdx.x, list.count)], base, s_all);
 }
 
 // ======================================================================================================
@@ -1102,11 +1067,16 @@ __device__ __forceinline__ uint32_t wave_from_above(uint32_t v)      // lane i <
 {
     return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x130, 0xF, 0xF, false));
 }
-// one unit `u` (cam << 24 | uy << 12 | ux: PS_W x R outputs of level l + 1) by the calling wave
-template <int R, bool COH_IN = false, bool COH_OUT = false>
-__device__ __forceinline__ void pyrdown_stream_unit(const CamDesc* __restrict__ cams, uint32_t u, int l)
+template <int R>
+__global__ __launch_bounds__(256) void k_pyrdown_stream(const CamDesc* __restrict__ cams_all, const uint32_t* __restrict__ units,
+                                                        int n_units, int l, int n_cams)
 {
+    const CamDesc* __restrict__ cams = cams_all + blockIdx.y * n_cams;
     const int lane = static_cast<int>(threadIdx.x & 63u);
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int ui = xcd_run_index(blockIdx.x, (n_units + 3) >> 2) * 4 + wave;
+    if (ui >= n_units) return;                                   // (wave-uniform)
+    const uint32_t u = units[ui];
     const int cam = (u >> 24) & 0x7F, uy = (u >> 12) & 0xFFF, ux = u & 0xFFF;
     const CamDesc& c = cams[cam];
     const int sw = c.lw[l], sh = c.lh[l], dw = c.lw[l + 1], dh = c.lh[l + 1];
@@ -1131,7 +1101,8 @@ __device__ __forceinline__ void pyrdown_stream_unit(const CamDesc* __restrict__ 
     uint2 raw[kRows];
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
-        raw[t] = pyr_ld2<COH_IN>(col + __umul24(static_cast<uint32_t>(row_of(min(2 * oy0 + t - 2, sh))), static_cast<uint32_t>(sw)));
+        const GPix v = *(const GPix MST_GLOBAL*)(col + __umul24(static_cast<uint32_t>(row_of(min(2 * oy0 + t - 2, sh))), static_cast<uint32_t>(sw)));
+        raw[t] = make_uint2(v.x, v.y);
     }
     Row h[5];
 #pragma unroll
@@ -1142,124 +1113,13 @@ __device__ __forceinline__ void pyrdown_stream_unit(const CamDesc* __restrict__ 
     for (int t = 0; t < R; ++t) {
         const uint32_t vbr = h[0].hbr + h[4].hbr + 4u * (h[1].hbr + h[3].hbr) + 6u * h[2].hbr;
         const uint32_t vg = h[0].hg + h[4].hg + 4u * (h[1].hg + h[3].hg) + 6u * h[2].hg;
-        if (col_ok && oy0 + t < dh) pyr_st<COH_OUT>(o, pyrdown_finish(vbr, vg));
+        if (col_ok && oy0 + t < dh) *o = pyrdown_finish(vbr, vg);
         o += dw;
         if (t + 1 < R) {
             h[0] = h[2]; h[1] = h[3]; h[2] = h[4];
             filter(raw[2 * t + 5], h[3]); filter(raw[2 * t + 6], h[4]);
         }
     }
-}
-
-template <int R>
-__global__ __launch_bounds__(256) void k_pyrdown_stream(const CamDesc* __restrict__ cams_all, const uint32_t* __restrict__ units,
-                                                        int n_units, int l, int n_cams)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    const int ui = xcd_run_index(blockIdx.x, (n_units + 3) >> 2) * 4 + wave;
-    if (ui >= n_units) return;                                   // (wave-uniform)
-    pyrdown_stream_unit<R>(cams_all + blockIdx.y * n_cams, units[ui], l);
-}
-
-// ======================================================================================================
-// B, fused form (round 5): every pyrDown step of a launch sequence -- the streaming levels and the chain -- as ONE launch
-// ======================================================================================================
-// A call of one frame set spends a quarter of its time in the three small pyramid launches (levels 1 -> 2, 2 -> 3 streaming,
-// 3 -> 5 chained: 26 of 96 us for a sixteenth of the pixels): each is a few hundred short blocks that cannot fill the chip, behind
-// a launch boundary.  As one grid the boundaries go -- but pixels then pass between blocks of ONE launch, and each of the eight
-// XCDs has its own write-back L2: a hand-over that is visible across XCDs costs an L2 write-back + invalidate per signal or
-// uncached accesses (both built and measured: 144 / 92 us for what the three launches do in 26).  Within an XCD the L2 IS the
-// point of coherence.  So a camera's whole chain runs on one XCD: block b of a frame set's share of the grid takes item b / 8 of
-// queue b % 8, a queue holds the items (four streaming units, or one chain tile) of the cameras c with c % 8 == its index, step
-// after step, and workgroups are dealt to the XCDs round-robin by index (what xcd_run_index has always assumed for speed).
-// Here correctness leans on it, so it is CHECKED: every block reads its XCC id (s_getreg HW_REG_XCC_ID) and flags a mismatch
-// in `status`; the engine probes the dealing once before it enables this path and reads `status` before every call.
-// Waiting: an item of step s polls the counter of (frame set, step s - 1, its camera) until it reaches epoch x that camera's
-// item count (the engine counts fused launches per buffer set; nothing is ever reset); producers sit earlier in the same queue,
-// i.e. in lower block indices, and blocks are dispatched in index order, so whatever a block waits for is running or done.  A
-// wait that does not end (2^22 polls) gives up and sets `status`: wrong pixels are reported, the GPU is never hung.
-// (PyrFusedSeg / PyrFusedArgs: device_types.hpp)
-__device__ __forceinline__ uint32_t xcc_id()
-{
-    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, 4 bits): the XCD this wave runs on
-    return static_cast<uint32_t>(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20)) & 0xFu;
-}
-__device__ __forceinline__ void pyr_fused_wait(const uint32_t* ctr, uint32_t target, uint32_t* status)
-{
-    // (one lane polls; the others of the wave sit at the reconvergence point)
-    if ((threadIdx.x & 63u) == 0) {
-        int polls = 0;
-        while (static_cast<int32_t>(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++polls > (1 << 22)) { __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-        }
-    }
-    // (no cache-wide acquire: what the waiting block reads of its producers it reads past its L1, pyr_ld<true>; the
-    // workgroup-scope fence keeps the compiler from moving those loads above the poll)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ void pyr_fused_drain()
-{
-    // the unit's pixels left as plain stores: once the memory counter has drained they are in this XCD's L2
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0) expcnt(0) lgkmcnt(0)
-}
-__global__ __launch_bounds__(256) void k_pyr_fused(const CamDesc* __restrict__ cams_all, PyrFusedArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t s_all[ChainLds<2>::dwords];
-    static_assert(ChainLds<1>::dwords <= ChainLds<2>::dwords && B_THREADS == 256, "one LDS block serves both chain depths");
-    const int set = static_cast<int>(blockIdx.x) / a.blocks_per_set;
-    const int b = static_cast<int>(blockIdx.x) - set * a.blocks_per_set;
-    const int q = b & 7, j = b >> 3;                             // queue (= the XCD this block is dealt to), item
-    if (xcc_id() != static_cast<uint32_t>(blockIdx.x & 7u) && threadIdx.x == 0)
-        (void)__hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (j >= a.queue_items[q]) return;                           // (block-uniform)
-    const CamDesc* __restrict__ cams = cams_all + set * a.n_cams;
-    // item word: segment << 28 | units << 24 | first unit (or tile) of the segment's list
-    const uint32_t item = a.items[a.queue_first[q] + j];
-    const int si = static_cast<int>(item >> 28), n_units = static_cast<int>((item >> 24) & 0xFu), first = static_cast<int>(item & 0xFFFFFFu);
-    const PyrFusedSeg sg = a.seg[si];
-    uint32_t* ctr_set = a.counters + (static_cast<size_t>(set) * kPyrFusedSegs) * kMaxCams;
-    const bool last = si + 1 == a.n_seg;
-    if (sg.kind == 0) {
-        const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-        if (wave >= n_units) return;                             // (wave-uniform)
-        const uint32_t u = sg.items[first + wave];
-        const int cam = (u >> 24) & 0x7F;
-        // (a segment's input crossed blocks of this launch unless it is the first)
-        if (si > 0) {
-            pyr_fused_wait(ctr_set + (si - 1) * kMaxCams + cam, a.epoch[set] * a.expect[(si - 1) * kMaxCams + cam], a.status);
-            pyrdown_stream_unit<PS_R, true, false>(cams, u, sg.level);
-        } else {
-            pyrdown_stream_unit<PS_R, false, false>(cams, u, sg.level);
-        }
-        if (!last) {
-            pyr_fused_drain();
-            if ((threadIdx.x & 63u) == 0) (void)__hip_atomic_fetch_add(ctr_set + si * kMaxCams + cam, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else {
-        const uint32_t t = sg.items[first];
-        const int cam = (t >> 24) & 0x7F;
-        if (si > 0) {
-            pyr_fused_wait(ctr_set + (si - 1) * kMaxCams + cam, a.epoch[set] * a.expect[(si - 1) * kMaxCams + cam], a.status);
-            __syncthreads();
-            if (sg.kind == 2) pyr_chain_tile<2, true, false>(cams, t, sg.level, s_all); else pyr_chain_tile<1, true, false>(cams, t, sg.level, s_all);
-        } else {
-            if (sg.kind == 2) pyr_chain_tile<2, false, false>(cams, t, sg.level, s_all); else pyr_chain_tile<1, false, false>(cams, t, sg.level, s_all);
-        }
-        if (!last) {
-            // (pyr_chain_tile ends on a barrier: every wave's stores are issued; each wave drains its own, then one lane signals)
-            pyr_fused_drain();
-            __syncthreads();
-            if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(ctr_set + si * kMaxCams + cam, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// What the dealing of workgroups to XCDs looks like on this device: block b writes its XCC id to out[b] (engine: probed once).
-__global__ void k_xcc_probe(uint32_t* __restrict__ out)
-{
-    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
 }
 
 // ======================================================================================================
@@ -2674,18 +2534,6 @@ const char* launch_pyrdown_stream(const CamDesc* d_cams, int n_cams, const uint3
     hipLaunchKernelGGL(k_pyrdown_stream<PS_R>, dim3((n_units + 3) / 4, batch), dim3(256), 0, s, d_cams, d_units, n_units, level, n_cams);
     static_assert(PS_R == 8, "kernel name below");
     return "k_pyrdown_stream<8>";
-}
-
-const char* launch_pyr_fused(const CamDesc* d_cams, const PyrFusedArgs& a, int batch, hipStream_t s)
-{
-    if (a.n_seg <= 0 || a.blocks_per_set <= 0 || batch <= 0) return nullptr;
-    hipLaunchKernelGGL(k_pyr_fused, dim3(a.blocks_per_set * batch), dim3(256), 0, s, d_cams, a);
-    return "k_pyr_fused";
-}
-
-void launch_xcc_probe(uint32_t* d_out, int n_blocks, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_xcc_probe, dim3(n_blocks), dim3(64), 0, s, d_out);
 }
 
 const char* launch_blend(const CamDesc* d_cams, const BlendArgs& a_in, int num_blocks, int num_coarse, int batch, size_t lds_bytes,
