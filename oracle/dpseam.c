@@ -11,7 +11,8 @@
  *   estimateSeam           :781-909      updateLabelsUsingSeam :912-1045
  *
  * OpenCV 2.4.11 primitives used by it and restated here (parity unpinned, like the rest of this oracle -- the
- * reference ships no test for this class and cannot be built in this image):
+ * reference ships no test for this class and cannot be built in this image -- EXCEPT Sobel's float sums and the 8-bit gray constants,
+ * which were read off the reference's shipped opencv_imgproc2411.dll: oracle/REFERENCE_BINARY_AUDIT.md):
  *   cv::floodFill(Mat_<int>, seed, newVal)         4-connected region of pixels EQUAL to the seed pixel (loDiff = upDiff = 0)
  *   cv::partition(points, labels, ClosePoints(10)) classes = connected components of the predicate graph, numbered in the
  *                                                  order of their first member (core/operations.hpp: union-find, then "enumerate classes")
@@ -291,11 +292,12 @@ static void gradients(const Img *im, float **gx, float **gy)
      *                 W8 <= x < W8 + (R & ~1) scalar pairs            (a + m * 2) + c            S[-cn] + S[0]*2 + S[cn]
      *                 x == W - 1, R odd       generic tail            m * 2 + (c + a)            kx[0]*S[0] + kx[1]*(S[j] + S[-j])
      *   col [1 2 1]   x < W8                 SSE body                t + (b + (m + m))          _mm_add_ps(s0, _mm_add_ps(s4, _mm_add_ps(s2, s2)))
-     *                 W8 <= x < W8 + (R & ~3) unrolled by four        (t + m * 2) + b            S0[i] + S1[i]*2 + S2[i] + _delta
-     *                 the rest                                        (t + b) + m * 2            (S0[i] + S2[i])*f1 + S1[i]*f0 + _delta
-     * (a / c: left / right neighbour, t / b: row above / below, REFLECT_101 at the borders; _delta = 0 adds nothing).  Restated
-     * from the published 2.4.11 source as the builder recalls it -- parity unpinned like the rest of this oracle; a second,
-     * separately written statement lives in tests/independent/dpseam_py.py. */
+     *                 W8 <= x                 unrolled by four + rest  (t + m * 2) + b            S0[i] + S1[i]*2 + S2[i] + _delta
+     * (a / c: left / right neighbour, t / b: row above / below, REFLECT_101 at the borders; _delta = 0 adds nothing).
+     * PINNED against the reference's own binary: tools/ref_binary_audit.py disassembles the x64 Release opencv_imgproc2411.dll the
+     * reference ships and runs, and prints the expression every store of these loops writes (oracle/REFERENCE_BINARY_AUDIT.md).
+     * That audit corrected the first round-5 statement of this table, which gave the columns after the unrolled fours the generic
+     * (t + b) + m * 2: in the shipped build every column past the SSE body is (t + m * 2) + b. */
     const int w8 = w & ~7, rem = w - w8;
     float *dxr = (float *)malloc((size_t)w * h * sizeof(float)), *smr = (float *)malloc((size_t)w * h * sizeof(float));
     for (int y = 0; y < h; ++y)
@@ -316,8 +318,7 @@ static void gradients(const Img *im, float **gx, float **gy)
             const float t = dxr[(size_t)ym * w + x], b = dxr[(size_t)yp * w + x], m = dxr[(size_t)y * w + x];
             float s;
             if (x < w8) { const float u = m + m; const float v = b + u; s = t + v; }
-            else if (x < w8 + (rem & ~3)) { const float u = m * 2.f; const float v = t + u; s = v + b; }
-            else { const float u = t + b; const float v = m * 2.f; s = u + v; }
+            else { const float u = m * 2.f; const float v = t + u; s = v + b; }
             (*gx)[(size_t)y * w + x] = s;
             (*gy)[(size_t)y * w + x] = smr[(size_t)yp * w + x] - smr[(size_t)ym * w + x];
         }

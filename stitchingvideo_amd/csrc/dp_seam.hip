@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void k_dp_gray(const void* __restrict__ img, s
 
 // Sobel(CV_32F, ksize 3, BORDER_REFLECT_101) = sepFilter2D, row pass then column pass.  The [1 2 1] sums are associated as the
 // loop of OpenCV 2.4.11's SymmRowSmallFilter / SymmColumnSmallFilter<float> (x64, SSE2) that produces the element does -- SSE
-// body for the first w & ~7 columns, then the scalar pairs / unrolled fours, then the generic tail; on non-integer float
-// images the forms differ by one ulp (oracle/dpseam.c: gradients() has the table and the source lines).
+// body for the first w & ~7 columns, then the scalar pairs and the generic tail (rows) / the scalar form (columns); on non-integer
+// float images the forms differ by one ulp.  Read off the reference's shipped x64 DLL (oracle/REFERENCE_BINARY_AUDIT.md).
 __global__ __launch_bounds__(256) void k_dp_sobel(const float* __restrict__ gray, int w, int h, float* __restrict__ gx, float* __restrict__ gy)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_dp_sobel(const float* __restrict__ gray
     const int xm = reflect<1>(x - 1, w), xp = reflect<1>(x + 1, w), ym = reflect<1>(y - 1, h), yp = reflect<1>(y + 1, h);
     const int w8 = w & ~7, rem = w - w8;
     const int row_form = x < w8 ? 0 : x < w8 + (rem & ~1) ? 1 : 2;
-    const int col_form = x < w8 ? 0 : x < w8 + (rem & ~3) ? 1 : 2;
+    const int col_form = x < w8 ? 0 : 1;       // (the shipped build has two column forms: SSE body, then (t + 2 m) + b to the end)
     auto row = [&](int yy, float& d, float& s) {
         const float a = gray[static_cast<size_t>(yy) * w + xm], c = gray[static_cast<size_t>(yy) * w + xp], m = gray[static_cast<size_t>(yy) * w + x];
         d = c - a;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_dp_sobel(const float* __restrict__ gray
     };
     float d0, s0, d1, s1, d2, s2;
     row(ym, d0, s0); row(y, d1, s1); row(yp, d2, s2);
-    gx[static_cast<size_t>(y) * w + x] = col_form == 0 ? d0 + (d2 + (d1 + d1)) : col_form == 1 ? (d0 + d1 * 2.f) + d2 : (d0 + d2) + d1 * 2.f;
+    gx[static_cast<size_t>(y) * w + x] = col_form == 0 ? d0 + (d2 + (d1 + d1)) : (d0 + d1 * 2.f) + d2;
     gy[static_cast<size_t>(y) * w + x] = s2 - s0;
 }
 

@@ -110,14 +110,13 @@ def _sum121_row(l, c, r, w):
 
 
 def _sum121_col(u, m, d, w):
-    """[1 2 1] down a column as SymmColumnSmallFilter<Cast<float, float>, SymmColumnSmallVec_32f> leaves it: SSE body on columns
-    [0, w & ~7): u + (d + (m + m)); then the loop unrolled by four: (u + m*2) + d; the rest: (u + d)*1 + m*2."""
+    """[1 2 1] down a column as SymmColumnSmallFilter<Cast<float, float>, SymmColumnSmallVec_32f> leaves it in the x64 build the
+    reference ships (oracle/REFERENCE_BINARY_AUDIT.md): SSE body on columns [0, w & ~7): u + (d + (m + m)); every column after it --
+    the loop unrolled by four and what is left -- (u + m*2) + d."""
     w8 = w & ~7
-    fours_end = w8 + ((w - w8) & ~3)
     out = np.empty_like(m)
     out[:, :w8] = (u[:, :w8] + (d[:, :w8] + (m[:, :w8] + m[:, :w8]).astype(F)).astype(F)).astype(F)
-    out[:, w8:fours_end] = ((u[:, w8:fours_end] + (m[:, w8:fours_end] * F(2)).astype(F)).astype(F) + d[:, w8:fours_end]).astype(F)
-    out[:, fours_end:] = ((u[:, fours_end:] + d[:, fours_end:]).astype(F) + (m[:, fours_end:] * F(2)).astype(F)).astype(F)
+    out[:, w8:] = ((u[:, w8:] + (m[:, w8:] * F(2)).astype(F)).astype(F) + d[:, w8:]).astype(F)
     return out
 
 

@@ -1,0 +1,105 @@
+"""The oracle's order-sensitive float primitives against the reference's OWN machine code: tools/ref_binary_audit.py disassembles the
+x64 Release opencv_imgproc2411.dll the reference ships and prints the expression every store of the audited loops writes
+(oracle/REFERENCE_BINARY_AUDIT.md).  Runs where /root/reference exists (this container); skipped elsewhere -- the GPU box has no
+reference tree, and nothing of the DLL is copied into the repository."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_binary_audit as A          # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(A.DLL) or shutil.which("objdump") is None,
+                                reason="needs the reference tree (/root/reference) and binutils objdump")
+
+SHA = "5f0902d99da96d26db4bb304f047365eb7e308af53da1f47bd0c0907d1344a0f"
+
+
+@pytest.fixture(scope="module")
+def audit():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_binary_audit.py")], capture_output=True, text=True, check=True).stdout
+    lines = out.strip().splitlines()
+    assert lines[0].endswith(SHA), lines[0]
+    got = {}
+    for ln in lines[1:]:
+        name, rest = ln.split("  ", 1)
+        got.setdefault(name, []).append(rest)
+    return got
+
+
+def _shape(expr):
+    """the expression with every memory operand / register replaced by a letter per distinct operand, in order of appearance"""
+    import re
+    names = {}
+
+    def sub(m):
+        return names.setdefault(m.group(0), chr(ord("A") + len(names)))
+    return re.sub(r"\[[^\]]*\]|xmm\d+", sub, expr.split(" = ", 1)[1])
+
+
+def test_sobel_row_forms(audit):
+    # SSE body: ((m + m) + c) + a -- the doubled operand is added to itself first, the two neighbours one after the other
+    assert [_shape(e) for e in audit["row121_sse"]] == ["(((A + A) + B) + C)"] * 2
+    # scalar pairs: ((m * 2) + a) + c
+    assert [_shape(e) for e in audit["row121_pairs"]] == ["(((A * B) + C) + D)"] * 2
+    # generic tail: (S[j] + S[-j]) * kx[k] + kx[0]*S[0]
+    assert [_shape(e) for e in audit["row_generic_tail"]] == ["(((A + B) * C) + D)"]
+
+
+def test_sobel_column_forms(audit):
+    # SSE body: (((m + m) + b) + t) + delta
+    assert [_shape(e) for e in audit["col121_sse"]] == ["((((A + A) + B) + C) + D)"] * 2
+    # every column after it -- the fours AND the rest: (((m * 2) + t) + b) + delta
+    assert [_shape(e) for e in audit["col121_unrolled"]] == ["((((A * B) + C) + D) + E)"] * 4
+    assert [_shape(e) for e in audit["col121_rest"]] == ["((((A * B) + C) + D) + E)"]
+    # ... with the SAME operand roles in both: the doubled row is S1, the first neighbour added is the one at the loop's base pointer
+    assert "[r9-0x30" in audit["col121_sse"][0] and "[rcx-0x14" in audit["col121_unrolled"][0] and "[rax-0x4" in audit["col121_rest"][0]
+
+
+def test_pyrdown_float_forms(audit):
+    assert [_shape(e) for e in audit["pyrdown32f_sse"]] == ["(((((A + B) + C) * D) + ((E + F) + (C + C))) * G)"] * 2
+    assert [_shape(e) for e in audit["pyrdown32f_tail"]] == ["((((((A + B) * C) * D) + ((E * F) * D)) + (G * D)) + (H * D))"]
+
+
+def test_gray_float_is_left_to_right(audit):
+    # (g * cg + b * cb) + r * cr: the first two products summed first, the third added last -- b*0.114f + g*0.587f + r*0.299f left to right
+    e = audit["rgb2gray_f32"][0]
+    assert _shape(e) == "(((A * B) + (C * D)) + (E * F))" and e.endswith("+ ([r11+0x8] * xmm6))")
+
+
+def test_constants_present(audit):
+    assert audit["rgb2gray_u8_coeffs"][0].startswith("4899,9617,1868  at 0x")
+    assert audit["yuv420sp_coeffs"][0].startswith("1220542,2116026  at 0x")
+
+
+def test_oracle_sobel_is_the_audited_table():
+    """The forms above, evaluated in float32 on values that split them, against oracle/dpseam.c through mo_dp_gradients."""
+    import oracle_lib as O
+    F = np.float32
+    w = 13                                    # W8 = 8: columns 0..7 SSE, 8..11 pairs / fours, 12 tail / rest
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 255, size=(9, w, 3)).astype(np.float32)
+    img[..., 0] = 0
+    img[..., 2] = 0                           # gray = g * 0.587f: one product, no sum
+    gx, gy = O.dp_gradients(img)
+    g = (img[..., 1] * F(0.587)).astype(F)
+    r = lambda i, n: -i if i < 0 else (2 * n - 2 - i if i >= n else i)       # noqa: E731  (REFLECT_101)
+    y = 4
+    for x in range(w):
+        a = [g[yy, r(x - 1, w)] for yy in (y - 1, y, y + 1)]
+        m = [g[yy, x] for yy in (y - 1, y, y + 1)]
+        c = [g[yy, r(x + 1, w)] for yy in (y - 1, y, y + 1)]
+        d = [F(c[k] - a[k]) for k in range(3)]
+        if x < 8:
+            s = [F(a[k] + F(F(m[k] + m[k]) + c[k])) for k in range(3)]
+            want_gx = F(d[0] + F(d[2] + F(d[1] + d[1])))
+        else:
+            s = [F(F(a[k] + F(m[k] * F(2))) + c[k]) if x < 12 else F(F(m[k] * F(2)) + F(c[k] + a[k])) for k in range(3)]
+            want_gx = F(F(d[0] + F(d[1] * F(2))) + d[2])
+        assert gx[y, x] == want_gx, x
+        assert gy[y, x] == F(s[2] - s[0]), x

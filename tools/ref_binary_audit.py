@@ -1,0 +1,141 @@
+"""What the reference's OWN binaries compute, read off their machine code.
+
+The reference cannot be built or run in this image (OpenCV 2.4.11 + <windows.h>), and it ships no test vectors -- but it does ship the
+x64 Release DLLs it runs (`/root/reference/stitching/OpenCV2.4.11-Stitching-64bit/x64/Release/opencv_imgproc2411.dll`).  Where the oracle
+restates an OpenCV primitive whose result depends on the ORDER of floating-point operations (the SSE body of a filter associates a
+three-term sum differently from its scalar tail), the published source alone does not settle what the shipped build does: the compiler's
+schedule does.  This tool disassembles the DLL (binutils `objdump`), symbolically executes the few SSE instructions of the loop bodies in
+question (loads become symbols, addps / addss / subps / subss / mulps / mulss build expression trees, stores print them) and prints the
+expression every store writes -- commutative operands sorted, so that `a + b` and `b + a` read the same, association kept.
+
+    python tools/ref_binary_audit.py            -> one line per audited store / constant; exit code 1 if the DLL is not the audited one
+
+`tests/test_reference_binary_audit.py` runs it where /root/reference exists and compares with the forms the oracle implements
+(oracle/REFERENCE_BINARY_AUDIT.md explains every block: which function it is, how the operands map to rows and neighbours).
+Nothing of the DLL is copied into this repository: only the facts read off it."""
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+DLL = "/root/reference/stitching/OpenCV2.4.11-Stitching-64bit/x64/Release/opencv_imgproc2411.dll"
+DLL_SHA256 = "5f0902d99da96d26db4bb304f047365eb7e308af53da1f47bd0c0907d1344a0f"      # the audited file; a different one is reported (exit code 1), not trusted
+
+# (name, first address, last address) of straight-line loop bodies inside .text
+BLOCKS = [
+    ("row121_sse", 0x180061970, 0x1800619b5),        # SymmRowSmallVec_32f::operator(), ksize 3, kx = [1 2 1]: 8 outputs per trip
+    ("row121_pairs", 0x18006a0c0, 0x18006a100),      # SymmRowSmallFilter<float,float,...>::operator(): scalar pairs after the SSE body
+    ("row_generic_tail", 0x18006a4f2, 0x18006a538),  # ... its generic loop for what is left: kx[0]*S[0] + kx[k]*(S[-j] + S[j])
+    ("col121_sse", 0x180065c40, 0x180065c80),        # SymmColumnSmallVec_32f::operator(), ky = [1 2 1]
+    ("col121_unrolled", 0x1800801e0, 0x18008026a),   # SymmColumnSmallFilter<Cast<float,float>,...>::operator(): is_1_2_1, four per trip
+    ("col121_rest", 0x180080375, 0x18008039b),       # ... and the elements left after the fours
+    ("pyrdown32f_sse", 0x180130020, 0x180130090),    # pyrDown_<FltCast<float,8>, PyrDownVec_32f>: vertical pass, 8 outputs per trip
+    ("pyrdown32f_tail", 0x1801300d0, 0x180130120),   # ... its scalar tail
+    ("rgb2gray_f32", 0x180025880, 0x1800258b2),      # RGB2Gray<float>::operator(): xmm4 / xmm5 / xmm6 = coeffs[0 .. 2] (cb, cg, cr for BGR input)
+]
+# immediates that must appear as a group in one function: (name, values)
+CONSTANT_GROUPS = [
+    ("rgb2gray_u8_coeffs", [0x1323, 0x2591, 0x74C]),               # RGB2Gray<uchar>: R2Y 4899, G2Y 9617, B2Y 1868 (>> 14)
+    ("yuv420sp_coeffs", [0x129FBE, 0x2049BA]),                     # ITUR_BT_601_CY 1220542, CUB 2116026
+]
+
+LINE = re.compile(r"^\s*([0-9a-f]+):\s+(\S+)\s*(.*)$")
+
+
+def disassemble():
+    out = subprocess.run(["objdump", "-d", "-M", "intel", "--no-show-raw-insn", DLL], capture_output=True, text=True, check=True).stdout
+    code = {}
+    for ln in out.splitlines():
+        m = LINE.match(ln)
+        if m:
+            code[int(m.group(1), 16)] = (m.group(2), m.group(3).split("#")[0].strip())
+    return code
+
+
+def canon(e):
+    """expression tree -> string; operands of + and * sorted"""
+    if isinstance(e, str):
+        return e
+    op, a, b = e
+    sa, sb = canon(a), canon(b)
+    if op in "+*" and sb < sa:
+        sa, sb = sb, sa
+    return "(%s %s %s)" % (sa, op, sb)
+
+
+def mem(operand):
+    m = re.search(r"\[(.*)\]", operand)
+    return "[" + m.group(1).replace(" ", "") + "]"
+
+
+def run_block(code, first, last):
+    """-> list of (store operand, expression) in program order.  Registers hold expression trees; an xmm register read before it is
+    written is a loop-invariant (a broadcast constant: named by the register)."""
+    regs, stores = {}, []
+    # pointer bumps inside the body move later operands: track `add reg, imm` so that [rcx-0x20] after `add rcx,0x20` names the same cell
+    bump = {}
+
+    def norm(operand):
+        s = mem(operand)
+        for r, d in bump.items():
+            # rewrite r+disp by the accumulated bump (only plain `r` occurrences with optional +-hex displacement are shifted as a whole)
+            if re.search(r"\b%s\b" % r, s):
+                s = s[:-1] + ("%+d]" % d if d else "]")
+        return s
+    for addr in sorted(a for a in code if first <= a <= last):
+        op, args = code[addr]
+        parts = [p.strip() for p in args.split(",")] if args else []
+        if op in ("movups", "movaps", "movss", "movdqa", "movdqu"):
+            dst, src = parts
+            if "PTR" in dst:
+                stores.append((norm(dst), canon(regs.get(src, src))))
+            elif "PTR" in src:
+                regs[dst] = norm(src)
+            else:
+                regs[dst] = regs.get(src, src)
+        elif op in ("addps", "addss", "subps", "subss", "mulps", "mulss"):
+            dst, src = parts
+            rhs = norm(src) if "PTR" in src else regs.get(src, src)
+            regs[dst] = ({"a": "+", "s": "-", "m": "*"}[op[0]], regs.get(dst, dst), rhs)
+        elif op == "add" and len(parts) == 2 and re.fullmatch(r"0x[0-9a-f]+", parts[1]) and not parts[0].startswith("e"):
+            bump[parts[0]] = bump.get(parts[0], 0) + int(parts[1], 16)
+        # (everything else -- counters, lea, jumps -- does not touch the audited data flow)
+    return stores
+
+
+def find_constant_group(code, values):
+    """first address window of 64 instructions whose immediates contain every value"""
+    addrs = sorted(code)
+    imm = {}
+    for i, a in enumerate(addrs):
+        for v in values:
+            if re.search(r"\b0x%x\b" % v, code[a][1]):
+                imm.setdefault(v, []).append(i)
+    for i in imm.get(values[0], []):
+        if all(any(abs(j - i) < 64 for j in imm.get(v, [])) for v in values[1:]):
+            return addrs[i]
+    return None
+
+
+def main():
+    if not os.path.exists(DLL):
+        print("reference DLL not present: %s" % DLL)
+        return 2
+    sha = hashlib.sha256(open(DLL, "rb").read()).hexdigest()
+    print("dll %s sha256 %s" % (os.path.basename(DLL), sha))
+    if sha != DLL_SHA256:
+        print("not the audited file (%s): the addresses below would mean nothing" % DLL_SHA256)
+        return 1
+    code = disassemble()
+    for name, first, last in BLOCKS:
+        for dst, expr in run_block(code, first, last):
+            print("%s  %s = %s" % (name, dst, expr))
+    for name, values in CONSTANT_GROUPS:
+        at = find_constant_group(code, values)
+        print("%s  %s  %s" % (name, ",".join(str(v) for v in values), ("at 0x%x" % at) if at else "NOT FOUND"))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
