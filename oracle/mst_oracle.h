@@ -18,9 +18,12 @@
  * Round 5, a first pin: the reference ships the x64 DLLs it runs, and the order-sensitive
  * FLOAT primitives -- Sobel(CV_32F, ksize 3) and the float pyrDown of the blend weights,
  * by loop (SSE body / scalar tails) -- plus the fixed-point gray and NV12 constants were read
- * off opencv_imgproc2411.dll's machine code (tools/ref_binary_audit.py,
- * oracle/REFERENCE_BINARY_AUDIT.md, tests/test_reference_binary_audit.py).  Everything else
- * stays "parity unpinned".
+ * off opencv_imgproc2411.dll's machine code; the scalar float steps of the blenders (feed
+ * product + truncation, normalisation by true division: opencv_stitching2411.dll) and of the gain
+ * applies (float product, double rounding to nearest even: the exe's own
+ * BlocksGainCompensator::apply, opencv_core2411.dll's cvtScale) were read the same way
+ * (tools/ref_binary_audit.py, oracle/REFERENCE_BINARY_AUDIT.md,
+ * tests/test_reference_binary_audit.py).  Everything else stays "parity unpinned".
  *
  * Path alias: R64 = /root/reference/stitching/OpenCV2.4.11-Stitching-64bit/
  *                   OpenCV2.4.11-Stitching

@@ -27,6 +27,9 @@ def audit():
     assert lines[0].endswith(SHA), lines[0]
     got = {}
     for ln in lines[1:]:
+        if ln.startswith("binary "):                      # the other audited binaries, each with its digest
+            assert ln.split()[-1] == dict([A.STITCHING, A.CORE, A.EXE])[ln.split()[1]], ln
+            continue
         name, rest = ln.split("  ", 1)
         got.setdefault(name, []).append(rest)
     return got
@@ -103,3 +106,59 @@ def test_oracle_sobel_is_the_audited_table():
             want_gx = F(F(d[0] + F(d[1] * F(2))) + d[2])
         assert gx[y, x] == want_gx, x
         assert gy[y, x] == F(s[2] - s[0]), x
+
+
+# ---- the blender and the gain apply: which conversions and operations run, in which order ------------------------------------------------
+
+def _chain(audit, name):
+    return audit[name][0].split("chain: ", 1)[1].split()
+
+
+def test_blender_chains(audit):
+    px = ["movsx", "cvtdq2ps", "mulss", "cvttss2si", "add16"]            # dst += short(float(src) * w): ONE float product, truncated
+    assert _chain(audit, "mb_feed_32f") == px * 3 + ["addss", "store32"]  # ... and dst_weight += w
+    assert _chain(audit, "feather_feed") == px * 3 + ["addss"]
+    # normalizeUsingWeightMap: v / (w + eps) -- the sum redone and a true division per channel (no reciprocal), truncated
+    assert _chain(audit, "normalize_32f") == ["movsx", "cvtdq2ps", "addss", "divss", "cvttss2si"] * 3
+    # the CV_16S weight forms: (src * w) >> 8 and (v << 8) / (w + 1)
+    assert _chain(audit, "mb_feed_16s")[:15] == ["movsx", "movsx", "imul", "sar", "add16"] * 3
+    assert _chain(audit, "normalize_16s") == ["movsx", "inc", "movsx", "shl", "idiv", "movsx", "shl", "idiv", "movsx", "shl", "idiv"]
+
+
+def test_gain_apply_chains(audit):
+    # saturate_cast<uchar>(uchar * float): a float product, widened to double, rounded to nearest even by cvtsd2si, clamped
+    assert _chain(audit, "blocks_gain_apply") == ["movzx", "cvtdq2ps", "mulss", "cvtps2pd", "cvtsd2si"]
+    # `image *= gain` -> cvtScale_<uchar,uchar,float>: src * (float)scale + (float)shift, the same rounding
+    assert _chain(audit, "cvtscale_8u8u")[:6] == ["movzx", "cvtdq2ps", "mulss", "addss", "cvtps2pd", "cvtsd2si"]
+    # weight.convertTo(CV_32F, 1./255.): src * scale + shift in float, two per trip
+    want = ["movzx", "cvtdq2ps", "mulss", "addss", "store32"] * 2
+    want.remove("movzx")                                   # (the first of the two loads sits above the window)
+    assert sorted(_chain(audit, "cvtscale_8u32f")) == sorted(want)
+
+
+def test_oracle_blender_arithmetic_is_the_audited_chain():
+    """The chains above evaluated in numpy float32 on values chosen to split the alternatives (a reciprocal multiply, a rounded instead of
+    a truncated conversion, a double product), against the oracle's own entry points."""
+    import ctypes as C
+    import oracle_lib as O
+    F = np.float32
+    rng = np.random.default_rng(11)
+    n = 4096
+    v = rng.integers(-32768, 32767, size=(1, n, 3)).astype(np.int16)
+    w = rng.uniform(0, 6, size=(1, n)).astype(F)
+    w[0, :64] = 0                                              # the eps alone divides
+    got = v.copy()
+    O.lib().mo_normalize_using_weight_map_32f(w.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), n, 1)
+    q = (v.astype(F) / (w + F(1e-5))[..., None]).astype(F)      # divss on float32 operands
+    want = np.trunc(q).astype(np.int64).astype(np.int32)
+    want = np.where(np.abs(q) >= 2147483648.0, np.int32(-2147483648), want).astype(np.int32).astype(np.int16)   # cvttss2si, then the low 16 bits
+    assert np.array_equal(got, want)
+    recip = np.trunc(v.astype(F) * (F(1) / (w + F(1e-5)))[..., None]).astype(np.int64).astype(np.int32).astype(np.int16)
+    assert not np.array_equal(recip, want)                     # the sample does tell a reciprocal multiply from the division
+
+    img = rng.integers(0, 256, size=(8, 64, 3)).astype(np.uint8)
+    g = rng.uniform(0.5, 1.9, size=(8, 64)).astype(F)
+    got = O.blocks_gain_apply(img.copy(), g)
+    p = (img.astype(F) * g[..., None]).astype(F)               # mulss
+    want = np.clip(np.rint(p.astype(np.float64)), 0, 255).astype(np.uint8)     # cvtsd2si = nearest even, then the clamp
+    assert np.array_equal(got, want)

@@ -34,6 +34,26 @@ BLOCKS = [
     ("pyrdown32f_tail", 0x1801300d0, 0x180130120),   # ... its scalar tail
     ("rgb2gray_f32", 0x180025880, 0x1800258b2),      # RGB2Gray<float>::operator(): xmm4 / xmm5 / xmm6 = coeffs[0 .. 2] (cb, cg, cr for BGR input)
 ]
+# The blender and the gain apply are scalar loops whose results hang on WHICH conversions and operations run, in which order (a true
+# division or a reciprocal multiply; truncation or rounding; a float or a double product).  For those the audit prints the chain of
+# arithmetic mnemonics between two addresses of one of the reference's other binaries: (name, binary, sha256, first, last).
+RELEASE = os.path.dirname(DLL)
+STITCHING = ("opencv_stitching2411.dll", "0d9365a326abaa4d8cd3a0e0ed6b80d3848927fff24ff146d0c56b6e3c0d09c3")
+CORE = ("opencv_core2411.dll", "cfedf4b256c68aa18a89ce1f7f75d4e3fdaa6fd721b3133b63577919be5c1e60")
+EXE = ("OpenCV2.4.11-Stitching.exe", "6ea54dc72eefb94e8f2681ec31bac41f731c7e7dca44de49348a4e2aea2f6997")
+CHAINS = [
+    ("mb_feed_32f", STITCHING, 0x18000c2a1, 0x18000c2f4),          # MultiBandBlender::feed, CV_32F weights: one pixel (3 channels + the weight sum)
+    ("mb_feed_16s", STITCHING, 0x18000c450, 0x18000c48e),          # ... CV_16S weights: (src * w) >> 8
+    ("normalize_32f", STITCHING, 0x1800089a0, 0x1800089f4),        # normalizeUsingWeightMap, float weights: one pixel
+    ("normalize_16s", STITCHING, 0x180008ba0, 0x180008bce),        # ... CV_16S weights: (v << 8) / (w + 1)
+    ("feather_feed", STITCHING, 0x1800093f3, 0x180009442),         # FeatherBlender::feed: one pixel
+    ("blocks_gain_apply", EXE, 0x140008170, 0x1400081a3),          # BlocksGainCompensator::apply (the exe's own copy): one channel
+    ("cvtscale_8u8u", CORE, 0x18004e080, 0x18004e0b4),             # cvtScale_<uchar,uchar,float>: `image *= gain` of GainCompensator::apply
+    ("cvtscale_8u32f", CORE, 0x180052205, 0x18005222a),            # cvtScale_<uchar,float,float>: weight.convertTo(CV_32F, 1./255.), two per trip
+]
+ARITH = {"movsx", "movzx", "cvtdq2ps", "cvtsi2ss", "mulss", "addss", "subss", "divss", "cvttss2si", "cvtss2si", "cvtps2pd", "cvtss2sd", "cvtsd2si",
+         "cvttsd2si", "imul", "idiv", "inc", "sar", "shl", "mulsd", "addsd", "divsd", "rcpss", "rcpps"}
+
 # immediates that must appear as a group in one function: (name, values)
 CONSTANT_GROUPS = [
     ("rgb2gray_u8_coeffs", [0x1323, 0x2591, 0x74C]),               # RGB2Gray<uchar>: R2Y 4899, G2Y 9617, B2Y 1868 (>> 14)
@@ -43,8 +63,8 @@ CONSTANT_GROUPS = [
 LINE = re.compile(r"^\s*([0-9a-f]+):\s+(\S+)\s*(.*)$")
 
 
-def disassemble():
-    out = subprocess.run(["objdump", "-d", "-M", "intel", "--no-show-raw-insn", DLL], capture_output=True, text=True, check=True).stdout
+def disassemble(path=DLL):
+    out = subprocess.run(["objdump", "-d", "-M", "intel", "--no-show-raw-insn", path], capture_output=True, text=True, check=True).stdout
     code = {}
     for ln in out.splitlines():
         m = LINE.match(ln)
@@ -104,6 +124,21 @@ def run_block(code, first, last):
     return stores
 
 
+def run_chain(code, first, last):
+    """-> the arithmetic mnemonics between two addresses, in program order; a 16-bit read-modify-write `add WORD PTR [..], reg` prints as
+    add16 and a float store as store32 (they are where a result lands)"""
+    out = []
+    for addr in sorted(a for a in code if first <= a <= last):
+        op, args = code[addr]
+        if op in ARITH:
+            out.append(op)
+        elif op == "add" and args.startswith("WORD PTR"):
+            out.append("add16")
+        elif op == "movss" and args.startswith("DWORD PTR"):
+            out.append("store32")
+    return out
+
+
 def find_constant_group(code, values):
     """first address window of 64 instructions whose immediates contain every value"""
     addrs = sorted(code)
@@ -134,7 +169,19 @@ def main():
     for name, values in CONSTANT_GROUPS:
         at = find_constant_group(code, values)
         print("%s  %s  %s" % (name, ",".join(str(v) for v in values), ("at 0x%x" % at) if at else "NOT FOUND"))
-    return 0
+    rc, listings = 0, {}
+    for name, (binary, want), first, last in CHAINS:
+        path = os.path.join(RELEASE, binary)
+        if binary not in listings:
+            got = hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+            print("binary %s sha256 %s" % (binary, got))
+            listings[binary] = disassemble(path) if got == want else None
+            if got != want:
+                print("not the audited file (%s)" % want)
+                rc = 1
+        if listings[binary] is not None:
+            print("%s  chain: %s" % (name, " ".join(run_chain(listings[binary], first, last))))
+    return rc
 
 
 if __name__ == "__main__":
