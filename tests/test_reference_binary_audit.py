@@ -28,7 +28,7 @@ def audit():
     got = {}
     for ln in lines[1:]:
         if ln.startswith("binary "):                      # the other audited binaries, each with its digest
-            assert ln.split()[-1] == dict([A.STITCHING, A.CORE, A.EXE])[ln.split()[1]], ln
+            assert ln.split()[-1] == dict([A.STITCHING, A.CORE, A.EXE, A.IMGPROC])[ln.split()[1]], ln
             continue
         name, rest = ln.split("  ", 1)
         got.setdefault(name, []).append(rest)
@@ -121,8 +121,8 @@ def test_blender_chains(audit):
     # normalizeUsingWeightMap: v / (w + eps) -- the sum redone and a true division per channel (no reciprocal), truncated
     assert _chain(audit, "normalize_32f") == ["movsx", "cvtdq2ps", "addss", "divss", "cvttss2si"] * 3
     # the CV_16S weight forms: (src * w) >> 8 and (v << 8) / (w + 1)
-    assert _chain(audit, "mb_feed_16s")[:15] == ["movsx", "movsx", "imul", "sar", "add16"] * 3
-    assert _chain(audit, "normalize_16s") == ["movsx", "inc", "movsx", "shl", "idiv", "movsx", "shl", "idiv", "movsx", "shl", "idiv"]
+    assert _chain(audit, "mb_feed_16s")[:15] == ["movsx", "movsx", "imul", "sar8", "add16"] * 3
+    assert _chain(audit, "normalize_16s") == ["movsx", "inc", "movsx", "shl8", "idiv", "movsx", "shl8", "idiv", "movsx", "shl8", "idiv"]
 
 
 def test_gain_apply_chains(audit):
@@ -134,6 +134,19 @@ def test_gain_apply_chains(audit):
     want = ["movzx", "cvtdq2ps", "mulss", "addss", "store32"] * 2
     want.remove("movzx")                                   # (the first of the two loads sits above the window)
     assert sorted(_chain(audit, "cvtscale_8u32f")) == sorted(want)
+
+
+def test_integer_constants_and_the_map_rounding(audit):
+    # remapBilinear, 8-bit 3 channels: four products, + (1 << 14), >> 15
+    assert _chain(audit, "remap_bilinear_8uc3") == ["movzx", "imul"] * 4 + ["lea+16384", "sar15"]
+    # float maps -> fixed point: x * 32 rounded to NEAREST EVEN (cvtps2dq, not a truncation), & 31 for the table index, >> 5 and a
+    # saturating pack for the integer part
+    c = _chain(audit, "remap_maps_to_fixed")
+    assert c[:8] == ["mulps", "cvtps2dq"] * 4 and "cvttps2dq" not in c
+    assert c.count("psrad5") == 4 and c.count("packssdw") == 4 and "psllw5" in c and c.count("pand") == 4
+    # the integer pyramids' casts
+    assert _chain(audit, "fixptcast_8") == ["lea+128", "sar8"]
+    assert _chain(audit, "fixptcast_6") == ["lea+32", "sar6"]
 
 
 def test_oracle_blender_arithmetic_is_the_audited_chain():

@@ -39,6 +39,7 @@ BLOCKS = [
 # arithmetic mnemonics between two addresses of one of the reference's other binaries: (name, binary, sha256, first, last).
 RELEASE = os.path.dirname(DLL)
 STITCHING = ("opencv_stitching2411.dll", "0d9365a326abaa4d8cd3a0e0ed6b80d3848927fff24ff146d0c56b6e3c0d09c3")
+IMGPROC = (os.path.basename(DLL), DLL_SHA256)
 CORE = ("opencv_core2411.dll", "cfedf4b256c68aa18a89ce1f7f75d4e3fdaa6fd721b3133b63577919be5c1e60")
 EXE = ("OpenCV2.4.11-Stitching.exe", "6ea54dc72eefb94e8f2681ec31bac41f731c7e7dca44de49348a4e2aea2f6997")
 CHAINS = [
@@ -50,9 +51,15 @@ CHAINS = [
     ("blocks_gain_apply", EXE, 0x140008170, 0x1400081a3),          # BlocksGainCompensator::apply (the exe's own copy): one channel
     ("cvtscale_8u8u", CORE, 0x18004e080, 0x18004e0b4),             # cvtScale_<uchar,uchar,float>: `image *= gain` of GainCompensator::apply
     ("cvtscale_8u32f", CORE, 0x180052205, 0x18005222a),            # cvtScale_<uchar,float,float>: weight.convertTo(CV_32F, 1./255.), two per trip
+    # integer work: order-free, so what is read is the CONSTANTS (rounding offset and shift) and the rounding mode of the float -> fixed step
+    ("remap_bilinear_8uc3", IMGPROC, 0x1800ff0ab, 0x1800ff0d7),    # remapBilinear<FixedPtCast<int,uchar,15>, RemapVec_8u, short>, cn == 3: one channel
+    ("remap_maps_to_fixed", IMGPROC, 0x1800dcd30, 0x1800dcdb6),    # remap(): CV_32FC1 map pair -> CV_16SC2 + the 5-bit table index, 16 per trip
+    ("fixptcast_8", IMGPROC, 0x18012cc30, 0x18012cc36),            # FixPtCast<short, 8>::operator(): the integer pyrDown's (v + 128) >> 8
+    ("fixptcast_6", IMGPROC, 0x18012ccb0, 0x18012ccb3),            # FixPtCast<short, 6>::operator(): the integer pyrUp's (v + 32) >> 6
 ]
 ARITH = {"movsx", "movzx", "cvtdq2ps", "cvtsi2ss", "mulss", "addss", "subss", "divss", "cvttss2si", "cvtss2si", "cvtps2pd", "cvtss2sd", "cvtsd2si",
-         "cvttsd2si", "imul", "idiv", "inc", "sar", "shl", "mulsd", "addsd", "divsd", "rcpss", "rcpps"}
+         "cvttsd2si", "imul", "idiv", "inc", "sar", "shl", "mulsd", "addsd", "divsd", "rcpss", "rcpps",
+         "mulps", "cvtps2dq", "cvttps2dq", "pand", "por", "packssdw", "psllw", "psrad"}
 
 # immediates that must appear as a group in one function: (name, values)
 CONSTANT_GROUPS = [
@@ -126,12 +133,17 @@ def run_block(code, first, last):
 
 def run_chain(code, first, last):
     """-> the arithmetic mnemonics between two addresses, in program order; a 16-bit read-modify-write `add WORD PTR [..], reg` prints as
-    add16 and a float store as store32 (they are where a result lands)"""
+    add16 and a float store as store32 (they are where a result lands); shifts carry their count, a 32-bit `lea reg, [.. + imm]` prints as lea+imm"""
     out = []
     for addr in sorted(a for a in code if first <= a <= last):
         op, args = code[addr]
-        if op in ARITH:
+        imm = re.search(r",(0x[0-9a-f]+)$", args)
+        if op in ("sar", "shl", "psrad", "psllw") and imm:
+            out.append("%s%d" % (op, int(imm.group(1), 16)))               # the shift count is the point
+        elif op in ARITH:
             out.append(op)
+        elif op == "lea" and re.search(r"\+0x[0-9a-f]+\]$", args) and not args.startswith("r"):
+            out.append("lea+%d" % int(re.search(r"\+(0x[0-9a-f]+)\]$", args).group(1), 16))   # a 32-bit lea with a displacement: the rounding offset
         elif op == "add" and args.startswith("WORD PTR"):
             out.append("add16")
         elif op == "movss" and args.startswith("DWORD PTR"):
