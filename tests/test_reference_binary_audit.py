@@ -147,6 +147,8 @@ def test_integer_constants_and_the_map_rounding(audit):
     # the integer pyramids' casts
     assert _chain(audit, "fixptcast_8") == ["lea+128", "sar8"]
     assert _chain(audit, "fixptcast_6") == ["lea+32", "sar6"]
+    # the 8-bit vertical resize of the mask fix-up: (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
+    assert _chain(audit, "vresize_linear_8u") == ["sar4", "sar4", "imul", "sar16", "imul", "sar16", "lea+2", "sar2"]
 
 
 def test_oracle_blender_arithmetic_is_the_audited_chain():

@@ -56,6 +56,7 @@ CHAINS = [
     ("remap_maps_to_fixed", IMGPROC, 0x1800dcd30, 0x1800dcdb6),    # remap(): CV_32FC1 map pair -> CV_16SC2 + the 5-bit table index, 16 per trip
     ("fixptcast_8", IMGPROC, 0x18012cc30, 0x18012cc36),            # FixPtCast<short, 8>::operator(): the integer pyrDown's (v + 128) >> 8
     ("fixptcast_6", IMGPROC, 0x18012ccb0, 0x18012ccb3),            # FixPtCast<short, 6>::operator(): the integer pyrUp's (v + 32) >> 6
+    ("vresize_linear_8u", IMGPROC, 0x1800e8f20, 0x1800e8f48),      # VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>: the mask fix-up's resize, one output
 ]
 ARITH = {"movsx", "movzx", "cvtdq2ps", "cvtsi2ss", "mulss", "addss", "subss", "divss", "cvttss2si", "cvtss2si", "cvtps2pd", "cvtss2sd", "cvtsd2si",
          "cvttsd2si", "imul", "idiv", "inc", "sar", "shl", "mulsd", "addsd", "divsd", "rcpss", "rcpps",
