@@ -197,7 +197,7 @@ void mo_blocks_gain_feed(int n, const int *corners_xy, const uint8_t *const *ima
         mo_gain_map_size(sizes_wh[2 * i], sizes_wh[2 * i + 1], bl_width_, bl_height_, &gw, &gh);
         total += gw * gh;
     }
-    sub_image *bl = (sub_image *)malloc(sizeof(sub_image) * (size_t)total);
+    sub_image *bl = (sub_image *)calloc((size_t)total + 1, sizeof(sub_image));
     int k = 0;
     for (int i = 0; i < n; ++i) {
         const int cols = sizes_wh[2 * i], rows = sizes_wh[2 * i + 1];
