@@ -13,8 +13,16 @@ from stitchingvideo_amd import capi, rig as rigmod
 K_DRV = np.array([[655.6, 0, 625.06], [0, 656.4, 361.96], [0, 0, 1]], np.float64)
 D_DRV = [-0.382, 0.195, -0.00363, 0.00237]
 
+# the chessboard calibration the reference ships next to its x64 executable (x64/Release/camera-mp4.yml, "03/18/16", 1280x720, the
+# standard 5-coefficient model with k3, average reprojection error 7.6 px): a strongly non-monotonic map -- the whole 1280 x 720
+# frame samples columns 290 .. 1184 and rows 5 .. 686 of the source, folding back towards the corners -- as a reference-owned fixture
+# beside the driver's hard-coded intrinsics
+K_YML = np.array([[1.3240283915995651e+003, 0., 6.6179009310103982e+002], [0., 1.4000828762189344e+003, 3.6776239396487273e+002], [0., 0., 1.]], np.float64)
+D_YML = [-5.3287487456559879e-001, -7.0767524066484535e+000, -5.4286244387084424e-002, 8.8021459012654110e-002, 1.6610642543619203e+001]
+
 CASES = [
     (K_DRV, D_DRV, None, None, (1280, 720)),
+    (K_YML, D_YML, None, None, (1280, 720)),
     (K_DRV, [0.1, -0.05, 0.001, 0.002, 0.03], None, None, (333, 211)),
     (K_DRV, [0.2, -0.1, 0.0, 0.0, 0.01, 0.05, -0.02, 0.003],
      np.array([[0.99, 0.01, 0.02], [-0.01, 0.999, 0.03], [-0.02, -0.03, 0.998]]),
@@ -82,10 +90,10 @@ def _frame(w, h, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size,dist", [((1280, 720), D_DRV), ((160, 120), [-0.9, 0.6, 0.02, -0.03]), ((31, 17), [0.4, 0, 0, 0])])
+@pytest.mark.parametrize("size,dist", [((1280, 720), D_DRV), ((1280, 720), D_YML), ((160, 120), [-0.9, 0.6, 0.02, -0.03]), ((31, 17), [0.4, 0, 0, 0])])
 def test_remap_fixed_bit_exact(size, dist):
     w, h = size
-    K = K_DRV if size == (1280, 720) else np.array([[w * 0.6, 0, w * 0.47], [0, w * 0.62, h * 0.55], [0, 0, 1]])
+    K = K_YML if dist is D_YML else K_DRV if size == (1280, 720) else np.array([[w * 0.6, 0, w * 0.47], [0, w * 0.62, h * 0.55], [0, 0, 1]])
     m1, m2 = S.init_undistort_rectify_map(K, dist, size)
     img = _frame(w, h, 5)
     assert np.array_equal(S.remap_fixed(img, m1, m2), O.remap_fixed(img, m1, m2))
