@@ -28,7 +28,7 @@ def audit():
     got = {}
     for ln in lines[1:]:
         if ln.startswith("binary "):                      # the other audited binaries, each with its digest
-            assert ln.split()[-1] == dict([A.STITCHING, A.CORE, A.EXE, A.IMGPROC])[ln.split()[1]], ln
+            assert ln.split()[-1] == dict([A.STITCHING, A.CORE, A.EXE, A.EXE32, A.IMGPROC])[ln.split()[1]], ln
             continue
         name, rest = ln.split("  ", 1)
         got.setdefault(name, []).append(rest)
@@ -134,6 +134,32 @@ def test_gain_apply_chains(audit):
     want = ["movzx", "cvtdq2ps", "mulss", "addss", "store32"] * 2
     want.remove("movzx")                                   # (the first of the two loads sits above the window)
     assert sorted(_chain(audit, "cvtscale_8u32f")) == sorted(want)
+
+
+def test_the_32_bit_build_parts_from_the_x64_build(audit):
+    """The stock sample's 32-bit build (x64/Release/old-exe-stitch, x87 code, its own compiled blenders.cpp) keeps the weighted product
+    and the normalisation's sum and quotient at the FPU's precision before truncating; the x64 build rounds each to float first.  They
+    disagree on about one product in 3000 -- the oracle (and the engine) follow the x64 build, SURVEY 8c's choice."""
+    px = ["fild", "fmul", "call:0x448600", "add16"]                       # short(x87(src * w)): no float rounding between fmul and _ftol2_sse
+    c = [m for m in _chain(audit, "win32_mb_feed_32f") if m not in ("movsx", "inc")]
+    assert c == px * 3 + ["fadd", "fstp32"]
+    c = [m for m in _chain(audit, "win32_normalize_32f") if m != "movsx"]
+    assert c == ["fild", "fadd", "fdivp", "call:0x448600"] * 3
+    # a sample on which the two forms differ, and which one the oracle computes
+    import ctypes as C
+    import oracle_lib as O
+    F = np.float32
+    v = np.array([[[26003, 15182, 24431]]], np.int16)
+    w = np.array([[1.4341636]], F)
+    x64 = np.trunc((v.astype(F) / (w + F(1e-5))[..., None]).astype(F)).astype(np.int16)
+    x87 = np.trunc(v.astype(np.float64) / (w.astype(np.float64) + np.float64(F(1e-5)))[..., None]).astype(np.int16)
+    assert x64[0, 0, 0] == 18131 and x87[0, 0, 0] == 18130
+    got = v.copy()
+    O.lib().mo_normalize_using_weight_map_32f(w.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), 1, 1)
+    assert np.array_equal(got, x64)
+    for src, wt, a, b in ((24544, 0.9827656, 24121, 24120), (15182, 0.8517982, 12932, 12931)):
+        assert int(np.trunc(F(F(src) * F(wt)))) == a and int(np.trunc(float(src) * float(F(wt)))) == b
+        assert O.lib().mo_trunc_s16(C.c_float(float(F(F(src) * F(wt))))) == a
 
 
 def test_integer_constants_and_the_map_rounding(audit):

@@ -42,6 +42,9 @@ STITCHING = ("opencv_stitching2411.dll", "0d9365a326abaa4d8cd3a0e0ed6b80d3848927
 IMGPROC = (os.path.basename(DLL), DLL_SHA256)
 CORE = ("opencv_core2411.dll", "cfedf4b256c68aa18a89ce1f7f75d4e3fdaa6fd721b3133b63577919be5c1e60")
 EXE = ("OpenCV2.4.11-Stitching.exe", "6ea54dc72eefb94e8f2681ec31bac41f731c7e7dca44de49348a4e2aea2f6997")
+# the 32-bit build of the stock sample that sits in x64/Release/old-exe-stitch with 32-bit DLLs of its own (PE32, i386; its PDB names
+# blenders.cpp: this one DOES hold the project's own compiled blenders) -- x87 code, audited to record where the two builds part
+EXE32 = (os.path.join("old-exe-stitch", "OpenCV2.4.11-Stitching.exe"), "ca6114ce2a6b4d15e7f766b9186b59be3166e246130f5bb445c1e20d22c60d51")
 CHAINS = [
     ("mb_feed_32f", STITCHING, 0x18000c2a1, 0x18000c2f4),          # MultiBandBlender::feed, CV_32F weights: one pixel (3 channels + the weight sum)
     ("mb_feed_16s", STITCHING, 0x18000c450, 0x18000c48e),          # ... CV_16S weights: (src * w) >> 8
@@ -51,6 +54,8 @@ CHAINS = [
     ("blocks_gain_apply", EXE, 0x140008170, 0x1400081a3),          # BlocksGainCompensator::apply (the exe's own copy): one channel
     ("cvtscale_8u8u", CORE, 0x18004e080, 0x18004e0b4),             # cvtScale_<uchar,uchar,float>: `image *= gain` of GainCompensator::apply
     ("cvtscale_8u32f", CORE, 0x180052205, 0x18005222a),            # cvtScale_<uchar,float,float>: weight.convertTo(CV_32F, 1./255.), two per trip
+    ("win32_mb_feed_32f", EXE32, 0x40536c, 0x4053c1),              # MultiBandBlender::feed of the 32-bit build: fild / fmul / _ftol2_sse -- the product is NOT rounded to float
+    ("win32_normalize_32f", EXE32, 0x405e08, 0x405e54),            # normalizeUsingWeightMap of the 32-bit build: w + eps and the quotient at the FPU's precision
     # integer work: order-free, so what is read is the CONSTANTS (rounding offset and shift) and the rounding mode of the float -> fixed step
     ("remap_bilinear_8uc3", IMGPROC, 0x1800ff0ab, 0x1800ff0d7),    # remapBilinear<FixedPtCast<int,uchar,15>, RemapVec_8u, short>, cn == 3: one channel
     ("remap_maps_to_fixed", IMGPROC, 0x1800dcd30, 0x1800dcdb6),    # remap(): CV_32FC1 map pair -> CV_16SC2 + the 5-bit table index, 16 per trip
@@ -60,7 +65,8 @@ CHAINS = [
 ]
 ARITH = {"movsx", "movzx", "cvtdq2ps", "cvtsi2ss", "mulss", "addss", "subss", "divss", "cvttss2si", "cvtss2si", "cvtps2pd", "cvtss2sd", "cvtsd2si",
          "cvttsd2si", "imul", "idiv", "inc", "sar", "shl", "mulsd", "addsd", "divsd", "rcpss", "rcpps",
-         "mulps", "cvtps2dq", "cvttps2dq", "pand", "por", "packssdw", "psllw", "psrad"}
+         "mulps", "cvtps2dq", "cvttps2dq", "pand", "por", "packssdw", "psllw", "psrad",
+         "fild", "fmul", "fmulp", "fadd", "faddp", "fdiv", "fdivp", "fdivr", "fdivrp", "fistp", "fisttp"}
 
 # immediates that must appear as a group in one function: (name, values)
 CONSTANT_GROUPS = [
@@ -149,6 +155,10 @@ def run_chain(code, first, last):
             out.append("add16")
         elif op == "movss" and args.startswith("DWORD PTR"):
             out.append("store32")
+        elif op == "call" and re.fullmatch(r"0x[0-9a-f]+", args):
+            out.append("call:%s" % args)                                        # (the 32-bit build truncates through _ftol2_sse)
+        elif op == "fstp" and args.startswith("DWORD PTR"):
+            out.append("fstp32")
     return out
 
 
