@@ -20,7 +20,32 @@
  *   mst_warp                  <- RotationWarper::warp            detail/warpers_inl.hpp:88-99
  *   mst_exposure_apply        <- ExposureCompensator::apply      R64/src/exposure_compensate.cpp:150-153,
  *                                                                 225-246 (== BlockApply, DRV:310-331)
- *   mst_multiband_geometry    <- MultiBandBlender::prepare/feed ROI maths  R64/src/blenders.cpp:203-269
+ *   mst_multiband_geometry, mst_num_bands <- MultiBandBlender::prepare/feed ROI maths  R64/src/blenders.cpp:203-269
+ *   mst_compose_device, _device_batch, _device_batch_ex <- the same frame loop with the frames already on the device: what
+ *                                 StitchingAll() is once GetMemData's memcpy (R64/stitching_sharemem.cpp:96-123) lands in HBM
+ *                                 (include/mi355_ingest.h); the batch and the event arguments have no reference counterpart
+ *   mst_pipeline_submit / _wait / _pending, mst_host_alloc / _free <- the loop's three stages overlapped: GetMemData ->
+ *                                 remap ... feedSizeRemap -> convertTo(8U) / imshow            DRV:736-764
+ *   mst_acquire_calibration / mst_release_calibration <- the Upflag / UpdateMat() swap between the calibration thread and
+ *                                 the frame loop                                                DRV:829-836, 696-722
+ *   mst_camera_mask           <- the warped + fixed-up seam mask the loop blends with          R64/src/stitcher.cpp:278-294, DRV:676-678
+ *   mst_build_maps_host       <- buildMaps of the projectors that call libm per pixel          detail/warpers_inl.hpp:302-759
+ *   mst_warp_kind_from_name   <- the --warp switch                                             CLI:556-570
+ *   mst_exposure_feed, mst_gain_map_size <- GainCompensator / BlocksGainCompensator::feed      R64/src/exposure_compensate.cpp:73-147, 165-222
+ *   mst_seam_voronoi          <- VoronoiSeamFinder (PairwiseSeamFinder::run + findInPair)      R64/src/seam_finders.cpp:74-85, 108-160
+ *   mst_seam_dp               <- DpSeamFinder::find                                            R64/src/seam_finders.cpp:163-1045
+ *   mst_init_undistort_rectify_map, mst_remap_fixed <- RunTestEyeFishMap (initUndistortRectifyMap, CV_16SC2) and the per-frame
+ *                                 remap through those maps                                      DRV:201-238, 741
+ *   mst_compose_lens_maps     <- SURVEY.md 8 f1 as written (lens maps composed into the warp map); no reference call
+ *   mst_cvt_nv12_bgr          <- SURVEY.md 8 f3 (cv::cvtColor(COLOR_YUV2BGR_NV12) of 2.4.11); the reference is BGR-only
+ *                                 (R64/stitching_sharemem.cpp:112-115)
+ *   mst_strip                 <- SURVEY.md 8e, second form (the canvas in column strips, one per GPU); no reference counterpart
+ *   mst_stage_cameras / _canvas / _select_set, mst_payload_bytes / _pack / _unpack, mst_pyramid_buffer
+ *                             <- SURVEY.md 8e, first form (cameras one per GPU, one gather of the per-camera pyramids before
+ *                                 Blender::blend, R64/src/blenders.cpp:359-377); no reference counterpart
+ *   mst_calibration_blob_size / _save / _load <- none (what GetPreStruct() produces, DRV:348-694, kept in a file)
+ *   mst_compose_profile, _profile_batch, mst_debug_read, mst_synth_frame, mst_build_info, mst_synchronize, mst_last_error,
+ *   mst_destroy               <- none: per-stage timing (the reference prints its own, 20160308.cpp:807-836), diagnostics, lifetime
  *
  * Conventions (mirroring cv::Mat): images are 8-bit, BGR interleaved for colour, row-major
  * with an explicit byte stride (cv::Mat::data / cv::Mat::step); the caller owns every frame
