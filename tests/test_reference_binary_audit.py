@@ -162,6 +162,16 @@ def test_the_32_bit_build_parts_from_the_x64_build(audit):
         assert O.lib().mo_trunc_s16(C.c_float(float(F(F(src) * F(wt))))) == a
 
 
+def test_lu_solve_sums_in_source_order(audit):
+    """cv::solve(DECOMP_LU, CV_64F) behind the exposure gains: the row update is element by element and the back substitution subtracts its
+    products strictly one after the other (unrolled by four, not reassociated), then multiplies by the stored reciprocal of the pivot --
+    oracle/exposure_feed.c: mo_solve_lu_64f is written in exactly that order."""
+    assert [_shape(e) for e in audit["lu_row_update"]] == ["((A * B) + C)"] * 4
+    assert all(e.split(" = ")[0] == e.split(" + ")[-1].rstrip(")") for e in audit["lu_row_update"])          # A[j][k] = ... + A[j][k]
+    assert _shape(audit["lu_back_substitution"][0]) == "((((A - (B * C)) - (D * E)) - (F * G)) - (H * I))"
+    assert _shape(audit["lu_back_substitution_end"][0]) == "((A - (B * C)) * D)"
+
+
 def test_integer_constants_and_the_map_rounding(audit):
     # remapBilinear, 8-bit 3 channels: four products, + (1 << 14), >> 15
     assert _chain(audit, "remap_bilinear_8uc3") == ["movzx", "imul"] * 4 + ["lea+16384", "sar15"]

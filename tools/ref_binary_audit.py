@@ -34,6 +34,14 @@ BLOCKS = [
     ("pyrdown32f_tail", 0x1801300d0, 0x180130120),   # ... its scalar tail
     ("rgb2gray_f32", 0x180025880, 0x1800258b2),      # RGB2Gray<float>::operator(): xmm4 / xmm5 / xmm6 = coeffs[0 .. 2] (cb, cg, cr for BGR input)
 ]
+# cv::solve(DECOMP_LU, CV_64F) behind the exposure gains = LUImpl<double> in opencv_core2411.dll: double sums whose ORDER is the result
+# (name, first, last, register to print at the end or None)
+CORE_BLOCKS = [
+    ("lu_row_update", 0x1800a1060, 0x1800a10b7, None),             # A[j][k] += alpha * A[i][k], four per trip (xmm2 = alpha)
+    ("lu_back_substitution", 0x1800a13c0, 0x1800a13ff, "xmm2"),    # s -= A[i][k] * b[k], four per trip: strictly one after the other
+    ("lu_back_substitution_end", 0x1800a1441, 0x1800a1476, None),  # ... the rest one by one, then b[i] = s * A[i][i] (the stored -d = 1 / pivot)
+]
+
 # The blender and the gain apply are scalar loops whose results hang on WHICH conversions and operations run, in which order (a true
 # division or a reciprocal multiply; truncation or rounding; a float or a double product).  For those the audit prints the chain of
 # arithmetic mnemonics between two addresses of one of the reference's other binaries: (name, binary, sha256, first, last).
@@ -103,7 +111,7 @@ def mem(operand):
     return "[" + m.group(1).replace(" ", "") + "]"
 
 
-def run_block(code, first, last):
+def run_block(code, first, last, result_reg=None):
     """-> list of (store operand, expression) in program order.  Registers hold expression trees; an xmm register read before it is
     written is a loop-invariant (a broadcast constant: named by the register)."""
     regs, stores = {}, []
@@ -120,7 +128,7 @@ def run_block(code, first, last):
     for addr in sorted(a for a in code if first <= a <= last):
         op, args = code[addr]
         parts = [p.strip() for p in args.split(",")] if args else []
-        if op in ("movups", "movaps", "movss", "movdqa", "movdqu"):
+        if op in ("movups", "movaps", "movss", "movdqa", "movdqu", "movsd", "movapd", "movupd"):
             dst, src = parts
             if "PTR" in dst:
                 stores.append((norm(dst), canon(regs.get(src, src))))
@@ -128,13 +136,15 @@ def run_block(code, first, last):
                 regs[dst] = norm(src)
             else:
                 regs[dst] = regs.get(src, src)
-        elif op in ("addps", "addss", "subps", "subss", "mulps", "mulss"):
+        elif op in ("addps", "addss", "subps", "subss", "mulps", "mulss", "addsd", "subsd", "mulsd", "divsd", "divss"):
             dst, src = parts
             rhs = norm(src) if "PTR" in src else regs.get(src, src)
-            regs[dst] = ({"a": "+", "s": "-", "m": "*"}[op[0]], regs.get(dst, dst), rhs)
+            regs[dst] = ({"a": "+", "s": "-", "m": "*", "d": "/"}[op[0]], regs.get(dst, dst), rhs)
         elif op == "add" and len(parts) == 2 and re.fullmatch(r"0x[0-9a-f]+", parts[1]) and not parts[0].startswith("e"):
             bump[parts[0]] = bump.get(parts[0], 0) + int(parts[1], 16)
         # (everything else -- counters, lea, jumps -- does not touch the audited data flow)
+    if result_reg:
+        stores.append((result_reg, canon(regs.get(result_reg, result_reg))))
     return stores
 
 
@@ -193,6 +203,13 @@ def main():
         at = find_constant_group(code, values)
         print("%s  %s  %s" % (name, ",".join(str(v) for v in values), ("at 0x%x" % at) if at else "NOT FOUND"))
     rc, listings = 0, {}
+    core_path = os.path.join(RELEASE, CORE[0])
+    if os.path.exists(core_path) and hashlib.sha256(open(core_path, "rb").read()).hexdigest() == CORE[1]:
+        listings[CORE[0]] = disassemble(core_path)
+        print("binary %s sha256 %s" % CORE)
+        for name, first, last, reg in CORE_BLOCKS:
+            for dst, expr in run_block(listings[CORE[0]], first, last, reg):
+                print("%s  %s = %s" % (name, dst, expr))
     for name, (binary, want), first, last in CHAINS:
         path = os.path.join(RELEASE, binary)
         if binary not in listings:
