@@ -162,6 +162,21 @@ def test_the_32_bit_build_parts_from_the_x64_build(audit):
         assert O.lib().mo_trunc_s16(C.c_float(float(F(F(src) * F(wt))))) == a
 
 
+def test_spherical_map_backward_as_compiled_into_the_exe(audit):
+    """warpers_inl.hpp:253-268 as the x64 exe holds it (/fp:precise): u / scale and v / scale by true divisions, sinv = sinf(pi - v),
+    x_ = sinv * sinf(u), y_ = cosf(pi - v), z_ = sinv * cosf(u), each output (k0 * x_ + k1 * y_) + k2 * z_ in float, then a true division
+    by z -- the order oracle/warpers.c and the engine's per-axis tables follow."""
+    outs = [e for e in audit["spherical_map_backward"] if not e.startswith("[rsp")]
+    assert len(outs) == 4
+    x, y, xd, yd = outs
+    # the same three products summed the same way for x, y and z; f_ed76 = sinf, f_ed7c = cosf (two thunks, two arguments)
+    core = "((((f_ed76((A - (B / C))) * f_ed76((D / C))) * E) + (F * f_ed7c((A - (B / C))))) + ((f_ed76((A - (B / C))) * f_ed7c((D / C))) * G))"
+    assert _shape(x) == core and _shape(y) == core
+    assert xd.startswith("[rdi] = ([rdi] / (") and yd.startswith("[rax] = ([rax] / (")
+    assert xd.split(" / ", 1)[1] == yd.split(" / ", 1)[1]                 # both by the same z
+    assert "[rbx+0x70]" in x and "[rbx+0x74]" in x and "[rbx+0x78]" in x and "[rbx+0x88]" in xd and "[rbx+0x90]" in xd   # k_rinv[0..2], [6..8]
+
+
 def test_lu_solve_sums_in_source_order(audit):
     """cv::solve(DECOMP_LU, CV_64F) behind the exposure gains: the row update is element by element and the back substitution subtracts its
     products strictly one after the other (unrolled by four, not reassociated), then multiplies by the stored reciprocal of the pivot --

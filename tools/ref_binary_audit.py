@@ -42,6 +42,11 @@ CORE_BLOCKS = [
     ("lu_back_substitution_end", 0x1800a1441, 0x1800a1476, None),  # ... the rest one by one, then b[i] = s * A[i][i] (the stored -d = 1 / pivot)
 ]
 
+# the exe's own compiled projector (warpers_inl.hpp:253-268, /fp:precise): the float products and sums of SphericalProjector::mapBackward
+EXE_BLOCKS = [
+    ("spherical_map_backward", 0x14002118a, 0x14002128e, None),
+]
+
 # The blender and the gain apply are scalar loops whose results hang on WHICH conversions and operations run, in which order (a true
 # division or a reciprocal multiply; truncation or rounding; a float or a double product).  For those the audit prints the chain of
 # arithmetic mnemonics between two addresses of one of the reference's other binaries: (name, binary, sha256, first, last).
@@ -140,6 +145,8 @@ def run_block(code, first, last, result_reg=None):
             dst, src = parts
             rhs = norm(src) if "PTR" in src else regs.get(src, src)
             regs[dst] = ({"a": "+", "s": "-", "m": "*", "d": "/"}[op[0]], regs.get(dst, dst), rhs)
+        elif op == "call" and re.fullmatch(r"0x[0-9a-f]+", args):
+            regs["xmm0"] = "f_%s(%s)" % (args[-4:], canon(regs.get("xmm0", "xmm0")))          # a float function of xmm0 (sinf / cosf thunks)
         elif op == "add" and len(parts) == 2 and re.fullmatch(r"0x[0-9a-f]+", parts[1]) and not parts[0].startswith("e"):
             bump[parts[0]] = bump.get(parts[0], 0) + int(parts[1], 16)
         # (everything else -- counters, lea, jumps -- does not touch the audited data flow)
@@ -209,6 +216,13 @@ def main():
         print("binary %s sha256 %s" % CORE)
         for name, first, last, reg in CORE_BLOCKS:
             for dst, expr in run_block(listings[CORE[0]], first, last, reg):
+                print("%s  %s = %s" % (name, dst, expr))
+    exe_path = os.path.join(RELEASE, EXE[0])
+    if os.path.exists(exe_path) and hashlib.sha256(open(exe_path, "rb").read()).hexdigest() == EXE[1]:
+        listings[EXE[0]] = disassemble(exe_path)
+        print("binary %s sha256 %s" % EXE)
+        for name, first, last, reg in EXE_BLOCKS:
+            for dst, expr in run_block(listings[EXE[0]], first, last, reg):
                 print("%s  %s = %s" % (name, dst, expr))
     for name, (binary, want), first, last in CHAINS:
         path = os.path.join(RELEASE, binary)
