@@ -1,0 +1,130 @@
+"""TEST INFRASTRUCTURE: the reference's own shipped x64 machine code, run in place on numpy buffers (oracle/ref_run/pe_run.c maps a DLL,
+points every import at a trap and calls import-free leaf functions by address).  Only where /root/reference exists; each DLL in a
+process of its own (all three want the same base address) -- `python tests/ref_run.py <job> <in.npz> <out.npz>` is that process,
+`run(job, **arrays)` the caller's side.  cv::Mat headers are laid out by hand (OpenCV 2.4.11, x64: 96 bytes)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RELEASE = "/root/reference/stitching/OpenCV2.4.11-Stitching-64bit/x64/Release"
+DLLS = {"core": "opencv_core2411.dll", "imgproc": "opencv_imgproc2411.dll", "stitching": "opencv_stitching2411.dll"}
+SRC = os.path.join(ROOT, "oracle", "ref_run", "pe_run.c")
+LIB = os.path.join(ROOT, "oracle", "ref_run", "libpe_run.so")
+
+
+def available():
+    return all(os.path.exists(os.path.join(RELEASE, d)) for d in DLLS.values())
+
+
+def build():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-o", LIB, SRC], check=True)
+    return LIB
+
+
+class Mat(C.Structure):              # cv::Mat of OpenCV 2.4.11 on x64
+    _fields_ = [("flags", C.c_int), ("dims", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("data", C.c_void_p), ("refcount", C.c_void_p),
+                ("datastart", C.c_void_p), ("dataend", C.c_void_p), ("datalimit", C.c_void_p), ("allocator", C.c_void_p),
+                ("size_p", C.c_void_p), ("step_p", C.c_void_p), ("step_buf", C.c_size_t * 2)]
+
+
+DEPTH = {np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.uint16): 2, np.dtype(np.int16): 3, np.dtype(np.int32): 4,
+         np.dtype(np.float32): 5, np.dtype(np.float64): 6}
+
+
+def mat(a):
+    """a cv::Mat header over a C-contiguous numpy array (h, w) or (h, w, cn); the array must outlive it"""
+    assert a.flags["C_CONTIGUOUS"] and a.ndim in (2, 3)
+    cn = a.shape[2] if a.ndim == 3 else 1
+    m = Mat()
+    m.flags = 0x42FF0000 | (1 << 14) | (DEPTH[a.dtype] + ((cn - 1) << 3))
+    m.dims, m.rows, m.cols = 2, a.shape[0], a.shape[1]
+    m.data = m.datastart = a.ctypes.data
+    m.dataend = m.datalimit = a.ctypes.data + a.nbytes
+    m.refcount = m.allocator = None
+    m.size_p = C.addressof(m) + Mat.rows.offset
+    m.step_p = C.addressof(m) + Mat.step_buf.offset
+    m.step_buf[0], m.step_buf[1] = a.shape[1] * cn * a.itemsize, cn * a.itemsize
+    return m
+
+
+class Image:
+    def __init__(self, which):
+        self.L = C.CDLL(build())
+        self.L.pe_load.restype = C.c_uint64
+        self.L.pe_load.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+        self.L.pe_call.restype = C.c_uint64
+        self.L.pe_call.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
+        n = C.c_int()
+        self.base = self.L.pe_load(os.path.join(RELEASE, DLLS[which]).encode(), C.byref(n))
+        assert self.base == 0x180000000, "the image did not map at its preferred base"
+
+    def call(self, addr, *args):
+        a = (C.c_uint64 * 8)(*([int(x) & 0xFFFFFFFFFFFFFFFF for x in args] + [0] * (8 - len(args))))
+        return self.L.pe_call(addr, a)
+
+
+# ---- jobs (each runs in its own process) ---------------------------------------------------------------------------------------
+
+def job_normalize_32f(weight, src):
+    """cv::detail::normalizeUsingWeightMap(const Mat& weight, Mat& src), opencv_stitching2411.dll export at 0x1800087d0"""
+    img = Image("stitching")
+    w, s = np.ascontiguousarray(weight, np.float32), np.ascontiguousarray(src, np.int16).copy()
+    mw, ms = mat(w), mat(s)
+    img.call(0x1800087D0, C.addressof(mw), C.addressof(ms))
+    return {"out": s}
+
+
+# cv::pyrDown / cv::pyrUp pick a function by depth (the table of `lea`s at 0x1801340d1.. / 0x180134537..): PyrFunc(const Mat& src, Mat& dst,
+# int borderType) -- internal, import-free while the row buffers fit cv::AutoBuffer's 4 KB of stack (destination rows of <= 64 pixels x 3)
+PYR_DOWN = {np.dtype(np.uint8): 0x18012CFF0, np.dtype(np.int16): 0x18012DB30, np.dtype(np.uint16): 0x18012E640, np.dtype(np.float32): 0x18012F150}
+PYR_UP = {np.dtype(np.uint8): 0x180131160, np.dtype(np.int16): 0x180131810, np.dtype(np.uint16): 0x180131ED0, np.dtype(np.float32): 0x180132580}
+BORDER_REFLECT_101 = 4
+
+
+def job_pyr_down(src):
+    """pyrDown_<CastOp, VecOp>(src, dst, BORDER_DEFAULT) of opencv_imgproc2411.dll; dst = ((h + 1) / 2, (w + 1) / 2) as cv::pyrDown sizes it"""
+    img = Image("imgproc")
+    s = np.ascontiguousarray(src)
+    shape = ((s.shape[0] + 1) // 2, (s.shape[1] + 1) // 2) + s.shape[2:]
+    d = np.zeros(shape, s.dtype)
+    ms, md = mat(s), mat(d)
+    img.call(PYR_DOWN[s.dtype], C.addressof(ms), C.addressof(md), BORDER_REFLECT_101)
+    return {"out": d}
+
+
+def job_pyr_up(src, dsize):
+    """pyrUp_<CastOp, VecOp>(src, dst, BORDER_DEFAULT); dsize = (w, h) of the destination (|dsize - 2 ssize| <= 1)"""
+    img = Image("imgproc")
+    s = np.ascontiguousarray(src)
+    d = np.zeros((int(dsize[1]), int(dsize[0])) + s.shape[2:], s.dtype)
+    ms, md = mat(s), mat(d)
+    img.call(PYR_UP[s.dtype], C.addressof(ms), C.addressof(md), BORDER_REFLECT_101)
+    return {"out": d}
+
+
+JOBS = {"normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up}
+
+
+def run(job, **arrays):
+    """-> dict of output arrays, from a fresh process"""
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.npz"), os.path.join(d, "out.npz")
+        np.savez(fin, **arrays)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), job, fin, fout], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError("ref_run %s failed (%d): %s" % (job, r.returncode, r.stderr.strip()[-400:]))
+        with np.load(fout) as z:
+            return {k: z[k] for k in z.files}
+
+
+if __name__ == "__main__":
+    name, fin, fout = sys.argv[1:4]
+    with np.load(fin) as z:
+        out = JOBS[name](**{k: z[k] for k in z.files})
+    np.savez(fout, **out)
