@@ -47,6 +47,20 @@ static uint64_t __attribute__((ms_abi)) check_hardware_support(int feature)
     return (!g_no_sse && feature >= 1 && feature <= 3) ? 1u : 0u;
 }
 
+/* a fault inside the mapped code: say where (instruction and address), then exit 78 */
+#include <signal.h>
+#include <ucontext.h>
+static void on_fault(int sig, siginfo_t *si, void *uc_)
+{
+    ucontext_t *uc = (ucontext_t *)uc_;
+    char msg[200];
+    int n = snprintf(msg, sizeof msg, "pe_run: signal %d at rip %p touching %p (rsp %p)\n", sig, (void *)uc->uc_mcontext.gregs[REG_RIP], si->si_addr,
+                     (void *)uc->uc_mcontext.gregs[REG_RSP]);
+    ssize_t r = write(2, msg, (size_t)n);
+    (void)r;
+    _exit(78);
+}
+
 static uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
 static uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -57,6 +71,14 @@ uint64_t pe_load(const char *path, int *n_imports)
     FILE *f = fopen(path, "rb");
     if (!f) return 0;
     g_no_sse = getenv("PE_RUN_NO_SSE") != NULL;
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = on_fault;
+    sa.sa_flags = SA_SIGINFO;
+    sigaction(SIGSEGV, &sa, NULL);
+    sigaction(SIGILL, &sa, NULL);
+    sigaction(SIGBUS, &sa, NULL);
+    sigaction(SIGFPE, &sa, NULL);
     fseek(f, 0, SEEK_END);
     long len = ftell(f);
     fseek(f, 0, SEEK_SET);

@@ -1,0 +1,86 @@
+"""Golden vectors FROM THE REFERENCE ITSELF: inputs made here, outputs computed by the reference's shipped x64 machine code run in place
+(tests/ref_run.py).  Runs only in a container that has /root/reference; writes tests/golden/ref_runs.npz, which travels to the GPU
+box.  `python tests/make_ref_goldens.py` regenerates the file; tests/test_reference_code_runs.py checks that a regeneration
+reproduces the committed bytes."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O          # noqa: E402  (only for the warp maps of the rig case: geometry, not pixels)
+import ref_run as R             # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "ref_runs.npz")
+
+
+def cases():
+    rng = np.random.default_rng(20261004)
+    g = {}
+    # ---- cv::remap, 8-bit fixed-point bilinear (the warp and the lens undistort) -------------------------------------------------
+    src = rng.integers(0, 256, (61, 83, 3)).astype(np.uint8)
+    xm = rng.uniform(-9, 83 + 9, (45, 70)).astype(np.float32)
+    ym = rng.uniform(-9, 61 + 9, (45, 70)).astype(np.float32)
+    xm[0, :6] = [-1, 0, 82, 82.5, 83, -0.5]
+    ym[0, :6] = [-1, 0, 60, 60.5, 61, -0.5]
+    g["remap_src"], g["remap_xmap"], g["remap_ymap"] = src, xm, ym
+    xy, fxy = R.fixed_maps(xm, ym)
+    for border, name in ((2, "reflect"), (1, "replicate"), (4, "reflect101")):
+        g["remap_out_" + name] = R.run("remap_bilinear", src=src, xy=xy, fxy=fxy, border=np.array(border))["out"]
+    # BORDER_CONSTANT where every pixel keeps at least one tap inside (a pixel with none is filled through the C runtime's memcpy: not a leaf)
+    xc = rng.uniform(-0.95, 83 - 0.05, (61, 83)).astype(np.float32)
+    yc = rng.uniform(-0.95, 61 - 0.05, (61, 83)).astype(np.float32)
+    g["remapc_xy"], g["remapc_fxy"] = R.fixed_maps(xc, yc)
+    g["remapc_out"] = R.run("remap_bilinear", src=src, xy=g["remapc_xy"], fxy=g["remapc_fxy"], border=np.array(0))["out"]
+    gray = rng.integers(0, 256, (90, 120)).astype(np.uint8)
+    xg = rng.uniform(-30, 150, (70, 100)).astype(np.float32)
+    yg = rng.uniform(-30, 120, (70, 100)).astype(np.float32)
+    g["remapg_src"], g["remapg_xmap"], g["remapg_ymap"] = gray, xg, yg
+    a, b = R.fixed_maps(xg, yg)
+    g["remapg_out_reflect"] = R.run("remap_bilinear", src=gray, xy=a, fxy=b, border=np.array(2))["out"]
+    # a whole warp: a spherical camera of a small rig, the maps from the projector, the frame through the reference's remap with BORDER_REFLECT
+    K = np.array([[150.0, 0, 80.0], [0, 150.0, 45.0], [0, 0, 1]], np.float32)
+    yaw = np.deg2rad(25.0)
+    Rm = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]], np.float32)
+    frame = rng.integers(0, 256, (90, 160, 3)).astype(np.uint8)
+    roi, wx, wy = O.build_maps(1, 150.0, K, Rm, 160, 90)                # MO_WARP_SPHERICAL
+    g["warp_K"], g["warp_R"], g["warp_frame"], g["warp_roi"] = K, Rm, frame, np.array(roi)
+    a, b = R.fixed_maps(wx, wy)
+    g["warp_out"] = R.run("remap_bilinear", src=frame, xy=a, fxy=b, border=np.array(2))["out"]
+    # ---- the pyramids ------------------------------------------------------------------------------------------------------------
+    for i, (h, w) in enumerate(((40, 64), (37, 51), (5, 5), (2, 2), (3, 128))):
+        s = rng.integers(-3000, 3000, (h, w, 3)).astype(np.int16)
+        g["pd16_src_%d" % i], g["pd16_out_%d" % i] = s, R.run("pyr_down", src=s)["out"]
+    for i, (h, w) in enumerate(((20, 32), (19, 26), (4, 3), (1, 1))):
+        s = rng.integers(-3000, 3000, (h, w, 3)).astype(np.int16)
+        g["pu16_src_%d" % i], g["pu16_out_%d" % i] = s, R.run("pyr_up", src=s, dsize=np.array((2 * w, 2 * h)))["out"]
+    for i, (h, w) in enumerate(((40, 64), (33, 77), (12, 19), (2, 2))):
+        s = rng.uniform(0, 1, (h, w)).astype(np.float32)
+        s[rng.uniform(size=s.shape) < 0.3] = 1.0
+        g["pd32_src_%d" % i], g["pd32_out_%d" % i] = s, R.run("pyr_down", src=s)["out"]
+    s = rng.integers(0, 256, (31, 50, 3)).astype(np.uint8)
+    g["pd8_src"], g["pd8_out"] = s, R.run("pyr_down", src=s)["out"]
+    # ---- the blender's normalisation and the conversions -------------------------------------------------------------------------
+    w = rng.uniform(0, 4, (37, 53)).astype(np.float32)
+    w[:3] = 0
+    v = rng.integers(-32768, 32767, (37, 53, 3)).astype(np.int16)
+    g["norm_weight"], g["norm_src"], g["norm_out"] = w, v, R.run("normalize_32f", weight=w, src=v)["out"]
+    img = rng.integers(0, 256, (31, 47, 3)).astype(np.uint8)
+    g["gain_src"] = img
+    gains = np.array([1.0, 0.7312345, 1.2345678, 2.5, 0.999999, 1.5], np.float32)
+    g["gain_values"] = gains
+    for i, gv in enumerate(gains):
+        g["gain_out_%d" % i] = R.run("cvt_scale", src=img, scale=np.array(gv), shift=np.array(0.0), to_float=np.array(0))["out"]
+    m = rng.integers(0, 256, (20, 33)).astype(np.uint8)
+    m[:4] = 255
+    g["w255_src"] = m
+    g["w255_out"] = R.run("cvt_scale", src=m, scale=np.array(np.float32(1. / 255.)), shift=np.array(0.0), to_float=np.array(1))["out"]
+    return g
+
+
+if __name__ == "__main__":
+    if not R.available():
+        sys.exit("needs /root/reference (the shipped DLLs)")
+    np.savez_compressed(OUT, **cases())
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")

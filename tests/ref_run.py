@@ -108,7 +108,61 @@ def job_pyr_up(src, dsize):
     return {"out": d}
 
 
-JOBS = {"normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up}
+INIT_INTER_TAB_2D = 0x1800F7630        # static const void* initInterTab2D(int method, bool fixpt): called by cv::remap at 0x180106ee7
+REMAP_BILINEAR_8U = 0x1800FE9D0        # remapBilinear<FixedPtCast<int, uchar, 15>, RemapVec_8u, short>(src, dst, xy, fxy, wtab, borderType, borderValue)
+INIT_BILINEAR_TAB_IC4 = 0x1801A6AA0    # the DLL's own dynamic initializer of `BilinearTab_iC4 = alignPtr(buffer, 16)` (three instructions; the loader
+                                       # would have run it -- no DllMain runs here, so the job calls the one the path needs)
+INTER_LINEAR = 1
+
+
+def fixed_maps(xmap, ymap):
+    """float maps -> (CV_16SC2, CV_16UC1) as the loop inside cv::remap converts them (read off the binary, oracle/REFERENCE_BINARY_AUDIT.md:
+    x * 32 rounded to nearest even, & 31 into the table index, >> 5 saturated to short) -- the part of remap() this runner cannot call
+    (it sits between two allocations)"""
+    ix = np.rint(xmap.astype(np.float32) * np.float32(32)).astype(np.int64)
+    iy = np.rint(ymap.astype(np.float32) * np.float32(32)).astype(np.int64)
+    ix = np.where(np.isfinite(xmap) & (np.abs(ix) < 2 ** 31), ix, -2 ** 31)           # cvtps2dq's "integer indefinite"
+    iy = np.where(np.isfinite(ymap) & (np.abs(iy) < 2 ** 31), iy, -2 ** 31)
+    xy = np.stack([np.clip(ix >> 5, -32768, 32767), np.clip(iy >> 5, -32768, 32767)], axis=-1).astype(np.int16)
+    fxy = ((iy & 31) * 32 + (ix & 31)).astype(np.uint16)
+    return np.ascontiguousarray(xy), np.ascontiguousarray(fxy)
+
+
+def job_remap_bilinear(src, xy, fxy, border):
+    """the 8-bit fixed-point bilinear remap of opencv_imgproc2411.dll on CV_16SC2 + CV_16UC1 maps, with the DLL's own weight table"""
+    img = Image("imgproc")
+    s = np.ascontiguousarray(src, np.uint8)
+    m1, m2 = np.ascontiguousarray(xy, np.int16), np.ascontiguousarray(fxy, np.uint16)
+    d = np.zeros(m2.shape + s.shape[2:], np.uint8)
+    img.call(INIT_BILINEAR_TAB_IC4)
+    tab = img.call(INIT_INTER_TAB_2D, INTER_LINEAR, 1)
+    scalar = (C.c_double * 4)(0, 0, 0, 0)
+    ms, md, mxy, mf = mat(s), mat(d), mat(m1), mat(m2)
+    img.call(REMAP_BILINEAR_8U, C.addressof(ms), C.addressof(md), C.addressof(mxy), C.addressof(mf), tab, int(border), C.addressof(scalar))
+    return {"out": d}
+
+
+CVT_SCALE_8U8U = 0x18004E010           # cvtScale_<uchar, uchar, float>(src, sstep, dst, dstep, Size&, float scale, float shift)   (opencv_core2411.dll)
+CVT_SCALE_8U32F = 0x180052190          # cvtScale_<uchar, float, float>(...)
+
+
+def _f32bits(v):
+    return int(np.float32(v).view(np.uint32))
+
+
+def job_cvt_scale(src, scale, shift, to_float):
+    """Mat::convertTo(dst, type, scale, shift) for 8-bit sources: what `image *= gain` and `weight.convertTo(CV_32F, 1./255.)` run"""
+    img = Image("core")
+    s = np.ascontiguousarray(src, np.uint8)
+    s2 = s.reshape(s.shape[0], -1)
+    d = np.zeros(s2.shape, np.float32 if int(to_float) else np.uint8)
+    size = (C.c_int * 2)(s2.shape[1], s2.shape[0])                      # cv::Size {width, height}; the callee counts height down
+    img.call(CVT_SCALE_8U32F if int(to_float) else CVT_SCALE_8U8U, s2.ctypes.data, s2.strides[0], d.ctypes.data, d.strides[0],
+             C.addressof(size), _f32bits(float(scale)), _f32bits(float(shift)))
+    return {"out": d.reshape(s.shape)}
+
+
+JOBS = {"cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):

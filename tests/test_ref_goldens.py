@@ -1,0 +1,68 @@
+"""The oracle -- and on a GPU the HIP engine -- against golden vectors computed BY THE REFERENCE ITSELF: tests/golden/ref_runs.npz holds
+inputs made here and the outputs the reference's shipped x64 machine code returned for them when run in place (tests/ref_run.py,
+tests/make_ref_goldens.py; generated in the container that has /root/reference).  This file needs no reference tree: it runs on the
+GPU box too."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_runs.npz")
+
+
+@pytest.fixture(scope="module")
+def g():
+    with np.load(G) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _bits(a):
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def test_oracle_remap_is_the_references(g):
+    for name, border in (("reflect", 2), ("replicate", 1), ("reflect101", 4)):
+        assert np.array_equal(O.remap(g["remap_src"], g["remap_xmap"], g["remap_ymap"], 1, border), g["remap_out_" + name]), name
+    assert np.array_equal(O.remap_fixed(g["remap_src"], g["remapc_xy"], g["remapc_fxy"]), g["remapc_out"])            # BORDER_CONSTANT, CV_16SC2 maps
+    assert np.array_equal(O.remap(g["remapg_src"], g["remapg_xmap"], g["remapg_ymap"], 1, 2), g["remapg_out_reflect"])  # one channel
+    roi, wx, wy = O.build_maps(1, 150.0, g["warp_K"], g["warp_R"], 160, 90)
+    assert tuple(roi) == tuple(g["warp_roi"])
+    assert np.array_equal(O.remap(g["warp_frame"], wx, wy, 1, 2), g["warp_out"])
+
+
+def test_oracle_pyramids_are_the_references(g):
+    for i in range(5):
+        assert np.array_equal(O.pyr_down_16s(g["pd16_src_%d" % i]), g["pd16_out_%d" % i]), i
+    for i in range(4):
+        assert np.array_equal(O.pyr_up_16s(g["pu16_src_%d" % i]), g["pu16_out_%d" % i]), i
+        assert np.array_equal(_bits(O.pyr_down_32f(g["pd32_src_%d" % i])), _bits(g["pd32_out_%d" % i])), i
+
+
+def test_oracle_normalise_and_conversions_are_the_references(g):
+    v = g["norm_src"].copy()
+    w = np.ascontiguousarray(g["norm_weight"])
+    O.lib().mo_normalize_using_weight_map_32f(w.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), w.shape[1], w.shape[0])
+    assert np.array_equal(v, g["norm_out"])
+    for i, gv in enumerate(g["gain_values"]):
+        assert np.array_equal(O.gain_apply(g["gain_src"].copy(), float(gv)), g["gain_out_%d" % i]), float(gv)
+    m = g["w255_src"]
+    assert np.array_equal(_bits((m.astype(np.float32) * np.float32(1. / 255.)).astype(np.float32)), _bits(g["w255_out"]))
+    assert (g["w255_out"][m == 255] == 1.0).all()                      # a full mask weighs exactly 1.0f
+
+
+@pytest.mark.gpu
+def test_engine_stages_are_the_references(g):
+    """The HIP stage-level entry points on the reference's own outputs: the warp of a whole camera (maps from the projector, BORDER_REFLECT),
+    the fixed-point-map remap of the lens undistort (BORDER_CONSTANT) and the scalar gain apply."""
+    import stitchingvideo_amd as S
+    from stitchingvideo_amd import capi
+    corner, out = S.SphericalWarper(150.0).warp(g["warp_frame"], g["warp_K"], g["warp_R"], capi.INTER_LINEAR, capi.BORDER_REFLECT)
+    assert tuple(corner) == tuple(g["warp_roi"][:2]) and np.array_equal(out, g["warp_out"])
+    assert np.array_equal(S.remap_fixed(g["remap_src"], g["remapc_xy"], g["remapc_fxy"]), g["remapc_out"])
+    for i, gv in enumerate(g["gain_values"]):
+        img = g["gain_src"].copy()
+        S.GainCompensator([float(gv)]).apply(0, (0, 0), img, None)
+        assert np.array_equal(img, g["gain_out_%d" % i]), float(gv)

@@ -1,0 +1,82 @@
+"""The reference's shipped x64 machine code, RUN in place, against the oracle (tests/ref_run.py; oracle/ref_run/pe_run.c): fresh random
+inputs every primitive the runner can reach without an import, and the committed golden file regenerated bit for bit.  Needs
+/root/reference: skipped on the GPU box, where tests/test_ref_goldens.py checks the committed vectors instead."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O          # noqa: E402
+import ref_run as R             # noqa: E402
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="needs the reference tree (/root/reference): its DLLs are run in place")
+
+
+def test_goldens_regenerate_bit_for_bit():
+    import make_ref_goldens as M
+    fresh = M.cases()
+    with np.load(M.OUT) as z:
+        assert sorted(z.files) == sorted(fresh)
+        for k in z.files:
+            assert fresh[k].dtype == z[k].dtype and np.array_equal(fresh[k].view(np.uint8), z[k].view(np.uint8)), k
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_remap_runs_equal_the_oracle(seed):
+    rng = np.random.default_rng(seed)
+    sh, sw = int(rng.integers(20, 90)), int(rng.integers(20, 120))
+    cn = (3, 1)[seed % 2]
+    src = rng.integers(0, 256, (sh, sw) + ((3,) if cn == 3 else ())).astype(np.uint8)
+    dh, dw = int(rng.integers(10, 80)), int(rng.integers(10, 100))
+    xm = rng.uniform(-sw * 0.6, sw * 1.6, (dh, dw)).astype(np.float32)          # far outside: several reflections deep
+    ym = rng.uniform(-sh * 0.6, sh * 1.6, (dh, dw)).astype(np.float32)
+    xy, fxy = R.fixed_maps(xm, ym)
+    for border in (2, 1, 4):
+        out = R.run("remap_bilinear", src=src, xy=xy, fxy=fxy, border=np.array(border))["out"]
+        assert np.array_equal(out, O.remap(src, xm, ym, 1, border)), border
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_pyramid_runs_equal_the_oracle(seed):
+    rng = np.random.default_rng(100 + seed)
+    h, w = int(rng.integers(2, 60)), int(rng.integers(2, 126))
+    s16 = rng.integers(-32768, 32767, (h, w, 3)).astype(np.int16)                # full range: the casts saturate nowhere, they wrap nowhere
+    assert np.array_equal(R.run("pyr_down", src=s16)["out"], O.pyr_down_16s(s16))
+    hu, wu = (h + 1) // 2, min((w + 1) // 2, 54)             # (pyrUp's row buffers stay on cv::AutoBuffer's stack up to 111 destination pixels)
+    u16 = rng.integers(-8000, 8000, (hu, wu, 3)).astype(np.int16)
+    assert np.array_equal(R.run("pyr_up", src=u16, dsize=np.array((2 * wu, 2 * hu)))["out"], O.pyr_up_16s(u16))
+    f = rng.uniform(0, 1, (h, w)).astype(np.float32)
+    assert np.array_equal(R.run("pyr_down", src=f)["out"].view(np.uint32), O.pyr_down_32f(f).view(np.uint32))
+
+
+def test_float_pyrdown_scalar_loops_alone_differ_from_the_sse_bodies():
+    """PE_RUN_NO_SSE=1 answers cv::checkHardwareSupport with "no": the reference's scalar loops then process every column, and the last
+    bits move -- the association the audit read off the SSE body is real, and the oracle follows the SSE build."""
+    rng = np.random.default_rng(7)
+    f = rng.uniform(0, 1, (40, 64)).astype(np.float32)
+    sse = R.run("pyr_down", src=f)["out"]
+    os.environ["PE_RUN_NO_SSE"] = "1"
+    try:
+        scalar = R.run("pyr_down", src=f)["out"]
+    finally:
+        del os.environ["PE_RUN_NO_SSE"]
+    assert np.array_equal(sse.view(np.uint32), O.pyr_down_32f(f).view(np.uint32))
+    assert np.abs(sse - scalar).max() < 1e-6 and not np.array_equal(sse.view(np.uint32), scalar.view(np.uint32))
+
+
+def test_normalise_and_conversion_runs_equal_the_oracle():
+    rng = np.random.default_rng(11)
+    w = rng.uniform(0, 6, (29, 41)).astype(np.float32)
+    w[rng.uniform(size=w.shape) < 0.1] = 0
+    v = rng.integers(-32768, 32767, (29, 41, 3)).astype(np.int16)
+    exp = v.copy()
+    O.lib().mo_normalize_using_weight_map_32f(w.ctypes.data_as(C.c_void_p), exp.ctypes.data_as(C.c_void_p), 41, 29)
+    assert np.array_equal(R.run("normalize_32f", weight=w, src=v)["out"], exp)
+    img = rng.integers(0, 256, (17, 23, 3)).astype(np.uint8)
+    for gv in rng.uniform(0.3, 3.0, 6).astype(np.float32):
+        out = R.run("cvt_scale", src=img, scale=np.array(gv), shift=np.array(0.0), to_float=np.array(0))["out"]
+        assert np.array_equal(out, O.gain_apply(img.copy(), float(gv))), float(gv)
