@@ -59,8 +59,6 @@ def cases():
         s = rng.uniform(0, 1, (h, w)).astype(np.float32)
         s[rng.uniform(size=s.shape) < 0.3] = 1.0
         g["pd32_src_%d" % i], g["pd32_out_%d" % i] = s, R.run("pyr_down", src=s)["out"]
-    s = rng.integers(0, 256, (31, 50, 3)).astype(np.uint8)
-    g["pd8_src"], g["pd8_out"] = s, R.run("pyr_down", src=s)["out"]
     # ---- the blender's normalisation and the conversions -------------------------------------------------------------------------
     w = rng.uniform(0, 4, (37, 53)).astype(np.float32)
     w[:3] = 0
@@ -76,6 +74,15 @@ def cases():
     m[:4] = 255
     g["w255_src"] = m
     g["w255_out"] = R.run("cvt_scale", src=m, scale=np.array(np.float32(1. / 255.)), shift=np.array(0.0), to_float=np.array(1))["out"]
+    # ---- calibration-side and ingest primitives -----------------------------------------------------------------------------------
+    for i, ((h, w), p) in enumerate((((40, 64), 0.02), ((37, 51), 0.2), ((120, 200), 0.001), ((30, 30), None), ((12, 9), 2.0))):
+        m = (rng.uniform(size=(h, w)) > (p or 0)).astype(np.uint8) * 255
+        if p is None:
+            m[0, 0] = 0                                                  # one zero in a corner: the longest chamfer paths
+        g["dist_mask_%d" % i], g["dist_out_%d" % i] = m, R.run("distance_l1", mask=m)["out"]     # (p = 2: no zero at all)
+    yuv = rng.integers(0, 256, (36, 40)).astype(np.uint8)                # a 40 x 24 NV12 frame, full-range bytes (clamps on both sides)
+    g["nv12_src"] = yuv
+    g["nv12_out"] = R.run("nv12", yuv=yuv, fn=np.array(R.NV12_TO_BGR))["out"]
     return g
 
 

@@ -162,7 +162,47 @@ def job_cvt_scale(src, scale, shift, to_float):
     return {"out": d.reshape(s.shape)}
 
 
-JOBS = {"cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
+DIST_3X3 = 0x1800518C0                 # icvDistanceTransform_3x3_C1R(src, srcstep, temp, tempstep, dist, diststep, CvSize, metrics): cvDistTransform's
+DIST_MASK = 0x180051680                # function pointer for a 3 x 3 mask without labels; icvGetDistanceTransformMask(type, metrics)
+
+
+def job_distance_l1(mask):
+    """distanceTransform(mask, CV_DIST_L1, 3) as cvDistTransform runs it: the metrics from the DLL's own table (type 31 = L1 + 3 x 3 * 10),
+    a (h + 2) x (w + 2) CV_32S work buffer, the 3 x 3 chamfer kernel"""
+    img = Image("imgproc")
+    m = np.ascontiguousarray(mask, np.uint8)
+    h, w = m.shape
+    metrics = (C.c_float * 4)()
+    assert img.call(DIST_MASK, 31, C.addressof(metrics)) & 0xFFFFFFFF == 0
+    temp = np.zeros((h + 2, w + 2), np.int32)
+    dist = np.zeros((h, w), np.float32)
+    img.call(DIST_3X3, m.ctypes.data, m.strides[0], temp.ctypes.data, temp.strides[0], dist.ctypes.data, dist.strides[0], w | (h << 32),
+             C.addressof(metrics))
+    return {"out": dist, "metrics": np.array(list(metrics)[:2], np.float32)}
+
+
+NV12_TO_BGR = 0x180020180              # YUV420sp2RGB888Invoker<0, 0>::operator(): bIdx 0 (BGR), uIdx 0 (NV12) -- the first of the four instantiations
+                                       # cvtColor's switch(dcn * 100 + bIdx * 10 + uIdx) picks from (0x180020540 <0,1>, 0x180020900 <2,0>, 0x180020cc0 <2,1>)
+
+
+class _Nv12Invoker(C.Structure):       # YUV420sp2RGB888Invoker<bIdx, uIdx> : ParallelLoopBody  (vptr unused by operator())
+    _fields_ = [("vptr", C.c_void_p), ("dst", C.c_void_p), ("my1", C.c_void_p), ("muv", C.c_void_p), ("width", C.c_int), ("stride", C.c_int)]
+
+
+def job_nv12(yuv, fn):
+    """one of the YUV420sp2RGB888Invoker<bIdx, uIdx>::operator()(const Range&) instantiations (fn = its address) over all row pairs"""
+    img = Image("imgproc")
+    y = np.ascontiguousarray(yuv, np.uint8)
+    h, w = y.shape[0] * 2 // 3, y.shape[1]
+    d = np.zeros((h, w, 3), np.uint8)
+    md = mat(d)
+    inv = _Nv12Invoker(None, C.addressof(md), y.ctypes.data, y.ctypes.data + h * y.strides[0], w, y.strides[0])
+    rng = (C.c_int * 2)(0, h // 2)
+    img.call(int(fn), C.addressof(inv), C.addressof(rng))
+    return {"out": d}
+
+
+JOBS = {"nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):

@@ -53,6 +53,12 @@ def test_oracle_normalise_and_conversions_are_the_references(g):
     assert (g["w255_out"][m == 255] == 1.0).all()                      # a full mask weighs exactly 1.0f
 
 
+def test_oracle_distance_transform_and_nv12_are_the_references(g):
+    for i in range(5):
+        assert np.array_equal(_bits(O.distance_transform_l1(g["dist_mask_%d" % i])), _bits(g["dist_out_%d" % i])), i
+    assert np.array_equal(O.cvt_nv12_bgr(g["nv12_src"]), g["nv12_out"])
+
+
 @pytest.mark.gpu
 def test_engine_stages_are_the_references(g):
     """The HIP stage-level entry points on the reference's own outputs: the warp of a whole camera (maps from the projector, BORDER_REFLECT),
@@ -66,3 +72,4 @@ def test_engine_stages_are_the_references(g):
         img = g["gain_src"].copy()
         S.GainCompensator([float(gv)]).apply(0, (0, 0), img, None)
         assert np.array_equal(img, g["gain_out_%d" % i]), float(gv)
+    assert np.array_equal(S.cvt_nv12_bgr(g["nv12_src"]), g["nv12_out"])
