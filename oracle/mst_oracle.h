@@ -7,7 +7,11 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
  * library; the product (libmi355stitch.so) never links or calls it.
  *
- * PARITY STATUS: "parity unpinned" -- the reference ships no tests, no golden
+ * PARITY STATUS (round 5): PINNED for remap (8-bit bilinear, every border mode), pyrDown / pyrUp (16S), pyrDown (32F),
+ * normalizeUsingWeightMap, cvtScale (gain apply, mask -> weight), distanceTransform (L1, 3 x 3) and the NV12 conversion against
+ * OUTPUTS OF THE REFERENCE ITSELF: its shipped x64 DLLs are run in place (oracle/ref_run/pe_run.c, tests/ref_run.py) and the
+ * results committed as tests/golden/ref_runs.npz; everything below that is not in that list stays as it was:
+ * "parity unpinned" -- the reference ships no tests, no golden
  * vectors and no source for OpenCV 2.4.11 imgproc/core (Windows DLLs only), and
  * cannot be compiled or run in this image.  Reference-owned
  * loops (the .cpp files under R64/src) are followed line by line and cited below; the
