@@ -202,7 +202,17 @@ def job_nv12(yuv, fn):
     return {"out": d}
 
 
-JOBS = {"nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
+BORDER_INTERPOLATE = 0x1800662F0       # cv::borderInterpolate(int p, int len, int borderType), an export
+
+
+def job_border_interpolate(p, length, border):
+    img = Image("imgproc")
+    out = np.array([C.c_int32(img.call(BORDER_INTERPOLATE, int(a), int(b), int(c)) & 0xFFFFFFFF).value
+                    for a, b, c in zip(p.ravel(), length.ravel(), border.ravel())], np.int32)
+    return {"out": out.reshape(p.shape)}
+
+
+JOBS = {"border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):

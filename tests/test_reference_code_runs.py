@@ -80,3 +80,25 @@ def test_normalise_and_conversion_runs_equal_the_oracle():
     for gv in rng.uniform(0.3, 3.0, 6).astype(np.float32):
         out = R.run("cvt_scale", src=img, scale=np.array(gv), shift=np.array(0.0), to_float=np.array(0))["out"]
         assert np.array_equal(out, O.gain_apply(img.copy(), float(gv))), float(gv)
+
+
+def test_border_interpolate_runs_equal_the_oracle():
+    """cv::borderInterpolate (an export): REPLICATE, REFLECT, WRAP and REFLECT_101 for lengths 1 .. 8 and positions several lengths outside"""
+    ps, ls, bs = [], [], []
+    for b in (1, 2, 3, 4):
+        for n in range(1, 9):
+            for p in range(-3 * n - 2, 4 * n + 3):
+                ps.append(p); ls.append(n); bs.append(b)
+    ps, ls, bs = (np.array(a, np.int32) for a in (ps, ls, bs))
+    out = R.run("border_interpolate", p=ps, length=ls, border=bs)["out"]
+    exp = np.array([O.lib().mo_border_interpolate(int(a), int(b), int(c)) for a, b, c in zip(ps, ls, bs)], np.int32)
+    assert np.array_equal(out, exp)
+
+
+def test_distance_transform_and_nv12_runs_equal_the_oracle():
+    rng = np.random.default_rng(21)
+    for p in (0.01, 0.3, 2.0):
+        m = (rng.uniform(size=(33, 47)) > p).astype(np.uint8) * 255
+        assert np.array_equal(R.run("distance_l1", mask=m)["out"].view(np.uint32), O.distance_transform_l1(m).view(np.uint32)), p
+    yuv = rng.integers(0, 256, (30, 36)).astype(np.uint8)
+    assert np.array_equal(R.run("nv12", yuv=yuv, fn=np.array(R.NV12_TO_BGR))["out"], O.cvt_nv12_bgr(yuv))
