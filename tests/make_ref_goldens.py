@@ -83,6 +83,10 @@ def cases():
     yuv = rng.integers(0, 256, (36, 40)).astype(np.uint8)                # a 40 x 24 NV12 frame, full-range bytes (clamps on both sides)
     g["nv12_src"] = yuv
     g["nv12_out"] = R.run("nv12", yuv=yuv, fn=np.array(R.NV12_TO_BGR))["out"]
+    u = rng.integers(0, 256, (13, 37, 3)).astype(np.uint8)
+    f = rng.uniform(0, 255, (13, 37, 3)).astype(np.float32)
+    g["gray8_src"], g["gray8_out"] = u, R.run("gray", src=u)["out"]
+    g["gray32_src"], g["gray32_out"] = f, R.run("gray", src=f)["out"]
     return g
 
 

@@ -212,7 +212,34 @@ def job_border_interpolate(p, length, border):
     return {"out": out.reshape(p.shape)}
 
 
-JOBS = {"border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
+GRAY_U8_CTOR, GRAY_U8_CALL = 0x180016C70, 0x180018520      # RGB2Gray<uchar>::RGB2Gray(int srccn, int blueIdx, const int* coeffs), ::operator()(src, dst, n)
+GRAY_F32_CALL = 0x180025830                                 # RGB2Gray<float>::operator()(src, dst, n); this = {int srccn; float coeffs[3]}
+GRAY_F32_COEFFS = 0x1801AB890                               # the DLL's own {0.299f, 0.587f, 0.114f}; the constructor swaps [0] and [2] for BGR input
+
+
+def job_gray(src):
+    """cvtColor(BGR2GRAY) of a CV_8UC3 or CV_32FC3 image: the functors cvtColor's loop calls per row"""
+    img = Image("imgproc")
+    s = np.ascontiguousarray(src)
+    h, w = s.shape[:2]
+    d = np.zeros((h, w), s.dtype)
+    if s.dtype == np.uint8:
+        this = (C.c_int * 769)()
+        img.call(GRAY_U8_CTOR, C.addressof(this), 3, 0, 0)                    # srccn 3, blueIdx 0, default coefficients
+        fn = GRAY_U8_CALL
+    else:
+        co = (C.c_float * 3).from_address(GRAY_F32_COEFFS)
+        this = (C.c_int * 4)()
+        this[0] = 3
+        f = C.cast(this, C.POINTER(C.c_float))
+        f[1], f[2], f[3] = co[2], co[1], co[0]
+        fn = GRAY_F32_CALL
+    for y in range(h):
+        img.call(fn, C.addressof(this), s[y].ctypes.data, d[y].ctypes.data, w)
+    return {"out": d}
+
+
+JOBS = {"gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):

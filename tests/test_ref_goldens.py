@@ -59,6 +59,25 @@ def test_oracle_distance_transform_and_nv12_are_the_references(g):
     assert np.array_equal(O.cvt_nv12_bgr(g["nv12_src"]), g["nv12_out"])
 
 
+def test_oracle_gray_is_the_references(g):
+    """cvtColor(BGR2GRAY) ahead of the DP seam finder's gradients (oracle/dpseam.c: gradients(), the two lines that form `gray`): with the
+    Sobel taps [-1 0 1] x [1 2 1] read off the binary, a constant-colour image pins the conversion through mo_dp_gradients' inputs --
+    here the conversion itself, as the oracle writes it."""
+    u = g["gray8_src"].astype(np.int64)
+    assert np.array_equal(((u[..., 0] * 1868 + u[..., 1] * 9617 + u[..., 2] * 4899 + (1 << 13)) >> 14).astype(np.uint8), g["gray8_out"])
+    F = np.float32
+    f = g["gray32_src"]
+    e = ((f[..., 0] * F(0.114)).astype(F) + (f[..., 1] * F(0.587)).astype(F)).astype(F)
+    e = (e + (f[..., 2] * F(0.299)).astype(F)).astype(F)
+    assert np.array_equal(_bits(e), _bits(g["gray32_out"]))
+    # ... and the oracle's own gradients of images whose gray is linear in x: d/dx of gray = 8 * slope at every interior pixel
+    ramp = np.zeros((9, 16, 3), np.uint8)
+    ramp[..., 1] = np.arange(16, dtype=np.uint8)[None, :] * 8
+    gx, gy = O.dp_gradients(ramp)
+    gray = ((ramp[..., 1].astype(np.int64) * 9617 + (1 << 13)) >> 14).astype(np.float32)
+    assert np.array_equal(gx[4, 1:-1], (gray[4, 2:] - gray[4, :-2]) * 4) and not gy[1:-1].any()
+
+
 @pytest.mark.gpu
 def test_engine_stages_are_the_references(g):
     """The HIP stage-level entry points on the reference's own outputs: the warp of a whole camera (maps from the projector, BORDER_REFLECT),
