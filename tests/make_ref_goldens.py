@@ -64,6 +64,10 @@ def cases():
     w[:3] = 0
     v = rng.integers(-32768, 32767, (37, 53, 3)).astype(np.int16)
     g["norm_weight"], g["norm_src"], g["norm_out"] = w, v, R.run("normalize_32f", weight=w, src=v)["out"]
+    w16 = rng.integers(0, 1200, (23, 31)).astype(np.int16)                # MultiBandBlender(weight_type = CV_16S): weights * 256, sums up to a few cameras
+    w16[:2] = 0
+    v16 = rng.integers(-32768, 32767, (23, 31, 3)).astype(np.int16)
+    g["norm16_weight"], g["norm16_src"], g["norm16_out"] = w16, v16, R.run("normalize_32f", weight=w16, src=v16)["out"]
     img = rng.integers(0, 256, (31, 47, 3)).astype(np.uint8)
     g["gain_src"] = img
     gains = np.array([1.0, 0.7312345, 1.2345678, 2.5, 0.999999, 1.5], np.float32)

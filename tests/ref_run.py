@@ -74,7 +74,8 @@ class Image:
 def job_normalize_32f(weight, src):
     """cv::detail::normalizeUsingWeightMap(const Mat& weight, Mat& src), opencv_stitching2411.dll export at 0x1800087d0"""
     img = Image("stitching")
-    w, s = np.ascontiguousarray(weight, np.float32), np.ascontiguousarray(src, np.int16).copy()
+    w = np.ascontiguousarray(weight, np.int16 if weight.dtype == np.int16 else np.float32)      # (CV_16S weights: the `(v << 8) / (w + 1)` branch)
+    s = np.ascontiguousarray(src, np.int16).copy()
     mw, ms = mat(w), mat(s)
     img.call(0x1800087D0, C.addressof(mw), C.addressof(ms))
     return {"out": s}

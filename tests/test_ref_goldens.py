@@ -46,6 +46,10 @@ def test_oracle_normalise_and_conversions_are_the_references(g):
     w = np.ascontiguousarray(g["norm_weight"])
     O.lib().mo_normalize_using_weight_map_32f(w.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), w.shape[1], w.shape[0])
     assert np.array_equal(v, g["norm_out"])
+    v, w = g["norm16_src"].copy(), np.ascontiguousarray(g["norm16_weight"])           # the CV_16S weight form: (v << 8) / (w + 1)
+    O.lib().mo_normalize_using_weight_map_16s.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    O.lib().mo_normalize_using_weight_map_16s(w.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), w.shape[1], w.shape[0])
+    assert np.array_equal(v, g["norm16_out"])
     for i, gv in enumerate(g["gain_values"]):
         assert np.array_equal(O.gain_apply(g["gain_src"].copy(), float(gv)), g["gain_out_%d" % i]), float(gv)
     m = g["w255_src"]
