@@ -102,3 +102,15 @@ def test_distance_transform_and_nv12_runs_equal_the_oracle():
         assert np.array_equal(R.run("distance_l1", mask=m)["out"].view(np.uint32), O.distance_transform_l1(m).view(np.uint32)), p
     yuv = rng.integers(0, 256, (30, 36)).astype(np.uint8)
     assert np.array_equal(R.run("nv12", yuv=yuv, fn=np.array(R.NV12_TO_BGR))["out"], O.cvt_nv12_bgr(yuv))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 5), (5, 1), (2, 2)])
+def test_remap_runs_on_degenerate_sources(shape):
+    """one-pixel and one-row sources under maps seven pixels outside: every tap is a reflection of a reflection"""
+    rng = np.random.default_rng(shape[0] * 10 + shape[1])
+    src = rng.integers(0, 256, shape + (3,)).astype(np.uint8)
+    xm = rng.uniform(-7, shape[1] + 7, (11, 13)).astype(np.float32)
+    ym = rng.uniform(-7, shape[0] + 7, (11, 13)).astype(np.float32)
+    xy, fxy = R.fixed_maps(xm, ym)
+    for border in (2, 1, 4):
+        assert np.array_equal(R.run("remap_bilinear", src=src, xy=xy, fxy=fxy, border=np.array(border))["out"], O.remap(src, xm, ym, 1, border)), border
