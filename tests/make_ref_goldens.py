@@ -91,6 +91,15 @@ def cases():
     f = rng.uniform(0, 255, (13, 37, 3)).astype(np.float32)
     g["gray8_src"], g["gray8_out"] = u, R.run("gray", src=u)["out"]
     g["gray32_src"], g["gray32_out"] = f, R.run("gray", src=f)["out"]
+    # Sobel(CV_32F, ksize 3) of the gray image above widths of every residue mod 8, and the block-gain smoothing
+    for i, (h, w) in enumerate(((9, 13), (7, 8), (5, 23), (4, 9), (12, 16), (3, 1), (8, 31))):
+        im = rng.uniform(0, 255, (h, w, 3)).astype(np.float32)
+        gray = R.run("gray", src=im)["out"]
+        r = R.run("sobel32f", gray=gray)
+        g["sobel_src_%d" % i], g["sobel_gx_%d" % i], g["sobel_gy_%d" % i] = im, r["gx"], r["gy"]
+    for i, (h, w) in enumerate(((32, 52), (7, 9), (3, 3), (1, 5))):
+        m = rng.uniform(0.7, 1.4, (h, w)).astype(np.float32)
+        g["smooth_src_%d" % i], g["smooth_out_%d" % i] = m, R.run("smooth3", src=m)["out"]
     return g
 
 

@@ -240,7 +240,83 @@ def job_gray(src):
     return {"out": d}
 
 
-JOBS = {"gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
+ROW_FILTER_32F = 0x180069F40           # SymmRowSmallFilter<float, float, SymmRowSmallVec_32f>::operator()(src, dst, width, cn)
+COL_FILTER_32F = 0x180080010           # SymmColumnSmallFilter<Cast<float, float>, SymmColumnSmallVec_32f>::operator()(src rows, dst, dststep, count, width)
+
+
+def _kernel_mat(k):
+    k = np.ascontiguousarray(k, np.float32).reshape(1, -1)
+    return k, mat(k)
+
+
+def _row_filter(k, symmetry):
+    """the object as BaseRowFilter lays it out: ksize +8, anchor +0xc, Mat kernel +0x10, vecOp {Mat kernel; int symmetryType} +0x70, symmetryType +0xd8"""
+    buf = (C.c_uint8 * 0x100)()
+    base = C.addressof(buf)
+    kk, km = _kernel_mat(k)
+    C.c_int.from_address(base + 0x8).value = kk.size
+    C.c_int.from_address(base + 0xC).value = kk.size // 2
+    C.memmove(base + 0x10, C.addressof(km), C.sizeof(Mat))
+    C.memmove(base + 0x70, C.addressof(km), C.sizeof(Mat))
+    C.c_int.from_address(base + 0xD0).value = symmetry
+    C.c_int.from_address(base + 0xD8).value = symmetry
+    return buf, kk
+
+
+def _col_filter(k, symmetry, delta=0.0):
+    """ksize +8, anchor +0xc, Mat kernel +0x10, vecOp {int symmetryType; float delta; Mat kernel} +0x78, delta +0xe0, symmetryType +0xe8"""
+    buf = (C.c_uint8 * 0x100)()
+    base = C.addressof(buf)
+    kk, km = _kernel_mat(k)
+    C.c_int.from_address(base + 0x8).value = kk.size
+    C.c_int.from_address(base + 0xC).value = kk.size // 2
+    C.memmove(base + 0x10, C.addressof(km), C.sizeof(Mat))
+    C.c_int.from_address(base + 0x78).value = symmetry
+    C.c_float.from_address(base + 0x7C).value = delta
+    C.memmove(base + 0x80, C.addressof(km), C.sizeof(Mat))
+    C.c_float.from_address(base + 0xE0).value = delta
+    C.c_int.from_address(base + 0xE8).value = symmetry
+    return buf, kk
+
+
+def _sep_filter_3(img, gray, kx, sx, ky, sy):
+    """a 3-tap separable filter over a CV_32FC1 image with BORDER_REFLECT_101, the way FilterEngine feeds its row and column filters:
+    every row with one mirrored pixel on either side through the row filter, then windows of three rows through the column filter"""
+    h, w = gray.shape
+    r101 = lambda p, n: 0 if n == 1 else (-p if p < 0 else (2 * n - 2 - p if p >= n else p))      # noqa: E731
+    rowf, keep1 = _row_filter(kx, sx)
+    colf, keep2 = _col_filter(ky, sy)
+    pitch = (w + 3) // 4 * 4 + 4                                           # FilterEngine's row buffers: every row 16-byte aligned (the SSE bodies store with movaps)
+    raw = np.zeros(h * pitch + 8, np.float32)
+    off = (-raw.ctypes.data // 4) % 4
+    tmp = raw[off:off + h * pitch].reshape(h, pitch)[:, :w]
+    assert tmp.ctypes.data % 16 == 0
+    for y in range(h):
+        padded = np.ascontiguousarray(np.concatenate([[gray[y, r101(-1, w)]], gray[y], [gray[y, r101(w, w)]]]).astype(np.float32))
+        img.call(ROW_FILTER_32F, C.addressof(rowf), padded.ctypes.data, tmp[y].ctypes.data, w, 1)
+    rows = (C.c_void_p * (h + 2))(*[tmp[r101(y, h)].ctypes.data for y in range(-1, h + 1)])
+    out = np.zeros((h, w), np.float32)
+    img.call(COL_FILTER_32F, C.addressof(colf), C.addressof(rows), out.ctypes.data, out.strides[0], h, w)
+    return out
+
+
+def job_sobel32f(gray):
+    """Sobel(gray, CV_32F, 1, 0) and (0, 1), ksize 3, on a CV_32FC1 image: getDerivKernels' [-1 0 1] and [1 2 1] through the DLL's own
+    row and column filter objects (kernel types as getKernelType reports them: 2 = asymmetrical, 1 = symmetrical)"""
+    img = Image("imgproc")
+    g = np.ascontiguousarray(gray, np.float32)
+    gx = _sep_filter_3(img, g, [-1, 0, 1], 2, [1, 2, 1], 1)
+    gy = _sep_filter_3(img, g, [1, 2, 1], 1, [-1, 0, 1], 2)
+    return {"gx": gx, "gy": gy}
+
+
+def job_smooth3(src):
+    """sepFilter2D(m, m, CV_32F, [.25 .5 .25], [.25 .5 .25]): the block-gain maps' smoothing (exposure_compensate.cpp:207-220)"""
+    img = Image("imgproc")
+    return {"out": _sep_filter_3(img, np.ascontiguousarray(src, np.float32), [0.25, 0.5, 0.25], 1, [0.25, 0.5, 0.25], 1)}
+
+
+JOBS = {"sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):

@@ -82,6 +82,20 @@ def test_oracle_gray_is_the_references(g):
     assert np.array_equal(gx[4, 1:-1], (gray[4, 2:] - gray[4, :-2]) * 4) and not gy[1:-1].any()
 
 
+def test_oracle_float_sobel_and_gain_smoothing_are_the_references(g):
+    """Sobel(CV_32F, ksize 3) through the DLL's own row / column filter objects, widths of every residue mod 8 (the SSE bodies, the
+    scalar pairs, the tails): oracle/dpseam.c's position-dependent sums, confirmed by execution; and sepFilter2D([.25 .5 .25]) of the
+    block-gain maps."""
+    for i in range(7):
+        gx, gy = O.dp_gradients(g["sobel_src_%d" % i])
+        assert np.array_equal(_bits(gx), _bits(g["sobel_gx_%d" % i])) and np.array_equal(_bits(gy), _bits(g["sobel_gy_%d" % i])), i
+    O.lib().mo_smooth_gain_map.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    for i in range(4):
+        m = g["smooth_src_%d" % i].copy()
+        O.lib().mo_smooth_gain_map(m.ctypes.data_as(C.c_void_p), m.shape[1], m.shape[0])
+        assert np.array_equal(_bits(m), _bits(g["smooth_out_%d" % i])), i
+
+
 @pytest.mark.gpu
 def test_engine_stages_are_the_references(g):
     """The HIP stage-level entry points on the reference's own outputs: the warp of a whole camera (maps from the projector, BORDER_REFLECT),
