@@ -39,14 +39,17 @@ void mo_camera_K(double focal, double aspect, double ppx, double ppy, float K[9]
         K[i] = (float)k[i];
 }
 
-/* cv::invert, DECOMP_LU, 3x3 CV_32F: determinant in float arithmetic (the det3
- * macro multiplies float operands), cofactors in double, scaled by 1/det. */
+/* cv::invert, DECOMP_LU, 3x3 CV_32F: determinant AND cofactors in double, scaled by 1/det.
+ * Round 5, read off the shipped opencv_core2411.dll (0x1800af63f-0x1800af728: every operand through cvtps2pd, mulsd / subsd / addsd,
+ * then divsd): det3 is ((m11 m22 - m12 m21) m00 - (m10 m22 - m12 m20) m01) + (m10 m21 - m11 m20) m02 in DOUBLE -- 2.4.11's macro casts
+ * its inner products to double.  The first statement of this function (rounds 1-4) had the determinant in float: corrected. */
 void mo_invert3x3_32f(const float m[9], float out[9], int *ok)
 {
 #define Sf(y, x) m[(y) * 3 + (x)]
-    double d = Sf(0,0) * (Sf(1,1) * Sf(2,2) - Sf(1,2) * Sf(2,1)) -
-               Sf(0,1) * (Sf(1,0) * Sf(2,2) - Sf(1,2) * Sf(2,0)) +
-               Sf(0,2) * (Sf(1,0) * Sf(2,1) - Sf(1,1) * Sf(2,0));
+#define Sd(y, x) ((double)m[(y) * 3 + (x)])
+    double d = Sd(0,0) * (Sd(1,1) * Sd(2,2) - Sd(1,2) * Sd(2,1)) -
+               Sd(0,1) * (Sd(1,0) * Sd(2,2) - Sd(1,2) * Sd(2,0)) +
+               Sd(0,2) * (Sd(1,0) * Sd(2,1) - Sd(1,1) * Sd(2,0));
     if (d != 0.) {
         float t[9];
         d = 1. / d;
@@ -66,6 +69,7 @@ void mo_invert3x3_32f(const float m[9], float out[9], int *ok)
         if (ok) *ok = 0;
     }
 #undef Sf
+#undef Sd
 }
 
 /* cv::gemm fast path for len==3, CV_32F, no C: float products summed left to right */

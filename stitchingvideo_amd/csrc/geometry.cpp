@@ -14,20 +14,21 @@ namespace {
 
 constexpr double kPi = 3.1415926535897932384626433832795;   // CV_PI
 
-// cv::Mat::inv() for a 3x3 CV_32F matrix (closed form of cv::invert): determinant evaluated in
-// float, adjugate terms in double, each scaled by 1/det and rounded to float.
+// cv::Mat::inv() for a 3x3 CV_32F matrix (closed form of cv::invert): determinant and adjugate terms in double (every operand
+// widened first -- read off the reference's shipped opencv_core2411.dll in round 5, oracle/REFERENCE_BINARY_AUDIT.md; rounds 1-4 had
+// the determinant in float), each term scaled by 1/det and rounded to float.
 void invert3x3(const float m[9], float out[9])
 {
     auto S = [&](int r, int c) { return m[r * 3 + c]; };
-    double det = S(0, 0) * (S(1, 1) * S(2, 2) - S(1, 2) * S(2, 1)) -
-                 S(0, 1) * (S(1, 0) * S(2, 2) - S(1, 2) * S(2, 0)) +
-                 S(0, 2) * (S(1, 0) * S(2, 1) - S(1, 1) * S(2, 0));
+    auto D = [&](int r, int c) { return static_cast<double>(m[r * 3 + c]); };
+    double det = D(0, 0) * (D(1, 1) * D(2, 2) - D(1, 2) * D(2, 1)) -
+                 D(0, 1) * (D(1, 0) * D(2, 2) - D(1, 2) * D(2, 0)) +
+                 D(0, 2) * (D(1, 0) * D(2, 1) - D(1, 1) * D(2, 0));
     if (det == 0.) {
         std::memset(out, 0, 9 * sizeof(float));
         return;
     }
     const double d = 1. / det;
-    auto D = [&](int r, int c) { return static_cast<double>(m[r * 3 + c]); };
     float t[9];
     t[0] = static_cast<float>((D(1, 1) * S(2, 2) - D(1, 2) * S(2, 1)) * d);
     t[1] = static_cast<float>((D(0, 2) * S(2, 1) - D(0, 1) * S(2, 2)) * d);

@@ -177,6 +177,37 @@ def test_spherical_map_backward_as_compiled_into_the_exe(audit):
     assert "[rbx+0x70]" in x and "[rbx+0x74]" in x and "[rbx+0x78]" in x and "[rbx+0x88]" in xd and "[rbx+0x90]" in xd   # k_rinv[0..2], [6..8]
 
 
+def test_invert3x3_determinant_is_in_double(audit):
+    """cv::invert of a 3 x 3 CV_32F matrix (K.inv() in ProjectorBase::setCameraParams): 2.4.11's det3 casts its inner products to double, and
+    the shipped DLL widens EVERY operand before it multiplies -- nine double products, no float one.  Rounds 1-4 restated the determinant in
+    float; oracle/warpers.c and csrc/geometry.cpp were corrected from this reading."""
+    c = _chain(audit, "invert3x3_det")
+    assert not {"mulss", "subss", "addss"} & set(c)
+    assert c.count("mulsd") == 9 and c.count("subsd") == 4 and c.count("addsd") == 1 and c.count("divsd") == 1 and c.count("cvtps2pd") >= 15
+    # a matrix on which the two forms give different floats, and which one the oracle returns
+    import oracle_lib as O
+    import ctypes as C
+    K = np.array([[1250.1234, 0.0, 961.77], [0.0, 1249.8765, 539.31], [0.0, 0.0, 1.0]], np.float32)
+    rng = np.random.default_rng(5)
+    found = False
+    for _ in range(2000):
+        M = (K + rng.normal(0, 3, (3, 3)).astype(np.float32) * np.array([[1, 1e-3, 1], [1e-3, 1, 1], [1e-6, 1e-6, 1e-3]], np.float32)).astype(np.float32)
+        m = M.astype(np.float64)
+        det64 = m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0]) + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0])
+        F = np.float32
+        det32 = F(F(M[0, 0] * F(F(M[1, 1] * M[2, 2]) - F(M[1, 2] * M[2, 1]))) - F(M[0, 1] * F(F(M[1, 0] * M[2, 2]) - F(M[1, 2] * M[2, 0])))) + F(M[0, 2] * F(F(M[1, 0] * M[2, 1]) - F(M[1, 1] * M[2, 0])))
+        a = np.float32((m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) * (1.0 / det64))
+        b = np.float32((m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) * (1.0 / float(det32)))
+        if a != b:
+            out = np.zeros(9, np.float32)
+            O.lib().mo_invert3x3_32f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            O.lib().mo_invert3x3_32f(np.ascontiguousarray(M).ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), None)
+            assert out[0] == a
+            found = True
+            break
+    assert found
+
+
 def test_lu_solve_sums_in_source_order(audit):
     """cv::solve(DECOMP_LU, CV_64F) behind the exposure gains: the row update is element by element and the back substitution subtracts its
     products strictly one after the other (unrolled by four, not reassociated), then multiplies by the stored reciprocal of the pivot --

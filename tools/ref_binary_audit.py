@@ -69,6 +69,7 @@ CHAINS = [
     ("cvtscale_8u32f", CORE, 0x180052205, 0x18005222a),            # cvtScale_<uchar,float,float>: weight.convertTo(CV_32F, 1./255.), two per trip
     ("win32_mb_feed_32f", EXE32, 0x40536c, 0x4053c1),              # MultiBandBlender::feed of the 32-bit build: fild / fmul / _ftol2_sse -- the product is NOT rounded to float
     ("win32_normalize_32f", EXE32, 0x405e08, 0x405e54),            # normalizeUsingWeightMap of the 32-bit build: w + eps and the quotient at the FPU's precision
+    ("invert3x3_det", CORE, 0x1800AF63F, 0x1800AF728),             # cv::invert, 3 x 3 CV_32F: det3 -- every float widened (cvtps2pd) BEFORE its product
     # integer work: order-free, so what is read is the CONSTANTS (rounding offset and shift) and the rounding mode of the float -> fixed step
     ("remap_bilinear_8uc3", IMGPROC, 0x1800ff0ab, 0x1800ff0d7),    # remapBilinear<FixedPtCast<int,uchar,15>, RemapVec_8u, short>, cn == 3: one channel
     ("remap_maps_to_fixed", IMGPROC, 0x1800dcd30, 0x1800dcdb6),    # remap(): CV_32FC1 map pair -> CV_16SC2 + the 5-bit table index, 16 per trip
@@ -77,7 +78,7 @@ CHAINS = [
     ("vresize_linear_8u", IMGPROC, 0x1800e8f20, 0x1800e8f48),      # VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>: the mask fix-up's resize, one output
 ]
 ARITH = {"movsx", "movzx", "cvtdq2ps", "cvtsi2ss", "mulss", "addss", "subss", "divss", "cvttss2si", "cvtss2si", "cvtps2pd", "cvtss2sd", "cvtsd2si",
-         "cvttsd2si", "imul", "idiv", "inc", "sar", "shl", "mulsd", "addsd", "divsd", "rcpss", "rcpps",
+         "cvttsd2si", "imul", "idiv", "inc", "sar", "shl", "mulsd", "addsd", "subsd", "divsd", "rcpss", "rcpps",
          "mulps", "cvtps2dq", "cvttps2dq", "pand", "por", "packssdw", "psllw", "psrad",
          "fild", "fmul", "fmulp", "fadd", "faddp", "fdiv", "fdivp", "fdivr", "fdivrp", "fistp", "fisttp"}
 
