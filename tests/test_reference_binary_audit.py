@@ -208,6 +208,22 @@ def test_invert3x3_determinant_is_in_double(audit):
     assert found
 
 
+def test_undistort_model_in_source_order(audit):
+    """initUndistortRectifyMap's per-pixel model in the shipped imgproc DLL, every operation in double and in the order of the published source:
+    w = 1 / _w, x = w _x, y = w _y, r2 = x x + y y, _2xy = (x 2) y, kr = (((k3 r2 + k2) r2 + k1) r2 + 1) / (((k6 r2 + k5) r2 + k4) r2 + 1),
+    u = ((kr x + _2xy p1) + (x2 2 + r2) p2) fx + u0, v = ((kr y + (r2 + y2 2) p1) + _2xy p2) fy + v0 -- oracle/undistort.c and the engine's host map
+    builder (csrc/geometry.cpp) are written in exactly this order."""
+    def simplify(e):
+        e = e.split(" = ", 1)[1]
+        e = e.replace("((xmm8 / xmm9) * xmm10)", "X").replace("((xmm8 / xmm9) * xmm11)", "Y").replace("((X * X) + (Y * Y))", "R2")
+        e = e.replace("((((((R2 * xmm0) + [rsp+0x58]) * R2) + [rsp+0x68]) * R2) + xmm8)", "NUM")
+        e = e.replace("((((((R2 * xmm13) + xmm14) * R2) + xmm15) * R2) + xmm8)", "DEN")
+        return e.replace("(NUM / DEN)", "KR")
+    u, v = simplify(audit["undistort_u"][0]), simplify(audit["undistort_v"][0])
+    assert u == "(((((KR * X) + (((X * [rip+0x36d64]) * Y) * [rsp+0x38])) + ((((X * X) * [rip+0x36cfa]) + R2) * [rsp+0x40])) * [rsp+0x48]) + [rsp+0x50])"
+    assert v == "(((((KR * Y) + ((R2 + ((Y * Y) * [rip+0x36cd5])) * [rsp+0x38])) + (((X * [rip+0x36d64]) * Y) * [rsp+0x40])) * [rsp+0x60]) + [rsp+0x70])"
+
+
 def test_lu_solve_sums_in_source_order(audit):
     """cv::solve(DECOMP_LU, CV_64F) behind the exposure gains: the row update is element by element and the back substitution subtracts its
     products strictly one after the other (unrolled by four, not reassociated), then multiplies by the stored reciprocal of the pivot --

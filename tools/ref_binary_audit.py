@@ -34,6 +34,11 @@ BLOCKS = [
     ("pyrdown32f_tail", 0x1801300d0, 0x180130120),   # ... its scalar tail
     ("rgb2gray_f32", 0x180025880, 0x1800258b2),      # RGB2Gray<float>::operator(): xmm4 / xmm5 / xmm6 = coeffs[0 .. 2] (cb, cg, cr for BGR input)
 ]
+# initUndistortRectifyMap's per-pixel distortion model (double): (name, first, last, register that holds the result)
+IMGPROC_REG_BLOCKS = [
+    ("undistort_u", 0x1801776d0, 0x1801777bd, "xmm8"),     # u = fx * (x kr + p1 _2xy + p2 (r2 + 2 x2)) + u0
+    ("undistort_v", 0x1801776d0, 0x1801777bd, "xmm7"),     # v = fy * (y kr + p1 (r2 + 2 y2) + p2 _2xy) + v0
+]
 # cv::solve(DECOMP_LU, CV_64F) behind the exposure gains = LUImpl<double> in opencv_core2411.dll: double sums whose ORDER is the result
 # (name, first, last, register to print at the end or None)
 CORE_BLOCKS = [
@@ -207,6 +212,8 @@ def main():
     for name, first, last in BLOCKS:
         for dst, expr in run_block(code, first, last):
             print("%s  %s = %s" % (name, dst, expr))
+    for name, first, last, reg in IMGPROC_REG_BLOCKS:
+        print("%s  %s = %s" % (name, reg, run_block(code, first, last, reg)[-1][1]))
     for name, values in CONSTANT_GROUPS:
         at = find_constant_group(code, values)
         print("%s  %s  %s" % (name, ",".join(str(v) for v in values), ("at 0x%x" % at) if at else "NOT FOUND"))
