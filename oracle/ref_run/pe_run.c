@@ -5,8 +5,10 @@
  * (/root/reference/stitching/OpenCV2.4.11-Stitching-64bit/x64/Release/opencv_{core,imgproc,stitching}2411.dll).  This maps one of those
  * PE32+ images read-only-from-disk into memory at its preferred base (no relocation needed), points EVERY import at a trap (so the code
  * can reach no library, no allocator, no system call -- only its own arithmetic), and calls a function at a given address with the
- * Microsoft x64 calling convention.  Nothing of the reference is copied or rebuilt: no headers, no libraries, no stand-ins -- a function
- * that needs an import on the path taken aborts the process (exit code 77) and is simply not usable this way.
+ * Microsoft x64 calling convention.  Nothing of the reference is copied or rebuilt: no headers, no libraries -- a function that needs an
+ * import on the path taken aborts the process (exit code 77) and is simply not usable this way.  Four imports are ANSWERED instead of
+ * trapped, and listed where they are defined below: the reference's own cv::checkHardwareSupport, and the C runtime's memset / memcpy /
+ * memmove.
  *
  * tests/ref_run.py drives it (a subprocess per DLL: all three images want the same base) with hand-laid cv::Mat headers over numpy
  * buffers, compares what the reference's own code returns with oracle/*.c, and writes the golden vectors under tests/golden/ref_*.npz.
@@ -60,6 +62,13 @@ static void on_fault(int sig, siginfo_t *si, void *uc_)
     (void)r;
     _exit(78);
 }
+
+/* ... and the C runtime's three byte movers, answered by the host C library's: memset, memcpy, memmove (MSVCR100 is not in the tree).  They
+ * move or fill bytes -- no arithmetic, nothing a restatement could get wrong -- and without them a loop that zero-fills a local array or
+ * copies a border pixel could not run.  Every other import of the C runtime (allocation, math, I/O, locale ...) stays trapped. */
+static void *__attribute__((ms_abi)) crt_memset(void *d, int c, size_t n) { return memset(d, c, n); }
+static void *__attribute__((ms_abi)) crt_memcpy(void *d, const void *s, size_t n) { return memcpy(d, s, n); }
+static void *__attribute__((ms_abi)) crt_memmove(void *d, const void *s, size_t n) { return memmove(d, s, n); }
 
 static uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
@@ -117,6 +126,12 @@ uint64_t pe_load(const char *path, int *n_imports)
                 if (!(names[k] >> 63) && names[k] + 2 < image_size &&
                     strcmp((const char *)(img + names[k] + 2), "?checkHardwareSupport@cv@@YA_NH@Z") == 0)
                     iat[k] = (uint64_t)(uintptr_t)&check_hardware_support;
+                if (!(names[k] >> 63) && names[k] + 2 < image_size) {
+                    const char *nm = (const char *)(img + names[k] + 2);
+                    if (strcmp(nm, "memset") == 0) iat[k] = (uint64_t)(uintptr_t)&crt_memset;
+                    else if (strcmp(nm, "memcpy") == 0) iat[k] = (uint64_t)(uintptr_t)&crt_memcpy;
+                    else if (strcmp(nm, "memmove") == 0) iat[k] = (uint64_t)(uintptr_t)&crt_memmove;
+                }
             }
         }
     const uint32_t dimp_rva = rd32(opt + 112 + 8 * 13);                                        /* delay imports: their IAT too */

@@ -28,9 +28,9 @@ def cases():
     xy, fxy = R.fixed_maps(xm, ym)
     for border, name in ((2, "reflect"), (1, "replicate"), (4, "reflect101")):
         g["remap_out_" + name] = R.run("remap_bilinear", src=src, xy=xy, fxy=fxy, border=np.array(border))["out"]
-    # BORDER_CONSTANT where every pixel keeps at least one tap inside (a pixel with none is filled through the C runtime's memcpy: not a leaf)
-    xc = rng.uniform(-0.95, 83 - 0.05, (61, 83)).astype(np.float32)
-    yc = rng.uniform(-0.95, 61 - 0.05, (61, 83)).astype(np.float32)
+    # BORDER_CONSTANT (the lens undistort's mode), pixels with no tap inside included (those are filled through memcpy, one of the answered imports)
+    xc = rng.uniform(-5, 83 + 5, (61, 83)).astype(np.float32)
+    yc = rng.uniform(-5, 61 + 5, (61, 83)).astype(np.float32)
     g["remapc_xy"], g["remapc_fxy"] = R.fixed_maps(xc, yc)
     g["remapc_out"] = R.run("remap_bilinear", src=src, xy=g["remapc_xy"], fxy=g["remapc_fxy"], border=np.array(0))["out"]
     gray = rng.integers(0, 256, (90, 120)).astype(np.uint8)
@@ -100,6 +100,12 @@ def cases():
     for i, (h, w) in enumerate(((32, 52), (7, 9), (3, 3), (1, 5))):
         m = rng.uniform(0.7, 1.4, (h, w)).astype(np.float32)
         g["smooth_src_%d" % i], g["smooth_out_%d" % i] = m, R.run("smooth3", src=m)["out"]
+    # cv::resize(INTER_LINEAR) of a block-gain map up to a frame's size (exposure_compensate.cpp:233) and of a mask (stitcher.cpp:292)
+    for i, ((sh, sw), (dw, dh)) in enumerate((((32, 52), (300, 200)), ((7, 9), (100, 64)), ((3, 3), (40, 30)), ((1, 5), (50, 7)), ((20, 33), (33, 20)))):
+        m = rng.uniform(0.7, 1.4, (sh, sw)).astype(np.float32)
+        u = (rng.uniform(size=(sh, sw)) > 0.4).astype(np.uint8) * 255
+        g["rsz32_src_%d" % i], g["rsz32_out_%d" % i] = m, R.run("resize_linear", src=m, dsize=np.array((dw, dh)))["out"]
+        g["rsz8_src_%d" % i], g["rsz8_out_%d" % i] = u, R.run("resize_linear", src=u, dsize=np.array((dw, dh)))["out"]
     return g
 
 

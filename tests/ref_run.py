@@ -316,7 +316,70 @@ def job_smooth3(src):
     return {"out": _sep_filter_3(img, np.ascontiguousarray(src, np.float32), [0.25, 0.5, 0.25], 1, [0.25, 0.5, 0.25], 1)}
 
 
-JOBS = {"sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
+RESIZE_LINEAR_8U = 0x1800E9360         # resizeGeneric_Invoker<HResizeLinear<uchar,int,short,2048,..>, VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>,..>>::operator()
+RESIZE_LINEAR_32F = 0x1800EC910        # ... <HResizeLinear<float,float,float,1,..>, VResizeLinear<float,float,float,Cast<float,float>,VResizeLinearVec_32f>>::operator()
+
+
+def _linear_coeffs(sn, dn, fixpt, vertical=False):
+    """cv::resize's table of source offsets and weights for INTER_LINEAR along one axis (imgwarp.cpp of 2.4.11, restated: this part of
+    resize() sits between its allocations and cannot be called) -> offsets, weights (2 per output), first / one-past-last interior output"""
+    scale = 1.0 / (float(dn) / sn)
+    ofs = np.zeros(dn, np.int32)
+    wts = np.zeros(2 * dn, np.int16 if fixpt else np.float32)
+    lo, hi = 0, dn
+    for d in range(dn):
+        f = np.float32((d + 0.5) * scale - 0.5)
+        s_ = int(np.floor(f))
+        f = np.float32(f - np.float32(s_))
+        if vertical:                         # rows: the offset is stored as it is (the row loop clamps it) and the weights are kept
+            ofs[d] = s_
+            c = (np.float32(1) - f, f)
+            for k in range(2):
+                wts[2 * d + k] = np.int16(np.rint(np.float64(np.float32(c[k] * np.float32(2048))))) if fixpt else c[k]
+            continue
+        if s_ < 0:
+            lo = d + 1
+            f, s_ = np.float32(0), 0
+        if s_ + 1 >= sn:
+            hi = min(hi, d)
+            if s_ >= sn - 1:
+                f, s_ = np.float32(0), sn - 1
+        ofs[d] = s_
+        c = (np.float32(1) - f, f)
+        for k in range(2):
+            wts[2 * d + k] = np.int16(np.rint(np.float64(np.float32(c[k] * np.float32(2048))))) if fixpt else c[k]
+    return ofs, wts, lo, hi
+
+
+def job_resize_linear(src, dsize):
+    """the row loop of cv::resize(INTER_LINEAR) for a one-channel CV_8U or CV_32F image: the DLL's invoker (horizontal pass into its row ring,
+    vertical pass, row clamping) on coefficient tables built as resize() builds them"""
+    img = Image("imgproc")
+    s = np.ascontiguousarray(src)
+    fixpt = s.dtype == np.uint8
+    dw, dh = int(dsize[0]), int(dsize[1])
+    d = np.zeros((dh, dw), s.dtype)
+    xofs, alpha, xmin, xmax = _linear_coeffs(s.shape[1], dw, fixpt)
+    yofs, beta, _, _ = _linear_coeffs(s.shape[0], dh, fixpt, vertical=True)
+    ms, md = mat(s), mat(d)
+    obj = (C.c_uint8 * 0x110)()
+    base = C.addressof(obj)
+    C.memmove(base + 0x08, C.addressof(ms), C.sizeof(Mat))
+    C.memmove(base + 0x68, C.addressof(md), C.sizeof(Mat))
+    # (the copied headers' size / step pointers must point into the copies)
+    for off in (0x08, 0x68):
+        C.c_void_p.from_address(base + off + Mat.size_p.offset).value = base + off + Mat.rows.offset
+        C.c_void_p.from_address(base + off + Mat.step_p.offset).value = base + off + Mat.step_buf.offset
+    for off, arr in ((0xC8, xofs), (0xD0, yofs), (0xD8, alpha), (0xE0, beta)):
+        C.c_void_p.from_address(base + off).value = arr.ctypes.data
+    for off, v in ((0xE8, s.shape[1]), (0xEC, s.shape[0]), (0xF0, dw), (0xF4, dh), (0xF8, 2), (0xFC, xmin), (0x100, xmax)):
+        C.c_int.from_address(base + off).value = v
+    rng = (C.c_int * 2)(0, dh)
+    img.call(RESIZE_LINEAR_8U if fixpt else RESIZE_LINEAR_32F, base, C.addressof(rng))
+    return {"out": d}
+
+
+JOBS = {"resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):

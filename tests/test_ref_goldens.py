@@ -96,6 +96,15 @@ def test_oracle_float_sobel_and_gain_smoothing_are_the_references(g):
         assert np.array_equal(_bits(m), _bits(g["smooth_out_%d" % i])), i
 
 
+def test_oracle_linear_resize_is_the_references(g):
+    """cv::resize(INTER_LINEAR): the float one of the block-gain maps, the 8-bit fixed-point one of the mask fix-up (edge rows keep both weights)"""
+    for i in range(5):
+        o = g["rsz32_out_%d" % i]
+        assert np.array_equal(_bits(O.resize_linear_32f(g["rsz32_src_%d" % i], o.shape[1], o.shape[0])), _bits(o)), i
+        o = g["rsz8_out_%d" % i]
+        assert np.array_equal(O.resize_linear_8u(g["rsz8_src_%d" % i], o.shape[1], o.shape[0]), o), i
+
+
 @pytest.mark.gpu
 def test_engine_stages_are_the_references(g):
     """The HIP stage-level entry points on the reference's own outputs: the warp of a whole camera (maps from the projector, BORDER_REFLECT),

@@ -114,3 +114,25 @@ def test_remap_runs_on_degenerate_sources(shape):
     xy, fxy = R.fixed_maps(xm, ym)
     for border in (2, 1, 4):
         assert np.array_equal(R.run("remap_bilinear", src=src, xy=xy, fxy=fxy, border=np.array(border))["out"], O.remap(src, xm, ym, 1, border)), border
+
+
+def test_linear_resize_runs_equal_the_oracle():
+    rng = np.random.default_rng(31)
+    for _ in range(6):
+        sh, sw = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+        dw, dh = int(rng.integers(1, 400)), int(rng.integers(1, 200))
+        m = rng.uniform(0.5, 2.0, (sh, sw)).astype(np.float32)
+        assert np.array_equal(R.run("resize_linear", src=m, dsize=np.array((dw, dh)))["out"].view(np.uint32),
+                              O.resize_linear_32f(m, dw, dh).view(np.uint32)), (sw, sh, dw, dh)
+        u = rng.integers(0, 256, (sh, sw)).astype(np.uint8)
+        assert np.array_equal(R.run("resize_linear", src=u, dsize=np.array((dw, dh)))["out"], O.resize_linear_8u(u, dw, dh)), (sw, sh, dw, dh)
+
+
+def test_constant_border_remap_with_no_tap_inside():
+    rng = np.random.default_rng(33)
+    src = rng.integers(0, 256, (30, 41, 3)).astype(np.uint8)
+    xm = rng.uniform(-20, 61, (25, 37)).astype(np.float32)
+    ym = rng.uniform(-20, 50, (25, 37)).astype(np.float32)
+    xy, fxy = R.fixed_maps(xm, ym)
+    out = R.run("remap_bilinear", src=src, xy=xy, fxy=fxy, border=np.array(0))["out"]
+    assert np.array_equal(out, O.remap(src, xm, ym, 1, 0)) and np.array_equal(out, O.remap_fixed(src, xy, fxy))
