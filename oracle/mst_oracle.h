@@ -8,7 +8,9 @@
  * library; the product (libmi355stitch.so) never links or calls it.
  *
  * PARITY STATUS (round 5): PINNED for remap (8-bit bilinear, every border mode), pyrDown / pyrUp (16S), pyrDown (32F),
- * normalizeUsingWeightMap, cvtScale (gain apply, mask -> weight), distanceTransform (L1, 3 x 3) and the NV12 conversion against
+ * normalizeUsingWeightMap (both weight types), cvtScale (gain apply, mask -> weight), distanceTransform (L1, 3 x 3), the row loops of
+ * resize(INTER_LINEAR) (32F, 8U), the float Sobel row / column filters, the gain-map smoothing, BGR2GRAY (8U, 32F), borderInterpolate
+ * and the NV12 conversion against
  * OUTPUTS OF THE REFERENCE ITSELF: its shipped x64 DLLs are run in place (oracle/ref_run/pe_run.c, tests/ref_run.py) and the
  * results committed as tests/golden/ref_runs.npz; everything below that is not in that list stays as it was:
  * "parity unpinned" -- the reference ships no tests, no golden
