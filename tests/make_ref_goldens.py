@@ -39,6 +39,15 @@ def cases():
     g["remapg_src"], g["remapg_xmap"], g["remapg_ymap"] = gray, xg, yg
     a, b = R.fixed_maps(xg, yg)
     g["remapg_out_reflect"] = R.run("remap_bilinear", src=gray, xy=a, fxy=b, border=np.array(2))["out"]
+    # INTER_NEAREST (the mask warp, BORDER_CONSTANT) on one- and three-channel images, half-way coordinates included
+    xn, yn = xm.copy(), ym.copy()
+    xn[1, :4] = [-0.5, 0.5, 81.5, 1.5]
+    yn[1, :4] = [0.5, -0.5, 59.5, 2.5]
+    g["remapn_xmap"], g["remapn_ymap"] = xn, yn
+    nxy = R.nearest_maps(xn, yn)
+    g["remapn_out_constant"] = R.run("remap_nearest", src=src, xy=nxy, border=np.array(0))["out"]
+    g["remapn_mask_out_constant"] = R.run("remap_nearest", src=np.full((61, 83), 255, np.uint8), xy=nxy, border=np.array(0))["out"]
+    g["remapn_out_reflect"] = R.run("remap_nearest", src=src, xy=nxy, border=np.array(2))["out"]
     # a whole warp: a spherical camera of a small rig, the maps from the projector, the frame through the reference's remap with BORDER_REFLECT
     K = np.array([[150.0, 0, 80.0], [0, 150.0, 45.0], [0, 0, 1]], np.float32)
     yaw = np.deg2rad(25.0)

@@ -379,7 +379,31 @@ def job_resize_linear(src, dsize):
     return {"out": d}
 
 
-JOBS = {"resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
+REMAP_NEAREST_8U = 0x1800DE1F0         # remapNearest<uchar>(src, dst, xy, borderType, borderValue): nn_tab[CV_8U] of cv::remap (the table at 0x180218a60;
+                                       # linear_tab[CV_8U] at 0x180218a20 holds REMAP_BILINEAR_8U: the dispatch the DLL itself uses)
+
+
+def nearest_maps(xmap, ymap):
+    """float maps -> CV_16SC2 as cv::remap converts them for INTER_NEAREST: saturate_cast<short>(x) = round to nearest even, clamped"""
+    def conv(m):
+        r = np.rint(m.astype(np.float32)).astype(np.float64)
+        r = np.where(np.isfinite(m), r, -2.0 ** 31)
+        return np.clip(r, -32768, 32767).astype(np.int16)
+    return np.ascontiguousarray(np.stack([conv(xmap), conv(ymap)], axis=-1))
+
+
+def job_remap_nearest(src, xy, border):
+    img = Image("imgproc")
+    s = np.ascontiguousarray(src, np.uint8)
+    m1 = np.ascontiguousarray(xy, np.int16)
+    d = np.zeros(m1.shape[:2] + s.shape[2:], np.uint8)
+    scalar = (C.c_double * 4)(0, 0, 0, 0)
+    ms, md, mxy = mat(s), mat(d), mat(m1)
+    img.call(REMAP_NEAREST_8U, C.addressof(ms), C.addressof(md), C.addressof(mxy), int(border), C.addressof(scalar))
+    return {"out": d}
+
+
+JOBS = {"remap_nearest": job_remap_nearest, "resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):

@@ -28,6 +28,10 @@ def test_oracle_remap_is_the_references(g):
         assert np.array_equal(O.remap(g["remap_src"], g["remap_xmap"], g["remap_ymap"], 1, border), g["remap_out_" + name]), name
     assert np.array_equal(O.remap_fixed(g["remap_src"], g["remapc_xy"], g["remapc_fxy"]), g["remapc_out"])            # BORDER_CONSTANT, CV_16SC2 maps
     assert np.array_equal(O.remap(g["remapg_src"], g["remapg_xmap"], g["remapg_ymap"], 1, 2), g["remapg_out_reflect"])  # one channel
+    # INTER_NEAREST: an image and the all-255 mask of stitcher.cpp:278-280 (BORDER_CONSTANT), and BORDER_REFLECT
+    assert np.array_equal(O.remap(g["remap_src"], g["remapn_xmap"], g["remapn_ymap"], 0, 0), g["remapn_out_constant"])
+    assert np.array_equal(O.remap(np.full((61, 83), 255, np.uint8), g["remapn_xmap"], g["remapn_ymap"], 0, 0), g["remapn_mask_out_constant"])
+    assert np.array_equal(O.remap(g["remap_src"], g["remapn_xmap"], g["remapn_ymap"], 0, 2), g["remapn_out_reflect"])
     roi, wx, wy = O.build_maps(1, 150.0, g["warp_K"], g["warp_R"], 160, 90)
     assert tuple(roi) == tuple(g["warp_roi"])
     assert np.array_equal(O.remap(g["warp_frame"], wx, wy, 1, 2), g["warp_out"])
