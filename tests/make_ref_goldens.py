@@ -57,6 +57,7 @@ def cases():
     g["warp_K"], g["warp_R"], g["warp_frame"], g["warp_roi"] = K, Rm, frame, np.array(roi)
     a, b = R.fixed_maps(wx, wy)
     g["warp_out"] = R.run("remap_bilinear", src=frame, xy=a, fxy=b, border=np.array(2))["out"]
+    g["warp_mask_out"] = R.run("remap_nearest", src=np.full((90, 160), 255, np.uint8), xy=R.nearest_maps(wx, wy), border=np.array(0))["out"]
     # ---- the pyramids ------------------------------------------------------------------------------------------------------------
     for i, (h, w) in enumerate(((40, 64), (37, 51), (5, 5), (2, 2), (3, 128))):
         s = rng.integers(-3000, 3000, (h, w, 3)).astype(np.int16)

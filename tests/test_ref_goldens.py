@@ -35,6 +35,7 @@ def test_oracle_remap_is_the_references(g):
     roi, wx, wy = O.build_maps(1, 150.0, g["warp_K"], g["warp_R"], 160, 90)
     assert tuple(roi) == tuple(g["warp_roi"])
     assert np.array_equal(O.remap(g["warp_frame"], wx, wy, 1, 2), g["warp_out"])
+    assert np.array_equal(O.remap(np.full((90, 160), 255, np.uint8), wx, wy, 0, 0), g["warp_mask_out"])
 
 
 def test_oracle_pyramids_are_the_references(g):
@@ -117,6 +118,8 @@ def test_engine_stages_are_the_references(g):
     from stitchingvideo_amd import capi
     corner, out = S.SphericalWarper(150.0).warp(g["warp_frame"], g["warp_K"], g["warp_R"], capi.INTER_LINEAR, capi.BORDER_REFLECT)
     assert tuple(corner) == tuple(g["warp_roi"][:2]) and np.array_equal(out, g["warp_out"])
+    _, mask = S.SphericalWarper(150.0).warp(np.full((90, 160), 255, np.uint8), g["warp_K"], g["warp_R"], capi.INTER_NEAREST, capi.BORDER_CONSTANT)
+    assert np.array_equal(mask, g["warp_mask_out"])                      # the warped all-255 mask of stitcher.cpp:278-280
     assert np.array_equal(S.remap_fixed(g["remap_src"], g["remapc_xy"], g["remapc_fxy"]), g["remapc_out"])
     for i, gv in enumerate(g["gain_values"]):
         img = g["gain_src"].copy()
