@@ -1,4 +1,6 @@
-"""What the reference's OWN binaries compute, read off their machine code.
+"""What the reference's OWN binaries compute, read off their machine code (part one of oracle/REFERENCE_BINARY_AUDIT.md; part two RUNS the
+same binaries: oracle/ref_run/pe_run.c, tests/ref_run.py).  Besides opencv_imgproc2411.dll it reads opencv_core2411.dll,
+opencv_stitching2411.dll, the x64 exe and the 32-bit build of the stock sample, each checked against its SHA-256 first.
 
 The reference cannot be built or run in this image (OpenCV 2.4.11 + <windows.h>), and it ships no test vectors -- but it does ship the
 x64 Release DLLs it runs (`/root/reference/stitching/OpenCV2.4.11-Stitching-64bit/x64/Release/opencv_imgproc2411.dll`).  Where the oracle
