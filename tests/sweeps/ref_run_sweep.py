@@ -14,7 +14,41 @@ import ref_run as R             # noqa: E402
 
 
 def one(rng, i):
-    kind = ("remap", "pyr_down16", "pyr_up16", "pyr_down32", "normalize", "gain", "distance", "nv12")[i % 8]
+    kind = ("remap", "pyr_down16", "pyr_up16", "pyr_down32", "normalize", "gain", "distance", "nv12", "nearest", "resize32", "resize8", "sobel", "smooth")[i % 13]
+    if kind == "nearest":
+        sh, sw = int(rng.integers(1, 80)), int(rng.integers(1, 100))
+        cn = int(rng.choice((1, 3)))
+        src = rng.integers(0, 256, (sh, sw) + ((3,) if cn == 3 else ())).astype(np.uint8)
+        dh, dw = int(rng.integers(1, 60)), int(rng.integers(1, 80))
+        xm = rng.uniform(-sw, 2 * sw, (dh, dw)).astype(np.float32)
+        ym = rng.uniform(-sh, 2 * sh, (dh, dw)).astype(np.float32)
+        xm[rng.uniform(size=xm.shape) < 0.2] = np.float32(rng.integers(-3, sw + 3)) + np.float32(0.5)        # ties: round half to even
+        border = int(rng.choice((0, 1, 2, 4)))
+        ok = np.array_equal(R.run("remap_nearest", src=src, xy=R.nearest_maps(xm, ym), border=np.array(border))["out"], O.remap(src, xm, ym, 0, border))
+        return ok, "%s %dx%dx%d -> %dx%d border %d" % (kind, sw, sh, cn, dw, dh, border)
+    if kind in ("resize32", "resize8"):
+        sh, sw = int(rng.integers(1, 50)), int(rng.integers(1, 70))
+        dw, dh = int(rng.integers(1, 500)), int(rng.integers(1, 300))
+        if kind == "resize32":
+            m = rng.uniform(0.5, 2.0, (sh, sw)).astype(np.float32)
+            ok = np.array_equal(R.run("resize_linear", src=m, dsize=np.array((dw, dh)))["out"].view(np.uint32), O.resize_linear_32f(m, dw, dh).view(np.uint32))
+        else:
+            u = rng.integers(0, 256, (sh, sw)).astype(np.uint8)
+            ok = np.array_equal(R.run("resize_linear", src=u, dsize=np.array((dw, dh)))["out"], O.resize_linear_8u(u, dw, dh))
+        return ok, "%s %dx%d -> %dx%d" % (kind, sw, sh, dw, dh)
+    if kind == "sobel":
+        h, w = int(rng.integers(1, 30)), int(rng.integers(1, 70))
+        im = rng.uniform(0, 255, (h, w, 3)).astype(np.float32)
+        r = R.run("sobel32f", gray=R.run("gray", src=im)["out"])
+        gx, gy = O.dp_gradients(im)
+        return np.array_equal(r["gx"].view(np.uint32), gx.view(np.uint32)) and np.array_equal(r["gy"].view(np.uint32), gy.view(np.uint32)), "%s %dx%d" % (kind, w, h)
+    if kind == "smooth":
+        h, w = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+        m = rng.uniform(0.5, 2.0, (h, w)).astype(np.float32)
+        e = m.copy()
+        O.lib().mo_smooth_gain_map.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        O.lib().mo_smooth_gain_map(e.ctypes.data_as(C.c_void_p), w, h)
+        return np.array_equal(R.run("smooth3", src=m)["out"].view(np.uint32), e.view(np.uint32)), "%s %dx%d" % (kind, w, h)
     if kind == "remap":
         sh, sw = int(rng.integers(1, 120)), int(rng.integers(1, 160))
         cn = int(rng.choice((1, 3)))
