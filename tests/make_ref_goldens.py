@@ -116,6 +116,13 @@ def cases():
         u = (rng.uniform(size=(sh, sw)) > 0.4).astype(np.uint8) * 255
         g["rsz32_src_%d" % i], g["rsz32_out_%d" % i] = m, R.run("resize_linear", src=m, dsize=np.array((dw, dh)))["out"]
         g["rsz8_src_%d" % i], g["rsz8_out_%d" % i] = u, R.run("resize_linear", src=u, dsize=np.array((dw, dh)))["out"]
+    # BlocksGainCompensator::apply as the reference runs it per frame (exposure_compensate.cpp:225-246): the block-gain map up-sized by the
+    # DLL's resize row loop, then the exe's OWN compiled apply() over the frame
+    small = rng.uniform(0.6, 1.7, (3, 5)).astype(np.float32)
+    fr = rng.integers(0, 256, (72, 136, 3)).astype(np.uint8)
+    full = R.run("resize_linear", src=small, dsize=np.array((136, 72)))["out"]
+    g["bgain_map"], g["bgain_frame"], g["bgain_full"] = small, fr, full
+    g["bgain_out"] = R.run("blocks_gain_apply", image=fr, gain_map=full)["out"]
     return g
 
 

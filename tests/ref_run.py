@@ -12,7 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RELEASE = "/root/reference/stitching/OpenCV2.4.11-Stitching-64bit/x64/Release"
-DLLS = {"core": "opencv_core2411.dll", "imgproc": "opencv_imgproc2411.dll", "stitching": "opencv_stitching2411.dll"}
+DLLS = {"core": "opencv_core2411.dll", "imgproc": "opencv_imgproc2411.dll", "stitching": "opencv_stitching2411.dll",
+        "exe": "OpenCV2.4.11-Stitching.exe"}                    # (the x64 executable maps at 0x140000000: the reference's OWN compiled sources)
 SRC = os.path.join(ROOT, "oracle", "ref_run", "pe_run.c")
 LIB = os.path.join(ROOT, "oracle", "ref_run", "libpe_run.so")
 
@@ -62,7 +63,7 @@ class Image:
         self.L.pe_call.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
         n = C.c_int()
         self.base = self.L.pe_load(os.path.join(RELEASE, DLLS[which]).encode(), C.byref(n))
-        assert self.base == 0x180000000, "the image did not map at its preferred base"
+        assert self.base == (0x140000000 if which == "exe" else 0x180000000), "the image did not map at its preferred base"
 
     def call(self, addr, *args):
         a = (C.c_uint64 * 8)(*([int(x) & 0xFFFFFFFFFFFFFFFF for x in args] + [0] * (8 - len(args))))
@@ -403,7 +404,29 @@ def job_remap_nearest(src, xy, border):
     return {"out": d}
 
 
-JOBS = {"remap_nearest": job_remap_nearest, "resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
+BLOCKS_GAIN_APPLY = 0x140007DD0        # cv::detail::BlocksGainCompensator::apply(int index, Point corner, Mat& image, const Mat& mask) as compiled INTO THE EXE
+                                       # (exposure_compensate.cpp:225-246, /fp:precise; address from the exe's own PDB)
+
+
+def job_blocks_gain_apply(image, gain_map):
+    """the reference's per-frame gain loop itself: with a gain map already of the image's size apply() takes `gain_map = gain_maps_[index]`
+    (no resize, no allocation) and multiplies every pixel: saturate_cast<uchar>(pixel * gain)"""
+    img = Image("exe")
+    im = np.ascontiguousarray(image, np.uint8).copy()
+    gm = np.ascontiguousarray(gain_map, np.float32)
+    assert gm.shape == im.shape[:2]
+    mg, mi = mat(gm), mat(im)
+    mask = np.zeros((1, 1), np.uint8)
+    mm = mat(mask)
+    this = (C.c_uint64 * 8)()                                           # {vptr, (allocator), vector<Mat_<float>> gain_maps_ {first, last, end}}
+    this[2] = C.addressof(mg)
+    this[3] = this[4] = C.addressof(mg) + C.sizeof(Mat)
+    corner = (C.c_int * 2)(0, 0)
+    img.call(BLOCKS_GAIN_APPLY, C.addressof(this), 0, C.addressof(corner), C.addressof(mi), C.addressof(mm))
+    return {"out": im}
+
+
+JOBS = {"blocks_gain_apply": job_blocks_gain_apply, "remap_nearest": job_remap_nearest, "resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):

@@ -101,6 +101,12 @@ def test_oracle_float_sobel_and_gain_smoothing_are_the_references(g):
         assert np.array_equal(_bits(m), _bits(g["smooth_out_%d" % i])), i
 
 
+def test_oracle_blocks_gain_apply_is_the_references(g):
+    """the reference's per-frame gain step end to end: resize (the imgproc DLL's row loop) + the exe's own compiled apply()"""
+    assert np.array_equal(_bits(O.resize_linear_32f(g["bgain_map"], 136, 72)), _bits(g["bgain_full"]))
+    assert np.array_equal(O.blocks_gain_apply(g["bgain_frame"].copy(), g["bgain_map"]), g["bgain_out"])
+
+
 def test_oracle_linear_resize_is_the_references(g):
     """cv::resize(INTER_LINEAR): the float one of the block-gain maps, the 8-bit fixed-point one of the mask fix-up (edge rows keep both weights)"""
     for i in range(5):
@@ -126,3 +132,6 @@ def test_engine_stages_are_the_references(g):
         S.GainCompensator([float(gv)]).apply(0, (0, 0), img, None)
         assert np.array_equal(img, g["gain_out_%d" % i]), float(gv)
     assert np.array_equal(S.cvt_nv12_bgr(g["nv12_src"]), g["nv12_out"])
+    img = g["bgain_frame"].copy()
+    S.BlocksGainCompensator([g["bgain_map"]]).apply(0, (0, 0), img, None)            # the block-gain map up-sized and applied on the device
+    assert np.array_equal(img, g["bgain_out"])

@@ -136,3 +136,12 @@ def test_constant_border_remap_with_no_tap_inside():
     xy, fxy = R.fixed_maps(xm, ym)
     out = R.run("remap_bilinear", src=src, xy=xy, fxy=fxy, border=np.array(0))["out"]
     assert np.array_equal(out, O.remap(src, xm, ym, 1, 0)) and np.array_equal(out, O.remap_fixed(src, xy, fxy))
+
+
+def test_blocks_gain_apply_of_the_exe_equals_the_oracle():
+    """the reference's OWN compiled per-frame gain loop (BlocksGainCompensator::apply inside OpenCV2.4.11-Stitching.exe, found through its PDB)"""
+    rng = np.random.default_rng(41)
+    for h, w in ((31, 47), (5, 3), (64, 96)):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        gm = rng.uniform(0.3, 3.0, (h, w)).astype(np.float32)
+        assert np.array_equal(R.run("blocks_gain_apply", image=img, gain_map=gm)["out"], O.blocks_gain_apply(img.copy(), gm)), (h, w)
