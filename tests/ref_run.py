@@ -426,7 +426,24 @@ def job_blocks_gain_apply(image, gain_map):
     return {"out": im}
 
 
-JOBS = {"blocks_gain_apply": job_blocks_gain_apply, "remap_nearest": job_remap_nearest, "resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
+ADD_16S, SUB_16S = 0x180018C40, 0x180019390          # add16s / sub16s(src1, step1, src2, step2, dst, step, Size&, void*): cv::add / cv::subtract on CV_16S
+USE_SSE2_FLAG = 0x180266C98                          # core's `static volatile bool USE_SSE2`, set at load time by a dynamic initialiser (cpuid): not run here
+
+
+def job_arith16s(a, b, sub, sse):
+    """cv::subtract / cv::add on CV_16S (the Laplacian levels and their collapse): the scalar loop (the flag as an unloaded image leaves it)
+    or the SSE2 one (the flag as the loader's initialiser sets it on any x86-64 CPU)"""
+    img = Image("core")
+    C.c_uint8.from_address(USE_SSE2_FLAG).value = 1 if int(sse) else 0
+    x, y = np.ascontiguousarray(a, np.int16), np.ascontiguousarray(b, np.int16)
+    x2, y2 = x.reshape(x.shape[0], -1), y.reshape(y.shape[0], -1)
+    d = np.zeros(x2.shape, np.int16)
+    size = (C.c_int * 2)(x2.shape[1], x2.shape[0])
+    img.call(SUB_16S if int(sub) else ADD_16S, x2.ctypes.data, x2.strides[0], y2.ctypes.data, y2.strides[0], d.ctypes.data, d.strides[0], C.addressof(size), 0)
+    return {"out": d.reshape(x.shape)}
+
+
+JOBS = {"arith16s": job_arith16s, "blocks_gain_apply": job_blocks_gain_apply, "remap_nearest": job_remap_nearest, "resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):

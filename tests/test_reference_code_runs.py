@@ -145,3 +145,14 @@ def test_blocks_gain_apply_of_the_exe_equals_the_oracle():
         img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
         gm = rng.uniform(0.3, 3.0, (h, w)).astype(np.float32)
         assert np.array_equal(R.run("blocks_gain_apply", image=img, gain_map=gm)["out"], O.blocks_gain_apply(img.copy(), gm)), (h, w)
+
+
+def test_saturating_16_bit_add_and_subtract():
+    """cv::subtract (the Laplacian levels) and cv::add (their collapse) on CV_16S SATURATE, in the scalar loop and in the SSE2 one alike"""
+    rng = np.random.default_rng(43)
+    a = rng.integers(-32768, 32767, (11, 29, 3)).astype(np.int16)
+    b = rng.integers(-32768, 32767, (11, 29, 3)).astype(np.int16)
+    for sub in (1, 0):
+        exp = np.clip(a.astype(np.int32) - b if sub else a.astype(np.int32) + b, -32768, 32767).astype(np.int16)
+        for sse in (0, 1):
+            assert np.array_equal(R.run("arith16s", a=a, b=b, sub=np.array(sub), sse=np.array(sse))["out"], exp), (sub, sse)
