@@ -68,7 +68,9 @@
 extern "C" {
 #endif
 
-#define MST_VERSION 100
+/* 101 (round 6): the round-4 strip-halo entries (mst_strip_halo_bytes, mst_strip_front_batch, mst_strip_back_batch, MST_FLAG_STRIP_HALO)
+ * are gone from the ABI -- a host built against 100 that used them must not bind this library silently */
+#define MST_VERSION 101
 
 /* error codes */
 #define MST_OK                 0

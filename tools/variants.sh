@@ -14,10 +14,14 @@ print('$1', 'in-flight', d['value'], d['roofline']['frac'], '| serial', d.get('s
       'one-per-call in flight', d.get('latency_mode',{}).get('pipelined_calls',{}).get('frames_per_s'))"; }
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  W=/tmp/mst_var_$name
+  # the scratch copy is keyed on the sources AND the flags (a stale copy under the same name is never timed); VARIANT_REUSE=1 keeps
+  # an existing copy of the same key (repeat timings of one build), a failed build removes its directory
+  key=$( (cat $SRC/stitchingvideo_amd/csrc/*.hip $SRC/stitchingvideo_amd/csrc/*.[ch]pp $SRC/include/*.h $SRC/bench.py; echo "$flags") | sha256sum | cut -c1-12)
+  W=/tmp/mst_var_${name}_$key
+  [ -z "$VARIANT_REUSE" ] && rm -rf $W
   if [ ! -d $W ]; then
     mkdir -p $W; cp -r $SRC/stitchingvideo_amd $SRC/include $SRC/tools $SRC/bench.py $SRC/tests $SRC/oracle $SRC/__graft_entry__.py $W/ 2>/dev/null
-    (cd $W/stitchingvideo_amd/csrc && rm -rf build && make -j16 CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $flags" > $W/build.log 2>&1) || { echo "$name: build failed"; tail -5 $W/build.log; continue; }
+    (cd $W/stitchingvideo_amd/csrc && rm -rf build && make -j16 CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $flags" > $W/build.log 2>&1) || { echo "$name: build failed"; tail -5 $W/build.log; rm -rf $W; continue; }
     case " $VARIANT_PARITY " in *" $name "*) (cd $W && python3 -m pytest tests -m gpu -x -q 2>&1 | tail -2 | sed "s/^/$name parity: /");; esac
   fi
   # VARIANT_LATENCY=1: with the one-frame-set legs (latency_mode) -- the host-buffer and ingest legs ride along, so it takes longer
