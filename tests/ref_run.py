@@ -1,8 +1,17 @@
-"""TEST INFRASTRUCTURE: the reference's own shipped x64 machine code, run in place on numpy buffers (oracle/ref_run/pe_run.c maps a DLL,
-points every import at a trap and calls import-free leaf functions by address).  Only where /root/reference exists; each DLL in a
-process of its own (all three want the same base address) -- `python tests/ref_run.py <job> <in.npz> <out.npz>` is that process,
-`run(job, **arrays)` the caller's side.  cv::Mat headers are laid out by hand (OpenCV 2.4.11, x64: 96 bytes)."""
+"""TEST INFRASTRUCTURE, OPT-IN: the reference's own shipped x64 machine code, run in place on numpy buffers (oracle/ref_run/pe_run.c maps
+the images and calls functions by address).  Nothing here runs unless MST_RUN_REFERENCE_BINARIES=1 is set AND /root/reference holds
+the four binaries with the SHA-256 pinned below; the default build and test paths only read the committed vectors these runs produced
+(tests/golden/ref_runs.npz, tests/golden/ref_blend.npz).
+
+Every run happens in a short-lived child process -- `python tests/ref_run.py <job> <in.npz> <out.npz> <scratch>` is that process,
+`run(job, **arrays)` the caller's side -- which, after mapping the images and before the first instruction of theirs executes, confines
+ITSELF (pe_lockdown: uid/gid nobody when it was root, an empty scratch directory, no_new_privs, a seccomp filter on all threads that
+leaves memory management, reads/writes on descriptors already open, clocks and exit).  pe_call refuses to run in an unconfined process.
+The parent reads the answer as plain arrays (np.load, allow_pickle off).  cv::Mat headers are laid out by hand (OpenCV 2.4.11, x64: 96
+bytes)."""
 import ctypes as C
+import hashlib
+import io
 import os
 import subprocess
 import sys
@@ -14,17 +23,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RELEASE = "/root/reference/stitching/OpenCV2.4.11-Stitching-64bit/x64/Release"
 DLLS = {"core": "opencv_core2411.dll", "imgproc": "opencv_imgproc2411.dll", "stitching": "opencv_stitching2411.dll",
         "exe": "OpenCV2.4.11-Stitching.exe"}                    # (the x64 executable maps at 0x140000000: the reference's OWN compiled sources)
+PINNED = {"core": "cfedf4b256c68aa18a89ce1f7f75d4e3fdaa6fd721b3133b63577919be5c1e60",
+          "imgproc": "5f0902d99da96d26db4bb304f047365eb7e308af53da1f47bd0c0907d1344a0f",
+          "stitching": "0d9365a326abaa4d8cd3a0e0ed6b80d3848927fff24ff146d0c56b6e3c0d09c3",
+          "exe": "6ea54dc72eefb94e8f2681ec31bac41f731c7e7dca44de49348a4e2aea2f6997"}      # the files the audit read; anything else is not run
+OPT_IN = "MST_RUN_REFERENCE_BINARIES"
 SRC = os.path.join(ROOT, "oracle", "ref_run", "pe_run.c")
 LIB = os.path.join(ROOT, "oracle", "ref_run", "libpe_run.so")
+PE_LEAF, PE_FULL = 0, 1
+SCRATCH = None                  # the empty directory the child confines itself to (argv[4] of the job process)
+
+
+def opted_in():
+    return os.environ.get(OPT_IN) == "1"
 
 
 def available():
-    return all(os.path.exists(os.path.join(RELEASE, d)) for d in DLLS.values())
+    """the reference binaries may be run here: opted in, present, and byte for byte the pinned files"""
+    return opted_in() and all(os.path.exists(os.path.join(RELEASE, d)) for d in DLLS.values())
+
+
+def image_bytes(which):
+    data = open(os.path.join(RELEASE, DLLS[which]), "rb").read()
+    sha = hashlib.sha256(data).hexdigest()
+    if sha != PINNED[which]:
+        raise RuntimeError("%s is not the pinned file (sha256 %s): refusing to run it" % (DLLS[which], sha))
+    return data
 
 
 def build():
+    if not opted_in():
+        raise RuntimeError("running the reference's binaries is opt-in: set %s=1" % OPT_IN)
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-o", LIB, SRC], check=True)
+        subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-o", LIB, SRC, "-lm"], check=True)
     return LIB
 
 
@@ -54,20 +85,210 @@ def mat(a):
     return m
 
 
+_L = None
+
+
+def _lib():
+    global _L
+    if _L is not None:
+        return _L
+    L = _L = C.CDLL(build())
+    L.pe_map.restype = C.c_int
+    L.pe_map.argtypes = [C.c_char_p, C.c_long, C.c_uint64, C.c_char_p]
+    L.pe_bind.restype = C.c_int
+    L.pe_bind.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pe_export.restype = C.c_uint64
+    L.pe_export.argtypes = [C.c_int, C.c_char_p]
+    L.pe_base.restype = L.pe_entry.restype = C.c_uint64
+    L.pe_base.argtypes = L.pe_entry.argtypes = [C.c_int]
+    L.pe_lockdown.restype = C.c_int
+    L.pe_lockdown.argtypes = [C.c_char_p]
+    L.pe_call.restype = C.c_uint64
+    L.pe_call.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
+    L.pe_call_d.restype = C.c_double
+    L.pe_call_d.argtypes = [C.c_uint64, C.POINTER(C.c_double)]
+    L.pe_call_pf.restype = C.c_uint64
+    L.pe_call_pf.argtypes = [C.c_uint64, C.c_uint64, C.c_float]
+    L.pe_call_ppidd.restype = C.c_uint64
+    L.pe_call_ppidd.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_double]
+    L.pe_phase.restype = C.c_int
+    L.pe_phase.argtypes = [C.c_int]
+    L.pe_math_log.restype = C.c_int
+    L.pe_math_log.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    return L
+
+
+def _confine(L):
+    """no instruction of the reference executes before this returns 0"""
+    if SCRATCH is None:
+        raise RuntimeError("reference code runs only in the job process (tests/ref_run.py <job> ...), which is given a scratch directory")
+    np.savez(io.BytesIO(), warm=np.zeros(1))                    # (pull in every lazy import the answer needs while files can still be opened)
+    rc = L.pe_lockdown(SCRATCH.encode())
+    if rc != 0:
+        raise RuntimeError("pe_lockdown failed (%d): not running reference code unconfined" % rc)
+
+
 class Image:
+    """ONE image at its preferred base, every import trapped but cv::checkHardwareSupport and memset / memcpy / memmove: leaf functions"""
+
     def __init__(self, which):
-        self.L = C.CDLL(build())
-        self.L.pe_load.restype = C.c_uint64
-        self.L.pe_load.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
-        self.L.pe_call.restype = C.c_uint64
-        self.L.pe_call.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
-        n = C.c_int()
-        self.base = self.L.pe_load(os.path.join(RELEASE, DLLS[which]).encode(), C.byref(n))
+        self.L = _lib()
+        assert self.L.pe_prepare() == 0
+        data = image_bytes(which)
+        idx = self.L.pe_map(data, len(data), 0, DLLS[which].encode())
+        assert idx == 0, "the image did not map"
+        self.base = self.L.pe_base(idx)
         assert self.base == (0x140000000 if which == "exe" else 0x180000000), "the image did not map at its preferred base"
+        assert self.L.pe_bind(idx, PE_LEAF, None, None) >= 0
+        _confine(self.L)
 
     def call(self, addr, *args):
         a = (C.c_uint64 * 8)(*([int(x) & 0xFFFFFFFFFFFFFFFF for x in args] + [0] * (8 - len(args))))
         return self.L.pe_call(addr, a)
+
+
+class Process:
+    """core + imgproc + stitching mapped TOGETHER (stitching at the shared preferred base, the other two relocated), imports bound to each
+    other's exports by name, loader / allocator services answered by the host (pe_run.c: PE_FULL), every other import trapped by name.
+    The images' own entry points run first, as the Windows loader would run them (_DllMainCRTStartup: the static initialisers -- cpuid
+    feature flags, the MatOp singletons, the lookup tables)."""
+    BASES = {"stitching": 0, "core": 0x190000000, "imgproc": 0x1A0000000}
+    ORDER = ("core", "imgproc", "stitching")                    # dependency order: the loader initialises imports first
+
+    def __init__(self, images=ORDER):
+        self.L = _lib()
+        assert self.L.pe_prepare() == 0
+        self.idx, self.base = {}, {}
+        for which in images:
+            data = image_bytes(which)
+            i = self.L.pe_map(data, len(data), self.BASES[which], DLLS[which].encode())
+            assert i >= 0, "%s did not map" % which
+            self.idx[which], self.base[which] = i, self.L.pe_base(i)
+        self.binding = {}
+        for which in images:
+            nb, na = C.c_int(), C.c_int()
+            trapped = self.L.pe_bind(self.idx[which], PE_FULL, C.byref(nb), C.byref(na))
+            assert trapped >= 0
+            self.binding[which] = {"bound_to_images": nb.value, "answered_by_host": na.value, "trapped": trapped}
+        _confine(self.L)
+        for which in images:                                    # DllMain(hinst, DLL_PROCESS_ATTACH, NULL) must return TRUE
+            assert self.call(self.L.pe_entry(self.idx[which]), self.base[which], 1, 0) & 0xFF == 1, which
+        self.trig_calls_in_initialisers = self.L.pe_phase(1)    # from here on sin / cos are trapped again
+        # cv::setNumThreads(0): cv::parallel_for_ then runs its body over the whole range on the calling thread instead of handing it
+        # to the Concurrency runtime (MSVCR100's, not in the tree).  Row-parallel loops: the results do not depend on the split.
+        if "core" in self.idx:
+            self.call(self.sym("core", "?setNumThreads@cv@@YAXH@Z"), 0)
+
+    def sym(self, which, name):
+        a = self.L.pe_export(self.idx[which], name.encode())
+        assert a, "%s does not export %s" % (which, name)
+        return a
+
+    def at(self, which, preferred_address):
+        """an address quoted for the image at its preferred base (0x180000000) -> where it is now"""
+        return preferred_address - 0x180000000 + self.base[which]
+
+    def call(self, addr, *args):
+        a = (C.c_uint64 * 8)(*([int(x) & 0xFFFFFFFFFFFFFFFF for x in args] + [0] * (8 - len(args))))
+        return self.L.pe_call(addr, a)
+
+    def call_f(self, addr, a0, f1):
+        """(pointer, float): the float travels in xmm1"""
+        return self.L.pe_call_pf(addr, int(a0), float(f1))
+
+    def call_convert_to(self, addr, this, out, rtype, alpha, beta):
+        """(pointer, pointer, int, double, double): rcx, rdx, r8d, xmm3, [rsp + 0x28]"""
+        return self.L.pe_call_ppidd(addr, int(this), int(out), int(rtype), float(alpha), float(beta))
+
+    def math_log(self):
+        out, fn, x, y = [], C.create_string_buffer(8), C.c_double(), C.c_double()
+        n = self.L.pe_math_log(-1, fn, C.byref(x), C.byref(y))
+        for i in range(n):
+            self.L.pe_math_log(i, fn, C.byref(x), C.byref(y))
+            out.append((fn.value.decode(), x.value, y.value))
+        return out
+
+
+def empty_mat():
+    """a default-constructed cv::Mat (flags = MAGIC_VAL, dims 0, size.p -> rows, step.p -> step.buf)"""
+    m = Mat()
+    m.flags = 0x42FF0000
+    m.size_p = C.addressof(m) + Mat.rows.offset
+    m.step_p = C.addressof(m) + Mat.step_buf.offset
+    return m
+
+
+TYPES = {0: np.uint8, 1: np.int8, 2: np.uint16, 3: np.int16, 4: np.int32, 5: np.float32, 6: np.float64}
+
+
+def mat_array(m):
+    """a copy of what a cv::Mat the reference allocated holds"""
+    depth, cn = m.flags & 7, ((m.flags >> 3) & 63) + 1
+    dt = np.dtype(TYPES[depth])
+    if not m.data or m.rows <= 0 or m.cols <= 0:
+        return np.zeros((0, 0) if cn == 1 else (0, 0, cn), dt)
+    step = C.c_size_t.from_address(m.step_p).value
+    raw = np.frombuffer(C.string_at(m.data, step * (m.rows - 1) + m.cols * cn * dt.itemsize), np.uint8)
+    rows = np.stack([raw[y * step:y * step + m.cols * cn * dt.itemsize] for y in range(m.rows)])
+    out = rows.view(dt).reshape((m.rows, m.cols) if cn == 1 else (m.rows, m.cols, cn))
+    return np.ascontiguousarray(out)
+
+
+BLENDER = {"no": ("??0Blender@detail@cv@@QEAA@XZ", "Blender"), "feather": ("??0FeatherBlender@detail@cv@@QEAA@M@Z", "FeatherBlender"),
+           "multiband": ("??0MultiBandBlender@detail@cv@@QEAA@HHH@Z", "MultiBandBlender")}
+MAT_CONVERT_TO = "?convertTo@Mat@cv@@QEBAXAEBV_OutputArray@2@HNN@Z"    # Mat::convertTo(OutputArray, int rtype, double alpha, double beta)
+OUTPUT_ARRAY_FROM_MAT = "??0_OutputArray@cv@@QEAA@AEAVMat@1@@Z"        # _OutputArray::_OutputArray(Mat&)
+
+
+def job_blend(kind, corners, dst_roi, num_bands, weight_type, sharpness, **planes):
+    """The reference's OWN blender, whole: cv::detail::{Blender, FeatherBlender, MultiBandBlender} of opencv_stitching2411.dll --
+    constructor, prepare(Rect), feed(img CV_16SC3, mask CV_8U, tl) per camera, blend(dst, dst_mask) -- over core and imgproc mapped beside
+    it, then `result.convertTo(pano, CV_8U)` as Stitcher::composePanorama / imwrite do (stitcher.cpp:320; DRV:787).  R64/src/blenders.cpp:
+    71-113 (Blender), 115-186 (Feather), 189-377 (MultiBand), 435-530 (pyramids)."""
+    kind = str(kind)
+    p = Process()
+    ctor, cls = BLENDER[kind]
+    this = (C.c_uint8 * 4096)()
+    obj = C.addressof(this)
+    if kind == "multiband":
+        p.call(p.sym("stitching", ctor), obj, 0, int(num_bands), int(weight_type))           # (try_gpu = false)
+    elif kind == "feather":
+        p.call_f(p.sym("stitching", ctor), obj, float(sharpness))
+    else:
+        p.call(p.sym("stitching", ctor), obj)
+    rect = (C.c_int * 4)(*[int(v) for v in dst_roi])
+    p.call(p.sym("stitching", "?prepare@%s@detail@cv@@UEAAXV?$Rect_@H@3@@Z" % cls), obj, C.addressof(rect))
+    feed = p.sym("stitching", "?feed@%s@detail@cv@@UEAAXAEBVMat@3@0V?$Point_@H@3@@Z" % cls)
+    keep = []
+    for i, (x, y) in enumerate(np.asarray(corners).reshape(-1, 2)):
+        img = np.ascontiguousarray(planes["img%d" % i], np.int16)
+        msk = np.ascontiguousarray(planes["mask%d" % i], np.uint8)
+        mi, mm = mat(img), mat(msk)
+        keep += [img, msk, mi, mm]
+        tl = (C.c_int * 2)(int(x), int(y))                      # cv::Point has a user-declared copy constructor: MSVC passes it by reference
+        p.call(feed, obj, C.addressof(mi), C.addressof(mm), C.addressof(tl))
+    dst, dst_mask = empty_mat(), empty_mat()
+    p.call(p.sym("stitching", "?blend@%s@detail@cv@@UEAAXAEAVMat@3@0@Z" % cls), obj, C.addressof(dst), C.addressof(dst_mask))
+    out = {"dst": mat_array(dst), "dst_mask": mat_array(dst_mask)}
+    if kind == "multiband":
+        out["num_bands"] = np.array(p.call(p.sym("stitching", "?numBands@MultiBandBlender@detail@cv@@QEBAHXZ"), obj) & 0xFFFFFFFF, np.int32)
+    # result.convertTo(pano, CV_8U): Mat::convertTo(_OutputArray(pano), CV_8U, 1.0, 0.0) -- the doubles travel in xmm3 and on the stack
+    pano = empty_mat()
+    oa = (C.c_uint8 * 64)()
+    p.call(p.sym("core", OUTPUT_ARRAY_FROM_MAT), C.addressof(oa), C.addressof(pano))
+    p.call_convert_to(p.sym("core", MAT_CONVERT_TO), C.addressof(dst), C.addressof(oa), 0, 1.0, 0.0)
+    out["pano"] = mat_array(pano)
+    log = p.math_log()
+    out["math_fn"] = np.array([l[0] for l in log], "S8")
+    out["math_xy"] = np.array([[l[1], l[2]] for l in log], np.float64).reshape(-1, 2)
+    print(p.binding, "trig calls in initialisers:", p.trig_calls_in_initialisers, file=sys.stderr)
+    return out
+
+
+def job_probe():
+    p = Process()
+    print(p.binding, file=sys.stderr)
+    return {"ok": np.array(1)}
 
 
 # ---- jobs (each runs in its own process) ---------------------------------------------------------------------------------------
@@ -443,23 +664,34 @@ def job_arith16s(a, b, sub, sse):
     return {"out": d.reshape(x.shape)}
 
 
-JOBS = {"arith16s": job_arith16s, "blocks_gain_apply": job_blocks_gain_apply, "remap_nearest": job_remap_nearest, "resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
+JOBS = {"probe": job_probe, "blend": job_blend, "arith16s": job_arith16s, "blocks_gain_apply": job_blocks_gain_apply, "remap_nearest": job_remap_nearest, "resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):
-    """-> dict of output arrays, from a fresh process"""
+    """-> dict of output arrays, from a fresh, self-confining process"""
+    if not available():
+        raise RuntimeError("reference binaries are not run here (set %s=1 where /root/reference exists)" % OPT_IN)
     with tempfile.TemporaryDirectory() as d:
-        fin, fout = os.path.join(d, "in.npz"), os.path.join(d, "out.npz")
+        fin, fout, scratch = os.path.join(d, "in.npz"), os.path.join(d, "out.npz"), os.path.join(d, "scratch")
+        os.mkdir(scratch)
+        os.chmod(d, 0o755)
         np.savez(fin, **arrays)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), job, fin, fout], capture_output=True, text=True, timeout=600)
+        env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), job, fin, fout, scratch], capture_output=True, text=True, timeout=900,
+                           env=env)
         if r.returncode != 0:
-            raise RuntimeError("ref_run %s failed (%d): %s" % (job, r.returncode, r.stderr.strip()[-400:]))
-        with np.load(fout) as z:
+            raise RuntimeError("ref_run %s failed (%d): %s" % (job, r.returncode, r.stderr.strip()[-600:]))
+        with np.load(fout, allow_pickle=False) as z:
             return {k: z[k] for k in z.files}
 
 
 if __name__ == "__main__":
-    name, fin, fout = sys.argv[1:4]
-    with np.load(fin) as z:
-        out = JOBS[name](**{k: z[k] for k in z.files})
-    np.savez(fout, **out)
+    name, fin, fout, SCRATCH = sys.argv[1:5]
+    if not available():
+        sys.exit("reference binaries are not run here (set %s=1 where /root/reference exists)" % OPT_IN)
+    with np.load(fin, allow_pickle=False) as z:
+        args = {k: z[k] for k in z.files}
+    with open(fout, "wb") as answer:                             # opened BEFORE the job confines the process
+        out = JOBS[name](**args)
+        assert _lib().pe_locked() == 1
+        np.savez(answer, **out)
