@@ -458,7 +458,7 @@ int pe_lockdown(const char *scratch)
         ALLOW(SYS_mmap), ALLOW(SYS_munmap), ALLOW(SYS_mremap), ALLOW(SYS_mprotect), ALLOW(SYS_brk), ALLOW(SYS_madvise),
         ALLOW(SYS_futex), ALLOW(SYS_rt_sigaction), ALLOW(SYS_rt_sigprocmask), ALLOW(SYS_rt_sigreturn), ALLOW(SYS_sigaltstack),
         ALLOW(SYS_clock_gettime), ALLOW(SYS_gettimeofday), ALLOW(SYS_getrandom), ALLOW(SYS_sched_yield),
-        ALLOW(SYS_getpid), ALLOW(SYS_gettid), ALLOW(SYS_exit), ALLOW(SYS_exit_group),
+        ALLOW(SYS_getpid), ALLOW(SYS_gettid), ALLOW(SYS_getuid), ALLOW(SYS_geteuid), ALLOW(SYS_exit), ALLOW(SYS_exit_group),
         BPF_STMT(BPF_RET | BPF_K, SECCOMP_RET_ERRNO | EPERM),                                   /* everything else: refused */
     };
     struct sock_fprog prog = {(unsigned short)(sizeof f / sizeof f[0]), f};
@@ -472,34 +472,18 @@ int pe_lockdown(const char *scratch)
 
 int pe_locked(void) { return g_locked; }
 
-typedef uint64_t (MS *ms_fn8)(uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t);
+typedef uint64_t (MS *ms_vfn)(uint64_t, ...);
 
-/* Calls the function at `addr` with up to eight integer / pointer arguments (Microsoft x64 convention; a callee that takes fewer
- * ignores the rest).  Returns rax.  Refuses (exit 76) in a process that is not confined. */
+/* Calls the function at `addr` (Microsoft x64 convention) with eight 8-byte argument slots.  Slots 1..3 are handed over as a variadic
+ * call hands floating-point arguments -- the same bits in the integer register AND in xmm1..3 -- so one shape serves pointer, integer,
+ * float and double parameters alike (a float's bits in the low half of its slot); slot 0 is integer-only (every function called here
+ * takes a pointer first); slots 4..7 go on the stack, where the type does not matter.  A callee that takes fewer ignores the rest.
+ * Returns rax.  Refuses (exit 76) in a process that is not confined. */
 uint64_t pe_call(uint64_t addr, const uint64_t *a)
 {
     if (!g_locked) { say("pe_run: pe_call before pe_lockdown -- refusing to run reference code unconfined\n"); _exit(76); }
     if (g_verbose) { char w[160], m[220]; snprintf(m, sizeof m, "pe_run: call %s\n", where(addr, w, sizeof w)); say(m); }
-    return ((ms_fn8)(uintptr_t)addr)(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
-}
-
-typedef double (MS *ms_fn_d)(double, double, double, double);
-double pe_call_d(uint64_t addr, const double *a)
-{
-    if (!g_locked) { say("pe_run: pe_call_d before pe_lockdown -- refusing to run reference code unconfined\n"); _exit(76); }
-    return ((ms_fn_d)(uintptr_t)addr)(a[0], a[1], a[2], a[3]);
-}
-
-/* mixed integer / floating-point signatures the whole-function runs need (ms_abi: the compiler places each argument by position) */
-typedef uint64_t (MS *ms_fn_pf)(uint64_t, float);
-uint64_t pe_call_pf(uint64_t addr, uint64_t a0, float f1)
-{
-    if (!g_locked) { say("pe_run: call before pe_lockdown -- refusing\n"); _exit(76); }
-    return ((ms_fn_pf)(uintptr_t)addr)(a0, f1);
-}
-typedef uint64_t (MS *ms_fn_ppidd)(uint64_t, uint64_t, int, double, double);
-uint64_t pe_call_ppidd(uint64_t addr, uint64_t a0, uint64_t a1, int a2, double d3, double d4)
-{
-    if (!g_locked) { say("pe_run: call before pe_lockdown -- refusing\n"); _exit(76); }
-    return ((ms_fn_ppidd)(uintptr_t)addr)(a0, a1, a2, d3, d4);
+    double d1, d2, d3;
+    memcpy(&d1, &a[1], 8); memcpy(&d2, &a[2], 8); memcpy(&d3, &a[3], 8);
+    return ((ms_vfn)(uintptr_t)addr)(a[0], d1, d2, d3, a[4], a[5], a[6], a[7]);
 }

@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O          # noqa: E402
 import ref_run as R             # noqa: E402
 
-pytestmark = pytest.mark.skipif(not R.available(), reason="needs the reference tree (/root/reference): its DLLs are run in place")
+pytestmark = pytest.mark.skipif(not R.available(), reason="opt-in: needs the reference tree (/root/reference) and MST_RUN_REFERENCE_BINARIES=1 "
+                                                           "(its binaries are run in place, sha256-pinned, in a seccomp-confined child)")
 
 
 def test_goldens_regenerate_bit_for_bit():
@@ -23,6 +24,32 @@ def test_goldens_regenerate_bit_for_bit():
         assert sorted(z.files) == sorted(fresh)
         for k in z.files:
             assert fresh[k].dtype == z[k].dtype and np.array_equal(fresh[k].view(np.uint8), z[k].view(np.uint8)), k
+
+
+def test_pipeline_goldens_regenerate_bit_for_bit():
+    """the reference's blender / whole functions / compose loop, run again: the committed panoramas come back byte for byte"""
+    import make_ref_pipeline_goldens as M
+    for fresh, path in ((M.cases(), M.OUT), (M.stills_case(), M.OUT_STILLS)):
+        with np.load(path) as z:
+            assert sorted(z.files) == sorted(fresh)
+            for k in z.files:
+                a, b = np.asarray(fresh[k]), z[k]
+                assert a.shape == b.shape and np.array_equal(a, b, equal_nan=a.dtype.kind == "f"), k
+
+
+def test_unconfined_process_cannot_call_reference_code():
+    """pe_call refuses (exit 76) before pe_lockdown: no instruction of the reference runs in an unconfined process"""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import ref_run as R, ctypes as C; L = R._lib(); L.pe_prepare(); d = R.image_bytes('core'); "
+            "i = L.pe_map(d, len(d), 0, b'core'); L.pe_bind(i, 0, None, None); a = (C.c_uint64 * 8)(); L.pe_call(L.pe_entry(i), a)") % os.path.join(ROOT, "tests")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ))
+    assert r.returncode == 76 and "refusing" in r.stderr, (r.returncode, r.stderr[-300:])
+
+
+def test_confined_process_cannot_open_or_connect():
+    """what the filter leaves: after the lockdown the job process cannot open a file, make a socket or start a program"""
+    out = R.run("confinement_probe")
+    assert int(out["open_errno"]) == 1 and int(out["socket_errno"]) == 1 and int(out["exec_errno"]) == 1 and int(out["uid"]) == 65534
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
