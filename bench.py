@@ -266,10 +266,13 @@ def main():
     n_cam = len(rig["cameras"])
     by_camera = args.shard == "cameras" and blend == "multiband"
     batch = 1 if by_camera else max(1, min(args.batch, 8))
-    # N > 1: the headline is the STRONG-scaling mode -- the canvas cut into N column strips, rank r composes strip r of every
-    # panorama (mst_config.strip_index / strip_count; no data-path collective).  The trivial mode (every
-    # GPU stitches its own frame sets, "replicas") is reported beside it, not as `value`.
-    strip_mode = (world > 1 or args.strip_headline) and not by_camera and blend == "multiband"
+    # N > 1: `value` keeps the meaning it has at N = 1 -- WHOLE panoramas delivered per second -- with per-GPU work fixed ("weak"): the
+    # frame sets are the independent units, rank r stitches frame sets r, r + N, r + 2N ... into whole panoramas in its own HBM, no
+    # data-path collective.  The modes that split ONE panorama over the GPUs are reported beside it under their own keys, each with
+    # its gather to one consumer inside the timed region: `camera_sharded` (the north star's C4 split: camera i on GPU i mod N, one
+    # grouped RCCL send/recv of the pyramid payloads to rank 0) and `strip_sharded` (the canvas cut into N column strips).
+    # --strip-headline puts the strip mode's strips-left-in-place rate into `value` instead (a one-GPU test hook, labelled "strong").
+    strip_mode = args.strip_headline and not by_camera and blend == "multiband"
     strip_kw = {"strip": (rank, world)} if strip_mode else {}
     eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
                            overlap_frames=args.overlap and not args.no_overlap and blend == "multiband" and not by_camera,
@@ -679,6 +682,7 @@ def main():
     # (when a leg fails on one rank only, its peers sit in the exchange and this rank would otherwise wait for them
     # there).  A run that ends through a watchdog has still printed the headline, and exits non-zero.
     watchdog = [None]
+    ranks_error = None
 
     def arm(leg, seconds=240.0):
         if watchdog[0] is not None:
@@ -711,9 +715,17 @@ def main():
             dist.all_gather_object(seen, ident)
         except Exception as e:          # noqa: BLE001
             seen = [{"error": "%s: %s" % (type(e).__name__, e)}]
+        n_ranks = len([r for r in seen if isinstance(r, dict) and "rank" in r])
+        n_devs = len({(r or {}).get("uuid") or (r or {}).get("pci") for r in seen if isinstance(r, dict)})
         if rank == 0:
-            out["ranks_seen"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": seen,
-                                 "distinct_devices": len({(r or {}).get("uuid") or (r or {}).get("pci") for r in seen if isinstance(r, dict)})}
+            out["ranks_seen"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": seen, "distinct_devices": n_devs}
+        # a job that does not span N ranks on N distinct GPUs is not the N-GPU measurement: say so in the line and exit non-zero
+        # (the one-GPU smoke hook, where the ranks share the visible devices on purpose, is exempt from the device count)
+        if n_ranks != world or dist.get_world_size() != args.gpus or (not smoke_backend and n_devs != world):
+            ranks_error = "ranks_seen: %d rank(s) on %d distinct device(s), expected %d (--gpus %d)" % (n_ranks, n_devs, world, args.gpus)
+            if rank == 0:
+                out["error"] = ranks_error
+                out["value"] = None
     # ---- N > 1: the north-star split measured beside the headline (C4: 8 cameras, camera i on rank i % N) ----
     if (world > 1 or args.camera_leg) and not by_camera and not args.no_camera_leg:
         arm("camera_sharded")
@@ -783,6 +795,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     arm(None)
+    if ranks_error:
+        sys.exit("bench.py: " + ranks_error)
 
 
 def host_buffer_leg(eng, host_sets, cw, ch, serial=True):

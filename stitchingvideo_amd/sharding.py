@@ -100,6 +100,13 @@ def pyramid_tensor(engine, camera, device):
     return torch.as_tensor(_DevicePtr(ptr, nbytes), device=device)
 
 
+def host_staged():
+    """True when the process group cannot move device memory (gloo): the exchanges then stage through pinned host buffers.  That is
+    the transport of the two-process ONE-GPU tests (RCCL refuses two ranks of a communicator on one device) -- never of a real
+    multi-GPU run, where the backend is "nccl" (RCCL) and the tensors stay in HBM."""
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl"
+
+
 def exchange_to_root(send, recv, owners, root, rank, tag_base=0):
     """One exchange step: every non-root owner sends its cameras' payload tensors to `root`.
 
@@ -146,6 +153,7 @@ class ShardedStitcher:
         self.sets = sets
         self.generation = None
         self.bufs = []               # per set: {camera: uint8 tensor}: send buffers (owners) / landing buffers (root)
+        self.hbufs = None            # their pinned host mirrors when the process group cannot move device memory
         self.pending = {}            # set -> (work handles, pano args)
 
     def refresh(self):
@@ -162,6 +170,9 @@ class ShardedStitcher:
             cams = [c for c in range(n) if self.owners[c] != self.root] if self.rank == self.root else self.mine
             self.bufs = [{c: torch.empty(self.engine.payload_bytes(c), dtype=torch.uint8, device=self.device) for c in cams}
                          for _ in range(self.sets)]
+            # (gloo: pinned host mirrors of the same buffers -- see host_staged())
+            self.hbufs = [{c: torch.empty(t.numel(), dtype=torch.uint8).pin_memory() for c, t in b.items()} for b in self.bufs] \
+                if self.world > 1 and host_staged() else None
             self.generation = gen
             self.pending = {}
         return gen
@@ -188,7 +199,16 @@ class ShardedStitcher:
             if self.rank != self.root:
                 for c in self.mine:
                     self.engine.payload_pack(c, self.bufs[k][c].data_ptr(), stream=stream)
-            works = exchange_to_root(self.bufs[k], self.bufs[k], self.owners, self.root, self.rank, tag_base=64 * k)
+            if self.hbufs is not None:
+                # host-staged transport: the packed payload leaves HBM on the same stream as the pack, and the stream is drained
+                # before the host tensors are handed to the process group
+                if self.rank != self.root:
+                    for c in self.mine:
+                        self.hbufs[k][c].copy_(self.bufs[k][c], non_blocking=True)
+                    torch.cuda.current_stream(self.device).synchronize()
+                works = exchange_to_root(self.hbufs[k], self.hbufs[k], self.owners, self.root, self.rank, tag_base=64 * k)
+            else:
+                works = exchange_to_root(self.bufs[k], self.bufs[k], self.owners, self.root, self.rank, tag_base=64 * k)
         self.pending[k] = works
 
     def finish(self, t, pano_ptr=None, pano_stride=0, stream=None):
@@ -203,6 +223,8 @@ class ShardedStitcher:
             if self.world > 1:
                 for c, owner in enumerate(self.owners):
                     if owner != self.root:
+                        if self.hbufs is not None:
+                            self.bufs[k][c].copy_(self.hbufs[k][c], non_blocking=True)         # (same stream as the unpack below)
                         self.engine.payload_unpack(c, self.bufs[k][c].data_ptr(), stream=stream)
             self.engine.stage_canvas(pano_ptr, pano_stride, stream=stream)
 
@@ -252,9 +274,10 @@ def gather_strips_to_root(strip, rects, root, rank, pano=None):
     travel.  All transfers go out as ONE batch_isend_irecv (ncclGroupStart/End on RCCL: every peer uses its own xGMI
     link to the root).  Returns `pano` on the root, None elsewhere."""
     world = len(rects)
+    staged = host_staged()           # (gloo: through host memory; .cpu() drains the producing stream first)
     if rank != root:
         if rects[rank][1] > 0:
-            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, strip, root, tag=100 + rank)]):
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, strip.cpu() if staged else strip, root, tag=100 + rank)]):
                 w.wait()
         return None
     ops, bufs = [], {}
@@ -262,7 +285,7 @@ def gather_strips_to_root(strip, rects, root, rank, pano=None):
         x, w = rects[r]
         if r == root or w <= 0:
             continue
-        bufs[r] = torch.empty((pano.shape[0], w, 3), dtype=torch.uint8, device=pano.device)
+        bufs[r] = torch.empty((pano.shape[0], w, 3), dtype=torch.uint8, device="cpu" if staged else pano.device)
         ops.append(dist.P2POp(dist.irecv, bufs[r], r, tag=100 + r))
     works = dist.batch_isend_irecv(ops) if ops else []
     x, w = rects[root]
@@ -272,7 +295,7 @@ def gather_strips_to_root(strip, rects, root, rank, pano=None):
         wk.wait()
     for r, b in bufs.items():
         x, w = rects[r]
-        pano[:, x:x + w] = b
+        pano[:, x:x + w] = b.to(pano.device) if staged else b
     return pano
 
 

@@ -72,7 +72,12 @@ void usage()
         "  --warp (plane|cylindrical|spherical|fisheye|stereographic|compressedPlaneA2B1|compressedPlaneA1.5B1|\n"
         "          compressedPlanePortraitA2B1|compressedPlanePortraitA1.5B1|paniniA2B1|paniniA1.5B1|paniniPortraitA2B1|\n"
         "          paniniPortraitA1.5B1|mercator|transverseMercator)                 default spherical (CLI:102)\n"
-        "  --expos_comp (no|gain_blocks)                     default gain_blocks (synthetic block gains)\n"
+        "  --expos_comp (no|gain|gain_blocks)                default gain_blocks (CLI:111; the gains are synthetic: registration is\n"
+        "                             out of scope -- `gain`: one factor per camera, `gain_blocks`: 32 x 32 block maps)\n"
+        "  --compose_megapix <float>  resolution of the compositing step, -1 = original (default, CLI:108-110): the inputs are resized\n"
+        "                             by min(1, sqrt(Mpx * 1e6 / area)) and focal / ppx / ppy / the warp scale follow (CLI:662-700)\n"
+        "  --seam_megapix <float>     accepted for compatibility (CLI:104): this tool finds seams at compose resolution\n"
+        "  --parse_only               print the parsed configuration and exit (no GPU touched)\n"
         "  --blend (no|feather|multiband)                    default multiband\n"
         "  --blend_strength <float>   [0,100], default 5 (same rule as the sample: width = sqrt(area)*s/100)\n"
         "  --seam (no|voronoi|dp_color|dp_colorgrad)          seam finder on the full-resolution warped images (CLI:106 has\n"
@@ -82,6 +87,57 @@ void usage()
         "  --lut                      the driver's hard-seam LUT composite with its crop margins\n"
         "  --frames <K>               frame-loop iterations (default 1)\n"
         "  --output <result.ppm>      default result.ppm\n");
+}
+
+// cv::resize(src, dst, Size(), f, f, INTER_LINEAR) on CV_8UC3 as the sample applies it to every input when --compose_megapix shrinks
+// them (CLI:699-700; imgwarp.cpp of 2.4.11: dsize = cvRound(size * f), scale = 1 / f, 11-bit horizontal coefficients, the vertical pass
+// `(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2`).  Host code like the sample's own imread + resize: it runs once per
+// input image, before the frame loop.
+int cv_round(double v) { return static_cast<int>(std::nearbyint(v)); }
+
+short resize_coef(float v) { return static_cast<short>(cv_round(static_cast<double>(v * 2048.f))); }
+
+Image resize_linear_bgr(const Image& src, double f)
+{
+    Image dst;
+    dst.w = cv_round(src.w * f); dst.h = cv_round(src.h * f);
+    dst.bgr.resize(static_cast<size_t>(dst.w) * dst.h * 3);
+    const double scale = 1. / f;
+    std::vector<int> xofs(dst.w);
+    std::vector<short> alpha(2 * static_cast<size_t>(dst.w));
+    int xmax = dst.w;
+    for (int dx = 0; dx < dst.w; ++dx) {
+        float fx = static_cast<float>((dx + 0.5) * scale - 0.5);
+        int sx = static_cast<int>(std::floor(fx));
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= src.w) xmax = std::min(xmax, dx);
+        if (sx >= src.w - 1) { fx = 0; sx = src.w - 1; }
+        xofs[dx] = sx;
+        alpha[2 * dx] = resize_coef(1.f - fx); alpha[2 * dx + 1] = resize_coef(fx);
+    }
+    std::vector<int> rows[2] = {std::vector<int>(static_cast<size_t>(dst.w) * 3), std::vector<int>(static_cast<size_t>(dst.w) * 3)};
+    for (int dy = 0; dy < dst.h; ++dy) {
+        float fy = static_cast<float>((dy + 0.5) * scale - 0.5);
+        const int sy = static_cast<int>(std::floor(fy));
+        fy -= sy;
+        const short b0 = resize_coef(1.f - fy), b1 = resize_coef(fy);
+        for (int k = 0; k < 2; ++k) {
+            const int yy = std::min(std::max(sy + k, 0), src.h - 1);                  // rows are clipped, the weights stay
+            const uint8_t* S = src.bgr.data() + static_cast<size_t>(yy) * src.w * 3;
+            int* D = rows[k].data();
+            for (int dx = 0; dx < dst.w; ++dx)
+                for (int c = 0; c < 3; ++c)
+                    D[3 * dx + c] = dx < xmax ? S[3 * xofs[dx] + c] * alpha[2 * dx] + S[3 * (xofs[dx] + 1) + c] * alpha[2 * dx + 1]
+                                              : S[3 * xofs[dx] + c] * 2048;
+        }
+        uint8_t* out = dst.bgr.data() + static_cast<size_t>(dy) * dst.w * 3;
+        for (int i = 0; i < dst.w * 3; ++i) {
+            const int v = (((b0 * (rows[0][i] >> 4)) >> 16) + ((b1 * (rows[1][i] >> 4)) >> 16) + 2) >> 2;
+            out[i] = static_cast<uint8_t>(std::min(std::max(v, 0), 255));
+        }
+    }
+    return dst;
 }
 
 void rot_y(double deg, float R[9])
@@ -104,7 +160,8 @@ int main(int argc, char** argv)
     std::vector<std::string> img_names;
     std::vector<double> yaws;
     int synthetic_n = 0, W = 0, H = 0, frames = 1;
-    double focal = 1250.0, blend_strength = 5.0;
+    double focal = 1250.0, blend_strength = 5.0, compose_megapix = -1, seam_megapix = 0.1;
+    bool parse_only = false;
     std::string warp_type = "spherical", expos = "gain_blocks", blend = "multiband", result_name = "result.ppm";
     std::string seam = "no", save_calib, load_calib;
     bool lut = false;
@@ -122,6 +179,9 @@ int main(int argc, char** argv)
         else if (a == "--expos_comp") expos = next();
         else if (a == "--blend") blend = next();
         else if (a == "--blend_strength") blend_strength = std::atof(next());
+        else if (a == "--compose_megapix") compose_megapix = std::atof(next());
+        else if (a == "--seam_megapix") seam_megapix = std::atof(next());
+        else if (a == "--parse_only") parse_only = true;
         else if (a == "--frames") frames = std::atoi(next());
         else if (a == "--output" || a == "--result") result_name = next();
         else if (a == "--lut") lut = true;
@@ -148,8 +208,28 @@ int main(int argc, char** argv)
     const int warp_kind = mst_warp_kind_from_name(warp_type.c_str());
     if (warp_kind < 0) { std::fprintf(stderr, "Bad warping method\n"); return 1; }       // CLI:573-577
     int blend_kind = blend == "no" ? MST_BLEND_NO : blend == "feather" ? MST_BLEND_FEATHER : MST_BLEND_MULTI_BAND;
-    const int expos_kind = expos == "no" ? MST_EXPOS_NO : MST_EXPOS_GAIN_BLOCKS;
-    const float scale = static_cast<float>(focal);
+    if (expos != "no" && expos != "gain" && expos != "gain_blocks") { std::printf("Bad exposure compensation method\n"); return -1; }   // CLI:286-290
+    if (blend != "no" && blend != "feather" && blend != "multiband") { std::printf("Bad blending method\n"); return -1; }             // CLI:312-316
+    const int expos_kind = expos == "no" ? MST_EXPOS_NO : expos == "gain" ? MST_EXPOS_GAIN : MST_EXPOS_GAIN_BLOCKS;
+    // --compose_megapix (CLI:662-700): one scale for the inputs, the intrinsics and the warp scale; the inputs are only resized when the
+    // scale is more than 10 % away from 1 (CLI:686, 699)
+    double compose_scale = 1.0;
+    if (compose_megapix > 0) compose_scale = std::min(1.0, std::sqrt(compose_megapix * 1e6 / (static_cast<double>(W) * H)));
+    const bool resize_inputs = std::abs(compose_scale - 1) > 1e-1;
+    const int full_w = W, full_h = H;
+    const double ppx = full_w / 2.0 * compose_scale, ppy = full_h / 2.0 * compose_scale, focal_c = focal * compose_scale;
+    const float scale = static_cast<float>(focal) * static_cast<float>(compose_scale);      // warped_image_scale *= (float)compose_work_aspect
+    if (resize_inputs) {
+        W = cv_round(full_w * compose_scale); H = cv_round(full_h * compose_scale);
+        for (auto& im : stills) im = resize_linear_bgr(im, compose_scale);
+    }
+    if (parse_only) {
+        std::printf("images %d size %dx%d -> %dx%d compose_scale %.9g focal %.9g ppx %.9g ppy %.9g warp %s scale %.9g seam %s seam_megapix %g "
+                    "expos_comp %s blend %s blend_strength %g output %s\n", num_images, full_w, full_h, W, H, compose_scale, focal_c, ppx, ppy,
+                    warp_type.c_str(), static_cast<double>(scale), seam.c_str(), seam_megapix, expos.c_str(), blend.c_str(), blend_strength,
+                    result_name.c_str());
+        return 0;
+    }
 
     // cameras: K from focal / principal point (CameraParams::K), R = R_y(yaw); corners and sizes from warpRoi
     std::vector<mst_camera> cams(num_images);
@@ -160,8 +240,8 @@ int main(int argc, char** argv)
         mst_camera& c = cams[i];
         std::memset(&c, 0, sizeof(c));
         c.src_width = W; c.src_height = H;
-        const float K[9] = {static_cast<float>(focal), 0, static_cast<float>(W / 2.0), 0, static_cast<float>(focal),
-                            static_cast<float>(H / 2.0), 0, 0, 1};
+        const float K[9] = {static_cast<float>(focal_c), 0, static_cast<float>(ppx), 0, static_cast<float>(focal_c),
+                            static_cast<float>(ppy), 0, 0, 1};
         std::memcpy(c.K, K, sizeof(K));
         rot_y(yaws[i], c.R);
         mst_rect roi;
@@ -181,7 +261,7 @@ int main(int argc, char** argv)
                         static_cast<float>(1.0 + 0.1 * std::sin(i + bx / 5.0) * std::cos(by / 3.0));
             c.gain_map = gain_maps[i].data(); c.gain_w = gw; c.gain_h = gh;
         }
-        c.gain = 1.f;
+        c.gain = expos_kind == MST_EXPOS_GAIN ? static_cast<float>(1.0 + 0.05 * std::sin(1.0 + i)) : 1.f;     // (synthetic, as stitchingvideo_amd/rig.py)
         tlx = std::min(tlx, roi.x); tly = std::min(tly, roi.y);
         brx = std::max(brx, roi.x + roi.width); bry = std::max(bry, roi.y + roi.height);
     }
@@ -200,7 +280,11 @@ int main(int argc, char** argv)
             mst_rect roi;
             CHECK(mst_warp_roi(warp_kind, scale, cams[i].K, cams[i].R, cams[i].T, W, H, &roi));
             xy[2 * i] = roi.x; xy[2 * i + 1] = roi.y; wh[2 * i] = roi.width; wh[2 * i + 1] = roi.height;
-            if (synthetic_n) CHECK(mst_synth_frame(i, 0, W, H, first.data(), static_cast<size_t>(W) * 3));
+            if (synthetic_n) {
+                Image full; full.w = full_w; full.h = full_h; full.bgr.resize(static_cast<size_t>(full_w) * full_h * 3);
+                CHECK(mst_synth_frame(i, 0, full_w, full_h, full.bgr.data(), static_cast<size_t>(full_w) * 3));
+                first = resize_inputs ? resize_linear_bgr(full, compose_scale).bgr : full.bgr;
+            }
             const uint8_t* src = synthetic_n ? first.data() : stills[i].bgr.data();
             warped[i].resize(static_cast<size_t>(roi.width) * roi.height * 3);
             CHECK(mst_warp(0, warp_kind, scale, cams[i].K, cams[i].R, cams[i].T, src, W, H, static_cast<size_t>(W) * 3, 3, MST_INTER_LINEAR,
@@ -274,7 +358,13 @@ int main(int argc, char** argv)
     double total = 0.0;
     for (int k = 0; k < frames; ++k) {
         for (int i = 0; i < num_images; ++i) {
-            if (synthetic_n) CHECK(mst_synth_frame(i, k, W, H, frame[i].data(), strides[i]));
+            if (synthetic_n) {
+                if (resize_inputs) {
+                    Image full; full.w = full_w; full.h = full_h; full.bgr.resize(static_cast<size_t>(full_w) * full_h * 3);
+                    CHECK(mst_synth_frame(i, k, full_w, full_h, full.bgr.data(), static_cast<size_t>(full_w) * 3));
+                    frame[i] = resize_linear_bgr(full, compose_scale).bgr;
+                } else CHECK(mst_synth_frame(i, k, W, H, frame[i].data(), strides[i]));
+            }
             ptrs[i] = synthetic_n ? frame[i].data() : stills[i].bgr.data();
         }
         const auto t0 = std::chrono::steady_clock::now();
