@@ -45,10 +45,11 @@ static short to_coef(float w)
     return (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
 }
 
-void mo_resize_linear_8u(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
+/* cv::resize(INTER_LINEAR) on CV_8UC(cn) with the two scale factors given (imgwarp.cpp of 2.4.11: `scale = 1 / inv_scale`, where
+ * inv_scale is dsize / ssize when the caller passed a size -- stitcher.cpp:292 -- and the caller's fx / fy when it passed Size() and
+ * factors -- the sample's `resize(full_img, img, Size(), compose_scale, compose_scale)`, CLI:699-700) */
+void mo_resize_linear_8u_cn(const uint8_t *src, int sw, int sh, int cn, uint8_t *dst, int dw, int dh, double scale_x, double scale_y)
 {
-    double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
-    double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
     int *xofs = (int *)malloc(sizeof(int) * (size_t)dw);
     short *alpha = (short *)malloc(sizeof(short) * 2 * (size_t)dw);
     int xmax = dw;
@@ -64,8 +65,8 @@ void mo_resize_linear_8u(const uint8_t *src, int sw, int sh, uint8_t *dst, int d
         alpha[2 * dx + 1] = to_coef(fx);
     }
     int *rows[2];
-    rows[0] = (int *)malloc(sizeof(int) * (size_t)dw);
-    rows[1] = (int *)malloc(sizeof(int) * (size_t)dw);
+    rows[0] = (int *)malloc(sizeof(int) * (size_t)dw * cn);
+    rows[1] = (int *)malloc(sizeof(int) * (size_t)dw * cn);
     for (int dy = 0; dy < dh; ++dy) {
         float fy = (float)((dy + 0.5) * scale_y - 0.5);
         int sy = mo_cv_floor(fy);
@@ -74,23 +75,27 @@ void mo_resize_linear_8u(const uint8_t *src, int sw, int sh, uint8_t *dst, int d
         for (int k = 0; k < 2; ++k) {
             int yy = sy + k;
             yy = yy < 0 ? 0 : (yy > sh - 1 ? sh - 1 : yy);        /* rows are clipped, the weights stay */
-            const uint8_t *S = src + (size_t)yy * sw;
+            const uint8_t *S = src + (size_t)yy * sw * cn;
             int *D = rows[k];
-            int dx = 0;
-            for (; dx < xmax; ++dx) {
+            for (int dx = 0; dx < dw; ++dx) {
                 int sx = xofs[dx];
-                D[dx] = S[sx] * alpha[2 * dx] + S[sx + 1] * alpha[2 * dx + 1];
+                for (int c = 0; c < cn; ++c)
+                    D[dx * cn + c] = dx < xmax ? S[sx * cn + c] * alpha[2 * dx] + S[(sx + 1) * cn + c] * alpha[2 * dx + 1] : S[sx * cn + c] * 2048;
             }
-            for (; dx < dw; ++dx)
-                D[dx] = S[xofs[dx]] * 2048;
         }
-        uint8_t *out = dst + (size_t)dy * dw;
-        for (int dx = 0; dx < dw; ++dx) {
-            int v = (((b0 * (rows[0][dx] >> 4)) >> 16) + ((b1 * (rows[1][dx] >> 4)) >> 16) + 2) >> 2;
-            out[dx] = mo_sat_u8(v);
+        uint8_t *out = dst + (size_t)dy * dw * cn;
+        for (int i = 0; i < dw * cn; ++i) {
+            int v = (((b0 * (rows[0][i] >> 4)) >> 16) + ((b1 * (rows[1][i] >> 4)) >> 16) + 2) >> 2;
+            out[i] = mo_sat_u8(v);
         }
     }
     free(rows[0]); free(rows[1]); free(xofs); free(alpha);
+}
+
+void mo_resize_linear_8u(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
+{
+    double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    mo_resize_linear_8u_cn(src, sw, sh, 1, dst, dw, dh, 1. / inv_x, 1. / inv_y);
 }
 
 /* stitcher.cpp:291-294: seam-scale mask -> final full-resolution mask */

@@ -182,6 +182,7 @@ void mo_distance_transform_l1(const uint8_t *mask, int w, int h, float *dist);
 /* ---- seam-mask fix-up (a9: stitcher.cpp:291-294) ------------------------------ */
 void mo_dilate3x3_8u(const uint8_t *src, int w, int h, uint8_t *dst);
 void mo_resize_linear_8u(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh);
+void mo_resize_linear_8u_cn(const uint8_t *src, int sw, int sh, int cn, uint8_t *dst, int dw, int dh, double scale_x, double scale_y);
 void mo_mask_fixup(const uint8_t *seam_mask, int sw, int sh, const uint8_t *mask_warped, int w, int h, uint8_t *out);
 
 /* ---- VoronoiSeamFinder (seam_finders.cpp:74-85, 108-160): masks tightly packed, updated in place ---- */

@@ -137,6 +137,11 @@ def cases():
         g["wrap3/rect"], g["wrap3/pano_" + tag], g["wrap3/pano_mask_" + tag] = o["rect"], o["pano"], o["pano_mask"]
     o = reference_panorama(rig, frames, "feather", 5, 0.02)
     g["wrap3/pano_feather"], g["wrap3/pano_mask_feather"] = o["pano"], o["pano_mask"]
+    # ---- the sample's --compose_megapix resize of an input: resize(full_img, img, Size(), f, f) on CV_8UC3 (CLI:699-700) ----------------
+    bgr = rng.integers(0, 256, (135, 240, 3)).astype(np.uint8)
+    g["resizef_src"] = bgr
+    for k, f in enumerate((0.537914354, 0.25, 0.8)):
+        g["resizef_f%d" % k], g["resizef_out%d" % k] = np.float64(f), whole("resize_factor", src=bgr, f=np.array(f))
     return g
 
 

@@ -404,6 +404,17 @@ def resize_linear_8u(src, dw, dh):
     return dst
 
 
+def resize_linear_8u_factor(src, f):
+    """cv::resize(src, dst, Size(), f, f, INTER_LINEAR) on CV_8UC1 / CV_8UC3 (the sample's --compose_megapix resize, CLI:699-700)"""
+    src = np.ascontiguousarray(src, np.uint8)
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dw, dh = int(np.rint(sw * f)), int(np.rint(sh * f))
+    dst = np.zeros((dh, dw) + src.shape[2:], np.uint8)
+    lib().mo_resize_linear_8u_cn(_ptr(src), sw, sh, cn, _ptr(dst), dw, dh, C.c_double(1.0 / f), C.c_double(1.0 / f))
+    return dst
+
+
 def mask_fixup(seam_mask, mask_warped):
     """stitcher.cpp:291-294: dilate -> resize to the warped size -> & the warped all-255 mask."""
     seam_mask = np.ascontiguousarray(seam_mask, np.uint8)

@@ -215,11 +215,13 @@ class Process:
         self.keep += [s, mx, my]
         return mat_array(dst)
 
-    def resize(self, src, dsize, interp=1):
-        """cv::resize(src, dst, dsize, 0, 0, interp), whole (the coefficient tables it builds included)"""
+    def resize(self, src, dsize, interp=1, fx=0.0, fy=0.0):
+        """cv::resize(src, dst, dsize, fx, fy, interp), whole (the coefficient tables it builds included); dsize (0, 0) + factors is the
+        sample's `resize(full_img, img, Size(), compose_scale, compose_scale)`"""
         s, dst, size = np.ascontiguousarray(src), empty_mat(), (C.c_int * 2)(int(dsize[0]), int(dsize[1]))
+        bits = lambda v: int(np.float64(v).view(np.uint64))                    # noqa: E731
         self.cv("imgproc", "?resize@cv@@YAXAEBV_InputArray@1@AEBV_OutputArray@1@V?$Size_@H@1@NNH@Z", self.ia(mat(s)), self.oa(dst),
-                C.addressof(size), 0, 0, int(interp))
+                C.addressof(size), bits(fx), bits(fy), int(interp))
         self.keep += [s]
         return mat_array(dst)
 
@@ -360,6 +362,8 @@ def job_whole(fn, **a):
         return {"out": p.remap(a["src"], a["xmap"], a["ymap"], int(a["interp"]), int(a["border"]))}
     if fn == "resize":
         return {"out": p.resize(a["src"], a["dsize"], int(a.get("interp", 1)))}
+    if fn == "resize_factor":
+        return {"out": p.resize(a["src"], (0, 0), 1, float(a["f"]), float(a["f"]))}
     if fn == "dilate":
         return {"out": p.dilate(a["src"])}
     if fn == "copy_make_border":

@@ -44,6 +44,12 @@ def test_whole_resize_32f_is_the_references(g):
     assert np.array_equal(out.view(np.uint32), g["resize32_out"].view(np.uint32))
 
 
+def test_whole_resize_by_factor_is_the_references(g):
+    """resize(full_img, img, Size(), f, f) on CV_8UC3: what --compose_megapix does to every input (CLI:699-700)"""
+    for k in range(3):
+        assert np.array_equal(O.resize_linear_8u_factor(g["resizef_src"], float(g["resizef_f%d" % k])), g["resizef_out%d" % k]), k
+
+
 def test_whole_copy_make_border_is_the_references(g):
     for b in (0, 1, 2, 4):
         assert np.array_equal(O.copy_make_border_16s(g["cmb_src"], 7, 22, 13, 5, b), g["cmb_out_%d" % b]), b
