@@ -863,26 +863,39 @@ def ingest_leg(rig, blend, local_rank, cw, ch, seconds=1.5):
             eng = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank,
                                    frames_nv12=(fmt == "nv12"), overlap_frames=True, overlap_depth=4)
             eng.update(rig["scale"], rig["cameras"])
-            st = ingest.IngestStitcher(eng, names, [c["size"] for c in rig["cameras"]], device=local_rank)
-
-            def loop(n):
-                for t in range(n):
-                    if t >= st.depth:
+            def measure(st):
+                def loop(n):
+                    for t in range(n):
+                        if t >= st.depth:
+                            st.wait()
+                        st.submit()
+                    while st.completed < st.submitted:
                         st.wait()
-                    st.submit()
-                while st.completed < st.submitted:
-                    st.wait()
-            loop(6)
-            t0 = time.perf_counter()
-            loop(20)
-            n = max(30, int(seconds / max((time.perf_counter() - t0) / 20, 1e-6)))
-            t0 = time.perf_counter()
-            loop(n)
-            dt = time.perf_counter() - t0
-            st.close()
+                loop(6)
+                t0 = time.perf_counter()
+                loop(20)
+                n = max(30, int(seconds / max((time.perf_counter() - t0) / 20, 1e-6)))
+                t0 = time.perf_counter()
+                loop(n)
+                dt = time.perf_counter() - t0
+                st.close()
+                return n, dt
+            bytes_in = sum((h * 3 // 2) * w if fmt == "nv12" else h * w * 3 for (w, h) in [c["size"] for c in rig["cameras"]])
+            # (1) the native form: one mst_pipeline_submit_shm call per frame set on the engine's own three-stage host pipeline
+            eng_n = S.PanoramaEngine(n_cam, warp=rig["warp"], blend=blend, expos=rig["expos"], num_bands=5, device=local_rank, frames_nv12=(fmt == "nv12"))
+            eng_n.update(rig["scale"], rig["cameras"])
+            try:
+                n, dt = measure(ingest.PipelineIngest(eng_n, names))
+            finally:
+                eng_n.close()
             res[fmt] = {"frames": n, "frames_per_s": round(n / dt, 1), "ms_per_frame": round(dt * 1e3 / n, 3),
-                        "mb_in_per_frame": round(st.bytes_in / 1e6, 1), "mb_out_per_frame": round(ch * cw * 3 / 1e6, 1),
-                        "pcie_in_gb_s": round(st.bytes_in * n / dt / 1e9, 2), "pcie_out_gb_s": round(ch * cw * 3 * n / dt / 1e9, 2)}
+                        "mb_in_per_frame": round(bytes_in / 1e6, 1), "mb_out_per_frame": round(ch * cw * 3 / 1e6, 1),
+                        "pcie_in_gb_s": round(bytes_in * n / dt / 1e9, 2), "pcie_out_gb_s": round(ch * cw * 3 * n / dt / 1e9, 2),
+                        "path": "mst_pipeline_submit_shm / mst_pipeline_wait (one native call per frame set)"}
+            # (2) the same loop assembled in Python from torch streams + mst_compose_device_batch_ex (calls in flight, events)
+            st = ingest.IngestStitcher(eng, names, [c["size"] for c in rig["cameras"]], device=local_rank)
+            n, dt = measure(st)
+            res[fmt]["python_streams_frames_per_s"] = round(n / dt, 1)
         finally:
             if eng is not None:
                 eng.close()

@@ -84,6 +84,29 @@ int  mst_shm_get_device(mst_shm *s, mst_frame_packet *hdr, void *d_dst, size_t d
  * are still consumed, and the first error is returned. */
 int  mst_shm_get_device_multi(mst_shm *const *s, int n, mst_frame_packet *hdr, void *const *d_dst, const size_t *dst_stride,
                               const size_t *dst_capacity, void *stream, int timeout_ms);
+/* The same with flags.  MST_SHM_PREFETCH: the moment a camera's pixels have left its segment (per camera, not per set) the camera is
+ * asked for its NEXT frame, so the capture processes refill their segments while the other cameras' copies are still on the bus and
+ * the next call finds the packets waiting -- the frame a call delivers was then requested when the previous call consumed that
+ * camera (at most one frame period earlier than Stitching_sharemem::GetMemData would have asked, R64/stitching_sharemem.cpp:96-123).
+ * Either way a camera's copy is queued when ITS packet lands (arrival order) and every copy is complete on return. */
+#define MST_SHM_PREFETCH 1
+/* MST_SHM_ASYNC (implies the prefetch): the call returns as soon as every camera's copy is QUEUED on `stream` (it still waits for the
+ * packets to land, not for the bus); the copies complete in stream order, and each camera is asked for its next frame by a host function
+ * queued behind its copy (hipLaunchHostFunc).  The caller orders its kernels behind `stream` (an event) and must keep the device buffers
+ * alive and unread-from-elsewhere until then -- the frame loop then never waits for a transfer, exactly as mst_pipeline_submit does not.
+ * Close a client only after `stream` has drained. */
+#define MST_SHM_ASYNC    2
+int  mst_shm_get_device_multi_ex(mst_shm *const *s, int n, mst_frame_packet *hdr, void *const *d_dst, const size_t *dst_stride,
+                                 const size_t *dst_capacity, void *stream, int timeout_ms, int flags);
+/* The reference's frame loop in ONE call per frame set (DRV:736-763: GetMemData x N -> StitchingAll -> imshow), as a stage of the
+ * engine's host pipeline (mst_pipeline_wait / mst_pipeline_pending of mi355_stitch.h): the frame set is pulled from the N capture
+ * processes' segments into the pipeline's device frames (MST_SHM_ASYNC on the pipeline's copy-in stream), composed behind the copies and
+ * copied into `pano` (page-locked host memory: mst_host_alloc) -- the call waits for the packets to land, never for a transfer; up to
+ * MST_PIPELINE_DEPTH frame sets are in flight.  clients[i] serves camera i; its packets must have the calibration's frame size and the
+ * engine's pixel format (MST_FLAG_FRAMES_NV12 or BGR). */
+struct mst_engine;
+int  mst_pipeline_submit_shm(struct mst_engine *e, mst_shm *const *clients, int num_clients, uint8_t *pano, size_t pano_stride,
+                             int timeout_ms);
 /* SharememClose(); the server side also unlinks the segment */
 void mst_shm_close(mst_shm *s);
 

@@ -55,7 +55,7 @@ EXPORTS = [
     "mst_multiband_geometry", "mst_debug_read", "mst_synth_frame", "mst_gain_map_size", "mst_exposure_feed", "mst_seam_voronoi", "mst_seam_dp",
     # include/mi355_ingest.h
     "mst_shm_serve", "mst_shm_publish", "mst_shm_publish_nv12", "mst_shm_packet_format", "mst_shm_attach", "mst_shm_get",
-    "mst_shm_get_device", "mst_shm_get_device_multi", "mst_shm_close",
+    "mst_shm_get_device", "mst_shm_get_device_multi", "mst_shm_get_device_multi_ex", "mst_pipeline_submit_shm", "mst_shm_close",
 ]
 
 

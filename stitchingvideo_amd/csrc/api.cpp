@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "engine.hpp"
+#include "../../include/mi355_ingest.h"
 #include "kernels.hpp"
 
 struct mst_engine {
@@ -376,6 +377,15 @@ int mst_pipeline_submit(mst_engine* e, const uint8_t* const* frames, const size_
 {
     if (!e) return MST_ERR_INVALID_ARG;
     return guarded(e, [&] { e->impl.pipeline_submit(frames, frame_strides, pano, pano_stride); });
+}
+
+int mst_pipeline_submit_shm(mst_engine* e, mst_shm* const* clients, int num_clients, uint8_t* pano, size_t pano_stride, int timeout_ms)
+{
+    if (!e || !clients) return MST_ERR_INVALID_ARG;
+    return guarded(e, [&] {
+        if (num_clients != e->impl.config().num_cameras) throw mst::Error{MST_ERR_INVALID_ARG, "one shared-memory client per camera"};
+        e->impl.pipeline_submit(nullptr, nullptr, pano, pano_stride, clients, timeout_ms);
+    });
 }
 
 int mst_pipeline_wait(mst_engine* e, uint8_t** pano, mst_rect* canvas)

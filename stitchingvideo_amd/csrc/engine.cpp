@@ -1,5 +1,6 @@
 // engine.cpp -- see engine.hpp.
 #include "engine.hpp"
+#include "../../include/mi355_ingest.h"
 
 #include <algorithm>
 #include <chrono>
@@ -1725,12 +1726,13 @@ void Engine::compose_host(const uint8_t* const* frames, const size_t* strides, u
     check_hip(hipStreamSynchronize(stream_), "hipStreamSynchronize(compose)");
 }
 
-void Engine::pipeline_submit(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride)
+void Engine::pipeline_submit(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride,
+                             ::mst_shm* const* clients, int timeout_ms)
 {
     select_device(cfg_.device);
     std::shared_ptr<CalibState> st = state();
     if (!st) throw Error{MST_ERR_NOT_CALIBRATED, "mst_pipeline_submit before a successful mst_update"};
-    if (!frames || !strides || !pano) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama pointer"};
+    if ((!clients && (!frames || !strides)) || !pano) throw Error{MST_ERR_INVALID_ARG, "null frame or panorama pointer"};
     if (pipeline_pending() >= kPipeDepth) throw Error{MST_ERR_INVALID_ARG, "pipeline full: call mst_pipeline_wait first"};
     const size_t prow = static_cast<size_t>(st->out_w) * 3, pbytes = prow * st->out_h;
     if (pano_stride < prow) throw Error{MST_ERR_INVALID_ARG, "panorama stride too small"};
@@ -1750,10 +1752,10 @@ void Engine::pipeline_submit(const uint8_t* const* frames, const size_t* strides
     std::vector<size_t> dstride(n);
     // stage 1 (copy-in stream): the slot's device frames were last read by kernels whose completion the matching
     // wait() has already observed (d2h_done follows compute_done), so the copies may start right away
+    const bool nv12 = (cfg_.flags & MST_FLAG_FRAMES_NV12) != 0;
     for (int i = 0; i < n; ++i) {
         const int w = st->cams[i].src_w, h = st->cams[i].src_h;
-        const bool nv12 = (cfg_.flags & MST_FLAG_FRAMES_NV12) != 0;
-        if (!frames[i] || strides[i] < static_cast<size_t>(w) * (nv12 ? 1 : 3)) throw Error{MST_ERR_INVALID_ARG, "bad frame"};
+        if (!clients && (!frames[i] || strides[i] < static_cast<size_t>(w) * (nv12 ? 1 : 3))) throw Error{MST_ERR_INVALID_ARG, "bad frame"};
         const size_t row = static_cast<size_t>(w) * (nv12 ? 1 : 3), rows = nv12 ? static_cast<size_t>(h) * 3 / 2 : h, bytes = row * rows;
         if (ps.d_frame_bytes[i] < bytes) {
             if (ps.d_frames[i]) (void)hipFree(ps.d_frames[i]);
@@ -1761,9 +1763,24 @@ void Engine::pipeline_submit(const uint8_t* const* frames, const size_t* strides
             check_hip(hipMalloc(reinterpret_cast<void**>(&ps.d_frames[i]), bytes + 16), "hipMalloc(frame)");
             ps.d_frame_bytes[i] = bytes;
         }
-        copy_rows(ps.d_frames[i], row, frames[i], strides[i], row, rows, hipMemcpyHostToDevice, pipe_in_);
+        if (!clients) copy_rows(ps.d_frames[i], row, frames[i], strides[i], row, rows, hipMemcpyHostToDevice, pipe_in_);
         dptr[i] = ps.d_frames[i];
         dstride[i] = row;
+    }
+    if (clients) {
+        // the frame set straight out of the capture processes' shared-memory segments (mi355_ingest.h): a camera's copy is queued on
+        // the copy-in stream when its packet lands, the camera is asked for its next frame by a host function behind that copy
+        // (MST_SHM_ASYNC) -- this call waits for packets, never for the bus
+        std::vector<mst_frame_packet> hdr(n);
+        std::vector<void*> dst(n);
+        std::vector<size_t> cap(n);
+        for (int i = 0; i < n; ++i) { dst[i] = ps.d_frames[i]; cap[i] = ps.d_frame_bytes[i]; }
+        const int rc = mst_shm_get_device_multi_ex(clients, n, hdr.data(), dst.data(), dstride.data(), cap.data(), pipe_in_, timeout_ms, MST_SHM_ASYNC);
+        if (rc != MST_OK) throw Error{rc, rc == MST_ERR_TIMEOUT ? "a capture process did not deliver its frame in time" : "bad frame packet"};
+        for (int i = 0; i < n; ++i)
+            if (hdr[i].width != st->cams[i].src_w || hdr[i].height != st->cams[i].src_h ||
+                mst_shm_packet_format(&hdr[i]) != (nv12 ? MST_PIXEL_NV12 : MST_PIXEL_BGR))
+                throw Error{MST_ERR_INVALID_ARG, "a frame packet's size or pixel format is not what the calibration expects"};
     }
     check_hip(hipEventRecord(ps.h2d_done, pipe_in_), "hipEventRecord");
     if (ps.d_pano_bytes < pbytes) {

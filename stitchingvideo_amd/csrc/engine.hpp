@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "../../include/mi355_stitch.h"
+
+struct mst_shm;          // a shared-memory frame client (include/mi355_ingest.h)
 #include "device_types.hpp"
 #include "geometry.hpp"
 #include "mb_plan.hpp"
@@ -186,7 +188,8 @@ public:
     // page-locked (host_alloc) -- pageable memory works but serialises the copies -- and must stay untouched between
     // submit and the matching wait.
     static constexpr int kPipeDepth = 3;
-    void pipeline_submit(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride);
+    void pipeline_submit(const uint8_t* const* frames, const size_t* strides, uint8_t* pano, size_t pano_stride,
+                         ::mst_shm* const* clients = nullptr, int timeout_ms = -1);
     uint8_t* pipeline_wait(mst_rect* canvas);
     int pipeline_pending() const { return pipe_submitted_ - pipe_completed_; }
     void synchronize();

@@ -3,6 +3,7 @@
 #include "../../include/mi355_ingest.h"
 
 #include <fcntl.h>
+#include <sched.h>
 #include <semaphore.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -63,6 +64,8 @@ struct mst_shm {
     void* base = nullptr;
     size_t bytes = 0;
     bool registered = false;      // page-locked for the device copies
+    bool requested = false;       // a request is outstanding (mst_shm_get_device_multi_ex with MST_SHM_PREFETCH left one behind)
+    hipEvent_t copied = nullptr;  // "this camera's pixels have left the segment" (created on first use)
     Control* ctl() const { return static_cast<Control*>(base); }
     uint8_t* data() const { return static_cast<uint8_t*>(base) + ctl()->data_offset; }
 };
@@ -203,8 +206,11 @@ int take_frame(mst_shm* s, mst_frame_packet* hdr, const uint8_t** pixels, int ti
 int request_frame(mst_shm* s, mst_frame_packet* hdr, const uint8_t** pixels, int timeout_ms)
 {
     if (!hdr) return MST_ERR_INVALID_ARG;
-    const int rc = post_request(s);
-    return rc != MST_OK ? rc : take_frame(s, hdr, pixels, timeout_ms);
+    // (a request a prefetching multi-get left outstanding is the one this call consumes)
+    const int rc = s && s->requested ? MST_OK : post_request(s);
+    if (rc != MST_OK) return rc;
+    s->requested = false;
+    return take_frame(s, hdr, pixels, timeout_ms);
 }
 // rows of a packet's pixel block: bytes per row, number of rows (BGR: h rows of 3 w; NV12: 3 h / 2 rows of w)
 void packet_rows(const mst_frame_packet& h, size_t* row, size_t* rows)
@@ -220,6 +226,8 @@ void register_segment(mst_shm* s)
     s->registered = hipHostRegister(s->base, s->bytes, hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();
 }
+// (stream callback of MST_SHM_ASYNC: "this camera's pixels have left the segment" -> SetEvent(hClientReadOver) for its next frame)
+void release_segment(void* p) { sem_post(&static_cast<mst_shm*>(p)->ctl()->client_ready); }
 hipError_t queue_copy(void* d_dst, size_t dst_stride, const uint8_t* px, size_t row, size_t rows, hipStream_t st)
 {
     return dst_stride == row ? hipMemcpyAsync(d_dst, px, row * rows, hipMemcpyHostToDevice, st)
@@ -258,40 +266,109 @@ int mst_shm_get_device(mst_shm* s, mst_frame_packet* hdr, void* d_dst, size_t ds
     return e == hipSuccess ? MST_OK : MST_ERR_HIP;
 }
 
-int mst_shm_get_device_multi(mst_shm* const* s, int n, mst_frame_packet* hdr, void* const* d_dst, const size_t* dst_stride,
-                             const size_t* dst_capacity, void* stream, int timeout_ms)
+int mst_shm_get_device_multi_ex(mst_shm* const* s, int n, mst_frame_packet* hdr, void* const* d_dst, const size_t* dst_stride,
+                                const size_t* dst_capacity, void* stream, int timeout_ms, int flags)
 {
-    if (!s || !hdr || !d_dst || !dst_stride || !dst_capacity || n <= 0) return MST_ERR_INVALID_ARG;
+    if (!s || !hdr || !d_dst || !dst_stride || !dst_capacity || n <= 0 || n > MST_MAX_CAMERAS) return MST_ERR_INVALID_ARG;
     for (int i = 0; i < n; ++i)
         if (!s[i] || s[i]->server || !d_dst[i]) return MST_ERR_INVALID_ARG;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MST_ERR_NO_DEVICE;
-    for (int i = 0; i < n; ++i) (void)post_request(s[i]);     // every capture process fills its segment at the same time
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    int first = MST_OK;
+    const bool async_release = (flags & MST_SHM_ASYNC) != 0;
+    const bool prefetch = (flags & MST_SHM_PREFETCH) != 0 || async_release;
+    // every capture process fills its segment at the same time (a camera whose next frame was asked for by the previous call's
+    // prefetch has been filling it since that camera's copy left the segment)
     for (int i = 0; i < n; ++i) {
-        const uint8_t* px = nullptr;
-        int rc = take_frame(s[i], &hdr[i], &px, timeout_ms);
-        if (rc == MST_OK) {
-            size_t row, rows;
-            packet_rows(hdr[i], &row, &rows);
-            if (dst_stride[i] < row || dst_capacity[i] < dst_stride[i] * (rows - 1) + row) rc = MST_ERR_INVALID_ARG;
-            else {
-                register_segment(s[i]);
-                if (queue_copy(d_dst[i], dst_stride[i], px, row, rows, st) != hipSuccess) rc = MST_ERR_HIP;
+        if (!s[i]->requested) { (void)post_request(s[i]); s[i]->requested = true; }
+        if (!s[i]->copied && hipEventCreateWithFlags(&s[i]->copied, hipEventDisableTiming) != hipSuccess) return MST_ERR_HIP;
+        register_segment(s[i]);
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    auto elapsed_ms = [&] {
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        return static_cast<long>(t.tv_sec - t0.tv_sec) * 1000L + (t.tv_nsec - t0.tv_nsec) / 1000000L;
+    };
+    enum { kWaiting, kCopying, kDone };
+    int state[MST_MAX_CAMERAS];
+    for (int i = 0; i < n; ++i) state[i] = kWaiting;
+    int first = MST_OK, open_cams = n;
+    auto fail = [&](int i, int rc) { if (first == MST_OK) first = rc; state[i] = kDone; --open_cams; };
+    // Frames are copied in the order they ARRIVE (one hipMemcpyAsync per camera as its packet lands), and a camera's segment is handed
+    // back to its capture process -- with MST_SHM_PREFETCH: by asking for its next frame -- the moment ITS copy has left it, not when the
+    // whole set has: the capture processes refill while the other cameras' copies are still on the bus.
+    for (unsigned spins = 0; open_cams > 0; ++spins) {
+        bool progress = false;
+        for (int i = 0; i < n; ++i) {
+            if (state[i] == kWaiting && sem_trywait(&s[i]->ctl()->server_wrote) == 0) {
+                progress = true;
+                s[i]->requested = false;
+                const uint8_t* q = s[i]->data();
+                std::memcpy(&hdr[i], q, sizeof(hdr[i]));
+                hdr[i].filePath[sizeof(hdr[i].filePath) - 1] = 0;
+                const size_t avail = s[i]->bytes - s[i]->ctl()->data_offset;
+                size_t row = 0, rows = 0;
+                if (hdr[i].width <= 0 || hdr[i].height <= 0 || hdr[i].flag < 0 || hdr[i].buferPointer < 0 ||
+                    static_cast<size_t>(hdr[i].buferPointer) + 1 + static_cast<size_t>(hdr[i].flag) > avail || mst_shm_packet_format(&hdr[i]) < 0) {
+                    fail(i, MST_ERR_INVALID_ARG);
+                    continue;
+                }
+                packet_rows(hdr[i], &row, &rows);
+                if (dst_stride[i] < row || dst_capacity[i] < dst_stride[i] * (rows - 1) + row) { fail(i, MST_ERR_INVALID_ARG); continue; }
+                if (queue_copy(d_dst[i], dst_stride[i], q + hdr[i].buferPointer + 1, row, rows, st) != hipSuccess) { fail(i, MST_ERR_HIP); continue; }
+                if (async_release) {
+                    // the camera is asked for its next frame by a host function that runs in stream order behind the copy: this
+                    // call does not wait for the bus (the request WILL be posted: the next call finds it outstanding)
+                    if (hipLaunchHostFunc(st, release_segment, s[i]) != hipSuccess) { fail(i, MST_ERR_HIP); continue; }
+                    s[i]->requested = true;
+                    state[i] = kDone;
+                    --open_cams;
+                    continue;
+                }
+                if (hipEventRecord(s[i]->copied, st) != hipSuccess) { fail(i, MST_ERR_HIP); continue; }
+                state[i] = kCopying;
+            } else if (state[i] == kCopying) {
+                const hipError_t e = hipEventQuery(s[i]->copied);
+                if (e == hipErrorNotReady) continue;
+                progress = true;
+                if (e != hipSuccess) { (void)hipGetLastError(); fail(i, MST_ERR_HIP); continue; }
+                state[i] = kDone;
+                --open_cams;
+                if (prefetch) { (void)post_request(s[i]); s[i]->requested = true; }
             }
         }
-        if (rc != MST_OK && first == MST_OK) first = rc;
+        if (progress) { spins = 0; continue; }
+        if (timeout_ms >= 0 && (spins & 63u) == 63u && elapsed_ms() > timeout_ms) {
+            // withdraw the requests the servers have not taken; one that was taken is on its way and has to be consumed (a stale
+            // "server wrote" would let the next request overlap with the server's next write)
+            for (int i = 0; i < n; ++i) {
+                if (state[i] != kWaiting) continue;
+                if (sem_trywait(&s[i]->ctl()->client_ready) != 0) (void)wait_sem(&s[i]->ctl()->server_wrote, -1);
+                s[i]->requested = false;
+                fail(i, MST_ERR_TIMEOUT);
+            }
+        }
+        if (spins > 2000u) sched_yield();
     }
-    // the servers may overwrite their segments as soon as the next frame is requested: the copies are complete on return
-    if (hipStreamSynchronize(st) != hipSuccess && first == MST_OK) first = MST_ERR_HIP;
     return first;
+}
+
+int mst_shm_get_device_multi(mst_shm* const* s, int n, mst_frame_packet* hdr, void* const* d_dst, const size_t* dst_stride,
+                             const size_t* dst_capacity, void* stream, int timeout_ms)
+{
+    return mst_shm_get_device_multi_ex(s, n, hdr, d_dst, dst_stride, dst_capacity, stream, timeout_ms, 0);
 }
 
 void mst_shm_close(mst_shm* s)
 {
     if (!s) return;
+    if (s->copied) (void)hipEventDestroy(s->copied);
     if (s->base) {
+        // (a prefetch request the server has not taken yet is withdrawn; one it has taken leaves a frame nobody reads: harmless)
+        // (one it has taken is consumed here, so that the next client to attach does not find a stale "server wrote")
+        if (!s->server && s->requested && sem_trywait(&s->ctl()->client_ready) != 0) (void)wait_sem(&s->ctl()->server_wrote, 1000);
         if (s->registered) (void)hipHostUnregister(s->base);
         if (s->server) {
             sem_destroy(&s->ctl()->client_ready);

@@ -530,6 +530,18 @@ class PanoramaEngine:
         strides = (C.c_size_t * n)(*[f.strides[0] for f in frames])
         self._check(self._L.mst_pipeline_submit(self._h, ptrs, strides, pano.ctypes.data, pano.strides[0]))
 
+    def pipeline_submit_shm(self, clients, pano, timeout_ms=20000):
+        """Queue one frame set pulled straight from the capture processes' shared-memory segments (mst_pipeline_submit_shm:
+        clients = one ingest.FrameClient per camera) into the host pipeline; `pano`: page-locked uint8 array for the panorama."""
+        n = len(clients)
+        L = self._L
+        if not getattr(L, "_submit_shm_ready", False):
+            L.mst_pipeline_submit_shm.restype = C.c_int
+            L.mst_pipeline_submit_shm.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+            L._submit_shm_ready = True
+        hs = (C.c_void_p * n)(*[c._h for c in clients])
+        self._check(L.mst_pipeline_submit_shm(self._h, hs, n, pano.ctypes.data, pano.strides[0], timeout_ms))
+
     def pipeline_wait(self):
         """Block until the oldest submitted frame is done -> (address of its panorama buffer, canvas rect)."""
         p, r = C.c_void_p(), capi.Rect()

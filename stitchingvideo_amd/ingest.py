@@ -38,6 +38,9 @@ def _lib():
         L.mst_shm_get_device_multi.restype = C.c_int
         L.mst_shm_get_device_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(FramePacket), C.POINTER(vp), C.POINTER(C.c_size_t),
                                                C.POINTER(C.c_size_t), vp, C.c_int]
+        L.mst_shm_get_device_multi_ex.restype = C.c_int
+        L.mst_shm_get_device_multi_ex.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(FramePacket), C.POINTER(vp), C.POINTER(C.c_size_t),
+                                                  C.POINTER(C.c_size_t), vp, C.c_int, C.c_int]
         L.mst_shm_close.restype = None
         L.mst_shm_close.argtypes = [vp]
         L._ingest_ready = True
@@ -99,9 +102,13 @@ def packet_format(hdr):
     return rc
 
 
-def get_device_multi(clients, device_ptrs, strides, capacities, stream=None, timeout_ms=-1):
-    """One frame from every client straight into device memory (mst_shm_get_device_multi): all servers are asked first
-    and fill their segments concurrently -> list of (width, height, format, path)."""
+SHM_PREFETCH, SHM_ASYNC = 1, 2
+
+
+def get_device_multi(clients, device_ptrs, strides, capacities, stream=None, timeout_ms=-1, prefetch=False, async_release=False):
+    """One frame from every client straight into device memory (mst_shm_get_device_multi_ex): all servers are asked first
+    and fill their segments concurrently; a camera's copy is queued when its packet lands; prefetch: each camera is asked for
+    its next frame the moment its copy has left the segment -> list of (width, height, format, path)."""
     n = len(clients)
     L = _lib()
     hs = (C.c_void_p * n)(*[c._h for c in clients])
@@ -109,9 +116,9 @@ def get_device_multi(clients, device_ptrs, strides, capacities, stream=None, tim
     dp = (C.c_void_p * n)(*device_ptrs)
     st = (C.c_size_t * n)(*strides)
     cp = (C.c_size_t * n)(*capacities)
-    rc = L.mst_shm_get_device_multi(hs, n, hdr, dp, st, cp, stream, timeout_ms)
+    rc = L.mst_shm_get_device_multi_ex(hs, n, hdr, dp, st, cp, stream, timeout_ms, (SHM_PREFETCH if prefetch else 0) | (SHM_ASYNC if async_release else 0))
     if rc:
-        raise IngestError(rc, "mst_shm_get_device_multi")
+        raise IngestError(rc, "mst_shm_get_device_multi_ex")
     return [(h.width, h.height, packet_format(h), h.filePath.decode(errors="replace")) for h in hdr]
 
 
@@ -182,8 +189,13 @@ class IngestStitcher:
     copies are DMA out of the page-locked segments), stage 2 composes frame set t, stage 3 copies panorama t - 1 into
     page-locked host memory.  BGR or NV12 packets (the engine's MST_FLAG_FRAMES_NV12 says which it composes from)."""
 
-    def __init__(self, engine, names, sizes, device=0, depth=3):
-        """engine: a calibrated PanoramaEngine; names: one segment name per camera; sizes: the cameras' (width, height)."""
+    def __init__(self, engine, names, sizes, device=0, depth=3, prefetch=True, async_release=True):
+        """engine: a calibrated PanoramaEngine; names: one segment name per camera; sizes: the cameras' (width, height);
+        prefetch: ask every camera for its next frame as soon as its copy has left the segment (MST_SHM_PREFETCH)."""
+        self.prefetch = bool(prefetch)
+        # async_release (MST_SHM_ASYNC): submit() does not wait for the bus -- the copies, the compose and the copy-out of a frame set
+        # are all queued at once and ordered by events; the capture processes are released by host functions behind the copies
+        self.async_release = bool(async_release)
         import torch
         self._torch = torch
         self.eng = engine
@@ -211,10 +223,12 @@ class IngestStitcher:
         if self.submitted - self.completed >= self.depth:
             raise RuntimeError("ring full: call wait() first")
         fs = self.sets[k]
-        # (stage 1 is complete on return: the servers may overwrite their segments at the next request; the slot's frames
+        if self.async_release and self.submitted >= self.depth:
+            self.s_in.wait_event(self.ev_c[k])          # the compose that last read this slot's frames (nobody waited for it on the host)
+        # (without async_release stage 1 is complete on return: the servers may overwrite their segments at the next request; the slot's frames
         # were last read by the compose of `depth` submits ago, whose completion wait() has observed)
         got = get_device_multi(self.clients, [t.data_ptr() for t in fs], [t.stride(0) for t in fs], [t.numel() for t in fs],
-                               stream=self.s_in.cuda_stream, timeout_ms=timeout_ms)
+                               stream=self.s_in.cuda_stream, timeout_ms=timeout_ms, prefetch=self.prefetch, async_release=self.async_release)
         want = PIXEL_NV12 if self.nv12 else PIXEL_BGR
         for (w, h, fmt, _), (ew, eh) in zip(got, self.sizes):
             if fmt != want or (w, h) != (ew, eh):
@@ -246,6 +260,41 @@ class IngestStitcher:
 
     def close(self):
         self._torch.cuda.synchronize(self.dev)
+        for c in self.clients:
+            c.close()
+
+
+class PipelineIngest:
+    """The same frame loop through ONE native call per frame set (mst_pipeline_submit_shm): the engine's own host pipeline -- its
+    copy-in, compute and copy-out streams, a ring of MST_PIPELINE_DEPTH device frame sets -- fed from the capture processes' segments.
+    No torch: what a C++ host links."""
+    depth = 3
+
+    def __init__(self, engine, names):
+        from .engine import PinnedArray
+        self.eng = engine
+        self.clients = [FrameClient(n) for n in names]
+        (_, _, self.cw, self.ch), _ = engine.acquire()
+        self._panos = [PinnedArray((self.ch, self.cw, 3)) for _ in range(self.depth)]
+        self.submitted = self.completed = 0
+
+    def submit(self, timeout_ms=20000):
+        if self.submitted - self.completed >= self.depth:
+            raise RuntimeError("ring full: call wait() first")
+        self.eng.pipeline_submit_shm(self.clients, self._panos[self.submitted % self.depth].array, timeout_ms)
+        self.submitted += 1
+
+    def wait(self):
+        """The oldest submitted panorama, complete in page-locked host memory (valid until `depth` more submits)."""
+        self.eng.pipeline_wait()
+        k = self.completed % self.depth
+        self.completed += 1
+        return self._panos[k].array
+
+    def close(self):
+        while self.completed < self.submitted:
+            self.wait()
+        self.eng.synchronize() if hasattr(self.eng, "synchronize") else None
         for c in self.clients:
             c.close()
 

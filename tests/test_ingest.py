@@ -136,6 +136,48 @@ def _spawn_producers(prefix, n, w, h, fmt, distinct, count):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["bgr", "nv12"])
+def test_native_pipeline_from_capture_processes(fmt):
+    """mst_pipeline_submit_shm: one native call per frame set -- capture processes -> shared memory -> the engine's host pipeline ->
+    panorama in page-locked memory; every panorama equals the oracle's on the frames the producers sent (three in flight)."""
+    import helpers as H
+    import oracle_lib as O
+    import stitchingvideo_amd as S
+    from stitchingvideo_amd import rig as rigmod
+    rig = rigmod.build_rig(rigmod.scaled_config("C3", 4 if fmt == "nv12" else 8))
+    n = len(rig["cameras"])
+    w, h = rig["size"]
+    eng = S.PanoramaEngine(n, warp=rig["warp"], blend=rig["blend"], expos=rig["expos"], num_bands=5, frames_nv12=(fmt == "nv12"))
+    eng.update(rig["scale"], rig["cameras"])
+    n_sets = 8
+    names, procs = _spawn_producers("/mst_nat_%s_%d" % (fmt, os.getpid()), n, w, h, fmt, 3, n_sets)
+    try:
+        st = ingest.PipelineIngest(eng, names)
+        got = []
+        for t in range(n_sets):
+            if t >= st.depth:
+                got.append(st.wait().copy())
+            st.submit()
+        while st.completed < st.submitted:
+            got.append(st.wait().copy())
+        st.close()
+    finally:
+        for p in procs:
+            p.stdin.close()
+        for p in procs:
+            p.wait(timeout=30)
+    assert len(got) == n_sets
+    expected = {}
+    for t, pano in enumerate(got):
+        k = t % 3
+        if k not in expected:
+            frames = [O.cvt_nv12_bgr(ingest.synth_nv12(i, k, w, h)) if fmt == "nv12" else rigmod.synth_frame(i, k, w, h) for i in range(n)]
+            expected[k] = H.oracle_compose(rig, frames)[1]
+        assert np.array_equal(pano, expected[k]), (fmt, t)
+    eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("depth", [0, 4])
 @pytest.mark.parametrize("fmt", ["bgr", "nv12"])
 def test_capture_processes_to_panorama_end_to_end(fmt, depth):
