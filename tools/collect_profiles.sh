@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the round's judged artefacts from gpurun_out/ (scratch) into profiles/ (tracked): tools/collect_profiles.sh r03
-TAG=${1:-r05}
+TAG=${1:-r06}
 for w in c3 c3_b1 C2 C5 C3-LUT C5-LUT; do
   d=gpurun_out/prof_${TAG}_$w
   [ -f $d/summary.txt ] || continue
@@ -13,6 +13,6 @@ cp gpurun_out/round/bench_batch1.json profiles/${TAG}_c3_bench_batch1.json
 cp gpurun_out/round/bench_undistort.json profiles/${TAG}_c3_bench_undistort.json
 cp gpurun_out/round/strip_model.jsonl profiles/${TAG}_strip_model.jsonl
 cp gpurun_out/round/time_update.txt profiles/${TAG}_time_update.txt
-for f in lone_call.json frame_loop.txt multi_gpu_loop.txt bench_strip_headline.json; do [ -f gpurun_out/round/$f ] && cp gpurun_out/round/$f profiles/${TAG}_$f; done
+for f in lone_call.json frame_loop.txt multi_gpu_loop.txt bench_strip_headline.json plan_stats.txt ingest_bench.json; do [ -f gpurun_out/round/$f ] && cp gpurun_out/round/$f profiles/${TAG}_$f; done
 cp gpurun_out/traffic.json profiles/traffic.json
 ls -la profiles/ | grep ${TAG}

@@ -4,7 +4,7 @@
 # that those carry it), bench.py (default, --batch 1, --undistort) and mst_update timing.  Outputs under
 # gpurun_out/round and gpurun_out/prof_<tag>; copy what should be judged into profiles/ (tools/collect_profiles.sh).
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out/round
 (time python -m pytest tests -m gpu -x -q) > gpurun_out/round/pytest.log 2>&1
 tail -3 gpurun_out/round/pytest.log
@@ -32,6 +32,13 @@ import json
 for f in ('bench_batch1','bench_undistort'):
     d=json.load(open('gpurun_out/round/%s.json'%f)); print(f, d['value'], d.get('serial'), [(k['name'],k['ms_per_frame']) for k in d['roofline']['kernels']])"
 python tools/strip_model.py > gpurun_out/round/strip_model.jsonl 2>/dev/null
+# the plan's tile statistics (how many tiles are pure / owned: profiles/r06_floor.md)
+MST_UPDATE_TIMING=1 python -c "
+import stitchingvideo_amd as S
+from stitchingvideo_amd import rig as R
+rig = R.build_rig(R.CONFIGS['C3'])
+e = S.PanoramaEngine(6, warp=rig['warp'], blend='multiband', expos=rig['expos'], num_bands=5, max_batch=8)
+e.update(rig['scale'], rig['cameras']); e.close()" 2>&1 | grep "plan:" | tee gpurun_out/round/plan_stats.txt
 python tools/time_update.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/round/time_update.txt | tail -20
 # round 5: the lone call by kernels, the C++ hosts (single GPU: calls in flight; multi-GPU loop with one rank, checked), the N > 1 headline path at N = 1
 python tools/lone_call.py C3 2>/dev/null | tee gpurun_out/round/lone_call.json
@@ -40,4 +47,5 @@ bash tools/multi_gpu_loop.sh 2>&1 | grep "^{\|^---\|rank" | tee gpurun_out/round
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-latency-leg --strip-headline 2>/dev/null > gpurun_out/round/bench_strip_headline.json
 python -c "
 import json; d=json.load(open('gpurun_out/round/bench_strip_headline.json')); print('N > 1 headline path at N = 1:', d['value'], d['scaling'], d['roofline']['frac'])"
-python tests/sweeps/fuzz_parity.py 400 41001 2>&1 | tail -2
+python tests/sweeps/fuzz_parity.py 400 61001 2>&1 | tail -2
+python tools/ingest_bench.py 2 2 2>/dev/null | tee gpurun_out/round/ingest_bench.json | cut -c1-400
