@@ -25,7 +25,9 @@
  *                registration, pointer encoding), clocks (constants).  None of these computes a pixel.  The two math imports the
  *                blender's prepare() needs -- log and ceil, for `ceil(log(max_len) / log(2.0))`, the band-count clamp -- are answered by
  *                the host libm and every such call is LOGGED (pe_math_log) so that the caller can check the clamp was nowhere near an
- *                integer boundary.  Every other import (math, I/O, locale, the other OpenCV modules) stays trapped by name.
+ *                integer boundary.  Also answered: sqrt (correctly rounded by definition), std::numeric_limits<T> members (constants), and --
+ *                only after pe_allow_libm(1), the warp-map jobs -- the projectors' float math library (sinf, cosf, atan2f ...), counted.
+ *                Every other import (math, I/O, locale, the other OpenCV modules) stays trapped by name.
  *
  * Build: gcc -O1 -shared -fPIC -o libpe_run.so pe_run.c -lm
  */
@@ -243,6 +245,38 @@ static double MS crt_cos(double x)
 }
 int pe_phase(int phase) { g_phase = phase; return g_n_trig; }
 
+/* sqrt (GainCompensator::feed's intensity sums, should the build call the CRT instead of inlining sqrtsd): IEEE 754 requires the correctly
+ * rounded result -- every conforming sqrt returns the same double.  std::numeric_limits<double>::epsilon() (cv::LU's singularity test) is the
+ * constant 2^-52. */
+static double MS crt_sqrt(double x) { return sqrt(x); }
+static double MS msvcp_dbl_epsilon(void) { return 2.220446049250313e-16; }
+static float MS msvcp_flt_epsilon(void) { return 1.1920929e-7f; }
+/* the other std::numeric_limits members MSVCP100 exports as functions: constants of the type, nothing computed */
+static int MS msvcp_int_max(void) { return 2147483647; }
+static int MS msvcp_int_min(void) { return -2147483647 - 1; }
+static float MS msvcp_flt_max(void) { return 3.402823466e+38f; }
+static float MS msvcp_flt_min(void) { return 1.175494351e-38f; }
+static double MS msvcp_dbl_max(void) { return 1.7976931348623158e+308; }
+static double MS msvcp_dbl_min(void) { return 2.2250738585072014e-308; }
+static float MS msvcp_flt_inf(void) { return __builtin_inff(); }
+static double MS msvcp_dbl_inf(void) { return __builtin_inf(); }
+
+/* The float math library behind the PROJECTORS (sinf, cosf, atan2f ... of MSVCR100, which the tree does not ship).  Answered by the host's
+ * libm ONLY after pe_allow_libm(1) -- the warp-map jobs, which say so in their output: such a run pins the projector's formulas, the order of
+ * its float operations, the ROI detection and the map layout against the oracle UNDER THE SAME libm; it cannot pin MSVCR100's function values. */
+static int g_allow_libm;
+static long g_n_libm;
+int pe_allow_libm(int on) { g_allow_libm = on; return (int)g_n_libm; }
+static void libm_gate(const char *fn)
+{
+    if (!g_allow_libm) { say("pe_run: the reference code called the float math library ("); say(fn); say(") in a run that did not allow it -- aborting\n"); _exit(77); }
+    ++g_n_libm;
+}
+#define LIBM1(name) static float MS crt_##name(float x) { libm_gate(#name); return name(x); }
+LIBM1(sinf) LIBM1(cosf) LIBM1(tanf) LIBM1(asinf) LIBM1(acosf) LIBM1(atanf) LIBM1(sinhf) LIBM1(coshf) LIBM1(logf) LIBM1(expf) LIBM1(sqrtf)
+static float MS crt_atan2f(float y, float x) { libm_gate("atan2f"); return atan2f(y, x); }
+static double MS crt_pow(double x, double y) { libm_gate("pow"); return pow(x, y); }
+
 int pe_math_log(int i, char *fn, double *x, double *y)
 {
     if (i < 0 || i >= g_n_math || i >= MATH_LOG_MAX) return g_n_math;
@@ -266,6 +300,16 @@ static const shim_t SHIMS[] = {
     {"_encode_pointer", (void *)crt_identity, PE_FULL}, {"_decode_pointer", (void *)crt_identity, PE_FULL}, {"_encoded_null", (void *)crt_null, PE_FULL},
     {"__clean_type_info_names_internal", (void *)crt_nop, PE_FULL}, {"_crt_debugger_hook", (void *)crt_nop, PE_FULL},
     {"log", (void *)crt_log, PE_FULL}, {"ceil", (void *)crt_ceil, PE_FULL}, {"sin", (void *)crt_sin, PE_FULL}, {"cos", (void *)crt_cos, PE_FULL},
+    {"sinf", (void *)crt_sinf, PE_FULL}, {"cosf", (void *)crt_cosf, PE_FULL}, {"tanf", (void *)crt_tanf, PE_FULL}, {"asinf", (void *)crt_asinf, PE_FULL},
+    {"acosf", (void *)crt_acosf, PE_FULL}, {"atanf", (void *)crt_atanf, PE_FULL}, {"atan2f", (void *)crt_atan2f, PE_FULL}, {"sinhf", (void *)crt_sinhf, PE_FULL},
+    {"coshf", (void *)crt_coshf, PE_FULL}, {"logf", (void *)crt_logf, PE_FULL}, {"expf", (void *)crt_expf, PE_FULL}, {"sqrtf", (void *)crt_sqrtf, PE_FULL},
+    {"pow", (void *)crt_pow, PE_FULL},
+    {"sqrt", (void *)crt_sqrt, PE_FULL}, {"?epsilon@?$numeric_limits@N@std@@SANXZ", (void *)msvcp_dbl_epsilon, PE_FULL},
+    {"?epsilon@?$numeric_limits@M@std@@SAMXZ", (void *)msvcp_flt_epsilon, PE_FULL},
+    {"?max@?$numeric_limits@H@std@@SAHXZ", (void *)msvcp_int_max, PE_FULL}, {"?min@?$numeric_limits@H@std@@SAHXZ", (void *)msvcp_int_min, PE_FULL},
+    {"?max@?$numeric_limits@M@std@@SAMXZ", (void *)msvcp_flt_max, PE_FULL}, {"?min@?$numeric_limits@M@std@@SAMXZ", (void *)msvcp_flt_min, PE_FULL},
+    {"?max@?$numeric_limits@N@std@@SANXZ", (void *)msvcp_dbl_max, PE_FULL}, {"?min@?$numeric_limits@N@std@@SANXZ", (void *)msvcp_dbl_min, PE_FULL},
+    {"?infinity@?$numeric_limits@M@std@@SAMXZ", (void *)msvcp_flt_inf, PE_FULL}, {"?infinity@?$numeric_limits@N@std@@SANXZ", (void *)msvcp_dbl_inf, PE_FULL},
     {"EncodePointer", (void *)crt_identity, PE_FULL}, {"DecodePointer", (void *)crt_identity, PE_FULL},
     {"InitializeCriticalSection", (void *)crt_nop, PE_FULL}, {"InitializeCriticalSectionAndSpinCount", (void *)crt_one, PE_FULL},
     {"DeleteCriticalSection", (void *)crt_nop, PE_FULL}, {"EnterCriticalSection", (void *)crt_nop, PE_FULL},

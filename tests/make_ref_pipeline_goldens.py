@@ -33,6 +33,14 @@ OUT_STILLS = os.path.join(ROOT, "tests", "golden", "ref_stills_full.npz")
 STILLS = "/root/reference/stitching/OpenCV2.4.11-Stitching/Release/output1"
 WRAP3 = dict(n=3, size=(240, 135), warp="spherical", blend="multiband", focal=90.0, yaws=[90.0, 180.0, -90.0])
 CV_16S, CV_32F = 3, 5
+# product warp name -> (the reference's warper, its A / B parameters)
+MAP_WARPS = {"plane": ("plane", (0, 0)), "spherical": ("spherical", (0, 0)), "cylindrical": ("cylindrical", (0, 0)), "fisheye": ("fisheye", (0, 0)),
+             "stereographic": ("stereographic", (0, 0)), "compressedPlaneA2B1": ("compressedPlane", (2, 1)),
+             "compressedPlaneA1.5B1": ("compressedPlane", (1.5, 1)), "compressedPlanePortraitA2B1": ("compressedPlanePortrait", (2, 1)),
+             "compressedPlanePortraitA1.5B1": ("compressedPlanePortrait", (1.5, 1)), "paniniA2B1": ("panini", (2, 1)), "paniniA1.5B1": ("panini", (1.5, 1)),
+             "paniniPortraitA2B1": ("paniniPortrait", (2, 1)), "paniniPortraitA1.5B1": ("paniniPortrait", (1.5, 1)), "mercator": ("mercator", (0, 0)),
+             "transverseMercator": ("transverseMercator", (0, 0)), "sphericalPortrait": ("sphericalPortrait", (0, 0)),
+             "cylindricalPortrait": ("cylindricalPortrait", (0, 0)), "planePortrait": ("planePortrait", (0, 0))}
 
 
 def whole(fn, **a):
@@ -142,6 +150,39 @@ def cases():
     g["resizef_src"] = bgr
     for k, f in enumerate((0.537914354, 0.25, 0.8)):
         g["resizef_f%d" % k], g["resizef_out%d" % k] = np.float64(f), whole("resize_factor", src=bgr, f=np.array(f))
+    # ---- the calibration side, whole: exposure compensators' feed, seam finders' find, the warpers' buildMaps --------------------------
+    corners, sizes = [(-30, -8), (25, 4), (70, -2), (110, 10)], [(80, 60), (90, 50), (70, 66), (64, 64)]
+    g["cal_corners"], g["cal_sizes"] = np.array(corners), np.array(sizes)
+    pl8, plf = {}, {}
+    for i, (w, h) in enumerate(sizes):
+        coarse = rng.uniform(0, 255, (h // 4 + 2, w // 4 + 2, 3)).astype(np.float32)          # smooth texture + noise: seams have something to follow
+        img = np.ascontiguousarray(np.kron(coarse, np.ones((4, 4, 1), np.float32))[:h, :w] + rng.uniform(0, 20, (h, w, 3)).astype(np.float32))
+        k = np.full((h, w), 255, np.uint8)
+        k[:4] = 0
+        k[:, :3] = 0
+        k[h // 2:, w - 9:] = 0
+        plf["img%d" % i], pl8["img%d" % i] = img, np.clip(img, 0, 255).astype(np.uint8)
+        plf["mask%d" % i] = pl8["mask%d" % i] = k
+        g["cal_imgf%d" % i], g["cal_img8_%d" % i], g["cal_mask%d" % i] = img, pl8["img%d" % i], k
+    g["cal_gains"] = R.run("exposure_feed", kind=np.array("gain"), corners=np.array(corners), block=np.array((32, 32)), **pl8)["gains"]
+    for bw, bh in ((32, 32), (16, 24)):
+        r = R.run("exposure_feed", kind=np.array("gain_blocks"), corners=np.array(corners), block=np.array((bw, bh)), **pl8)
+        for i in range(len(sizes)):
+            g["cal_gain_map_%dx%d_%d" % (bw, bh, i)] = r["map%d" % i]
+    for kind in ("voronoi", "dp_color", "dp_colorgrad"):
+        for tag, pl in (("f", plf), ("8", pl8)):
+            if kind == "voronoi" and tag == "8":
+                continue
+            r = R.run("seams", kind=np.array(kind), corners=np.array(corners), **pl)
+            for i in range(len(sizes)):
+                g["cal_seam_%s_%s_%d" % (kind, tag, i)] = r["mask%d" % i]
+    Kc, Rc = rigmod.intrinsics(90.0, 96, 54), rigmod.rot_y(25.0)
+    g["maps_K"], g["maps_R"] = Kc, Rc
+    for name in MAP_WARPS:
+        base, ab = MAP_WARPS[name]
+        r = R.run("build_maps", warp=np.array(base), scale=np.array(90.0, np.float32), ab=np.array(ab, np.float32), K=Kc, R=Rc, size=np.array((96, 54)))
+        assert (int(r["libm_calls"]) == 0) == base.startswith("plane"), name       # the plane projectors need no math library at all
+        g["maps_%s_roi" % name], g["maps_%s_x" % name], g["maps_%s_y" % name] = r["roi"], r["xmap"], r["ymap"]
     return g
 
 

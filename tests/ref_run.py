@@ -105,6 +105,8 @@ def _lib():
     L.pe_lockdown.argtypes = [C.c_char_p]
     L.pe_call.restype = C.c_uint64
     L.pe_call.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
+    L.pe_allow_libm.restype = C.c_int
+    L.pe_allow_libm.argtypes = [C.c_int]
     L.pe_phase.restype = C.c_int
     L.pe_phase.argtypes = [C.c_int]
     L.pe_math_log.restype = C.c_int
@@ -455,6 +457,136 @@ def job_confinement_probe():
             res[name + "_errno"] = np.array(e.errno if e.errno != errno.EACCES else 1)
     res["uid"] = np.array(os.getuid())
     return res
+
+
+class _Vec(C.Structure):               # std::vector<T> of MSVC 2010, release build: _Myfirst, _Mylast, _Myend, _Alval (padded)
+    _fields_ = [("first", C.c_void_p), ("last", C.c_void_p), ("end", C.c_void_p), ("alval", C.c_uint64)]
+
+
+def _vec(buf, nbytes):
+    v = _Vec()
+    v.first = C.addressof(buf)
+    v.last = v.end = C.addressof(buf) + nbytes
+    return v
+
+
+def _mat_into(slot_addr, a):
+    """a cv::Mat header over array `a`, written AT slot_addr (its size / step pointers point into the slot)"""
+    m = mat(a)
+    C.memmove(slot_addr, C.addressof(m), C.sizeof(Mat))
+    C.c_void_p.from_address(slot_addr + Mat.size_p.offset).value = slot_addr + Mat.rows.offset
+    C.c_void_p.from_address(slot_addr + Mat.step_p.offset).value = slot_addr + Mat.step_buf.offset
+
+
+def job_exposure_feed(kind, corners, block, **planes):
+    """cv::detail::GainCompensator::feed / BlocksGainCompensator::feed of opencv_stitching2411.dll, WHOLE (exposure_compensate.cpp:70-142,
+    172-222: overlap ROIs, the intensity sums, the normal equations, cv::solve(LU); for blocks: the per-block feed, the gain maps and their
+    sepFilter2D smoothing) on std::vector<Point>, std::vector<Mat>, std::vector<pair<Mat, uchar>> laid out by hand."""
+    kind = str(kind)
+    p = Process()
+    pts = np.ascontiguousarray(np.asarray(corners).reshape(-1, 2), np.int32)
+    n = len(pts)
+    imgs = [np.ascontiguousarray(planes["img%d" % i], np.uint8) for i in range(n)]
+    masks = [np.ascontiguousarray(planes["mask%d" % i], np.uint8) for i in range(n)]
+    v_images = (C.c_uint8 * (C.sizeof(Mat) * n))()
+    v_masks = (C.c_uint8 * (104 * n))()                          # pair<Mat, uchar>: 96 + 1, padded to 104
+    for i in range(n):
+        _mat_into(C.addressof(v_images) + C.sizeof(Mat) * i, imgs[i])
+        _mat_into(C.addressof(v_masks) + 104 * i, masks[i])
+        C.c_uint8.from_address(C.addressof(v_masks) + 104 * i + 96).value = 255
+    c_buf = (C.c_int32 * (2 * n))(*pts.ravel())
+    vc, vi, vm = _vec(c_buf, 8 * n), _vec(v_images, C.sizeof(Mat) * n), _vec(v_masks, 104 * n)
+    this = (C.c_uint8 * 1024)()
+    obj = C.addressof(this)
+    sig = ("@detail@cv@@UEAAXAEBV?$vector@V?$Point_@H@cv@@V?$allocator@V?$Point_@H@cv@@@std@@@std@@AEBV?$vector@VMat@cv@@V?$allocator@VMat@cv@@@std@@@5@"
+           "AEBV?$vector@U?$pair@VMat@cv@@E@std@@V?$allocator@U?$pair@VMat@cv@@E@std@@@2@@5@@Z")
+    if kind == "gain":
+        p.call(p.sym("stitching", "??0GainCompensator@detail@cv@@QEAA@XZ"), obj)
+        p.call(p.sym("stitching", "?feed@GainCompensator" + sig), obj, C.addressof(vc), C.addressof(vi), C.addressof(vm))
+        gains = Mat.from_address(obj + 8)                        # {vptr, Mat_<double> gains_}
+        return {"gains": mat_array(gains).reshape(-1)}
+    bw, bh = int(block[0]), int(block[1])
+    p.call(p.sym("stitching", "??0BlocksGainCompensator@detail@cv@@QEAA@HH@Z"), obj, bw, bh)
+    p.call(p.sym("stitching", "?feed@BlocksGainCompensator" + sig), obj, C.addressof(vc), C.addressof(vi), C.addressof(vm))
+    vec = _Vec.from_address(obj + 16)                            # {vptr, int bl_width_, bl_height_, vector<Mat_<float>> gain_maps_}
+    cnt = (vec.last - vec.first) // C.sizeof(Mat)
+    assert cnt == n, cnt
+    return {"map%d" % i: mat_array(Mat.from_address(vec.first + C.sizeof(Mat) * i)) for i in range(n)}
+
+
+def job_seams(kind, corners, **planes):
+    """cv::detail::VoronoiSeamFinder / DpSeamFinder(COLOR | COLOR_GRAD)::find of opencv_stitching2411.dll, WHOLE (seam_finders.cpp:49-160,
+    163-1045): images (CV_32FC3 as the sample passes them, or CV_8UC3), corners, masks modified in place."""
+    kind = str(kind)
+    p = Process()
+    pts = np.ascontiguousarray(np.asarray(corners).reshape(-1, 2), np.int32)
+    n = len(pts)
+    imgs = [np.ascontiguousarray(planes["img%d" % i]) for i in range(n)]
+    masks = [np.ascontiguousarray(planes["mask%d" % i], np.uint8).copy() for i in range(n)]
+    v_images = (C.c_uint8 * (C.sizeof(Mat) * n))()
+    v_masks = (C.c_uint8 * (C.sizeof(Mat) * n))()
+    for i in range(n):
+        _mat_into(C.addressof(v_images) + C.sizeof(Mat) * i, imgs[i])
+        _mat_into(C.addressof(v_masks) + C.sizeof(Mat) * i, masks[i])
+    c_buf = (C.c_int32 * (2 * n))(*pts.ravel())
+    vc, vi, vm = _vec(c_buf, 8 * n), _vec(v_images, C.sizeof(Mat) * n), _vec(v_masks, C.sizeof(Mat) * n)
+    this = (C.c_uint8 * 4096)()
+    obj = C.addressof(this)
+    sig = ("@detail@cv@@UEAAXAEBV?$vector@VMat@cv@@V?$allocator@VMat@cv@@@std@@@std@@AEBV?$vector@V?$Point_@H@cv@@V?$allocator@V?$Point_@H@cv@@@std@@@5@AEAV45@@Z")
+    if kind == "voronoi":
+        p.call(p.sym("stitching", "??0VoronoiSeamFinder@detail@cv@@QEAA@XZ"), obj)
+        p.call(p.sym("stitching", "?find@PairwiseSeamFinder" + sig), obj, C.addressof(vi), C.addressof(vc), C.addressof(vm))
+    else:
+        p.call(p.sym("stitching", "??0DpSeamFinder@detail@cv@@QEAA@W4CostFunction@012@@Z"), obj, {"dp_color": 0, "dp_colorgrad": 1}[kind])
+        p.call(p.sym("stitching", "?find@DpSeamFinder" + sig), obj, C.addressof(vi), C.addressof(vc), C.addressof(vm))
+    return {"mask%d" % i: masks[i] for i in range(n)}
+
+
+WARPERS = {"plane": ("PlaneWarper", "M"), "spherical": ("SphericalWarper", "M"), "cylindrical": ("CylindricalWarper", "M"),
+           "fisheye": ("FisheyeWarper", "M"), "stereographic": ("StereographicWarper", "M"),
+           "compressedPlane": ("CompressedRectilinearWarper", "MMM"), "compressedPlanePortrait": ("CompressedRectilinearPortraitWarper", "MMM"),
+           "panini": ("PaniniWarper", "MMM"), "paniniPortrait": ("PaniniPortraitWarper", "MMM"), "mercator": ("MercatorWarper", "M"),
+           "transverseMercator": ("TransverseMercatorWarper", "M"), "sphericalPortrait": ("SphericalPortraitWarper", "M"),
+           "cylindricalPortrait": ("CylindricalPortraitWarper", "M"), "planePortrait": ("PlanePortraitWarper", "M")}
+PROJECTOR = {"PlaneWarper": "PlaneProjector", "SphericalWarper": "SphericalProjector", "CylindricalWarper": "CylindricalProjector",
+             "FisheyeWarper": "FisheyeProjector", "StereographicWarper": "StereographicProjector",
+             "CompressedRectilinearWarper": "CompressedRectilinearProjector", "CompressedRectilinearPortraitWarper": "CompressedRectilinearPortraitProjector",
+             "PaniniWarper": "PaniniProjector", "PaniniPortraitWarper": "PaniniPortraitProjector", "MercatorWarper": "MercatorProjector",
+             "TransverseMercatorWarper": "TransverseMercatorProjector", "SphericalPortraitWarper": "SphericalPortraitProjector",
+             "CylindricalPortraitWarper": "CylindricalPortraitProjector", "PlanePortraitWarper": "PlanePortraitProjector"}
+
+
+def job_build_maps(warp, scale, ab, K, R, size):
+    """cv::detail::<X>Warper::buildMaps(src_size, K, R, xmap, ymap) of opencv_stitching2411.dll, WHOLE (warpers.hpp / warpers_inl.hpp:
+    setCameraParams, detectResultRoi[ByBorder], mapBackward per pixel): the float backward maps and the ROI.  The plane projector needs no
+    math library; every other one calls MSVCR100's sinf / cosf / atan2f ..., which the tree does not hold: they are answered by THIS host's
+    libm (pe_allow_libm), so such a run pins formulas, operation order and ROI detection, not the library's function values."""
+    warp = str(warp)
+    cls, sig = WARPERS[warp]
+    p = Process()
+    this = (C.c_uint8 * 512)()
+    obj = C.addressof(this)
+    f32 = lambda v: int(np.float32(v).view(np.uint32))          # noqa: E731
+    ctor = p.sym("stitching", "??0%s@detail@cv@@QEAA@%s@Z" % (cls, sig))
+    if sig == "M":
+        p.call(ctor, obj, f32(scale))
+    else:
+        p.call(ctor, obj, f32(scale), f32(ab[0]), f32(ab[1]))
+    k, r = np.ascontiguousarray(K, np.float32).reshape(3, 3), np.ascontiguousarray(R, np.float32).reshape(3, 3)
+    mk, mr, xmap, ymap = mat(k), mat(r), empty_mat(), empty_mat()
+    sz = (C.c_int * 2)(int(size[0]), int(size[1]))
+    roi = (C.c_int * 4)()
+    before = p.L.pe_allow_libm(0 if warp == "plane" else 1)
+    if warp == "plane":                                          # PlaneWarper's own overload with a translation (zeros: what the virtual one passes)
+        t = np.zeros((3, 1), np.float32)
+        mt = mat(t)
+        p.call(p.sym("stitching", "?buildMaps@PlaneWarper@detail@cv@@QEAA?AV?$Rect_@H@3@V?$Size_@H@3@AEBVMat@3@11AEAV63@2@Z"), obj, C.addressof(roi),
+               C.addressof(sz), C.addressof(mk), C.addressof(mr), C.addressof(mt), C.addressof(xmap), C.addressof(ymap))
+    else:
+        p.call(p.sym("stitching", "?buildMaps@?$RotationWarperBase@U%s@detail@cv@@@detail@cv@@UEAA?AV?$Rect_@H@3@V?$Size_@H@3@AEBVMat@3@1AEAV63@2@Z" % PROJECTOR[cls]),
+               obj, C.addressof(roi), C.addressof(sz), C.addressof(mk), C.addressof(mr), C.addressof(xmap), C.addressof(ymap))
+    calls = p.L.pe_allow_libm(0) - before
+    return {"roi": np.array(list(roi), np.int32), "xmap": mat_array(xmap), "ymap": mat_array(ymap), "libm_calls": np.array(calls, np.int64)}
 
 
 def job_probe():
@@ -836,7 +968,7 @@ def job_arith16s(a, b, sub, sse):
     return {"out": d.reshape(x.shape)}
 
 
-JOBS = {"probe": job_probe, "confinement_probe": job_confinement_probe, "pipeline": job_pipeline, "blend": job_blend, "whole": job_whole, "arith16s": job_arith16s, "blocks_gain_apply": job_blocks_gain_apply, "remap_nearest": job_remap_nearest, "resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
+JOBS = {"probe": job_probe, "build_maps": job_build_maps, "seams": job_seams, "exposure_feed": job_exposure_feed, "confinement_probe": job_confinement_probe, "pipeline": job_pipeline, "blend": job_blend, "whole": job_whole, "arith16s": job_arith16s, "blocks_gain_apply": job_blocks_gain_apply, "remap_nearest": job_remap_nearest, "resize_linear": job_resize_linear, "sobel32f": job_sobel32f, "smooth3": job_smooth3, "gray": job_gray, "border_interpolate": job_border_interpolate, "nv12": job_nv12, "distance_l1": job_distance_l1, "cvt_scale": job_cvt_scale, "normalize_32f": job_normalize_32f, "pyr_down": job_pyr_down, "pyr_up": job_pyr_up, "remap_bilinear": job_remap_bilinear}
 
 
 def run(job, **arrays):

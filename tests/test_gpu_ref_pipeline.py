@@ -7,7 +7,7 @@ import pytest
 
 import golden_util as G
 import helpers as H
-from test_ref_pipeline import wrap3_rig
+from test_ref_pipeline import MAP_WARPS, _cal, wrap3_rig
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -50,3 +50,43 @@ def test_engine_full_size_stills_equal_the_reference():
     assert np.array_equal(mask, z["pano_mask"]), H.diff_report(mask, z["pano_mask"])
     assert np.array_equal(pano, z["pano"]), H.diff_report(pano, z["pano"])
     eng.close()
+
+
+# ---- the calibration-side entry points of the product against the reference's own compensators, seam finders and warpers ---------------
+
+def test_device_gain_feeds_equal_the_reference(g):
+    import stitchingvideo_amd as S
+    corners, imgs, masks = _cal(g, "img8_")
+    comp = S.GainCompensator()
+    comp.feed(corners, imgs, masks)
+    assert np.array_equal(np.asarray(comp.gains).view(np.uint64), g["cal_gains"].view(np.uint64))
+    for bw, bh in ((32, 32), (16, 24)):
+        comp = S.BlocksGainCompensator(bl_width=bw, bl_height=bh)
+        comp.feed(corners, imgs, masks)
+        for i, m in enumerate(comp.gain_maps):
+            want = g["cal_gain_map_%dx%d_%d" % (bw, bh, i)]
+            assert m.shape == want.shape and np.array_equal(m.view(np.uint32), want.view(np.uint32)), (bw, bh, i)
+
+
+@pytest.mark.parametrize("kind,tag", [("voronoi", "f"), ("dp_color", "f"), ("dp_colorgrad", "f"), ("dp_color", "8"), ("dp_colorgrad", "8")])
+def test_device_seam_finders_equal_the_reference(g, kind, tag):
+    import stitchingvideo_amd as S
+    corners, imgs, masks = _cal(g, "imgf" if tag == "f" else "img8_")
+    got = [m.copy() for m in masks]
+    if kind == "voronoi":
+        S.VoronoiSeamFinder().find([(m.shape[1], m.shape[0]) for m in masks], corners, got)
+    else:
+        S.DpSeamFinder("color" if kind == "dp_color" else "color_grad").find(imgs, corners, got)
+    for i, m in enumerate(got):
+        want = g["cal_seam_%s_%s_%d" % (kind, tag, i)]
+        assert np.array_equal(m, want), (kind, tag, i, int((m != want).sum()))
+
+
+@pytest.mark.parametrize("name", MAP_WARPS)
+def test_engine_backward_maps_equal_the_reference(g, name):
+    from stitchingvideo_amd.engine import WARPERS
+    roi, xm, ym = WARPERS[name](90.0).buildMaps((96, 54), g["maps_K"], g["maps_R"])
+    r = tuple(int(v) for v in g["maps_%s_roi" % name])
+    assert (r[0], r[1], r[2] + 1, r[3] + 1) == tuple(roi)
+    assert np.array_equal(xm.view(np.uint32), g["maps_%s_x" % name].view(np.uint32))
+    assert np.array_equal(ym.view(np.uint32), g["maps_%s_y" % name].view(np.uint32))

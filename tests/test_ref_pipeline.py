@@ -112,3 +112,53 @@ def test_oracle_full_size_stills_equal_the_reference():
     assert rect == tuple(int(v) for v in z["rect"])
     assert np.array_equal(mask, z["pano_mask"])
     assert np.array_equal(pano, z["pano"]), H.diff_report(pano, z["pano"])
+
+
+# ---- the calibration side: the reference's exposure compensators, seam finders and warpers, run whole -----------------------------------------
+
+def _cal(g, kind):
+    n = len(g["cal_sizes"])
+    corners = [tuple(int(v) for v in c) for c in g["cal_corners"]]
+    return corners, [g["cal_%s%d" % (kind, i)] for i in range(n)], [g["cal_mask%d" % i] for i in range(n)]
+
+
+def test_oracle_gain_compensator_feed_is_the_references(g):
+    """GainCompensator::feed (overlap statistics, normal equations, cv::solve LU) and BlocksGainCompensator::feed (per-block feed, gain
+    maps, sepFilter2D smoothing): doubles and floats bit for bit"""
+    corners, imgs, masks = _cal(g, "img8_")
+    assert np.array_equal(np.asarray(O.gain_feed(corners, imgs, masks)).view(np.uint64), g["cal_gains"].view(np.uint64))
+    for bw, bh in ((32, 32), (16, 24)):
+        for i, m in enumerate(O.blocks_gain_feed(corners, imgs, masks, (bw, bh))):
+            want = g["cal_gain_map_%dx%d_%d" % (bw, bh, i)]
+            assert m.shape == want.shape and np.array_equal(m.view(np.uint32), want.view(np.uint32)), (bw, bh, i)
+
+
+@pytest.mark.parametrize("kind,tag", [("voronoi", "f"), ("dp_color", "f"), ("dp_colorgrad", "f"), ("dp_color", "8"), ("dp_colorgrad", "8")])
+def test_oracle_seam_finders_are_the_references(g, kind, tag):
+    """VoronoiSeamFinder::find, DpSeamFinder(COLOR | COLOR_GRAD)::find on CV_32FC3 (what the sample passes) and CV_8UC3 images"""
+    corners, imgs, masks = _cal(g, "imgf" if tag == "f" else "img8_")
+    got = O.voronoi_seams(corners, masks) if kind == "voronoi" else O.dp_seams(corners, imgs, masks, "color" if kind == "dp_color" else "color_grad")
+    changed = 0
+    for i, m in enumerate(got):
+        want = g["cal_seam_%s_%s_%d" % (kind, tag, i)]
+        assert np.array_equal(m, want), (kind, tag, i, int((m != want).sum()))
+        changed += int((want != masks[i]).sum())
+    assert changed > 500                                          # the reference's finder did carve seams
+
+
+MAP_WARPS = ["plane", "spherical", "cylindrical", "fisheye", "stereographic", "compressedPlaneA2B1", "compressedPlaneA1.5B1",
+             "compressedPlanePortraitA2B1", "compressedPlanePortraitA1.5B1", "paniniA2B1", "paniniA1.5B1", "paniniPortraitA2B1",
+             "paniniPortraitA1.5B1", "mercator", "transverseMercator", "sphericalPortrait", "cylindricalPortrait", "planePortrait"]
+
+
+@pytest.mark.parametrize("name", MAP_WARPS)
+def test_oracle_backward_maps_are_the_references(g, name):
+    """<X>Warper::buildMaps of the shipped DLL (setCameraParams, detectResultRoi, mapBackward per pixel).  plane / planePortrait: no math
+    library at all -- pinned outright; the others ran with THIS host's libm answering MSVCR100's sinf / cosf / atan2f ...: formulas,
+    operation order and ROI detection are the reference's, the library's function values are not pinnable."""
+    from stitchingvideo_amd import _capi as capi
+    roi, xm, ym = O.build_maps(capi.WARP_NAMES[name], 90.0, g["maps_K"], g["maps_R"], 96, 54)
+    r = tuple(int(v) for v in g["maps_%s_roi" % name])
+    assert (r[0], r[1], r[2] + 1, r[3] + 1) == tuple(roi)         # buildMaps returns Rect(tl, br); warpRoi / the maps are one larger (warpers_inl.hpp:58-74)
+    assert np.array_equal(xm.view(np.uint32), g["maps_%s_x" % name].view(np.uint32))
+    assert np.array_equal(ym.view(np.uint32), g["maps_%s_y" % name].view(np.uint32))
