@@ -183,6 +183,18 @@ def cases():
         r = R.run("build_maps", warp=np.array(base), scale=np.array(90.0, np.float32), ab=np.array(ab, np.float32), K=Kc, R=Rc, size=np.array((96, 54)))
         assert (int(r["libm_calls"]) == 0) == base.startswith("plane"), name       # the plane projectors need no math library at all
         g["maps_%s_roi" % name], g["maps_%s_x" % name], g["maps_%s_y" % name] = r["roi"], r["xmap"], r["ymap"]
+    # ---- the lens-undistort pre-pass as the driver runs it (DRV:201-238): initUndistortRectifyMap(K, D, Mat(), K, size, CV_16SC2) whole, then
+    # remap(frame, map1, map2, INTER_LINEAR) whole on those maps; and cvtColor(COLOR_YUV2BGR_NV12) whole --------------------------------
+    fw, fh = 320, 180
+    Ku = np.array([[655.6 * fw / 1280, 0, 625.06 * fw / 1280], [0, 656.4 * fh / 720, 361.96 * fh / 720], [0, 0, 1]])
+    dist = np.array([-0.382, 0.195, -0.00363, 0.00237])
+    r = R.run("whole", fn=np.array("init_undistort"), K=Ku, dist=dist, size=np.array((fw, fh)))
+    g["und_K"], g["und_dist"], g["und_map1"], g["und_map2"] = Ku, dist, r["map1"], r["map2"]
+    frame = rng.integers(0, 256, (fh, fw, 3)).astype(np.uint8)
+    g["und_frame"] = frame
+    g["und_out"] = R.run("whole", fn=np.array("remap_fixed"), src=frame, map1=r["map1"], map2=r["map2"])["out"]
+    yuv = rng.integers(0, 256, (fh * 3 // 2, fw)).astype(np.uint8)
+    g["nv12w_src"], g["nv12w_out"] = yuv, R.run("whole", fn=np.array("nv12"), src=yuv)["out"]
     return g
 
 

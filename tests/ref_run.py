@@ -378,6 +378,29 @@ def job_whole(fn, **a):
         return {"out": p.convert_to(a["src"], int(a["rtype"]), float(a["alpha"]), float(a["beta"]))}
     if fn == "distance_transform":
         return {"out": p.distance_transform(a["src"])}
+    if fn == "init_undistort":
+        # initUndistortRectifyMap(im1, D1, Mat(), im1, size, CV_16SC2, map1, map2) as RunTestEyeFishMap calls it (DRV:201-238)
+        k = np.ascontiguousarray(a["K"], np.float64).reshape(3, 3)
+        d = np.ascontiguousarray(a["dist"], np.float64).reshape(1, -1)
+        m1, m2, no_r = empty_mat(), empty_mat(), empty_mat()
+        size = (C.c_int * 2)(int(a["size"][0]), int(a["size"][1]))
+        mk, md = mat(k), mat(d)
+        p.cv("imgproc", "?initUndistortRectifyMap@cv@@YAXAEBV_InputArray@1@000V?$Size_@H@1@HAEBV_OutputArray@1@2@Z", p.ia(mk), p.ia(md), p.ia(no_r), p.ia(mk),
+             C.addressof(size), 11, p.oa(m1), p.oa(m2))             # CV_16SC2 = 3 + (1 << 3)
+        return {"map1": mat_array(m1), "map2": mat_array(m2)}
+    if fn == "remap_fixed":
+        # remap(Img, ImgUndistort, mapEye1, mapEye2, INTER_LINEAR): CV_16SC2 + CV_16UC1 maps straight in, BORDER_CONSTANT 0
+        src, m1, m2 = np.ascontiguousarray(a["src"]), np.ascontiguousarray(a["map1"], np.int16), np.ascontiguousarray(a["map2"], np.uint16)
+        dst, zero = empty_mat(), (C.c_double * 4)()
+        p.cv("imgproc", "?remap@cv@@YAXAEBV_InputArray@1@AEBV_OutputArray@1@00HHAEBV?$Scalar_@N@1@@Z", p.ia(mat(src)), p.oa(dst), p.ia(mat(m1)), p.ia(mat(m2)),
+             1, 0, C.addressof(zero))
+        p.keep += [src, m1, m2]
+        return {"out": mat_array(dst)}
+    if fn == "nv12":
+        src, dst = np.ascontiguousarray(a["src"], np.uint8), empty_mat()
+        p.cv("imgproc", "?cvtColor@cv@@YAXAEBV_InputArray@1@AEBV_OutputArray@1@HH@Z", p.ia(mat(src)), p.oa(dst), 91, 0)       # COLOR_YUV2BGR_NV12
+        p.keep += [src]
+        return {"out": mat_array(dst)}
     if fn == "mask_fixup":
         # stitcher.cpp:291-293 / DRV:700-702: dilate(masks_warped[i], dilated, Mat()); resize(dilated, seam_mask, mask_warped.size());
         # mask_warped = seam_mask & mask_warped

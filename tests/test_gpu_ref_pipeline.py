@@ -90,3 +90,9 @@ def test_engine_backward_maps_equal_the_reference(g, name):
     assert (r[0], r[1], r[2] + 1, r[3] + 1) == tuple(roi)
     assert np.array_equal(xm.view(np.uint32), g["maps_%s_x" % name].view(np.uint32))
     assert np.array_equal(ym.view(np.uint32), g["maps_%s_y" % name].view(np.uint32))
+
+
+def test_device_lens_undistort_and_nv12_equal_the_reference(g):
+    import stitchingvideo_amd as S
+    assert np.array_equal(S.remap_fixed(g["und_frame"], g["und_map1"], g["und_map2"]), g["und_out"])
+    assert np.array_equal(S.cvt_nv12_bgr(g["nv12w_src"]), g["nv12w_out"])

@@ -162,3 +162,19 @@ def test_oracle_backward_maps_are_the_references(g, name):
     assert (r[0], r[1], r[2] + 1, r[3] + 1) == tuple(roi)         # buildMaps returns Rect(tl, br); warpRoi / the maps are one larger (warpers_inl.hpp:58-74)
     assert np.array_equal(xm.view(np.uint32), g["maps_%s_x" % name].view(np.uint32))
     assert np.array_equal(ym.view(np.uint32), g["maps_%s_y" % name].view(np.uint32))
+
+
+def test_oracle_lens_undistort_and_nv12_are_the_references(g):
+    """initUndistortRectifyMap(K, D, Mat(), K, size, CV_16SC2) as RunTestEyeFishMap calls it (DRV:201-238), the remap on its fixed-point maps,
+    and cvtColor(COLOR_YUV2BGR_NV12) -- whole functions of the shipped imgproc"""
+    m1, m2 = O.init_undistort_rectify_map(g["und_K"], g["und_dist"], (320, 180))
+    assert np.array_equal(m1, g["und_map1"]) and np.array_equal(m2, g["und_map2"])
+    assert np.array_equal(O.remap_fixed(g["und_frame"], m1, m2), g["und_out"])
+    assert np.array_equal(O.cvt_nv12_bgr(g["nv12w_src"]), g["nv12w_out"])
+
+
+def test_product_host_rectify_maps_are_the_references(g):
+    """the product's own host-side map builder (csrc/geometry.cpp, no GPU needed)"""
+    import stitchingvideo_amd as S
+    m1, m2 = S.init_undistort_rectify_map(g["und_K"], list(g["und_dist"]), (320, 180))
+    assert np.array_equal(m1, g["und_map1"]) and np.array_equal(m2, g["und_map2"])
