@@ -710,7 +710,7 @@ def main():
     if world > 1:
         arm("ranks_seen", 120.0)
         props = torch.cuda.get_device_properties(local_rank)
-        ident = {"rank": rank, "local_rank": local_rank, "device": props.name,
+        ident = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "device": props.name,
                  "uuid": str(getattr(props, "uuid", "")), "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))}
         seen = [None] * world
         try:
@@ -718,7 +718,9 @@ def main():
         except Exception as e:          # noqa: BLE001
             seen = [{"error": "%s: %s" % (type(e).__name__, e)}]
         n_ranks = len([r for r in seen if isinstance(r, dict) and "rank" in r])
-        n_devs = len({(r or {}).get("uuid") or (r or {}).get("pci") for r in seen if isinstance(r, dict)})
+        # (distinct devices: by the index each rank made current -- one node, LOCAL_RANK = device index -- together with whatever the
+        # runtime reports as uuid / PCI address; a stack that reports neither still counts N devices for N device indices)
+        n_devs = len({((r or {}).get("uuid"), (r or {}).get("pci"), (r or {}).get("device_index")) for r in seen if isinstance(r, dict)})
         if rank == 0:
             out["ranks_seen"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": seen, "distinct_devices": n_devs}
         # a job that does not span N ranks on N distinct GPUs is not the N-GPU measurement: say so in the line and exit non-zero
