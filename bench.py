@@ -725,7 +725,7 @@ def main():
             out["ranks_seen"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": seen, "distinct_devices": n_devs}
         # a job that does not span N ranks on N distinct GPUs is not the N-GPU measurement: say so in the line and exit non-zero
         # (the one-GPU smoke hook, where the ranks share the visible devices on purpose, is exempt from the device count)
-        if n_ranks != world or dist.get_world_size() != args.gpus or (not smoke_backend and n_devs != world):
+        if n_ranks != world or (args.gpus > 1 and dist.get_world_size() != args.gpus) or (not smoke_backend and n_devs != world):
             ranks_error = "ranks_seen: %d rank(s) on %d distinct device(s), expected %d (--gpus %d)" % (n_ranks, n_devs, world, args.gpus)
             if rank == 0:
                 out["error"] = ranks_error
