@@ -856,8 +856,10 @@ def ingest_leg(rig, blend, local_rank, cw, ch, seconds=1.5):
     res = {}
     for fmt in ("bgr", "nv12"):
         names = ["/mst_bench_%s_%d_%d" % (fmt, os.getpid(), i) for i in range(n_cam)]
+        # (the capture side copies into its segment with non-temporal stores: its consumer is a DMA engine -- mi355_ingest.h, MST_SHM_STREAM_COPY)
         procs = [subprocess.Popen([sys.executable, "-m", "stitchingvideo_amd.ingest", names[i], str(i), str(fw), str(fh), fmt, "3", "0"],
-                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, cwd=ROOT) for i in range(n_cam)]
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, cwd=ROOT, env=dict(os.environ, MST_SHM_STREAM_COPY="1"))
+                 for i in range(n_cam)]
         eng = None
         try:
             for p in procs:

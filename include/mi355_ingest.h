@@ -48,6 +48,9 @@ typedef struct mst_shm mst_shm;
 int  mst_shm_serve(const char *name, size_t max_frame_bytes, mst_shm **out);
 /* server side: wait until the client asked for a frame (timeout_ms < 0: forever), write header + pixels, signal.
  * bgr rows are `stride` bytes apart and are packed tightly into the segment. */
+/* (Environment, capture side: MST_SHM_STREAM_COPY=1 makes mst_shm_publish* copy into the segment with non-temporal stores -- right when the
+ * consumer is the GPU's DMA engine (mst_shm_get_device*, mst_pipeline_submit_shm: no read-for-ownership of 6 MB per frame, a third of the
+ * copy's memory traffic), wrong when it copies with the CPU (mst_shm_get then misses on every line).  Default: plain memcpy.) */
 int  mst_shm_publish(mst_shm *s, const char *file_path, int width, int height, const uint8_t *bgr, size_t stride,
                      int timeout_ms);
 
