@@ -178,6 +178,44 @@ def test_native_pipeline_from_capture_processes(fmt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prefetch,async_release", [(False, False), (True, False)])
+def test_pull_modes_that_wait_for_the_bus(prefetch, async_release):
+    """the two older forms of the pull (MST_SHM flags 0 and MST_SHM_PREFETCH: the call returns when the copies are complete) through the same loop"""
+    import helpers as H
+    import stitchingvideo_amd as S
+    from stitchingvideo_amd import rig as rigmod
+    rig = rigmod.build_rig(rigmod.scaled_config("C3", 8))
+    n = len(rig["cameras"])
+    w, h = rig["size"]
+    eng = S.PanoramaEngine(n, warp=rig["warp"], blend=rig["blend"], expos=rig["expos"], num_bands=5, overlap_frames=True, overlap_depth=4)
+    eng.update(rig["scale"], rig["cameras"])
+    n_sets = 7
+    names, procs = _spawn_producers("/mst_pm_%d_%d_%d" % (prefetch, async_release, os.getpid()), n, w, h, "bgr", 3, n_sets)
+    try:
+        st = ingest.IngestStitcher(eng, names, [c["size"] for c in rig["cameras"]], prefetch=prefetch, async_release=async_release)
+        got = []
+        for t in range(n_sets):
+            if t >= 3:
+                got.append(st.wait().copy())
+            st.submit()
+        while st.completed < st.submitted:
+            got.append(st.wait().copy())
+        st.close()
+    finally:
+        for p in procs:
+            p.stdin.close()
+        for p in procs:
+            p.wait(timeout=30)
+    expected = {}
+    for t, pano in enumerate(got):
+        k = t % 3
+        if k not in expected:
+            expected[k] = H.oracle_compose(rig, [rigmod.synth_frame(i, k, w, h) for i in range(n)])[1]
+        assert np.array_equal(pano, expected[k]), (prefetch, t)
+    eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("depth", [0, 4])
 @pytest.mark.parametrize("fmt", ["bgr", "nv12"])
 def test_capture_processes_to_panorama_end_to_end(fmt, depth):
