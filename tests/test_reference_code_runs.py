@@ -37,6 +37,15 @@ def test_pipeline_goldens_regenerate_bit_for_bit():
                 assert a.shape == b.shape and np.array_equal(a, b, equal_nan=a.dtype.kind == "f"), k
 
 
+def test_full_size_digests_regenerate():
+    """C2 / C3 / C4 / C5 at full size through the reference's compose loop again: the committed SHA-256s come back"""
+    import json
+    import make_ref_full_size as F
+    fresh = F.cases()
+    with open(F.OUT) as f:
+        assert json.load(f) == json.loads(json.dumps(fresh))
+
+
 def test_unconfined_process_cannot_call_reference_code():
     """pe_call refuses (exit 76) before pe_lockdown: no instruction of the reference runs in an unconfined process"""
     import subprocess
